@@ -1,0 +1,351 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+//
+// extern "C" surface over the CPU restatement so that tests/ (ctypes), __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can drive it. Nothing under synthesis_amd/ links, loads or calls this library.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "connect4.hpp"
+#include "det_math.hpp"
+#include "mcts.hpp"
+#include "nn.hpp"
+#include "outcome.hpp"
+#include "rng.hpp"
+#include "selfplay.hpp"
+#include "tictactoe.hpp"
+
+using namespace oracle;
+
+extern "C" {
+
+// ---------------------------------------------------------------- Outcome lattice (game.rs:9-66)
+// kind: 0 Lose, 1 Draw, 2 Win; some: 0 = None
+int orc_outcome_cmp(int a_some, int a_kind, unsigned a_turns, int b_some, int b_kind, unsigned b_turns) {
+    OptOutcome a = a_some ? OptOutcome::of({(OutcomeKind)a_kind, a_turns}) : OptOutcome::none();
+    OptOutcome b = b_some ? OptOutcome::of({(OutcomeKind)b_kind, b_turns}) : OptOutcome::none();
+    return cmp(a, b);
+}
+void orc_outcome_reversed(int kind, unsigned turns, int* out_kind, unsigned* out_turns) {
+    Outcome r = reversed({(OutcomeKind)kind, turns});
+    *out_kind = r.kind;
+    *out_turns = r.turns;
+}
+int orc_outcome_from_reward(float v) { return outcome_from_reward(v).kind; }
+float orc_outcome_value(int kind) { return value({(OutcomeKind)kind, 0}); }
+
+// ---------------------------------------------------------------- Connect4 (connect4.rs)
+int orc_c4_won(uint64_t bb) { return Connect4::won(bb) ? 1 : 0; }
+
+// Plays `moves` from the empty board. Per move: over[i] = return value of step. Final state written out.
+// legal_before[i] / legal_after[i]: whether column moves[i] is offered by iter_actions before / after the move.
+void orc_c4_play(const uint8_t* moves, int n, uint8_t* over, uint8_t* legal_before, uint8_t* legal_after,
+                 uint64_t* my_bb, uint64_t* op_bb, int* player, int* winner, float* reward_red, float* reward_black,
+                 float* reward_to_move) {
+    Connect4 g = Connect4::new_game();
+    for (int i = 0; i < n; i++) {
+        int acts[9];
+        int na = g.legal_actions(acts);
+        legal_before[i] = 0;
+        for (int j = 0; j < na; j++) legal_before[i] |= (acts[j] == moves[i]);
+        over[i] = g.step(moves[i]) ? 1 : 0;
+        na = g.legal_actions(acts);
+        legal_after[i] = 0;
+        for (int j = 0; j < na; j++) legal_after[i] |= (acts[j] == moves[i]);
+    }
+    *my_bb = g.my_bb;
+    *op_bb = g.op_bb;
+    *player = g.player;
+    *winner = g.winner();
+    *reward_red = g.reward(0);
+    *reward_black = g.reward(1);
+    *reward_to_move = g.reward(g.player_id());
+}
+
+void orc_c4_features(const uint64_t* my_bb, const uint64_t* op_bb, int n, float* out) {
+    for (int i = 0; i < n; i++) Connect4::from_bitboards(my_bb[i], op_bb[i]).features(out + (size_t)i * 63);
+}
+
+// ---------------------------------------------------------------- slimnn layers
+void orc_linear_forward(int I, int O, const float* W, const float* b, const float* x, int batch, float* y, int mode) {
+    for (int n = 0; n < batch; n++) linear_forward(I, O, W, b, x + (size_t)n * I, y + (size_t)n * O, mode);
+}
+int orc_conv2d_forward(int CIN, int COUT, int K, int RP, int CP, int S, int H_IN, int W_IN, int H_OUT, int W_OUT,
+                       const float* W, const float* b, const float* x, int batch, float* y, int mode) {
+    for (int n = 0; n < batch; n++)
+        if (!conv2d_forward(CIN, COUT, K, RP, CP, S, H_IN, W_IN, H_OUT, W_OUT, W, b,
+                            x + (size_t)n * CIN * H_IN * W_IN, y + (size_t)n * COUT * H_OUT * W_OUT, mode))
+            return 1;
+    return 0;
+}
+void orc_relu(float* x, int n) { relu_inplace(x, n); }
+void orc_tanh(float* x, int n) { tanh_inplace(x, n); }
+void orc_softmax_slimnn(const float* x, float* y, int n) { softmax_slimnn(x, y, n); }
+void orc_softmax_stable(const float* x, float* y, int n) { softmax_stable(x, y, n); }
+void orc_det_expf(const float* x, float* y, int n) {
+    for (int i = 0; i < n; i++) y[i] = det_expf(x[i]);
+}
+
+// ---------------------------------------------------------------- Connect4Net (policies.rs)
+size_t orc_c4net_num_params() { return Connect4Net::NUM_PARAMS; }
+void orc_c4net_eval(const float* blob, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits,
+                    float* value, int mode) {
+    Connect4Net net;
+    net.blob = blob;
+    net.mode = mode;
+    for (int i = 0; i < n; i++)
+        net.eval(Connect4::from_bitboards(my_bb[i], op_bb[i]), logits + (size_t)i * 9, value + (size_t)i * 3);
+}
+void orc_c4net_forward_raw(const float* blob, const float* x63, int n, float* out12, int mode) {
+    Connect4Net net;
+    net.blob = blob;
+    net.mode = mode;
+    for (int i = 0; i < n; i++) net.forward(x63 + (size_t)i * 63, out12 + (size_t)i * 12);
+}
+
+// ---------------------------------------------------------------- RNG (rand 0.8 StdRng restatement)
+void orc_chacha_block(const uint32_t* key8, uint64_t counter, uint64_t stream, int rounds, uint32_t* out16) {
+    ChaChaRng::block(key8, counter, stream, rounds, out16);
+}
+void orc_stdrng_from_seed_u64s(const uint8_t* seed32, int rounds, int n, uint64_t* out) {
+    ChaChaRng r = ChaChaRng::from_seed(seed32, rounds);
+    for (int i = 0; i < n; i++) out[i] = r.next_u64();
+}
+void orc_stdrng_seed_from_u64_u32s(uint64_t seed, int rounds, int n, uint32_t* out) {
+    ChaChaRng r = ChaChaRng::seed_from_u64(seed, rounds);
+    for (int i = 0; i < n; i++) out[i] = r.next_u32();
+}
+void orc_stdrng_seed_from_u64_u64s(uint64_t seed, int rounds, int n, uint64_t* out) {
+    ChaChaRng r = ChaChaRng::seed_from_u64(seed, rounds);
+    for (int i = 0; i < n; i++) out[i] = r.next_u64();
+}
+void orc_stdrng_gen_range_u8(uint64_t seed, uint8_t range, int n, uint8_t* out) {
+    ChaChaRng r = ChaChaRng::seed_from_u64(seed);
+    for (int i = 0; i < n; i++) out[i] = r.gen_range_u8(range);
+}
+void orc_stdrng_weighted_index(uint64_t seed, const float* w, int nw, int n, int* out) {
+    ChaChaRng r = ChaChaRng::seed_from_u64(seed);
+    for (int i = 0; i < n; i++) out[i] = r.weighted_index(w, nw);
+}
+
+// ---------------------------------------------------------------- MCTS config marshalling
+struct orc_mcts_config {
+    int exploration;  // 0 Uct, 1 PolynomialUct
+    float c;
+    int solve, correct_values_on_solve, select_solved_nodes, auto_extend;
+    int fpu;  // 0 Const, 1 ParentQ
+    float fpu_value;
+    int noise;  // 0 None, 1 Equal
+    float noise_alpha, noise_weight;
+};
+struct orc_rollout_config {
+    int num_explores, random_actions_until, sample_actions_until, stop_games_when_solved;
+    int value_target;  // 0 Z, 1 Q, 2 QZaverage, 3 QtoZ
+    float vt_p, vt_from, vt_to;
+    int action;  // 0 Q, 1 NumVisits
+    orc_mcts_config mcts;
+};
+
+static MCTSConfig to_cfg(const orc_mcts_config& c) {
+    MCTSConfig m;
+    m.exploration = c.exploration;
+    m.c = c.c;
+    m.solve = c.solve != 0;
+    m.correct_values_on_solve = c.correct_values_on_solve != 0;
+    m.select_solved_nodes = c.select_solved_nodes != 0;
+    m.auto_extend = c.auto_extend != 0;
+    m.fpu = c.fpu;
+    m.fpu_value = c.fpu_value;
+    m.noise = c.noise;
+    m.noise_alpha = c.noise_alpha;
+    m.noise_weight = c.noise_weight;
+    return m;
+}
+static RolloutConfig to_rollout(const orc_rollout_config& c) {
+    RolloutConfig r;
+    r.num_explores = c.num_explores;
+    r.random_actions_until = c.random_actions_until;
+    r.sample_actions_until = c.sample_actions_until;
+    r.stop_games_when_solved = c.stop_games_when_solved != 0;
+    r.value_target = c.value_target;
+    r.vt_p = c.vt_p;
+    r.vt_from = c.vt_from;
+    r.vt_to = c.vt_to;
+    r.action = c.action;
+    r.mcts_cfg = to_cfg(c.mcts);
+    return r;
+}
+
+// ---------------------------------------------------------------- TicTacToe KATs (mcts.rs:691-868)
+// which: 0 = test_solve_win, 1 = test_solve_loss, 2 = test_solve_draw. rounds selects the ChaCha variant of the
+// rollout RNG (12 = rand 0.8 StdRng). Outputs: per-action child solution (some/kind/turns), best_action(Q),
+// nodes.len(), root solution, target policy.
+void orc_ttt_kat(int which, uint64_t seed, int rounds, int max_explores, int* child_some, int* child_kind,
+                 unsigned* child_turns, int* best_action_q, unsigned* num_nodes, int* root_some, int* root_kind,
+                 unsigned* root_turns, float* search_policy, float* target_q) {
+    ChaChaRng rng = ChaChaRng::seed_from_u64(seed, rounds);
+    RolloutPolicy<TicTacToe> policy{&rng};
+    TicTacToe game = TicTacToe::new_game();
+    if (which == 0) { game.step(0); game.step(2); }
+    else if (which == 1) { game.step(0); game.step(2); game.step(6); }
+    else { game.step(0); game.step(4); }
+    MCTSConfig cfg;
+    cfg.exploration = POLYNOMIAL_UCT;
+    cfg.c = 2.0f;
+    cfg.solve = true;
+    cfg.correct_values_on_solve = true;
+    cfg.select_solved_nodes = true;
+    cfg.auto_extend = true;
+    cfg.fpu = FPU_CONST;
+    cfg.fpu_value = std::numeric_limits<float>::infinity();
+    MCTS<TicTacToe, RolloutPolicy<TicTacToe>> mcts(1601, cfg, &policy, game);
+    int it = 0;
+    while (!mcts.nodes[mcts.root].solution.some && it < max_explores) {
+        mcts.explore();
+        it++;
+    }
+    for (int a = 0; a < 9; a++) {
+        OptOutcome s = mcts.solution(a);
+        child_some[a] = s.some;
+        child_kind[a] = s.o.kind;
+        child_turns[a] = s.o.turns;
+    }
+    *best_action_q = mcts.best_action(SELECT_Q);
+    *num_nodes = (unsigned)mcts.nodes.size();
+    *root_some = mcts.nodes[mcts.root].solution.some;
+    *root_kind = mcts.nodes[mcts.root].solution.o.kind;
+    *root_turns = mcts.nodes[mcts.root].solution.o.turns;
+    mcts.target_policy(search_policy);
+    mcts.target_q(target_q);
+}
+
+// test_add_noise's first half (mcts.rs:834-859): priors of the root's children after construction.
+void orc_ttt_root_priors(uint64_t seed, float* priors9, int* n_children) {
+    ChaChaRng rng = ChaChaRng::seed_from_u64(seed);
+    RolloutPolicy<TicTacToe> policy{&rng};
+    MCTSConfig cfg;
+    cfg.exploration = POLYNOMIAL_UCT;
+    cfg.c = 2.0f;
+    cfg.select_solved_nodes = false;
+    cfg.auto_extend = false;
+    cfg.fpu_value = std::numeric_limits<float>::infinity();
+    MCTS<TicTacToe, RolloutPolicy<TicTacToe>> mcts(1601, cfg, &policy, TicTacToe::new_game());
+    const auto& r = mcts.nodes[mcts.root];
+    *n_children = r.num_children;
+    for (uint32_t c = r.first_child; c < r.last_child(); c++) priors9[c - r.first_child] = mcts.nodes[c].action_prob;
+}
+
+// ---------------------------------------------------------------- Connect4 MCTS search on given roots
+// For each root i: builds MCTS::with_capacity(explores+1, cfg, policy, root) and runs explore_n(explores).
+// Outputs per root: child_* arrays are indexed by ACTION (column), zero where the column is not a child.
+void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn_mode, const uint64_t* my_bb,
+                        const uint64_t* op_bb, int n, int explores, int action_selection, float* child_N,
+                        float* child_W, float* child_P, int* child_sol, float* root_stat, int* root_sol,
+                        unsigned* num_nodes, int* best_action, float* target_pi, float* target_q) {
+    MCTSConfig cfg = to_cfg(*cfg_in);
+    Connect4Net net;
+    net.blob = blob;
+    net.mode = nn_mode;
+    for (int i = 0; i < n; i++) {
+        Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
+        MCTS<Connect4, Connect4Net> mcts((size_t)explores + 1, cfg, &net, root);
+        mcts.explore_n((size_t)explores);
+        const auto& r = mcts.nodes[mcts.root];
+        for (int a = 0; a < 9; a++) {
+            child_N[i * 9 + a] = 0;
+            child_P[i * 9 + a] = 0;
+            for (int j = 0; j < 3; j++) child_W[(i * 9 + a) * 3 + j] = 0;
+            for (int j = 0; j < 3; j++) child_sol[(i * 9 + a) * 3 + j] = 0;
+        }
+        for (uint32_t c = r.first_child; c < r.last_child(); c++) {
+            const auto& ch = mcts.nodes[c];
+            int a = ch.action;
+            child_N[i * 9 + a] = ch.num_visits;
+            child_P[i * 9 + a] = ch.action_prob;
+            for (int j = 0; j < 3; j++) child_W[(i * 9 + a) * 3 + j] = ch.outcome_probs[j];
+            child_sol[(i * 9 + a) * 3 + 0] = ch.solution.some;
+            child_sol[(i * 9 + a) * 3 + 1] = ch.solution.o.kind;
+            child_sol[(i * 9 + a) * 3 + 2] = (int)ch.solution.o.turns;
+        }
+        root_stat[i * 4 + 0] = r.num_visits;
+        for (int j = 0; j < 3; j++) root_stat[i * 4 + 1 + j] = r.outcome_probs[j];
+        root_sol[i * 3 + 0] = r.solution.some;
+        root_sol[i * 3 + 1] = r.solution.o.kind;
+        root_sol[i * 3 + 2] = (int)r.solution.o.turns;
+        num_nodes[i] = (unsigned)mcts.nodes.size();
+        best_action[i] = mcts.best_action(action_selection);
+        mcts.target_policy(target_pi + i * 9);
+        mcts.target_q(target_q + i * 3);
+    }
+}
+
+// ---------------------------------------------------------------- self-play (run_n_games / gather_experience)
+// Plays games [first_game, first_game + n_games) with per-game RNG seed_from_u64(base_seed + game_index), split over
+// `threads` OS threads the way gather_experience splits workers (alpha_zero.rs:132-154): each thread owns its
+// policy copy and, if use_cache, its own PolicyWithCache (alpha_zero.rs:196-198).
+// Outputs are indexed by (game - first_game): plies[n], states_bb[n][63][2], pis[n][63][9], vs[n][63][3],
+// actions[n][63], root_nodes[n][63], final_kind[n]. counters[9] = MCTSCounters fields summed; counters[9..11] =
+// cache hits, misses. Returns wall seconds.
+double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
+                       uint64_t first_game, int n_games, int threads, int use_cache, int* plies, uint64_t* states_bb,
+                       float* pis, float* vs, uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind,
+                       uint64_t* counters) {
+    RolloutConfig cfg = to_rollout(*cfg_in);
+    if (threads < 1) threads = 1;
+    std::vector<MCTSCounters> ctrs(threads);
+    std::vector<uint64_t> hits(threads, 0), misses(threads, 0);
+    auto t0 = std::chrono::steady_clock::now();
+    auto worker = [&](int w) {
+        // games_to_schedule / workers_left split, alpha_zero.rs:138
+        int start = 0, count = 0, left = n_games;
+        for (int i = 0; i <= w; i++) {
+            start += count;
+            count = left / (threads - i);
+            left -= count;
+        }
+        Connect4Net net;
+        net.blob = blob;
+        net.mode = nn_mode;
+        PolicyWithCache<Connect4Net> cached((size_t)Connect4::MAX_TURNS * (size_t)(count > 0 ? count : 1), &net);
+        for (int g = start; g < start + count; g++) {
+            ChaChaRng rng = ChaChaRng::seed_from_u64(base_seed + first_game + (uint64_t)g);
+            GameRecord rec;
+            if (use_cache) run_game(cfg, cached, rng, rec, &ctrs[w]);
+            else run_game(cfg, net, rng, rec, &ctrs[w]);
+            if (plies) plies[g] = rec.plies;
+            if (final_kind) final_kind[g] = rec.final_kind;
+            for (int k = 0; k < rec.plies; k++) {
+                size_t p = (size_t)g * 63 + k;
+                if (states_bb) { states_bb[p * 2] = rec.my_bb[k]; states_bb[p * 2 + 1] = rec.op_bb[k]; }
+                if (pis) for (int j = 0; j < 9; j++) pis[p * 9 + j] = rec.pi[k][j];
+                if (vs) for (int j = 0; j < 3; j++) vs[p * 3 + j] = rec.v[k][j];
+                if (actions) actions[p] = rec.action[k];
+                if (root_nodes) root_nodes[p] = rec.root_nodes[k];
+            }
+        }
+        hits[w] = cached.hits;
+        misses[w] = cached.misses;
+    };
+    std::vector<std::thread> pool;
+    for (int w = 1; w < threads; w++) pool.emplace_back(worker, w);
+    worker(0);
+    for (auto& t : pool) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    if (counters) {
+        for (int i = 0; i < 11; i++) counters[i] = 0;
+        for (int w = 0; w < threads; w++) {
+            const MCTSCounters& c = ctrs[w];
+            uint64_t v[9] = {c.explores, c.select_levels, c.children_scanned, c.expansions, c.new_nodes,
+                             c.policy_evals, c.backprop_levels, c.solver_children, c.solved_hits};
+            for (int i = 0; i < 9; i++) counters[i] += v[i];
+            counters[9] += hits[w];
+            counters[10] += misses[w];
+        }
+    }
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+}  // extern "C"

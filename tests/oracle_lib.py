@@ -1,0 +1,235 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement of the reference (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module. The product package
+(synthesis_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class MctsConfig(C.Structure):
+    _fields_ = [
+        ("exploration", C.c_int), ("c", C.c_float),
+        ("solve", C.c_int), ("correct_values_on_solve", C.c_int), ("select_solved_nodes", C.c_int),
+        ("auto_extend", C.c_int),
+        ("fpu", C.c_int), ("fpu_value", C.c_float),
+        ("noise", C.c_int), ("noise_alpha", C.c_float), ("noise_weight", C.c_float),
+    ]
+
+
+class RolloutConfig(C.Structure):
+    _fields_ = [
+        ("num_explores", C.c_int), ("random_actions_until", C.c_int), ("sample_actions_until", C.c_int),
+        ("stop_games_when_solved", C.c_int),
+        ("value_target", C.c_int), ("vt_p", C.c_float), ("vt_from", C.c_float), ("vt_to", C.c_float),
+        ("action", C.c_int),
+        ("mcts", MctsConfig),
+    ]
+
+
+def parity_mcts_config(**kw):
+    """policy_mcts_cfg of study-connect4/src/main.rs:58-66 (the deterministic variant of the self-play config)."""
+    d = dict(exploration=1, c=3.0, solve=1, correct_values_on_solve=1, select_solved_nodes=1, auto_extend=1,
+             fpu=0, fpu_value=1.0, noise=0, noise_alpha=0.0, noise_weight=0.0)
+    d.update(kw)
+    return MctsConfig(**d)
+
+
+def parity_rollout_config(num_explores=800, **kw):
+    """rollout_cfg of study-connect4/src/main.rs:28-50 with the deterministic FPU; explores per BASELINE.json."""
+    mc = kw.pop("mcts", None) or parity_mcts_config()
+    d = dict(num_explores=num_explores, random_actions_until=1, sample_actions_until=30, stop_games_when_solved=0,
+             value_target=1, vt_p=0.0, vt_from=0.0, vt_to=0.0, action=1, mcts=mc)
+    d.update(kw)
+    return RolloutConfig(**d)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    ACC_SLIMNN = 0
+    ACC_FMA = 1
+
+    def __init__(self, lib):
+        self.lib = lib
+        lib.orc_c4_selfplay.restype = C.c_double
+        lib.orc_c4net_num_params.restype = C.c_size_t
+        lib.orc_outcome_value.restype = C.c_float
+
+    # ---- outcome
+    def outcome_cmp(self, a, b):
+        """a, b: None or (kind, turns) with kind in 'Lose','Draw','Win'."""
+        k = {"Lose": 0, "Draw": 1, "Win": 2}
+        aa = (0, 0, 0) if a is None else (1, k[a[0]], a[1])
+        bb = (0, 0, 0) if b is None else (1, k[b[0]], b[1])
+        return self.lib.orc_outcome_cmp(aa[0], aa[1], C.c_uint(aa[2]), bb[0], bb[1], C.c_uint(bb[2]))
+
+    # ---- connect4
+    def c4_won(self, bb):
+        return bool(self.lib.orc_c4_won(C.c_uint64(bb)))
+
+    def c4_play(self, moves):
+        n = len(moves)
+        mv = np.asarray(moves, dtype=np.uint8)
+        over = np.zeros(n, np.uint8); lb = np.zeros(n, np.uint8); la = np.zeros(n, np.uint8)
+        my = C.c_uint64(); op = C.c_uint64(); player = C.c_int(); winner = C.c_int()
+        rr = C.c_float(); rb = C.c_float(); rm = C.c_float()
+        self.lib.orc_c4_play(_p(mv), n, _p(over), _p(lb), _p(la), C.byref(my), C.byref(op), C.byref(player),
+                             C.byref(winner), C.byref(rr), C.byref(rb), C.byref(rm))
+        return dict(over=over.astype(bool), legal_before=lb.astype(bool), legal_after=la.astype(bool), my_bb=my.value,
+                    op_bb=op.value, player=player.value, winner=winner.value, reward_red=rr.value,
+                    reward_black=rb.value, reward_to_move=rm.value)
+
+    def c4_features(self, my_bb, op_bb):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
+        out = np.zeros((my.size, 63), np.float32)
+        self.lib.orc_c4_features(_p(my), _p(op), int(my.size), _p(out))
+        return out
+
+    # ---- layers
+    def linear(self, W, b, x, mode=0):
+        W = np.ascontiguousarray(W, np.float32); b = np.ascontiguousarray(b, np.float32)
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, W.shape[1])
+        y = np.zeros((x.shape[0], W.shape[0]), np.float32)
+        self.lib.orc_linear_forward(W.shape[1], W.shape[0], _p(W), _p(b), _p(x), x.shape[0], _p(y), mode)
+        return y
+
+    def conv2d(self, W, b, x, row_pad, col_pad, stride, mode=0):
+        W = np.ascontiguousarray(W, np.float32); b = np.ascontiguousarray(b, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim == 3:
+            x = x[None]
+        cout, cin, k, _ = W.shape
+        n, _, h_in, w_in = x.shape
+        h_out = (h_in + 2 * row_pad - k) // stride + 1
+        w_out = (w_in + 2 * col_pad - k) // stride + 1
+        y = np.zeros((n, cout, h_out, w_out), np.float32)
+        rc = self.lib.orc_conv2d_forward(cin, cout, k, row_pad, col_pad, stride, h_in, w_in, h_out, w_out, _p(W), _p(b),
+                                         _p(x), n, _p(y), mode)
+        assert rc == 0
+        return y
+
+    def relu(self, x):
+        y = np.array(x, np.float32).ravel().copy()
+        self.lib.orc_relu(_p(y), int(y.size))
+        return y
+
+    def det_expf(self, x):
+        x = np.ascontiguousarray(x, np.float32).ravel()
+        y = np.zeros_like(x)
+        self.lib.orc_det_expf(_p(x), _p(y), int(x.size))
+        return y
+
+    def softmax_stable(self, x):
+        x = np.ascontiguousarray(x, np.float32).ravel()
+        y = np.zeros_like(x)
+        self.lib.orc_softmax_stable(_p(x), _p(y), int(x.size))
+        return y
+
+    # ---- Connect4Net
+    def c4net_eval(self, blob, my_bb, op_bb, mode=0):
+        blob = np.ascontiguousarray(blob, np.float32)
+        assert blob.size == self.lib.orc_c4net_num_params()
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
+        n = int(my.size)
+        logits = np.zeros((n, 9), np.float32); value = np.zeros((n, 3), np.float32)
+        self.lib.orc_c4net_eval(_p(blob), _p(my), _p(op), n, _p(logits), _p(value), mode)
+        return logits, value
+
+    # ---- rng
+    def stdrng_u32(self, seed, n, rounds=12):
+        out = np.zeros(n, np.uint32)
+        self.lib.orc_stdrng_seed_from_u64_u32s(C.c_uint64(seed), rounds, n, _p(out))
+        return out
+
+    def stdrng_from_seed_u64(self, seed32, n, rounds=12):
+        out = np.zeros(n, np.uint64)
+        self.lib.orc_stdrng_from_seed_u64s(bytes(seed32), rounds, n, _p(out))
+        return out
+
+    def chacha_block(self, key8, counter, stream, rounds):
+        key = np.ascontiguousarray(key8, np.uint32); out = np.zeros(16, np.uint32)
+        self.lib.orc_chacha_block(_p(key), C.c_uint64(counter), C.c_uint64(stream), rounds, _p(out))
+        return out
+
+    def gen_range_u8(self, seed, rng_range, n):
+        out = np.zeros(n, np.uint8)
+        self.lib.orc_stdrng_gen_range_u8(C.c_uint64(seed), C.c_uint8(rng_range), n, _p(out))
+        return out
+
+    def weighted_index(self, seed, w, n):
+        w = np.ascontiguousarray(w, np.float32); out = np.zeros(n, np.int32)
+        self.lib.orc_stdrng_weighted_index(C.c_uint64(seed), _p(w), int(w.size), n, _p(out))
+        return out
+
+    # ---- tictactoe KATs
+    def ttt_kat(self, which, seed=0, rounds=12, max_explores=100000):
+        cs = (C.c_int * 9)(); ck = (C.c_int * 9)(); ct = (C.c_uint * 9)()
+        ba = C.c_int(); nn = C.c_uint(); rs = C.c_int(); rk = C.c_int(); rt = C.c_uint()
+        sp = (C.c_float * 9)(); tq = (C.c_float * 3)()
+        self.lib.orc_ttt_kat(which, C.c_uint64(seed), rounds, max_explores, cs, ck, ct, C.byref(ba), C.byref(nn),
+                             C.byref(rs), C.byref(rk), C.byref(rt), sp, tq)
+        kinds = ["Lose", "Draw", "Win"]
+        return dict(child=[(kinds[ck[i]], ct[i]) if cs[i] else None for i in range(9)], best_action_q=ba.value,
+                    nodes_len=nn.value, root=(kinds[rk.value], rt.value) if rs.value else None,
+                    search_policy=np.array(sp[:], np.float32), target_q=np.array(tq[:], np.float32))
+
+    def ttt_root_priors(self, seed=0):
+        pr = (C.c_float * 9)(); n = C.c_int()
+        self.lib.orc_ttt_root_priors(C.c_uint64(seed), pr, C.byref(n))
+        return np.array(pr[: n.value], np.float32)
+
+    # ---- connect4 MCTS search
+    def c4_mcts_search(self, cfg, blob, my_bb, op_bb, explores, action_selection=1, nn_mode=1):
+        blob = np.ascontiguousarray(blob, np.float32)
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
+        n = int(my.size)
+        r = dict(child_N=np.zeros((n, 9), np.float32), child_W=np.zeros((n, 9, 3), np.float32),
+                 child_P=np.zeros((n, 9), np.float32), child_sol=np.zeros((n, 9, 3), np.int32),
+                 root_stat=np.zeros((n, 4), np.float32), root_sol=np.zeros((n, 3), np.int32),
+                 num_nodes=np.zeros(n, np.uint32), best_action=np.zeros(n, np.int32),
+                 target_pi=np.zeros((n, 9), np.float32), target_q=np.zeros((n, 3), np.float32))
+        self.lib.orc_c4_mcts_search(C.byref(cfg), _p(blob), nn_mode, _p(my), _p(op), n, explores, action_selection,
+                                    _p(r["child_N"]), _p(r["child_W"]), _p(r["child_P"]), _p(r["child_sol"]),
+                                    _p(r["root_stat"]), _p(r["root_sol"]), _p(r["num_nodes"]), _p(r["best_action"]),
+                                    _p(r["target_pi"]), _p(r["target_q"]))
+        return r
+
+    # ---- self-play
+    def c4_selfplay(self, cfg, blob, base_seed, n_games, first_game=0, threads=1, use_cache=False, nn_mode=1,
+                    outputs=True):
+        blob = np.ascontiguousarray(blob, np.float32)
+        r = dict(plies=np.zeros(n_games, np.int32), final_kind=np.zeros(n_games, np.uint8),
+                 counters=np.zeros(11, np.uint64))
+        if outputs:
+            r.update(states_bb=np.zeros((n_games, 63, 2), np.uint64), pis=np.zeros((n_games, 63, 9), np.float32),
+                     vs=np.zeros((n_games, 63, 3), np.float32), actions=np.zeros((n_games, 63), np.uint8),
+                     root_nodes=np.zeros((n_games, 63), np.uint32))
+        g = lambda k: _p(r[k]) if k in r else None
+        secs = self.lib.orc_c4_selfplay(C.byref(cfg), _p(blob), nn_mode, C.c_uint64(base_seed), C.c_uint64(first_game),
+                                        n_games, threads, int(use_cache), _p(r["plies"]), g("states_bb"), g("pis"),
+                                        g("vs"), g("actions"), g("root_nodes"), _p(r["final_kind"]), _p(r["counters"]))
+        r["seconds"] = secs
+        names = ["explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals",
+                 "backprop_levels", "solver_children", "solved_hits", "cache_hits", "cache_misses"]
+        r["counters"] = {k: int(v) for k, v in zip(names, r["counters"])}
+        return r
+
+
+def build():
+    subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+
+
+def load():
+    if not os.path.exists(LIB):
+        build()
+    return Oracle(C.CDLL(LIB))

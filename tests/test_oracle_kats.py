@@ -1,0 +1,261 @@
+"""Pins the CPU oracle (oracle/) against every reproducible known-answer test of the reference.
+
+The fixtures in tests/golden/ hold the reference tests' literal data (see tests/golden/make_golden.py); nothing
+here reads /root/reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+
+def load(golden_dir, name):
+    return json.load(open(os.path.join(golden_dir, name)))
+
+
+# ---------------------------------------------------------------- slimnn layers
+def test_conv2d_kats(oracle, golden_dir):
+    """slimnn/src/conv.rs:92-602 — all six Conv2d known answers, |y - t| < 1e-6 (the reference checks y - t < 1e-6)."""
+    kats = load(golden_dir, "slimnn_conv_kats.json")
+    assert len(kats) == 6
+    for k in kats:
+        W = np.array(k["weight"], np.float32)
+        x = np.array(k["x"], np.float32)
+        assert W.shape == (k["cout"], k["cin"], k["k"], k["k"])
+        assert x.shape == (k["cin"], k["h_in"], k["w_in"])
+        for mode in (oracle.ACC_SLIMNN, oracle.ACC_FMA):
+            y = oracle.conv2d(W, k["bias"], x, k["row_pad"], k["col_pad"], k["stride"], mode=mode)[0]
+            t = np.array(k["expected"], np.float32)
+            assert y.shape == t.shape == (k["cout"], k["h_out"], k["w_out"])
+            assert np.abs(y - t).max() < k["tolerance"], k["name"]
+
+
+def test_conv2d_matches_torch(oracle):
+    """Independent second opinion: slimnn Conv2d == NCHW cross-correlation with (row_pad, col_pad) zero padding."""
+    import torch
+
+    rng = np.random.RandomState(0)
+    for (cin, cout, k, rp, cp, s, h, w) in [(2, 4, 3, 1, 0, 3, 7, 9), (2, 8, 3, 1, 1, 1, 7, 9), (3, 5, 2, 0, 1, 2, 6, 5)]:
+        W = rng.randn(cout, cin, k, k).astype(np.float32)
+        b = rng.randn(cout).astype(np.float32)
+        x = rng.randn(3, cin, h, w).astype(np.float32)
+        y = oracle.conv2d(W, b, x, rp, cp, s)
+        t = torch.nn.functional.conv2d(torch.tensor(x, dtype=torch.float64), torch.tensor(W, dtype=torch.float64),
+                                       torch.tensor(b, dtype=torch.float64), stride=s, padding=(rp, cp)).numpy()
+        assert np.abs(y - t).max() < 1e-5
+
+
+def test_linear_and_relu_kats(oracle, golden_dir):
+    """slimnn/src/linear.rs:105-112 (exact) and slimnn/src/activations.rs:70-75 (exact)."""
+    k = load(golden_dir, "slimnn_linear_relu_kats.json")
+    for case in k["linear"]["cases"]:
+        for mode in (oracle.ACC_SLIMNN, oracle.ACC_FMA):
+            y = oracle.linear(k["linear"]["weight"], k["linear"]["bias"], case["x"], mode=mode)[0]
+            assert y.tolist() == case["expected"]
+    assert oracle.relu(k["relu"]["x"]).tolist() == k["relu"]["expected"]
+
+
+# ---------------------------------------------------------------- Outcome lattice
+def test_outcome_ordering(oracle, golden_dir):
+    """synthesis/src/game.rs:94-141 — cmp table at turns=0 and the Option<Outcome> comparisons."""
+    k = load(golden_dir, "outcome_kats.json")
+    for row in k["cmp"]:
+        assert oracle.outcome_cmp((row["a"], 0), (row["b"], 0)) == row["cmp"]
+    for row in k["option"]:
+        c = oracle.outcome_cmp((row["a"], 0), None if row["b"] is None else (row["b"], 0))
+        assert {"==": c == 0, ">": c > 0, "<": c < 0}[row["op"]]
+    # game.rs:49,53,58: fewer turns to a win is greater; more turns to a draw / loss is greater
+    assert oracle.outcome_cmp(("Win", 1), ("Win", 3)) > 0
+    assert oracle.outcome_cmp(("Draw", 1), ("Draw", 3)) < 0
+    assert oracle.outcome_cmp(("Lose", 1), ("Lose", 3)) < 0
+    assert oracle.outcome_cmp(None, None) == 0 and oracle.outcome_cmp(None, ("Lose", 9)) < 0
+
+
+# ---------------------------------------------------------------- Connect4
+def test_connect4_scripted_games(oracle, golden_dir):
+    """study-connect4/src/connect4.rs:299-447 — first-player win, second-player win, full 63-move draw."""
+    k = load(golden_dir, "connect4_kats.json")
+    pid = {"Red": 0, "Black": 1, None: -1}
+    for g in k["games"]:
+        moves = [e["col"] for e in g["events"] if e["op"] == "step"]
+        r = oracle.c4_play(moves)
+        i = 0
+        prefix = []
+        for e in g["events"]:
+            if e["op"] == "step":
+                assert bool(r["over"][i]) == e["is_over"], (g["name"], i)
+                prefix.append(e["col"])
+                i += 1
+            else:
+                # legality of a column in the position reached so far: replay the prefix plus a probe
+                probe = oracle.c4_play(prefix)
+                # column is offered iff its height < 7: read it back from the features plane (0.1 marks the free cell)
+                f = oracle.c4_features([probe["my_bb"]], [probe["op_bb"]])[0].reshape(7, 9)
+                offered = bool(np.any(np.isclose(f[:, e["col"]], 0.1)))
+                assert offered == e["expected"], (g["name"], len(prefix), e)
+        f = g["final"]
+        assert r["winner"] == pid[f["winner"]]
+        assert r["reward_red"] == f["reward_red"] and r["reward_black"] == f["reward_black"]
+        if f["player"] is not None:
+            assert r["player"] == pid[f["player"]]
+        if f["reward_to_move"] is not None:
+            assert r["reward_to_move"] == f["reward_to_move"]
+    assert len([e for e in k["games"][2]["events"] if e["op"] == "step"]) == 63
+
+
+def test_connect4_won_masks(oracle, golden_dir):
+    """study-connect4/src/connect4.rs:449-498 — every horizontal / vertical / diagonal 4-line is a win."""
+    k = load(golden_dir, "connect4_kats.json")
+    assert len(k["won_bitboards"]) == 42 + 36 + 24 + 24
+    for w in k["won_bitboards"]:
+        assert oracle.c4_won(w["bb"]), w
+    assert not oracle.c4_won(0)
+    # 3-in-a-row and wrap-around patterns are not wins (column-major layout: bit 6 -> bit 7 crosses a column)
+    assert not oracle.c4_won(0b111)
+    assert not oracle.c4_won((1 << 4) | (1 << 5) | (1 << 6) | (1 << 7))
+
+
+def test_connect4_features(oracle):
+    """connect4.rs:235-258 — +1 mine, -1 theirs, -0.1 empty, +0.1 lowest empty cell; index row*9 + col."""
+    r = oracle.c4_play([4, 4, 3])  # Red 4, Black 4, Red 3 -> Black to move
+    f = oracle.c4_features([r["my_bb"]], [r["op_bb"]])[0].reshape(7, 9)
+    assert f[0, 4] == np.float32(-1.0) and f[1, 4] == np.float32(1.0) and f[0, 3] == np.float32(-1.0)
+    assert f[2, 4] == np.float32(0.1) and f[1, 3] == np.float32(0.1) and f[0, 0] == np.float32(0.1)
+    assert f[3, 4] == np.float32(-0.1) and f[6, 8] == np.float32(-0.1)
+
+
+# ---------------------------------------------------------------- RNG restatement (third-party: rand 0.8 / rand_chacha 0.3)
+def test_chacha_known_vectors(oracle):
+    """ChaCha core vs RFC 7539 §2.3.2 (20 rounds); generator vs the value-stability constants published in the
+    rand / rand_core crates' own tests (StdRng from_seed -> first u64; seed_from_u64(0) -> first 8 seed bytes)."""
+    key = np.frombuffer(bytes(range(32)), dtype="<u4")
+    blk = oracle.chacha_block(key, 1 | (0x09000000 << 32), 0x4A000000, 20)
+    assert [int(x) for x in blk[:4]] == [0xE4E7F110, 0x15593BD1, 0x1FDD0F50, 0xC47120A3]
+    assert int(blk[15]) == 0x4E3C50A2
+    seed = bytes([1, 0, 0, 0, 23, 0, 0, 0, 200, 1, 0, 0, 210, 30, 0, 0] + [0] * 16)
+    assert int(oracle.stdrng_from_seed_u64(seed, 1, rounds=12)[0]) == 10719222850664546238  # rand 0.8 StdRng
+    assert int(oracle.stdrng_from_seed_u64(seed, 1, rounds=20)[0]) == 3950704604716924505   # rand 0.7 StdRng
+    # rand_core's seed_from_u64 sanity constant is the first 8 bytes of the expanded seed for state 0
+    MUL, INC, M = 6364136223846793005, 11634580027462260723, (1 << 64) - 1
+    s = (0 * MUL + INC) & M
+    w = []
+    for _ in range(2):
+        xs = (((s >> 18) ^ s) >> 27) & 0xFFFFFFFF
+        rot = s >> 59
+        w.append(((xs >> rot) | (xs << ((32 - rot) & 31))) & 0xFFFFFFFF)
+        s = (s * MUL + INC) & M
+    assert w[0] | (w[1] << 32) == 5029875928683246316
+
+
+def test_gen_range_and_weighted_index(oracle):
+    r = oracle.gen_range_u8(7, 9, 5000)
+    assert r.min() == 0 and r.max() == 8
+    assert np.all(np.bincount(r, minlength=9) > 400)
+    # widening-multiply mapping: value = (u32 * 9) >> 32 for accepted draws
+    u = oracle.stdrng_u32(7, 5000)
+    assert np.array_equal(r[:100], ((u[:100].astype(np.uint64) * 9) >> 32).astype(np.uint8))
+    w = np.array([0, 0.5, 0, 0.25, 0.25, 0, 0, 0, 0], np.float32)
+    idx = oracle.weighted_index(3, w, 4000)
+    assert set(np.unique(idx)) == {1, 3, 4}
+    frac = np.bincount(idx, minlength=9) / 4000.0
+    assert abs(frac[1] - 0.5) < 0.04 and abs(frac[3] - 0.25) < 0.04
+
+
+# ---------------------------------------------------------------- MCTS known answers (TicTacToe + RolloutPolicy)
+def test_tictactoe_mcts_kats(oracle, golden_dir):
+    """synthesis/src/mcts.rs:691-831. Active asserts reproduced: per-action solution() == None pattern,
+    best_action(Q) (6 / 1) and nodes.len() == 69 for test_solve_loss. The other two nodes.len() asserts
+    (311, 1533) are NOT reproduced by any reading of rand 0.8.3 we could construct (this restatement and the
+    SURVEY author's independent one both give 244 / 1467); they are stream-sensitive and the reference cannot be run
+    here -> treated as unpinned."""
+    kats = load(golden_dir, "tictactoe_mcts_kats.json")
+    got = {}
+    for k in kats:
+        r = oracle.ttt_kat(k["which"], seed=k["seed"])
+        got[k["name"]] = r
+        assert r["root"] is not None  # loop ran until the root was solved
+        for a in k["solution_none_actions"]:
+            assert r["child"][a] is None, (k["name"], a)
+        if k["best_action_q"] is not None:
+            assert r["best_action_q"] == k["best_action_q"], k["name"]
+    assert got["test_solve_loss"]["nodes_len"] == 69  # mcts.rs:781 — reproduced
+    # the commented-out (pre-Outcome(usize)) asserts still hold qualitatively:
+    assert got["test_solve_win"]["root"][0] == "Win" and got["test_solve_win"]["child"][6][0] == "Lose"
+    assert got["test_solve_loss"]["root"][0] == "Lose"
+    assert [c is not None and c[0] == "Win" for c in got["test_solve_loss"]["child"]] == \
+        [False, True, False, True, True, True, False, True, True]
+    assert got["test_solve_draw"]["root"][0] == "Draw"
+    assert [c is not None and c[0] == "Draw" for c in got["test_solve_draw"]["child"]] == \
+        [False, True, True, True, False, True, True, True, True]
+    assert int(np.argmax(got["test_solve_win"]["search_policy"])) == 6
+    # regression values of THIS restatement for the two unpinned counts (reference asserts 311 / 1533)
+    assert got["test_solve_win"]["nodes_len"] == 244
+    assert got["test_solve_draw"]["nodes_len"] == 1467
+
+
+def test_tictactoe_root_priors(oracle):
+    """mcts.rs:834-859: root priors are positive and sum to 1 (+-1e-6) after construction."""
+    p = oracle.ttt_root_priors(0)
+    assert p.size == 9 and np.all(p > 0) and abs(float(p.sum()) - 1.0) < 1e-6
+
+
+# ---------------------------------------------------------------- deterministic exp and the MLP
+def test_det_expf_accuracy(oracle):
+    x = np.concatenate([np.linspace(-103.9, 0, 200001), np.linspace(0, 88.7, 50001), [-0.0, 0.0, -1e-30]]).astype(np.float32)
+    y = oracle.det_expf(x).astype(np.float64)
+    t = np.exp(x.astype(np.float64))
+    normal = t > 1.2e-38
+    ulp = np.spacing(t[normal].astype(np.float32)).astype(np.float64)
+    assert np.max(np.abs(y[normal] - t[normal]) / ulp) < 1.0
+    assert np.all(np.abs(y[~normal] - t[~normal]) <= 1.5e-45)
+    assert oracle.det_expf([0.0])[0] == 1.0
+    assert oracle.det_expf([-200.0])[0] == 0.0 and np.isinf(oracle.det_expf([100.0])[0])
+    sm = oracle.softmax_stable([1.0, 2.0, 3.0])
+    np.testing.assert_allclose(sm, np.exp([1.0, 2, 3]) / np.exp([1.0, 2, 3]).sum(), rtol=3e-7)
+
+
+def test_c4net_matches_torch_goldens(oracle, golden_dir):
+    """Connect4Net has no test in the reference (parity unpinned there): check both accumulation modes against
+    torch float32/float64 outputs generated by make_golden.py. Tolerance = north_star's 1e-5."""
+    g = load(golden_dir, "c4net_torch_goldens.json")
+    blob = np.load(os.path.join(golden_dir, g["weights_file"]))
+    feats = oracle.c4_features(g["my_bb"], g["op_bb"])
+    assert np.array_equal(feats, np.array(g["features"], np.float32))
+    for mode in (oracle.ACC_SLIMNN, oracle.ACC_FMA):
+        logits, value = oracle.c4net_eval(blob, g["my_bb"], g["op_bb"], mode=mode)
+        assert np.abs(logits - np.array(g["logits_f64"])).max() < 1e-5
+        assert np.abs(value - np.array(g["value_f64"])).max() < 1e-5
+        assert np.abs(logits - np.array(g["logits_f32"], np.float32)).max() < 1e-5
+    a = oracle.c4net_eval(blob, g["my_bb"], g["op_bb"], mode=oracle.ACC_SLIMNN)
+    b = oracle.c4net_eval(blob, g["my_bb"], g["op_bb"], mode=oracle.ACC_FMA)
+    assert np.abs(a[0] - b[0]).max() < 2e-6 and np.abs(a[1] - b[1]).max() < 2e-6
+
+
+# ---------------------------------------------------------------- self-play driver properties
+def test_selfplay_oracle_properties(oracle, golden_dir):
+    from tests.oracle_lib import parity_rollout_config
+
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    cfg = parity_rollout_config(num_explores=48)
+    r = oracle.c4_selfplay(cfg, blob, base_seed=5, n_games=6, threads=2, use_cache=True)
+    r1 = oracle.c4_selfplay(cfg, blob, base_seed=5, n_games=6, threads=1, use_cache=False)
+    # per-game RNG: results do not depend on thread split or on the cache (semantics-neutral memoisation)
+    for k in ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind"):
+        assert np.array_equal(r[k], r1[k]), k
+    for g in range(6):
+        n = r["plies"][g]
+        assert 7 <= n <= 63
+        pis = r["pis"][g, :n]
+        np.testing.assert_allclose(pis.sum(axis=1), 1.0, atol=1e-5)
+        np.testing.assert_allclose(r["vs"][g, :n].sum(axis=1), 1.0, atol=1e-5)
+        # replaying the recorded actions reproduces the recorded states and ends exactly at ply n
+        rep = oracle.c4_play(list(r["actions"][g, :n]))
+        assert rep["over"][-1] and not rep["over"][:-1].any()
+        assert r["states_bb"][g, 0, 0] == 0 and r["states_bb"][g, 0, 1] == 0
+        # chosen actions had non-zero search probability
+        assert np.all(pis[np.arange(n), r["actions"][g, :n]] > 0)
+        # tree size bound of SURVEY §8(a1): <= 1 + 9 * (explores + 1)
+        assert r["root_nodes"][g, :n].max() <= 1 + 9 * 49
+    assert r["counters"]["cache_hits"] > 0 and r1["counters"]["cache_hits"] == 0
+    assert r1["counters"]["policy_evals"] == r["counters"]["policy_evals"]
