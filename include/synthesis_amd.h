@@ -1,0 +1,199 @@
+/* synthesis_amd — MI355X-native batched self-play engine: C ABI (drop-in boundary).
+ *
+ * The reference (coreylowman/synthesis) has no FFI; its plug-in surface is Rust generics:
+ *   trait Game<N>            synthesis/src/game.rs:68-88
+ *   trait Policy<G,N>        synthesis/src/policies/traits.rs:4-6   fn eval(&mut self,&G)->([f32;N],[f32;3])
+ *   trait NNPolicy<G,N>      synthesis/src/policies/traits.rs:8-11
+ *   MCTS<G,P,N>              synthesis/src/mcts.rs:102-147 (private module, reached through alpha_zero/evaluator)
+ *   run_n_games / run_game   synthesis/src/alpha_zero.rs:181-268
+ * Every entry point below is the batched, plain-C form of one of those; the doc comment on each names the reference
+ * interface it replaces. INTEGRATION.md shows the Rust `extern "C"` block + `impl Policy<Connect4, 9>` a maintainer
+ * would add on the reference side.
+ *
+ * Conventions: all functions return SYN_OK (0) or a negative syn_status; syn_last_error() gives the message of the
+ * last failure on that handle (or of the last failed syn_engine_create when handle == NULL). Nothing throws or unwinds
+ * across this boundary. Host pointers unless a parameter is documented as a device pointer. The caller owns every
+ * output buffer; the engine keeps no pointer past the call. One handle = one GPU + one stream; calls on a handle are
+ * not re-entrant; different handles are independent (the reference's one-policy-per-thread rule, alpha_zero.rs:192-198).
+ */
+#ifndef SYNTHESIS_AMD_H
+#define SYNTHESIS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum syn_status {
+    SYN_OK = 0,
+    SYN_ERR_INVALID_ARGUMENT = -1,
+    SYN_ERR_NO_DEVICE = -2,       /* no usable gfx950 device / HIP runtime failure at create */
+    SYN_ERR_HIP = -3,             /* a HIP call failed; see syn_last_error */
+    SYN_ERR_NO_WEIGHTS = -4,      /* policy/value network weights not loaded yet */
+    SYN_ERR_UNSUPPORTED = -5,     /* config variant not implemented on device (e.g. Fpu::Func, Dirichlet noise) */
+    SYN_ERR_CAPACITY = -6         /* node pool too small for the requested explores */
+} syn_status;
+
+/* ---- plain-data mirrors of synthesis/src/config.rs ---------------------------------------------------------- */
+
+/* config.rs:9-13 Exploration */
+enum { SYN_EXPLORATION_UCT = 0, SYN_EXPLORATION_POLYNOMIAL_UCT = 1 };
+/* config.rs:15-19 ActionSelection */
+enum { SYN_ACTION_Q = 0, SYN_ACTION_NUM_VISITS = 1 };
+/* config.rs:21-26 Fpu (Func(fn()->f32) is a host closure: rejected with SYN_ERR_UNSUPPORTED) */
+enum { SYN_FPU_CONST = 0, SYN_FPU_PARENT_Q = 1 };
+/* config.rs:39-44 PolicyNoise (Dirichlet needs rand_distr's gamma sampler: SYN_ERR_UNSUPPORTED for now) */
+enum { SYN_NOISE_NONE = 0, SYN_NOISE_EQUAL = 1, SYN_NOISE_DIRICHLET = 2 };
+/* config.rs:1-7 ValueTarget */
+enum { SYN_VALUE_Z = 0, SYN_VALUE_Q = 1, SYN_VALUE_QZ_AVERAGE = 2, SYN_VALUE_Q_TO_Z = 3 };
+/* Outcome kind, index order of mcts.rs:10-18 (Into<usize>) */
+enum { SYN_OUTCOME_LOSE = 0, SYN_OUTCOME_DRAW = 1, SYN_OUTCOME_WIN = 2 };
+
+/* config.rs:28-37 MCTSConfig */
+typedef struct syn_mcts_config {
+    int32_t exploration;              /* SYN_EXPLORATION_* */
+    float c;                          /* Uct{c} / PolynomialUct{c} */
+    int32_t solve;
+    int32_t correct_values_on_solve;
+    int32_t select_solved_nodes;
+    int32_t auto_extend;
+    int32_t fpu;                      /* SYN_FPU_* */
+    float fpu_value;                  /* Fpu::Const(value) */
+    int32_t root_policy_noise;        /* SYN_NOISE_* */
+    float noise_alpha;                /* Dirichlet{alpha,..} */
+    float noise_weight;               /* Equal{weight} / Dirichlet{..,weight} */
+} syn_mcts_config;
+
+/* config.rs:46-56 RolloutConfig (num_workers has no meaning here: concurrency is syn_engine_config.concurrent_games) */
+typedef struct syn_rollout_config {
+    int32_t num_explores;
+    int32_t random_actions_until;
+    int32_t sample_actions_until;
+    int32_t stop_games_when_solved;
+    int32_t value_target;             /* SYN_VALUE_* */
+    float value_target_p;             /* QZaverage{p} */
+    float value_target_from;          /* QtoZ{from,..} */
+    float value_target_to;            /* QtoZ{..,to} */
+    int32_t action;                   /* SYN_ACTION_* */
+    syn_mcts_config mcts_cfg;
+} syn_rollout_config;
+
+typedef struct syn_engine_config {
+    int32_t concurrent_games;   /* trees resident on the GPU at once (BASELINE: 4096); rounded up to a multiple of 16 */
+    int32_t max_explores;       /* node-pool slab per tree = 1 + 9*(max_explores+1) nodes */
+    int32_t reserved0;
+    int32_t reserved1;
+} syn_engine_config;
+
+typedef struct syn_engine syn_engine;
+
+/* Fills the deterministic parity configuration: policy_mcts_cfg of study-connect4/src/main.rs:58-66 inside the
+ * rollout_cfg of main.rs:28-36 (explores 800 per BASELINE.json; the reference default is 1600). */
+void syn_default_rollout_config(syn_rollout_config* cfg);
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------------- */
+
+/* Replaces: VarStore::new + P::new(&vs) per worker (alpha_zero.rs:192-193). Allocates the device node pool. */
+int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out);
+int syn_engine_destroy(syn_engine* h);
+const char* syn_last_error(const syn_engine* h);
+
+/* Replaces: vs.load(models/model_i.ot) (alpha_zero.rs:194). blob = l_1.weight[128x63], l_1.bias[128],
+ * l_2.weight[96x128], l_2.bias[96], l_3.weight[64x96], l_3.bias[64], l_4.weight[48x64], l_4.bias[48],
+ * l_5.weight[12x48], l_5.bias[12] (VarStore names, study-connect4/src/policies.rs:20-24), row-major [out][in],
+ * n_floats must be 30492. */
+int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats);
+
+/* ---- leaf evaluation ------------------------------------------------------------------------------------------- */
+
+/* Replaces: Policy::eval (study-connect4/src/policies.rs:47-59) for n states at once. State i is the position with
+ * bitboards (my_bb[i], op_bb[i]) in the layout of connect4.rs:3-13 (my_bb = side to move). Outputs: logits[n*9] raw
+ * policy logits, value[n*3] = softmax over [lose, draw, win]. */
+int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits,
+                          float* value);
+/* Same with all four pointers resident in device memory (no PCIe in the call); asynchronous on the engine stream
+ * unless sync != 0. */
+int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my_bb, const uint64_t* d_op_bb, int n,
+                                 float* d_logits, float* d_value, int sync);
+
+/* Replaces: Game::features (connect4.rs:235-258) for n states: out[n*63], index row*9 + col. */
+int syn_features_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* out);
+
+/* ---- slimnn layer semantics (slimnn/src/linear.rs:17-25, conv.rs:45-85, activations.rs) ------------------------- */
+/* y[batch][O] = b + sum_i x[batch][i] * W[o][i], accumulated in ascending i with separate multiply and add. */
+int syn_linear_forward(syn_engine* h, int I, int O, const float* W, const float* b, const float* x, int batch,
+                       float* y, int relu);
+/* NCHW cross-correlation; W[COUT][CIN][K][K]; x[batch][CIN][H_IN][W_IN]; y[batch][COUT][H_OUT][W_OUT]; accumulation
+ * order ci -> k1 -> k2. H_OUT/W_OUT must satisfy conv.rs:50-51 or SYN_ERR_INVALID_ARGUMENT is returned. */
+int syn_conv2d_forward(syn_engine* h, int CIN, int COUT, int K, int ROW_PAD, int COL_PAD, int STRIDE, int H_IN,
+                       int W_IN, int H_OUT, int W_OUT, const float* W, const float* b, const float* x, int batch,
+                       float* y, int relu);
+
+/* ---- search ---------------------------------------------------------------------------------------------------- */
+
+/* Per-root result of a search; child_* arrays are indexed by ACTION (column); entries of columns that are not
+ * children of the root are zero. */
+typedef struct syn_search_result {
+    float child_N[9];          /* Node::num_visits                     (mcts.rs:38) */
+    float child_W[9][3];       /* Node::outcome_probs [lose,draw,win]  (mcts.rs:37) */
+    float child_P[9];          /* Node::action_prob                    (mcts.rs:36) */
+    int32_t child_sol[9][3];   /* {is_some, kind, turns} of Node::solution (mcts.rs:34) */
+    float root_N;
+    float root_W[3];
+    int32_t root_sol[3];
+    uint32_t num_nodes;        /* nodes.len() */
+    int32_t best_action;       /* MCTS::best_action (mcts.rs:273-294) */
+    float target_pi[9];        /* MCTS::target_policy (mcts.rs:174-211) */
+    float target_q[3];         /* MCTS::target_q (mcts.rs:213-225) */
+} syn_search_result;
+
+/* Replaces: MCTS::with_capacity(explores+1, cfg, policy, root) + explore_n(explores) (mcts.rs:123-147) for n
+ * independent roots, each on its own device-resident tree. */
+int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
+                    int explores, int action_selection, syn_search_result* results);
+
+/* ---- self-play ------------------------------------------------------------------------------------------------- */
+
+/* Event counters summed over all games of a run (definitions: SURVEY.md §8d; used for algorithmic-bytes accounting) */
+typedef struct syn_counters {
+    uint64_t explores;          /* MCTS::explore calls + root visits */
+    uint64_t select_levels;     /* select_best_child calls */
+    uint64_t children_scanned;  /* children examined by select_best_child */
+    uint64_t expansions;        /* visit() bodies that created children */
+    uint64_t new_nodes;         /* nodes created */
+    uint64_t policy_evals;      /* Policy::eval calls = leaf evaluations */
+    uint64_t backprop_levels;   /* nodes updated by backprop */
+    uint64_t solver_children;   /* child solutions read by the solver branch of backprop */
+    uint64_t solved_hits;       /* explores that ended on an already solved node */
+    uint64_t moves;             /* plies played */
+    uint64_t games;             /* games finished */
+    uint64_t reserved;
+} syn_counters;
+
+/* Replaces: run_n_games (alpha_zero.rs:181-209) for games [first_game, first_game + n_games). Game g uses its own
+ * StdRng::seed_from_u64(base_seed + g). Output slot j = g - first_game. Any output pointer may be
+ * NULL.  plies[n]; states_bb[n][63][2] = (my_bb, op_bb) of every recorded position (ReplayBuffer.games, data.rs:151-158);
+ * pis[n][63][9]; vs[n][63][3] (after store_rewards, alpha_zero.rs:309-338); actions[n][63]; root_nodes[n][63] =
+ * nodes.len() of each move's tree; final_kind[n] = outcome kind for the side to move in the final position.
+ * counters may be NULL. */
+int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game,
+                     int n_games, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
+                     uint32_t* root_nodes, uint8_t* final_kind, syn_counters* counters);
+
+/* Timing of the last syn_selfplay_run / syn_mcts_search / *_device call on this handle, measured with HIP events on
+ * the engine stream: kernel_ms = device time of the dominant kernel launch(es), n_launches = how many. */
+int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches);
+
+/* Device-side RNG / math primitives exposed for parity tests against the oracle (no reference counterpart):
+ * out[i] = i-th u32 of StdRng::seed_from_u64(seed) as generated on the GPU. */
+int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out);
+/* y[i] = device det_expf(x[i]); q[i] = a[i] / b[i]; s[i] = sqrtf(a[i])  (IEEE-exactness checks) */
+int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
+                   float* out_sqrt_a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNTHESIS_AMD_H */

@@ -1,0 +1,116 @@
+"""Plain-data mirrors of synthesis/src/config.rs (same names, same fields, same meaning).
+
+`Fpu.Func` (config.rs:25) is a Rust closure and cannot cross the C ABI; `PolicyNoise.Dirichlet` needs rand_distr's
+gamma sampler and is not implemented on the device yet: both are representable here and rejected by the engine with
+SYN_ERR_UNSUPPORTED, mirroring "error, not silent fallback".
+"""
+import ctypes as C
+import enum
+from dataclasses import dataclass, field
+
+
+class Exploration(enum.IntEnum):          # config.rs:9-13
+    Uct = 0
+    PolynomialUct = 1
+
+
+class ActionSelection(enum.IntEnum):      # config.rs:15-19
+    Q = 0
+    NumVisits = 1
+
+
+class Fpu(enum.IntEnum):                  # config.rs:21-26
+    Const = 0
+    ParentQ = 1
+    Func = 2
+
+
+class PolicyNoise(enum.IntEnum):          # config.rs:39-44
+    NoNoise = 0
+    Equal = 1
+    Dirichlet = 2
+
+
+class ValueTarget(enum.IntEnum):          # config.rs:1-7
+    Z = 0
+    Q = 1
+    QZaverage = 2
+    QtoZ = 3
+
+
+class CMctsConfig(C.Structure):           # struct syn_mcts_config
+    _fields_ = [
+        ("exploration", C.c_int32), ("c", C.c_float),
+        ("solve", C.c_int32), ("correct_values_on_solve", C.c_int32), ("select_solved_nodes", C.c_int32),
+        ("auto_extend", C.c_int32),
+        ("fpu", C.c_int32), ("fpu_value", C.c_float),
+        ("root_policy_noise", C.c_int32), ("noise_alpha", C.c_float), ("noise_weight", C.c_float),
+    ]
+
+
+class CRolloutConfig(C.Structure):        # struct syn_rollout_config
+    _fields_ = [
+        ("num_explores", C.c_int32), ("random_actions_until", C.c_int32), ("sample_actions_until", C.c_int32),
+        ("stop_games_when_solved", C.c_int32),
+        ("value_target", C.c_int32), ("value_target_p", C.c_float), ("value_target_from", C.c_float),
+        ("value_target_to", C.c_float),
+        ("action", C.c_int32),
+        ("mcts_cfg", CMctsConfig),
+    ]
+
+
+class CEngineConfig(C.Structure):         # struct syn_engine_config
+    _fields_ = [("concurrent_games", C.c_int32), ("max_explores", C.c_int32), ("reserved0", C.c_int32),
+                ("reserved1", C.c_int32)]
+
+
+@dataclass
+class MCTSConfig:                         # config.rs:28-37
+    exploration: Exploration = Exploration.PolynomialUct
+    c: float = 3.0
+    solve: bool = True
+    correct_values_on_solve: bool = True
+    select_solved_nodes: bool = True
+    auto_extend: bool = True
+    fpu: Fpu = Fpu.Const
+    fpu_value: float = 1.0
+    root_policy_noise: PolicyNoise = PolicyNoise.NoNoise
+    noise_alpha: float = 0.0
+    noise_weight: float = 0.0
+
+    def to_c(self) -> CMctsConfig:
+        return CMctsConfig(int(self.exploration), float(self.c), int(self.solve), int(self.correct_values_on_solve),
+                           int(self.select_solved_nodes), int(self.auto_extend), int(self.fpu), float(self.fpu_value),
+                           int(self.root_policy_noise), float(self.noise_alpha), float(self.noise_weight))
+
+
+@dataclass
+class RolloutConfig:                      # config.rs:46-56 (num_workers -> Engine(concurrent_games=...))
+    num_explores: int = 800
+    random_actions_until: int = 1
+    sample_actions_until: int = 30
+    stop_games_when_solved: bool = False
+    value_target: ValueTarget = ValueTarget.Q
+    value_target_p: float = 0.0       # QZaverage { p }
+    value_target_from: float = 0.0    # QtoZ { from, to }
+    value_target_to: float = 0.0
+    action: ActionSelection = ActionSelection.NumVisits
+    mcts_cfg: MCTSConfig = field(default_factory=MCTSConfig)
+
+    def to_c(self) -> CRolloutConfig:
+        return CRolloutConfig(int(self.num_explores), int(self.random_actions_until), int(self.sample_actions_until),
+                              int(self.stop_games_when_solved), int(self.value_target), float(self.value_target_p),
+                              float(self.value_target_from), float(self.value_target_to), int(self.action),
+                              self.mcts_cfg.to_c())
+
+
+def parity_mcts_config(**kw) -> MCTSConfig:
+    """policy_mcts_cfg of study-connect4/src/main.rs:58-66: the deterministic variant (Fpu::Const(1.0)) of the
+    reference's self-play MCTS configuration (whose Fpu::Func samples N(1, 0.1) from thread_rng, main.rs:43-47)."""
+    return MCTSConfig(**kw)
+
+
+def parity_rollout_config(num_explores: int = 800, **kw) -> RolloutConfig:
+    """rollout_cfg of study-connect4/src/main.rs:28-36 with parity_mcts_config; explores = 800 per BASELINE.json
+    (the reference default is 1600, main.rs:30)."""
+    return RolloutConfig(num_explores=num_explores, **kw)

@@ -1,0 +1,224 @@
+// synthesis_amd — device primitives shared by every kernel (gfx950 only; wave = 64 lanes).
+//
+//  * det_expf            the deterministic f32 exp both sides of every parity test use (algorithm: DESIGN.md §numerics)
+//  * row16 primitives    a "group" is one DPP row = 16 consecutive lanes; one MCTS tree lives on one group
+//                        (4 trees per wave64, <= 9 lanes active = one lane per Connect4 column / child)
+//  * Connect4 bit ops    study-connect4/src/connect4.rs:37-83,221-258 as branch-free u64 arithmetic
+//  * StdRng              rand 0.8 StdRng (ChaCha12 + PCG32 seed expansion) — synthesis/src/alpha_zero.rs:189,281,286
+//
+// Everything here is compiled with -ffp-contract=off and -fhip-fp32-correctly-rounded-divide-sqrt: each f32 operation
+// is rounded exactly where the source says, so results are bit-identical to the C++ oracle built the same way.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace syn {
+
+#define SYN_DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------ det_expf
+SYN_DEV float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
+SYN_DEV uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+SYN_DEV float det_expf(float x) {
+    if (x != x) return x;
+    if (x > 88.72283f) return bits_f32(0x7F800000u);
+    if (x < -103.97208f) return 0.0f;
+    float t = x * 1.44269504f;
+    float n = __builtin_rintf(t);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    int ni = (int)n;
+    if (ni >= -125) return bits_f32(f32_bits(y) + ((uint32_t)ni << 23));
+    float z = bits_f32(f32_bits(y) + ((uint32_t)(ni + 64) << 23));
+    return z * bits_f32((uint32_t)(127 - 64) << 23);
+}
+
+// ------------------------------------------------------------------------------------------------ row16 primitives
+SYN_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// DPP controls (ISA: DPP_CTRL): quad_perm = 0x00-0xFF, row_half_mirror = 0x141, row_mirror = 0x140.
+template <int CTRL>
+SYN_DEV uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+SYN_DEV float dpp_f32(float v) { return bits_f32(dpp_u32<CTRL>(f32_bits(v))); }
+
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i within each 8
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i within the row
+
+// All-lanes max over the row. After the two quad steps every lane of a quad holds the quad result, so the mirrors
+// (which pair quad 0<->1 and then half 0<->1) complete an all-reduce without LDS traffic.
+SYN_DEV uint32_t row_max_u32(uint32_t v) {
+    uint32_t o;
+    o = dpp_u32<DPP_XOR1>(v); v = v > o ? v : o;
+    o = dpp_u32<DPP_XOR2>(v); v = v > o ? v : o;
+    o = dpp_u32<DPP_HALF_MIRROR>(v); v = v > o ? v : o;
+    o = dpp_u32<DPP_MIRROR>(v); v = v > o ? v : o;
+    return v;
+}
+// max ignoring NaN (Rust f32::max / v_max_f32 semantics); exact, so association order is irrelevant
+SYN_DEV float row_max_f32(float v) {
+    v = __builtin_fmaxf(v, dpp_f32<DPP_XOR1>(v));
+    v = __builtin_fmaxf(v, dpp_f32<DPP_XOR2>(v));
+    v = __builtin_fmaxf(v, dpp_f32<DPP_HALF_MIRROR>(v));
+    v = __builtin_fmaxf(v, dpp_f32<DPP_MIRROR>(v));
+    return v;
+}
+
+// Argmax with "first index wins ties": returns the winning index on every lane of the row.
+// Caller guarantees no NaN in v (see select: NaN is pre-mapped to the sequential-scan semantics).
+SYN_DEV int row_argmax_first(float v, int idx) {
+#define SYN_ARGMAX_STEP(CTRL)                                              \
+    {                                                                      \
+        float ov = dpp_f32<CTRL>(v);                                       \
+        int oi = (int)dpp_u32<CTRL>((uint32_t)idx);                        \
+        bool take = (ov > v) || (ov == v && oi < idx);                     \
+        v = take ? ov : v;                                                 \
+        idx = take ? oi : idx;                                             \
+    }
+    SYN_ARGMAX_STEP(DPP_XOR1)
+    SYN_ARGMAX_STEP(DPP_XOR2)
+    SYN_ARGMAX_STEP(DPP_HALF_MIRROR)
+    SYN_ARGMAX_STEP(DPP_MIRROR)
+#undef SYN_ARGMAX_STEP
+    return idx;
+}
+
+// value of lane `src` (0..15) of this lane's row
+SYN_DEV uint32_t row_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 16); }
+SYN_DEV float row_bcast_f32(float v, int src) { return __shfl(v, src, 16); }
+
+// 16-bit ballot of this lane's row
+SYN_DEV uint32_t row_ballot(bool p) {
+    unsigned long long b = __ballot(p);
+    return (uint32_t)(b >> (lane_id() & 48)) & 0xFFFFu;
+}
+
+// ------------------------------------------------------------------------------------------------ Connect4
+namespace c4 {
+constexpr int WIDTH = 9, HEIGHT = 7;
+constexpr uint64_t fab_row_c() {
+    uint64_t r = 0;
+    for (int c = 0; c < 9; c++) r |= 1ull << (7 * c);
+    return r;
+}
+constexpr uint64_t FAB_ROW = fab_row_c();
+constexpr uint64_t FULL = (1ull << 63) - 1;  // 63 cells
+constexpr uint64_t cols0to5_c() {
+    uint64_t r = 0;
+    for (int c = 0; c < 6; c++) r |= 0x7Full << (7 * c);
+    return r;
+}
+constexpr uint64_t rows_c(int lo, int hi) {
+    uint64_t r = 0;
+    for (int i = lo; i <= hi; i++) r |= fab_row_c() << i;
+    return r;
+}
+constexpr uint64_t D1_MASK = cols0to5_c() & rows_c(3, 6);
+constexpr uint64_t D2_MASK = cols0to5_c() & rows_c(0, 3);
+constexpr uint64_t H_MASK = cols0to5_c();
+constexpr uint64_t V_MASK = rows_c(0, 3);
+
+// connect4.rs:77-83
+SYN_DEV bool won(uint64_t bb) {
+    uint64_t d1 = bb & (bb >> 6) & (bb >> 12) & (bb >> 18) & D1_MASK;
+    uint64_t d2 = bb & (bb >> 8) & (bb >> 16) & (bb >> 24) & D2_MASK;
+    uint64_t h = bb & (bb >> 7) & (bb >> 14) & (bb >> 21) & H_MASK;
+    uint64_t v = bb & (bb >> 1) & (bb >> 2) & (bb >> 3) & V_MASK;
+    return (v | h | d1 | d2) != 0;
+}
+SYN_DEV int col_height(uint64_t occ, int col) { return __popcll(occ & (0x7Full << (7 * col))); }
+
+// Lowest empty cell of every non-full column (gravity keeps columns contiguous from the bottom):
+// a cell is "next free" iff it is empty and (it is in row 0 or the cell below is occupied).
+SYN_DEV uint64_t next_free_cells(uint64_t occ) { return ((occ << 1) | FAB_ROW) & ~occ & FULL; }
+
+// connect4.rs:235-258 for one flat feature index f = row*9 + col (f in 0..62)
+SYN_DEV float feature(uint64_t my, uint64_t op, uint64_t nextfree, int f) {
+    int row = f / 9, col = f - row * 9;
+    uint64_t bit = 1ull << (row + 7 * col);
+    float v = -0.1f;
+    v = (nextfree & bit) ? 0.1f : v;
+    v = (op & bit) ? -1.0f : v;
+    v = (my & bit) ? 1.0f : v;
+    return v;
+}
+}  // namespace c4
+
+// ------------------------------------------------------------------------------------------------ StdRng (ChaCha12)
+struct StdRng {
+    uint32_t key[8];
+    uint32_t index;  // words consumed so far (word i lives in block i/16)
+
+    SYN_DEV static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+
+    // rand_core 0.6 seed_from_u64: PCG32 fills the 32-byte key
+    SYN_DEV void seed_from_u64(uint64_t state) {
+        const uint64_t MUL = 6364136223846793005ull, INC = 11634580027462260723ull;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            state = state * MUL + INC;
+            uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            uint32_t rot = (uint32_t)(state >> 59);
+            key[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+        index = 0;
+    }
+
+    SYN_DEV uint32_t word(uint32_t i) const {
+        uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                          key[4], key[5], key[6], key[7], i >> 4, 0u, 0u, 0u};
+        uint32_t x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = s[k];
+#define SYN_QR(a, b, c, d)                          \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16); \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12); \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);  \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            SYN_QR(0, 4, 8, 12) SYN_QR(1, 5, 9, 13) SYN_QR(2, 6, 10, 14) SYN_QR(3, 7, 11, 15)
+            SYN_QR(0, 5, 10, 15) SYN_QR(1, 6, 11, 12) SYN_QR(2, 7, 8, 13) SYN_QR(3, 4, 9, 14)
+        }
+#undef SYN_QR
+        uint32_t w = i & 15, out = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) out = (w == (uint32_t)k) ? x[k] + s[k] : out;
+        return out;
+    }
+
+    SYN_DEV uint32_t next_u32() { return word(index++); }
+
+    // Rng::gen_range(0..n) for u8 (rand 0.8.3 UniformInt<u8>::sample_single): u32 widening multiply + modulus zone
+    SYN_DEV uint32_t gen_range_u8(uint32_t n) {
+        uint32_t ints_to_reject = (0xFFFFFFFFu - n + 1u) % n;
+        uint32_t zone = 0xFFFFFFFFu - ints_to_reject;
+        for (;;) {
+            uint32_t v = next_u32();
+            uint64_t m = (uint64_t)v * (uint64_t)n;
+            if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+        }
+    }
+
+    // Uniform<f32>::new(0, total).sample — rand 0.8.3 UniformFloat<f32>
+    SYN_DEV float uniform_0_to(float total) {
+        float v12 = bits_f32((next_u32() >> 9) | 0x3F800000u);
+        float v01 = v12 - 1.0f;
+        return v01 * total + 0.0f;
+    }
+};
+
+}  // namespace syn

@@ -1,0 +1,598 @@
+// synthesis_amd — host side of the engine and the C ABI (include/synthesis_amd.h).
+//
+// Host role (what the reference's Rust driver does around the hot path, synthesis/src/alpha_zero.rs:181-209):
+// own the device node pool and the weight image, turn the plain-C configs into kernel parameters, launch ONE fused
+// kernel per call and hand results back. No torch, no CPU fallback: every entry point either runs the HIP kernels on
+// the handle's GPU or returns an error code.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/synthesis_amd.h"
+#include "engine_kernels.cuh"
+
+using namespace syn;
+
+static_assert(sizeof(DevSearchResult) == sizeof(syn_search_result), "search result layout must match the C ABI");
+static_assert(sizeof(syn_counters) == sizeof(unsigned long long) * CTR_COUNT, "counter layout must match the C ABI");
+
+static thread_local std::string g_create_error;
+
+struct syn_engine {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int slots = 0;
+    int max_explores = 0;
+    uint32_t cap = 0;
+    float4* d_stat = nullptr;
+    uint4* d_edge = nullptr;
+    float* d_wimg = nullptr;
+    bool has_weights = false;
+    int* d_job_next = nullptr;
+    unsigned long long* d_counters = nullptr;
+    // self-play output buffers (device), grown on demand
+    int out_games = 0;
+    int* d_plies = nullptr;
+    unsigned long long* d_states = nullptr;
+    float* d_pis = nullptr;
+    float* d_vs = nullptr;
+    unsigned char* d_actions = nullptr;
+    uint32_t* d_root_nodes = nullptr;
+    unsigned char* d_final = nullptr;
+    // scratch for host-pointer entry points
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    std::string err;
+    float last_kernel_ms = 0.0f;
+    int last_launches = 0;
+};
+
+static int fail(syn_engine* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(h, SYN_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static int ensure_scratch(syn_engine* h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return SYN_OK;
+    if (h->d_scratch) HIP_TRY(h, hipFree(h->d_scratch));
+    h->d_scratch = nullptr;
+    h->scratch_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(h, hipMalloc(&h->d_scratch, want));
+    h->scratch_bytes = want;
+    return SYN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight image
+// blob order: l_k.weight[O][I] then l_k.bias[O] for k = 1..5 (study-connect4/src/policies.rs:20-24)
+static void build_weight_image(const float* blob, std::vector<float>& img) {
+    img.assign(MlpGeom::IMG_FLOATS, 0.0f);
+    size_t off = 0;
+    for (int l = 0; l < MlpGeom::NL; l++) {
+        const int K = MlpGeom::K[l], O = MlpGeom::O[l], S4 = MlpGeom::S4[l], NOB = MlpGeom::NOB[l];
+        const float* W = blob + off;
+        const float* b = W + (size_t)K * O;
+        off += (size_t)K * O + O;
+        for (int s4 = 0; s4 < S4; s4++)
+            for (int ob = 0; ob < NOB; ob++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int r = 0; r < 4; r++) {
+                        int i = lane & 15, q = lane >> 4;
+                        int unit = mlp_unit_of_row(l, ob, i);
+                        int k = 16 * s4 + 4 * r + q;
+                        float v = (unit < O && k < K) ? W[(size_t)unit * K + k] : 0.0f;
+                        img[MlpGeom::W_OFF[l] + ((s4 * NOB + ob) * 64 + lane) * 4 + r] = v;
+                    }
+        for (int ob = 0; ob < NOB; ob++)
+            for (int q = 0; q < 4; q++)
+                for (int r = 0; r < 4; r++) {
+                    int unit = mlp_unit_of_row(l, ob, 4 * q + r);
+                    img[MlpGeom::W_FLOATS + MlpGeom::B_OFF[l] + (ob * 4 + q) * 4 + r] = unit < O ? b[unit] : 0.0f;
+                }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ config checks
+static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) {
+    if (!c) return fail(h, SYN_ERR_INVALID_ARGUMENT, "mcts config is NULL");
+    if (c->exploration != SYN_EXPLORATION_UCT && c->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration %d", c->exploration);
+    if (c->fpu != SYN_FPU_CONST && c->fpu != SYN_FPU_PARENT_Q)
+        return fail(h, SYN_ERR_UNSUPPORTED, "Fpu::Func is a host closure and cannot run on the device");
+    if (c->root_policy_noise == SYN_NOISE_DIRICHLET)
+        return fail(h, SYN_ERR_UNSUPPORTED, "PolicyNoise::Dirichlet is not implemented on the device yet");
+    if (c->root_policy_noise != SYN_NOISE_NONE)
+        return fail(h, SYN_ERR_UNSUPPORTED, "root policy noise is not implemented on the device yet");
+    d.exploration = c->exploration;
+    d.c = c->c;
+    d.solve = c->solve != 0;
+    d.correct_values = c->correct_values_on_solve != 0;
+    d.select_solved = c->select_solved_nodes != 0;
+    d.auto_extend = c->auto_extend != 0;
+    d.fpu = c->fpu;
+    d.fpu_value = c->fpu_value;
+    d.noise = c->root_policy_noise;
+    d.noise_weight = c->noise_weight;
+    return SYN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ launches
+template <int MODE, bool COUNT>
+static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs) {
+    // workgroup size: 16 trees per 256 threads; grow the block (not the grid) past one workgroup per CU, because
+    // the 123 KB weight image allows exactly one resident workgroup per CU.
+    int want_slots = h->slots;
+    if (jobs < want_slots) want_slots = ((jobs + 15) / 16) * 16;
+    int nt = 256;
+    while (nt < 1024 && want_slots / (nt / 16) > h->num_cus) nt *= 2;
+    int grid = (want_slots + nt / 16 - 1) / (nt / 16);
+    if (grid < 1) grid = 1;
+    hipError_t e;
+#define SYN_LAUNCH(NT)                                                                                            \
+    {                                                                                                             \
+        auto k = selfplay_kernel<MODE, COUNT, NT>;                                                                \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                (int)EngineLds<NT>::BYTES);                                                       \
+        if (e != hipSuccess) return e;                                                                            \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), EngineLds<NT>::BYTES, h->stream, P);                          \
+    }
+    if (nt == 256) SYN_LAUNCH(256)
+    else if (nt == 512) SYN_LAUNCH(512)
+    else SYN_LAUNCH(1024)
+#undef SYN_LAUNCH
+    return hipGetLastError();
+}
+
+extern "C" {
+
+void syn_default_rollout_config(syn_rollout_config* cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->num_explores = 800;
+    cfg->random_actions_until = 1;
+    cfg->sample_actions_until = 30;
+    cfg->stop_games_when_solved = 0;
+    cfg->value_target = SYN_VALUE_Q;
+    cfg->action = SYN_ACTION_NUM_VISITS;
+    cfg->mcts_cfg.exploration = SYN_EXPLORATION_POLYNOMIAL_UCT;
+    cfg->mcts_cfg.c = 3.0f;
+    cfg->mcts_cfg.solve = 1;
+    cfg->mcts_cfg.correct_values_on_solve = 1;
+    cfg->mcts_cfg.select_solved_nodes = 1;
+    cfg->mcts_cfg.auto_extend = 1;
+    cfg->mcts_cfg.fpu = SYN_FPU_CONST;
+    cfg->mcts_cfg.fpu_value = 1.0f;
+    cfg->mcts_cfg.root_policy_noise = SYN_NOISE_NONE;
+}
+
+const char* syn_last_error(const syn_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out) {
+    if (!cfg || !out) return fail(nullptr, SYN_ERR_INVALID_ARGUMENT, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->concurrent_games < 1 || cfg->max_explores < 1)
+        return fail(nullptr, SYN_ERR_INVALID_ARGUMENT, "concurrent_games and max_explores must be >= 1");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SYN_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
+    if (device < 0 || device >= ndev)
+        return fail(nullptr, SYN_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, ndev);
+    syn_engine* h = new (std::nothrow) syn_engine();
+    if (!h) return fail(nullptr, SYN_ERR_HIP, "out of host memory");
+    h->device = device;
+    auto bail = [&](const char* what, hipError_t e) {
+        int rc = fail(nullptr, SYN_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+        syn_engine_destroy(h);
+        return rc;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, SYN_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                      prop.gcnArchName);
+        syn_engine_destroy(h);
+        return rc;
+    }
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    h->slots = ((cfg->concurrent_games + 15) / 16) * 16;
+    h->max_explores = cfg->max_explores;
+    // nodes.len() <= 1 + 9*(explores+1), rounded up to keep slabs 16-byte-record aligned per 4 nodes
+    h->cap = (uint32_t)(1 + 9 * (cfg->max_explores + 1));
+    h->cap = (h->cap + 3u) & ~3u;
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    // the launch may round the slot count up to a whole workgroup (<= 64 trees)
+    size_t nodes = (size_t)(((h->slots + 63) / 64) * 64) * h->cap;
+    if ((e = hipMalloc(&h->d_stat, nodes * sizeof(float4))) != hipSuccess) return bail("hipMalloc(stat)", e);
+    if ((e = hipMalloc(&h->d_edge, nodes * sizeof(uint4))) != hipSuccess) return bail("hipMalloc(edge)", e);
+    if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
+    if ((e = hipMalloc(&h->d_job_next, 64)) != hipSuccess) return bail("hipMalloc(job)", e);
+    if ((e = hipMalloc(&h->d_counters, sizeof(DevCounters))) != hipSuccess) return bail("hipMalloc(counters)", e);
+    *out = h;
+    return SYN_OK;
+}
+
+int syn_engine_destroy(syn_engine* h) {
+    if (!h) return SYN_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    hipFree(h->d_stat);
+    hipFree(h->d_edge);
+    hipFree(h->d_wimg);
+    hipFree(h->d_job_next);
+    hipFree(h->d_counters);
+    hipFree(h->d_plies);
+    hipFree(h->d_states);
+    hipFree(h->d_pis);
+    hipFree(h->d_vs);
+    hipFree(h->d_actions);
+    hipFree(h->d_root_nodes);
+    hipFree(h->d_final);
+    hipFree(h->d_scratch);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return SYN_OK;
+}
+
+int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!blob) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob is NULL");
+    if (n_floats != (size_t)MlpGeom::NUM_PARAMS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4Net has %d parameters, got %zu", MlpGeom::NUM_PARAMS, n_floats);
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<float> img;
+    build_weight_image(blob, img);
+    HIP_TRY(h, hipMemcpyAsync(h->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->has_weights = true;
+    return SYN_OK;
+}
+
+int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint64_t* d_op, int n, float* d_logits,
+                                 float* d_value, int sync) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!d_my || !d_op || !d_logits || !d_value)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_policy_eval_batch_device");
+    if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    constexpr int NT = 512;  // two waves per SIMD: one wave's LDS reads / feature math overlap the other's MFMAs
+    const size_t lds = (size_t)MlpGeom::IMG_FLOATS * 4;
+    auto k = policy_eval_kernel<NT>;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int ntiles = (n + 15) / 16;
+    int grid = (ntiles + NT / 64 - 1) / (NT / 64);
+    if (grid > h->num_cus) grid = h->num_cus;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, h->stream, h->d_wimg,
+                       reinterpret_cast<const unsigned long long*>(d_my),
+                       reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->last_launches = 1;
+    if (sync) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    }
+    return SYN_OK;
+}
+
+int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits,
+                          float* value) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!my_bb || !op_bb || !logits || !value)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_policy_eval_batch");
+    if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nb = (size_t)n;
+    int rc = ensure_scratch(h, nb * (8 + 8 + 36 + 12) + 256);
+    if (rc != SYN_OK) return rc;
+    char* base = static_cast<char*>(h->d_scratch);
+    uint64_t* d_my = reinterpret_cast<uint64_t*>(base);
+    uint64_t* d_op = d_my + nb;
+    float* d_logits = reinterpret_cast<float*>(d_op + nb);
+    float* d_value = d_logits + nb * 9;
+    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    rc = syn_policy_eval_batch_device(h, d_my, d_op, n, d_logits, d_value, 0);
+    if (rc != SYN_OK) return rc;
+    HIP_TRY(h, hipMemcpyAsync(logits, d_logits, nb * 36, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(value, d_value, nb * 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    return SYN_OK;
+}
+
+int syn_features_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* out) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!my_bb || !op_bb || !out))) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nb = (size_t)n;
+    int rc = ensure_scratch(h, nb * (16 + 252) + 256);
+    if (rc != SYN_OK) return rc;
+    uint64_t* d_my = reinterpret_cast<uint64_t*>(h->d_scratch);
+    uint64_t* d_op = d_my + nb;
+    float* d_out = reinterpret_cast<float*>(d_op + nb);
+    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    size_t total = nb * 63;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(features_kernel, dim3(grid), dim3(256), 0, h->stream,
+                       reinterpret_cast<const unsigned long long*>(d_my),
+                       reinterpret_cast<const unsigned long long*>(d_op), n, d_out);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out, d_out, total * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_linear_forward(syn_engine* h, int I, int O, const float* W, const float* b, const float* x, int batch,
+                       float* y, int relu) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (I < 1 || O < 1 || batch < 0 || !W || !b || (batch > 0 && (!x || !y)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_linear_forward");
+    if (batch == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nW = (size_t)I * O, nx = (size_t)batch * I, ny = (size_t)batch * O;
+    int rc = ensure_scratch(h, (nW + O + nx + ny) * 4 + 256);
+    if (rc != SYN_OK) return rc;
+    float* dW = static_cast<float*>(h->d_scratch);
+    float* db = dW + nW;
+    float* dx = db + O;
+    float* dy = dx + nx;
+    HIP_TRY(h, hipMemcpyAsync(dW, W, nW * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(db, b, (size_t)O * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dx, x, nx * 4, hipMemcpyHostToDevice, h->stream));
+    int grid = (int)((ny + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(linear_kernel, dim3(grid), dim3(256), 0, h->stream, I, O, dW, db, dx, batch, dy, relu);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(y, dy, ny * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_conv2d_forward(syn_engine* h, int CIN, int COUT, int K, int RP, int CP, int S, int H_IN, int W_IN, int H_OUT,
+                       int W_OUT, const float* W, const float* b, const float* x, int batch, float* y, int relu) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (CIN < 1 || COUT < 1 || K < 1 || RP < 0 || CP < 0 || S < 1 || H_IN < 1 || W_IN < 1 || batch < 0 || !W || !b ||
+        (batch > 0 && (!x || !y)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_conv2d_forward");
+    // slimnn asserts these (conv.rs:50-51)
+    if (W_IN + 2 * CP < K || H_IN + 2 * RP < K || W_OUT != ((W_IN + 2 * CP - K) / S) + 1 ||
+        H_OUT != ((H_IN + 2 * RP - K) / S) + 1)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "output dims must be ((IN + 2*PAD - K) / STRIDE) + 1");
+    if (batch == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nW = (size_t)COUT * CIN * K * K, nx = (size_t)batch * CIN * H_IN * W_IN,
+           ny = (size_t)batch * COUT * H_OUT * W_OUT;
+    int rc = ensure_scratch(h, (nW + COUT + nx + ny) * 4 + 256);
+    if (rc != SYN_OK) return rc;
+    float* dW = static_cast<float*>(h->d_scratch);
+    float* db = dW + nW;
+    float* dx = db + COUT;
+    float* dy = dx + nx;
+    HIP_TRY(h, hipMemcpyAsync(dW, W, nW * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(db, b, (size_t)COUT * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(dx, x, nx * 4, hipMemcpyHostToDevice, h->stream));
+    int grid = (int)((ny + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(conv2d_kernel, dim3(grid), dim3(256), 0, h->stream, CIN, COUT, K, RP, CP, S, H_IN, W_IN, H_OUT,
+                       W_OUT, dW, db, dx, batch, dy, relu);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(y, dy, ny * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+static int common_params(syn_engine* h, EngineParams& P, int explores) {
+    if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+    if (explores < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "explores must be >= 0");
+    if (explores > h->max_explores)
+        return fail(h, SYN_ERR_CAPACITY, "explores %d exceeds the engine's max_explores %d", explores, h->max_explores);
+    std::memset(&P, 0, sizeof(P));
+    P.wimg = h->d_wimg;
+    P.stat = h->d_stat;
+    P.edge = h->d_edge;
+    P.cap = h->cap;
+    P.job_next = h->d_job_next;
+    P.counters = h->d_counters;
+    return SYN_OK;
+}
+
+int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
+                    int explores, int action_selection, syn_search_result* results) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!my_bb || !op_bb || !results)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_mcts_search");
+    if (action_selection != SYN_ACTION_Q && action_selection != SYN_ACTION_NUM_VISITS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection %d", action_selection);
+    EngineParams P;
+    int rc = common_params(h, P, explores);
+    if (rc != SYN_OK) return rc;
+    rc = convert_mcts(h, cfg, P.mcts);
+    if (rc != SYN_OK) return rc;
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nb = (size_t)n;
+    rc = ensure_scratch(h, nb * (16 + sizeof(DevSearchResult)) + 256);
+    if (rc != SYN_OK) return rc;
+    unsigned long long* d_my = static_cast<unsigned long long*>(h->d_scratch);
+    unsigned long long* d_op = d_my + nb;
+    DevSearchResult* d_res = reinterpret_cast<DevSearchResult*>(d_op + nb);
+    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    P.roll.num_explores = explores;
+    P.n_jobs = n;
+    P.in_my = d_my;
+    P.in_op = d_op;
+    P.results = d_res;
+    P.action_selection = action_selection;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    HIP_TRY(h, (launch_engine<MODE_SEARCH, false>(h, P, n)));
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(results, d_res, nb * sizeof(DevSearchResult), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
+    return SYN_OK;
+}
+
+static int ensure_outputs(syn_engine* h, int n_games) {
+    if (n_games <= h->out_games) return SYN_OK;
+    hipFree(h->d_plies); hipFree(h->d_states); hipFree(h->d_pis); hipFree(h->d_vs);
+    hipFree(h->d_actions); hipFree(h->d_root_nodes); hipFree(h->d_final);
+    h->d_plies = nullptr; h->d_states = nullptr; h->d_pis = nullptr; h->d_vs = nullptr;
+    h->d_actions = nullptr; h->d_root_nodes = nullptr; h->d_final = nullptr;
+    h->out_games = 0;
+    size_t g = (size_t)n_games, p = g * 63;
+    HIP_TRY(h, hipMalloc(&h->d_plies, g * 4));
+    HIP_TRY(h, hipMalloc(&h->d_states, p * 16));
+    HIP_TRY(h, hipMalloc(&h->d_pis, p * 36));
+    HIP_TRY(h, hipMalloc(&h->d_vs, p * 12));
+    HIP_TRY(h, hipMalloc(&h->d_actions, p));
+    HIP_TRY(h, hipMalloc(&h->d_root_nodes, p * 4));
+    HIP_TRY(h, hipMalloc(&h->d_final, g));
+    h->out_games = n_games;
+    return SYN_OK;
+}
+
+int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game,
+                     int n_games, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
+                     uint32_t* root_nodes, uint8_t* final_kind, syn_counters* counters) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!cfg) return fail(h, SYN_ERR_INVALID_ARGUMENT, "rollout config is NULL");
+    if (n_games < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "n_games must be >= 0");
+    if (cfg->value_target < SYN_VALUE_Z || cfg->value_target > SYN_VALUE_Q_TO_Z)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown value target %d", cfg->value_target);
+    if (cfg->action != SYN_ACTION_Q && cfg->action != SYN_ACTION_NUM_VISITS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection %d", cfg->action);
+    EngineParams P;
+    int rc = common_params(h, P, cfg->num_explores);
+    if (rc != SYN_OK) return rc;
+    rc = convert_mcts(h, &cfg->mcts_cfg, P.mcts);
+    if (rc != SYN_OK) return rc;
+    if (counters) std::memset(counters, 0, sizeof(*counters));
+    if (n_games == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    rc = ensure_outputs(h, n_games);
+    if (rc != SYN_OK) return rc;
+    P.roll.num_explores = cfg->num_explores;
+    P.roll.random_until = cfg->random_actions_until;
+    P.roll.sample_until = cfg->sample_actions_until;
+    P.roll.stop_when_solved = cfg->stop_games_when_solved != 0;
+    P.roll.value_target = cfg->value_target;
+    P.roll.vt_p = cfg->value_target_p;
+    P.roll.vt_from = cfg->value_target_from;
+    P.roll.vt_to = cfg->value_target_to;
+    P.roll.action = cfg->action;
+    P.n_jobs = n_games;
+    P.base_seed = base_seed;
+    P.first_game = first_game;
+    P.plies = h->d_plies;
+    P.states_bb = h->d_states;
+    P.pis = h->d_pis;
+    P.vs = h->d_vs;
+    P.actions = h->d_actions;
+    P.root_nodes = h->d_root_nodes;
+    P.final_kind = h->d_final;
+    HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (counters) HIP_TRY(h, (launch_engine<MODE_SELFPLAY, true>(h, P, n_games)));
+    else HIP_TRY(h, (launch_engine<MODE_SELFPLAY, false>(h, P, n_games)));
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    size_t g = (size_t)n_games, p = g * 63;
+    if (plies) HIP_TRY(h, hipMemcpyAsync(plies, h->d_plies, g * 4, hipMemcpyDeviceToHost, h->stream));
+    if (states_bb) HIP_TRY(h, hipMemcpyAsync(states_bb, h->d_states, p * 16, hipMemcpyDeviceToHost, h->stream));
+    if (pis) HIP_TRY(h, hipMemcpyAsync(pis, h->d_pis, p * 36, hipMemcpyDeviceToHost, h->stream));
+    if (vs) HIP_TRY(h, hipMemcpyAsync(vs, h->d_vs, p * 12, hipMemcpyDeviceToHost, h->stream));
+    if (actions) HIP_TRY(h, hipMemcpyAsync(actions, h->d_actions, p, hipMemcpyDeviceToHost, h->stream));
+    if (root_nodes) HIP_TRY(h, hipMemcpyAsync(root_nodes, h->d_root_nodes, p * 4, hipMemcpyDeviceToHost, h->stream));
+    if (final_kind) HIP_TRY(h, hipMemcpyAsync(final_kind, h->d_final, g, hipMemcpyDeviceToHost, h->stream));
+    if (counters)
+        HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
+    return SYN_OK;
+}
+
+int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (kernel_ms) *kernel_ms = h->last_kernel_ms;
+    if (n_launches) *n_launches = h->last_launches;
+    return SYN_OK;
+}
+
+int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && !out)) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_scratch(h, (size_t)n * 4 + 256);
+    if (rc != SYN_OK) return rc;
+    uint32_t* d = static_cast<uint32_t*>(h->d_scratch);
+    hipLaunchKernelGGL(debug_rng_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (unsigned long long)seed, n, d);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
+                   float* out_sqrt_a) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!a || !b || !out_exp_a || !out_div || !out_sqrt_a)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nb = (size_t)n;
+    int rc = ensure_scratch(h, nb * 20 + 256);
+    if (rc != SYN_OK) return rc;
+    float* da = static_cast<float*>(h->d_scratch);
+    float* db = da + nb;
+    float* de = db + nb;
+    float* dd = de + nb;
+    float* ds = dd + nb;
+    HIP_TRY(h, hipMemcpyAsync(da, a, nb * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(db, b, nb * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, da, db, n, de, dd, ds);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_exp_a, de, nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_div, dd, nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_sqrt_a, ds, nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+}  // extern "C"

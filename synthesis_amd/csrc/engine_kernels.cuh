@@ -1,0 +1,566 @@
+// synthesis_amd — the fused self-play / search kernel and the stand-alone batched kernels.
+//
+// selfplay_kernel: ONE launch plays whole games. A workgroup owns TPW = blockDim/16 trees (one per DPP row) for its
+// entire life and keeps the 123 KB weight image in LDS; per explore it runs
+//     phase A  (all rows)   select + expand                       [node pool: HBM/L2, latency-bound gathers]
+//     phase B  (tile waves) Connect4Net on 16-position tiles      [f32 MFMA, weights from LDS]
+//     phase C  (all rows)   legal softmax -> priors, backprop, and — when a search finishes — the whole move step
+//                           of run_game (targets, action sampling, game step, next root / next game)
+// separated by two workgroup barriers. Trees never communicate across workgroups, so there is no grid barrier, no
+// inter-workgroup visibility protocol and no host round trip until every game of the call has finished. Finished games
+// pull the next game index from one global counter (a result depends only on the game index, never on the slot).
+#pragma once
+#include "mcts.cuh"
+#include "mlp.cuh"
+
+namespace syn {
+
+enum { MODE_SELFPLAY = 0, MODE_SEARCH = 1 };
+
+// mirrors syn_search_result (include/synthesis_amd.h)
+struct DevSearchResult {
+    float child_N[9];
+    float child_W[9][3];
+    float child_P[9];
+    int child_sol[9][3];
+    float root_N;
+    float root_W[3];
+    int root_sol[3];
+    uint32_t num_nodes;
+    int best_action;
+    float target_pi[9];
+    float target_q[3];
+};
+
+struct EngineParams {
+    DevMctsCfg mcts;
+    DevRolloutCfg roll;
+    const float* wimg;       // weight image, fragment order (MlpGeom::IMG_FLOATS floats)
+    float4* stat;            // node pool
+    uint4* edge;
+    uint32_t cap;            // nodes per tree slab
+    int n_jobs;              // games (self-play) or roots (search)
+    int* job_next;           // global job counter
+    unsigned long long* counters;  // DevCounters (may be null)
+    // self-play
+    unsigned long long base_seed;  // game g uses StdRng::seed_from_u64(base_seed + first_game + g)
+    unsigned long long first_game;
+    int* plies;
+    unsigned long long* states_bb;
+    float* pis;
+    float* vs;
+    unsigned char* actions;
+    uint32_t* root_nodes;
+    unsigned char* final_kind;
+    // search
+    const unsigned long long* in_my;
+    const unsigned long long* in_op;
+    DevSearchResult* results;
+    int action_selection;
+};
+
+// ---------------------------------------------------------------------------------------------- end-of-search helpers
+struct RootView {      // lane c = column c of the root
+    bool is_child;     // column c is a child of the root
+    float N, W0, W1, W2, P;
+    uint32_t meta;
+    uint32_t nc;
+    float rootN, rW0, rW1, rW2;
+    uint32_t root_meta;
+    uint32_t lmask;
+};
+
+SYN_DEV RootView load_root_view(const TreeCtx& T, int gl) {
+    RootView R;
+    uint4 e = T.edge[0];
+    float4 s = T.stat[0];
+    R.root_meta = e.y;
+    R.nc = meta_nc(e.y);
+    R.rootN = s.x; R.rW0 = s.y; R.rW1 = s.z; R.rW2 = s.w;
+    uint64_t occ = T.root_my | T.root_op;
+    bool legal = gl < 9 && c4::col_height(occ, gl < 9 ? gl : 0) < c4::HEIGHT;
+    R.lmask = row_ballot(legal);
+    // the root's children are its legal columns in ascending order (expansion order)
+    uint32_t idx = (uint32_t)__popc(R.lmask & ((1u << gl) - 1u));
+    R.is_child = legal && idx < R.nc;
+    uint32_t cid = e.x + (R.is_child ? idx : 0u);
+    float4 cs = T.stat[cid];
+    uint4 ce = T.edge[cid];
+    R.N = cs.x; R.W0 = cs.y; R.W1 = cs.z; R.W2 = cs.w;
+    R.P = bits_f32(ce.z);
+    R.meta = ce.y;
+    return R;
+}
+
+// MCTS::target_policy (mcts.rs:174-211): returns pi for column gl (0 for non-children)
+SYN_DEV float target_policy(const RootView& R, int gl) {
+    float v;
+    if (R.rootN == 1.0f) {
+        bool root_win = meta_some(R.root_meta) && meta_kind(R.root_meta) == 2u;
+        if (root_win) v = (meta_some(R.meta) && meta_kind(R.meta) == 0u) ? 1.0f : 0.0f;
+        else v = 1.0f;
+    } else {
+        v = R.N;
+    }
+    v = R.is_child ? v : 0.0f;
+    float total = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        float vc = row_bcast_f32(v, c);
+        if ((R.lmask >> c) & 1u) total += vc;
+    }
+    return v / total;
+}
+
+// MCTS::target_q (mcts.rs:213-225)
+SYN_DEV void target_q(const RootView& R, float& q0, float& q1, float& q2) {
+    if (meta_some(R.root_meta)) {
+        uint32_t k = meta_kind(R.root_meta);
+        q0 = k == 0u ? 1.0f : 0.0f;
+        q1 = k == 1u ? 1.0f : 0.0f;
+        q2 = k == 2u ? 1.0f : 0.0f;
+    } else {
+        q0 = R.rW0 / R.rootN;
+        q1 = R.rW1 / R.rootN;
+        q2 = R.rW2 / R.rootN;
+    }
+}
+
+// MCTS::best_action (mcts.rs:273-294): sequential scan in child order with Option<(f32,f32)> `>` semantics
+SYN_DEV int best_action(const RootView& R, int action_selection) {
+    float k0, k1;
+    if (meta_some(R.meta)) {
+        uint32_t kind = meta_kind(R.meta);
+        float t = (float)meta_turns(R.meta);
+        if (kind == 2u) { k0 = 0.0f; k1 = t; }
+        else if (kind == 1u) { k0 = 2.0f; k1 = -t; }
+        else { k0 = 3.0f; k1 = -t; }
+    } else {
+        k0 = 1.0f;
+        k1 = action_selection == 0 ? -((R.W2 - R.W0) / R.N) : R.N;
+    }
+    int best = -1;
+    float b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        float c0 = row_bcast_f32(k0, c), c1 = row_bcast_f32(k1, c);
+        bool child = row_bcast_u32(R.is_child ? 1u : 0u, c) != 0u;
+        bool gt = best < 0 || (c0 > b0) || (c0 == b0 && c1 > b1);
+        if (child && gt) { best = c; b0 = c0; b1 = c1; }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------------- the fused kernel
+struct GameCtx {          // self-play state of the game a row is playing
+    int job;              // game / root index, -1 = idle
+    int turn;             // plies played so far
+    uint32_t rng_index;   // StdRng words consumed by this game
+};
+
+template <int MODE>
+SYN_DEV void start_job(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl) {
+    int j = 0;
+    if (gl == 0) j = atomicAdd(P.job_next, 1);
+    j = (int)row_bcast_u32((uint32_t)j, 0);
+    G.job = j < P.n_jobs ? j : -1;
+    G.turn = 0;
+    G.rng_index = 0;
+    T.next_node = 0;
+    T.iter = 0;
+    T.root_solved = false;
+    if (MODE == MODE_SELFPLAY) {
+        T.root_my = 0;  // G::new() (connect4.rs:181-188)
+        T.root_op = 0;
+    } else if (G.job >= 0) {
+        T.root_my = P.in_my[G.job];
+        T.root_op = P.in_op[G.job];
+    }
+}
+
+// run_game's per-move tail (alpha_zero.rs:243-264) + game end (fill_state_info / store_rewards, 296-338)
+template <bool COUNT>
+SYN_DEV void selfplay_move_step(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl, uint32_t* ctr) {
+    const DevRolloutCfg& rc = P.roll;
+    RootView R = load_root_view(T, gl);
+    float pi = target_policy(R, gl);
+    float q0, q1, q2;
+    target_q(R, q0, q1, q2);
+    const size_t pos = (size_t)G.job * 63 + (size_t)G.turn;
+    // buffer.add(&game, &search_policy, ..) + StateInfo::q (alpha_zero.rs:248-250)
+    if (gl == 0) {
+        P.states_bb[pos * 2 + 0] = T.root_my;
+        P.states_bb[pos * 2 + 1] = T.root_op;
+        P.root_nodes[pos] = T.next_node;
+    }
+    if (gl < 9) P.pis[pos * 9 + gl] = pi;
+    if (gl < 3) P.vs[pos * 3 + gl] = gl == 0 ? q0 : (gl == 1 ? q1 : q2);
+
+    // sample_action (alpha_zero.rs:270-294)
+    int best = best_action(R, rc.action);
+    uint32_t best_meta = row_bcast_u32(R.meta, best);
+    int action;
+    if (G.turn < rc.random_until) {
+        StdRng rng;
+        rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)G.job);
+        rng.index = G.rng_index;
+        uint32_t n = (uint32_t)__popc(R.lmask);
+        uint32_t r = rng.gen_range_u8(n);
+        G.rng_index = rng.index;
+        uint32_t m = R.lmask;
+        for (uint32_t i = 0; i < r; i++) m &= m - 1u;  // iter_actions().nth(r)
+        action = __ffs((int)m) - 1;
+    } else if (G.turn < rc.sample_until && (!meta_some(best_meta) || !rc.stop_when_solved)) {
+        // WeightedIndex::new(search_policy).sample(rng): 9 weights by column
+        StdRng rng;
+        rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)G.job);
+        rng.index = G.rng_index;
+        float cum[8];
+        float total = row_bcast_f32(pi, 0);
+#pragma unroll
+        for (int c = 1; c < 9; c++) {
+            cum[c - 1] = total;
+            total += row_bcast_f32(pi, c);
+        }
+        float chosen = rng.uniform_0_to(total);
+        G.rng_index = rng.index;
+        int idx = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) idx = cum[c] <= chosen ? c + 1 : idx;
+        action = idx;
+    } else {
+        action = best;
+    }
+    if (gl == 0) P.actions[pos] = (unsigned char)action;
+
+    // solution = mcts.solution(&action) (alpha_zero.rs:254, mcts.rs:296-306)
+    bool a_child = row_bcast_u32(R.is_child ? 1u : 0u, action) != 0u;
+    uint32_t a_meta = row_bcast_u32(R.meta, action);
+    bool sol_some = a_child && meta_some(a_meta);
+    uint32_t sol_kind = meta_kind(a_meta);
+
+    // game.step(&action) (connect4.rs:221-233)
+    uint64_t occ = T.root_my | T.root_op;
+    int h = c4::col_height(occ, action);
+    uint64_t bit = 1ull << (h + 7 * action);
+    uint64_t nmy = T.root_op, nop = T.root_my | bit;
+    bool w = c4::won(nop);
+    bool full = (occ | bit) == c4::FULL;
+    if (w || full) {
+        sol_some = true;
+        sol_kind = w ? 0u : 1u;  // reward(player to move).into(): the mover won -> Lose(0); else Draw(0)
+    } else if (!rc.stop_when_solved) {
+        sol_some = false;
+    }
+    G.turn += 1;
+    if (COUNT) ctr[CTR_MOVES]++;
+
+    if (!sol_some) {
+        // next move: fresh tree on the new position (alpha_zero.rs:241-242)
+        T.root_my = nmy;
+        T.root_op = nop;
+        T.next_node = 0;
+        T.iter = 0;
+        T.root_solved = false;
+        return;
+    }
+
+    // ---- game over: fill_state_info(solution.reversed()) + store_rewards
+    const int n = G.turn;
+    const uint32_t last_kind = sol_kind == 1u ? 1u : 2u - sol_kind;  // kind of solution.reversed()
+    for (int i = gl; i < n; i += 16) {
+        // outcome seen from position i: reversed once per step back from the last position
+        bool flip = ((n - 1 - i) & 1) != 0;
+        uint32_t zk = (flip && last_kind != 1u) ? 2u - last_kind : last_kind;
+        float z0 = zk == 0u ? 1.0f : 0.0f, z1 = zk == 1u ? 1.0f : 0.0f, z2 = zk == 2u ? 1.0f : 0.0f;
+        float t = (float)(i + 1) / (float)n;
+        float* v = P.vs + ((size_t)G.job * 63 + (size_t)i) * 3;
+        float a0 = v[0], a1 = v[1], a2 = v[2];
+        float o0, o1, o2;
+        if (rc.value_target == 1) { o0 = a0; o1 = a1; o2 = a2; }
+        else if (rc.value_target == 0) { o0 = z0; o1 = z1; o2 = z2; }
+        else if (rc.value_target == 2) {
+            float p = rc.vt_p;
+            o0 = a0 * p + z0 * (1.0f - p);
+            o1 = a1 * p + z1 * (1.0f - p);
+            o2 = a2 * p + z2 * (1.0f - p);
+        } else {
+            float p = (1.0f - t) * rc.vt_from + t * rc.vt_to;
+            o0 = a0 * (1.0f - p) + z0 * p;
+            o1 = a1 * (1.0f - p) + z1 * p;
+            o2 = a2 * (1.0f - p) + z2 * p;
+        }
+        v[0] = o0; v[1] = o1; v[2] = o2;
+    }
+    if (gl == 0) {
+        P.plies[G.job] = n;
+        P.final_kind[G.job] = (unsigned char)sol_kind;
+    }
+    if (COUNT) ctr[CTR_GAMES]++;
+    start_job<MODE_SELFPLAY>(P, T, G, gl);
+}
+
+SYN_DEV void search_finish(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl) {
+    RootView R = load_root_view(T, gl);
+    float pi = target_policy(R, gl);
+    float q0, q1, q2;
+    target_q(R, q0, q1, q2);
+    int best = best_action(R, P.action_selection);
+    DevSearchResult* out = P.results + G.job;
+    if (gl < 9) {
+        bool ch = R.is_child;
+        out->child_N[gl] = ch ? R.N : 0.0f;
+        out->child_W[gl][0] = ch ? R.W0 : 0.0f;
+        out->child_W[gl][1] = ch ? R.W1 : 0.0f;
+        out->child_W[gl][2] = ch ? R.W2 : 0.0f;
+        out->child_P[gl] = ch ? R.P : 0.0f;
+        bool some = ch && meta_some(R.meta);
+        out->child_sol[gl][0] = some ? 1 : 0;
+        out->child_sol[gl][1] = some ? (int)meta_kind(R.meta) : 0;
+        out->child_sol[gl][2] = some ? (int)meta_turns(R.meta) : 0;
+        out->target_pi[gl] = pi;
+    }
+    if (gl == 0) {
+        out->root_N = R.rootN;
+        out->root_W[0] = R.rW0; out->root_W[1] = R.rW1; out->root_W[2] = R.rW2;
+        bool some = meta_some(R.root_meta);
+        out->root_sol[0] = some ? 1 : 0;
+        out->root_sol[1] = some ? (int)meta_kind(R.root_meta) : 0;
+        out->root_sol[2] = some ? (int)meta_turns(R.root_meta) : 0;
+        out->num_nodes = T.next_node;
+        out->best_action = best;
+        out->target_q[0] = q0; out->target_q[1] = q1; out->target_q[2] = q2;
+    }
+    start_job<MODE_SEARCH>(P, T, G, gl);
+}
+
+// LDS: [weight image 123,264 B][leaf boards: TPW x 16 B][net outputs: TPW x 64 B][tile flags 2 x 16 x 4 B]
+template <int NT>
+struct EngineLds {
+    static constexpr int TPW = NT / 16;
+    static constexpr int NTILES = TPW / 16;
+    static constexpr size_t BYTES = (size_t)MlpGeom::IMG_FLOATS * 4 + (size_t)TPW * 16 + (size_t)TPW * 64 + 128;
+};
+
+template <int MODE, bool COUNT, int NT>
+__global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TPW = NT / 16;
+    constexpr int NTILES = TPW / 16;
+    float* wimg = smem;
+    float* bimg = smem + MlpGeom::W_FLOATS;
+    uint4* leafbuf = reinterpret_cast<uint4*>(smem + MlpGeom::IMG_FLOATS);
+    float* outbuf = reinterpret_cast<float*>(leafbuf + TPW);
+    int* tileflag = reinterpret_cast<int*>(outbuf + TPW * 16);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int gl = tid & 15;
+    const int t = tid >> 4;  // tree (row) index inside the workgroup
+
+    stage_weight_image(smem, P.wimg, tid, NT);
+    if (tid < 32) tileflag[tid] = 0;
+
+    uint32_t ctr[COUNT ? CTR_COUNT : 1];
+#pragma unroll
+    for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) ctr[i] = 0;
+
+    TreeCtx T;
+    const size_t slot = (size_t)blockIdx.x * TPW + (size_t)t;
+    T.stat = P.stat + slot * P.cap;
+    T.edge = P.edge + slot * P.cap;
+    GameCtx G;
+    start_job<MODE>(P, T, G, gl);
+    __syncthreads();
+
+    const int n_explores = P.roll.num_explores;
+    int it = 0;
+    for (;;) {
+        const bool active = G.job >= 0;
+        ExploreCtx X = {};
+        if (active) {
+            tree_select_expand<COUNT>(P.mcts, T, X, gl, ctr);
+            if (X.needs_eval) {
+                if (gl == 0) {
+                    leafbuf[t] = make_uint4((uint32_t)X.leaf_my, (uint32_t)(X.leaf_my >> 32), (uint32_t)X.leaf_op,
+                                            (uint32_t)(X.leaf_op >> 32));
+                    tileflag[(it & 1) * 16 + (t >> 4)] = 1;
+                }
+                if (COUNT) ctr[CTR_POLICY_EVALS]++;
+            }
+        }
+        if (!__syncthreads_or(active ? 1 : 0)) break;  // barrier 1: leaf boards visible; exit when every row is idle
+
+        // ---- phase B: one wave per 16-position tile
+        if (wave < NTILES) {
+            if (tileflag[(it & 1) * 16 + wave]) {
+                const int j = lane & 15, q = lane >> 4;
+                uint4 b = leafbuf[wave * 16 + j];
+                uint64_t my = (uint64_t)b.x | ((uint64_t)b.y << 32), op = (uint64_t)b.z | ((uint64_t)b.w << 32);
+                f32x4 o = mlp_tile16(wimg, bimg, lane, my, op);
+                if (q == 2) {
+                    float v0 = o[1], v1 = o[2], v2 = o[3];
+                    value_softmax(v0, v1, v2);
+                    o[1] = v0; o[2] = v1; o[3] = v2;
+                }
+                if (q < 3) *reinterpret_cast<f32x4*>(outbuf + (wave * 16 + j) * 16 + q * 4) = o;
+            }
+            if (lane == 0) tileflag[((it + 1) & 1) * 16 + wave] = 0;
+        }
+        __syncthreads();
+
+        // ---- phase C
+        if (active) {
+            float d0 = X.p0, d1 = X.p1, d2 = X.p2;
+            if (X.needs_eval) {
+                const float* o = outbuf + t * 16;
+                float logit = o[gl < 9 ? gl : 0];
+                tree_write_priors(T, X, gl, logit);
+                // one 16-byte LDS read (also keeps these loads from being merged with the X.p* loads above into a
+                // pointer phi, which would pin X in scratch)
+                f32x4 ov = *reinterpret_cast<const f32x4*>(o + 8);
+                d0 = ov[1];
+                d1 = ov[2];
+                d2 = ov[3];
+            }
+            tree_backprop<COUNT>(P.mcts, T, X, gl, d0, d1, d2, X.solved, ctr);
+            T.iter += 1;
+            // explore_n (mcts.rs:139-147): the root visit, then up to n explores unless the root is solved
+            if (T.iter > n_explores || T.root_solved) {
+                if (MODE == MODE_SELFPLAY) selfplay_move_step<COUNT>(P, T, G, gl, ctr);
+                else search_finish(P, T, G, gl);
+            }
+        }
+        it++;
+    }
+
+    if (COUNT) {
+        if (P.counters && gl == 0) {
+#pragma unroll
+            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++)
+                if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stand-alone kernels
+// Batched Policy::eval (policies.rs:47-59): n positions -> logits[n][9], value[n][3]. Each wave walks 16-position
+// tiles grid-stride with the weight image resident in LDS.
+template <int NT>
+__global__ __launch_bounds__(NT) void policy_eval_kernel(const float* __restrict__ g_wimg,
+                                                         const unsigned long long* __restrict__ my_bb,
+                                                         const unsigned long long* __restrict__ op_bb, int n,
+                                                         float* __restrict__ logits, float* __restrict__ value) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    stage_weight_image(smem, g_wimg, tid, NT);
+    __syncthreads();
+    const float* wimg = smem;
+    const float* bimg = smem + MlpGeom::W_FLOATS;
+    const int ntiles = (n + 15) >> 4;
+    const int j = lane & 15, q = lane >> 4;
+    for (int tile = blockIdx.x * (NT / 64) + wave; tile < ntiles; tile += gridDim.x * (NT / 64)) {
+        // the weight fragments do not depend on the tile: make the LDS base opaque per iteration so their ~500 reads
+        // stay next to the MFMAs that consume them instead of being hoisted out of the loop into spilled registers
+        asm volatile("" : "+v"(wimg), "+v"(bimg));
+        int pos = tile * 16 + j;
+        bool valid = pos < n;
+        uint64_t my = valid ? my_bb[pos] : 0ull, op = valid ? op_bb[pos] : 0ull;
+        f32x4 o = mlp_tile16(wimg, bimg, lane, my, op);
+        if (valid) {
+            if (q < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) logits[(size_t)pos * 9 + q * 4 + r] = o[r];
+            } else if (q == 2) {
+                logits[(size_t)pos * 9 + 8] = o[0];
+                float v0 = o[1], v1 = o[2], v2 = o[3];
+                value_softmax(v0, v1, v2);
+                value[(size_t)pos * 3 + 0] = v0;
+                value[(size_t)pos * 3 + 1] = v1;
+                value[(size_t)pos * 3 + 2] = v2;
+            }
+        }
+    }
+}
+
+// Game::features (connect4.rs:235-258): out[n][63]
+__global__ void features_kernel(const unsigned long long* __restrict__ my_bb,
+                                const unsigned long long* __restrict__ op_bb, int n, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n * 63;
+    for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t pos = i / 63;
+        int f = (int)(i - pos * 63);
+        uint64_t my = my_bb[pos], op = op_bb[pos];
+        out[i] = c4::feature(my, op, c4::next_free_cells(my | op), f);
+    }
+}
+
+// slimnn::Linear::forward (linear.rs:17-25): separate multiply and add, ascending input index; one thread per output
+__global__ void linear_kernel(int I, int O, const float* __restrict__ W, const float* __restrict__ b,
+                              const float* __restrict__ x, int batch, float* __restrict__ y, int relu) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)batch * O;
+    for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t nb = i / O;
+        int o = (int)(i - nb * O);
+        float acc = b[o];
+        const float* xr = x + nb * I;
+        const float* wr = W + (size_t)o * I;
+        for (int k = 0; k < I; k++) acc += xr[k] * wr[k];
+        y[i] = relu ? __builtin_fmaxf(acc, 0.0f) : acc;
+    }
+}
+
+// slimnn::Conv2d::forward (conv.rs:45-85): accumulation order ci -> k1 -> k2 per output element
+__global__ void conv2d_kernel(int CIN, int COUT, int K, int RP, int CP, int S, int H_IN, int W_IN, int H_OUT,
+                              int W_OUT, const float* __restrict__ W, const float* __restrict__ b,
+                              const float* __restrict__ x, int batch, float* __restrict__ y, int relu) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t per = (size_t)COUT * H_OUT * W_OUT;
+    size_t total = (size_t)batch * per;
+    for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t nb = i / per;
+        size_t rem = i - nb * per;
+        int co = (int)(rem / ((size_t)H_OUT * W_OUT));
+        int rr = (int)(rem - (size_t)co * H_OUT * W_OUT);
+        int r = rr / W_OUT, c = rr - r * W_OUT;
+        float acc = b[co];
+        const float* xb = x + nb * (size_t)CIN * H_IN * W_IN;
+        for (int ci = 0; ci < CIN; ci++)
+            for (int k1 = 0; k1 < K; k1++) {
+                int in_row = r * S + k1;
+                if (RP <= in_row && in_row < H_IN + RP)
+                    for (int k2 = 0; k2 < K; k2++) {
+                        int in_col = c * S + k2;
+                        if (CP <= in_col && in_col < W_IN + CP) {
+                            float w = W[(((size_t)co * CIN + ci) * K + k1) * K + k2];
+                            float v = xb[((size_t)ci * H_IN + (in_row - RP)) * W_IN + (in_col - CP)];
+                            acc += w * v;
+                        }
+                    }
+            }
+        y[i] = relu ? __builtin_fmaxf(acc, 0.0f) : acc;
+    }
+}
+
+// parity probes for the device primitives
+__global__ void debug_rng_kernel(unsigned long long seed, int n, uint32_t* out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        StdRng r;
+        r.seed_from_u64(seed);
+        out[i] = r.word((uint32_t)i);
+    }
+}
+__global__ void debug_math_kernel(const float* a, const float* b, int n, float* e, float* d, float* s) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        e[i] = det_expf(a[i]);
+        d[i] = a[i] / b[i];
+        s[i] = sqrtf(a[i]);
+    }
+}
+
+}  // namespace syn

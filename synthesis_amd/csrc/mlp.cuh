@@ -1,0 +1,136 @@
+// synthesis_amd — Connect4Net leaf evaluation on the f32 matrix cores.
+//
+// Replaces study-connect4/src/policies.rs:28-59 (forward + eval): features -> 63->128->96->64->48->12 MLP (ReLU) ->
+// 9 raw policy logits + softmax over 3 outcome logits, for a tile of 16 positions per wave.
+//
+// MI355X mapping (v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[(l>>4)*4+r][l&15]):
+//   * A = weights, B = activations, D[unit][position].  The whole network for one 16-position tile runs in ONE wave's
+//     registers: the D registers of layer L (after ReLU) ARE the B operands of layer L+1, no LDS round trip and no
+//     cross-lane movement.  That works because the weight image is built so that A-row i of output block ob holds
+//     unit 16*ob + 4*(i&3) + (i>>2): D register r of block ob on lane (j,q) is then unit 16*ob + 4*r + q, exactly the
+//     k = 4*s + q element that step s = 4*ob + r of the next layer consumes.
+//   * f32-input MFMA is a k-ordered fused-multiply-add chain (one rounding per term, MI355X guide §3), so every output
+//     equals  fma(x[K-1],w[K-1], ... fma(x[1],w[1], fma(x[0],w[0], bias)))  bit for bit — the oracle's ACC_FMA mode.
+//   * The 30,144 weights + 348 biases live in LDS for the lifetime of the workgroup in "fragment order": one
+//     ds_read_b128 per lane fetches the A operands of 4 consecutive k-steps, conflict-free (lane-linear 16 B).
+#pragma once
+#include "device_common.cuh"
+
+namespace syn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MlpGeom {
+    static constexpr int NL = 5;
+    static constexpr int K[NL] = {63, 128, 96, 64, 48};      // inputs per layer
+    static constexpr int O[NL] = {128, 96, 64, 48, 12};      // outputs per layer
+    static constexpr int S4[NL] = {4, 8, 6, 4, 3};           // groups of 4 k-steps (k padded to 16*S4)
+    static constexpr int NOB[NL] = {8, 6, 4, 3, 1};          // 16-unit output blocks (O padded to 16*NOB)
+    // float offsets of each layer's fragment image: [s4][ob][lane 0..63][r 0..3]
+    static constexpr int W_OFF[NL + 1] = {0, 8192, 20480, 26624, 29696, 30464};
+    // bias image: [layer][ob][q 0..3][r 0..3]
+    static constexpr int B_OFF[NL + 1] = {0, 128, 224, 288, 336, 352};
+    static constexpr int W_FLOATS = 30464;
+    static constexpr int B_FLOATS = 352;
+    static constexpr int IMG_FLOATS = W_FLOATS + B_FLOATS;   // 30,816 floats = 123,264 B of LDS
+    static constexpr int NUM_PARAMS = 30492;
+};
+
+// Which network unit sits on A-row i of output block ob (see header comment). Last layer: natural order.
+__host__ __device__ inline int mlp_unit_of_row(int layer, int ob, int i) {
+    return layer == MlpGeom::NL - 1 ? 16 * ob + i : 16 * ob + 4 * (i & 3) + (i >> 2);
+}
+
+// One layer: acc[ob] (NOB blocks) = bias; for every group of 4 k-steps: 4*NOB MFMAs, interleaved over the blocks
+// so consecutive MFMAs never depend on each other (dependent latency 40 cycles > 32-cycle issue).
+template <int LAYER, int NOB, int S4, class BOperand>
+SYN_DEV void mlp_layer(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane, BOperand bop,
+                       f32x4 (&acc)[NOB]) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob++)
+        acc[ob] = *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[LAYER] + (ob * 4 + q) * 4);
+    const float* wl = wimg + MlpGeom::W_OFF[LAYER] + lane * 4;
+#pragma unroll
+    for (int s4 = 0; s4 < S4; s4++) {
+        f32x4 a[NOB];
+#pragma unroll
+        for (int ob = 0; ob < NOB; ob++) a[ob] = *reinterpret_cast<const f32x4*>(wl + (s4 * NOB + ob) * 256);
+        f32x4 b = bop(s4);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int ob = 0; ob < NOB; ob++)
+                acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][r], b[r], acc[ob], 0, 0, 0);
+    }
+}
+
+template <int NOB>
+SYN_DEV void relu_inplace(f32x4 (&acc)[NOB]) {
+#pragma unroll
+    for (int ob = 0; ob < NOB; ob++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[ob][r] = __builtin_fmaxf(acc[ob][r], 0.0f);  // x.max(0.0): NaN -> 0
+}
+
+// Evaluates the network for the 16 positions of this wave's tile. Lane l = (j = l&15, q = l>>4) must pass the
+// bitboards of position j. Returns the last layer's D registers: lane (j,q) register r = raw output 4*q + r of
+// position j (outputs 0..8 = policy logits, 9..11 = outcome logits, 12..15 = padding).
+SYN_DEV f32x4 mlp_tile16(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane, uint64_t my,
+                         uint64_t op) {
+    const int q = lane >> 4;
+    const uint64_t nextfree = c4::next_free_cells(my | op);
+
+    f32x4 h1[8];
+    mlp_layer<0, 8, 4>(wimg, bimg, lane, [&](int s4) {
+        f32x4 b;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int f = 16 * s4 + 4 * r + q;  // feature index consumed by this lane in step 4*s4 + r
+            b[r] = f < 63 ? c4::feature(my, op, nextfree, f) : 0.0f;
+        }
+        return b;
+    }, h1);
+    relu_inplace(h1);
+
+    f32x4 h2[6];
+    mlp_layer<1, 6, 8>(wimg, bimg, lane, [&](int s4) { return h1[s4]; }, h2);
+    relu_inplace(h2);
+
+    f32x4 h3[4];
+    mlp_layer<2, 4, 6>(wimg, bimg, lane, [&](int s4) { return h2[s4]; }, h3);
+    relu_inplace(h3);
+
+    f32x4 h4[3];
+    mlp_layer<3, 3, 4>(wimg, bimg, lane, [&](int s4) { return h3[s4]; }, h4);
+    relu_inplace(h4);
+
+    f32x4 out[1];
+    mlp_layer<4, 1, 3>(wimg, bimg, lane, [&](int s4) { return h4[s4]; }, out);
+    return out[0];
+}
+
+// policies.rs:54-57: softmax over the three outcome logits (libtorch: max-subtracted), exp = det_expf,
+// sum in index order. v[0..2] in, probabilities out.
+SYN_DEV void value_softmax(float& v0, float& v1, float& v2) {
+    float m = v0;
+    m = v1 > m ? v1 : m;
+    m = v2 > m ? v2 : m;
+    float e0 = det_expf(v0 - m), e1 = det_expf(v1 - m), e2 = det_expf(v2 - m);
+    float total = 0.0f;
+    total += e0;
+    total += e1;
+    total += e2;
+    v0 = e0 / total;
+    v1 = e1 / total;
+    v2 = e2 / total;
+}
+
+// Copies the prebuilt weight image (global, fragment order) into LDS. All threads of the block participate.
+SYN_DEV void stage_weight_image(float* __restrict__ lds_img, const float* __restrict__ g_img, int tid, int nthreads) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(g_img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_img);
+    for (int i = tid; i < MlpGeom::IMG_FLOATS / 4; i += nthreads) dst[i] = src[i];
+}
+
+}  // namespace syn

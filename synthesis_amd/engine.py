@@ -1,0 +1,251 @@
+"""ctypes binding of the C ABI (include/synthesis_amd.h) + the Engine convenience class.
+
+The library is loaded from synthesis_amd/libsynthesis_amd.so (built in-tree by `make -C synthesis_amd/csrc` or
+__graft_entry__.build()). Nothing here computes: every method forwards to a HIP kernel launch inside the library.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .config import CEngineConfig, CMctsConfig, CRolloutConfig, MCTSConfig, RolloutConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/policies.rs:20-24)
+
+# every symbol include/synthesis_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
+    "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
+    "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_debug_stdrng_u32",
+    "syn_debug_math",
+]
+
+
+class SynthesisAmdError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"synthesis_amd error {code}: {message}")
+        self.code = code
+
+
+class CSearchResult(C.Structure):  # struct syn_search_result
+    _fields_ = [
+        ("child_N", C.c_float * 9), ("child_W", (C.c_float * 3) * 9), ("child_P", C.c_float * 9),
+        ("child_sol", (C.c_int32 * 3) * 9),
+        ("root_N", C.c_float), ("root_W", C.c_float * 3), ("root_sol", C.c_int32 * 3),
+        ("num_nodes", C.c_uint32), ("best_action", C.c_int32),
+        ("target_pi", C.c_float * 9), ("target_q", C.c_float * 3),
+    ]
+
+
+class CCounters(C.Structure):  # struct syn_counters
+    _fields_ = [(n, C.c_uint64) for n in (
+        "explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals", "backprop_levels",
+        "solver_children", "solved_hits", "moves", "games", "reserved")]
+
+
+def library_path():
+    return os.path.join(_HERE, "libsynthesis_amd.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libsynthesis_amd.so; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise SynthesisAmdError(-100, f"{path} not found: build it with `make -C synthesis_amd/csrc` "
+                                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    lib.syn_last_error.restype = C.c_char_p
+    lib.syn_last_error.argtypes = [C.c_void_p]
+    lib.syn_engine_create.argtypes = [C.POINTER(CEngineConfig), C.c_int, C.POINTER(C.c_void_p)]
+    lib.syn_engine_destroy.argtypes = [C.c_void_p]
+    lib.syn_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.syn_policy_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.syn_policy_eval_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_int]
+    lib.syn_features_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.syn_linear_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int]
+    lib.syn_conv2d_forward.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                                      C.c_void_p, C.c_int]
+    lib.syn_mcts_search.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p]
+    lib.syn_selfplay_run.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int] + \
+                                    [C.c_void_p] * 8
+    lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.syn_debug_stdrng_u32.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def shard_games(n_games, rank, world_size):
+    """Static partition of game indices over ranks/GPUs (games share nothing: alpha_zero.rs:181-209). Rank r plays
+    games r, r + world, r + 2*world, ... expressed as (first_game, count, stride=1) blocks: we use contiguous blocks so
+    a rank's games are [first, first + count)."""
+    base, rem = divmod(n_games, world_size)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+class Engine:
+    """One handle = one GPU + one stream (the reference's one policy per worker thread, alpha_zero.rs:192-198)."""
+
+    def __init__(self, concurrent_games=4096, max_explores=800, device=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        cfg = CEngineConfig(int(concurrent_games), int(max_explores), 0, 0)
+        rc = self._lib.syn_engine_create(C.byref(cfg), int(device), C.byref(self._h))
+        if rc != 0:
+            msg = self._lib.syn_last_error(None)
+            raise SynthesisAmdError(rc, msg.decode() if msg else "syn_engine_create failed")
+        self.concurrent_games = int(concurrent_games)
+        self.max_explores = int(max_explores)
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.syn_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.syn_last_error(self._h)
+            raise SynthesisAmdError(rc, msg.decode() if msg else "")
+
+    # ---- weights (vs.load, alpha_zero.rs:194)
+    def load_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        self._check(self._lib.syn_load_weights(self._h, _p(blob), blob.size))
+
+    # ---- Policy::eval, batched (policies.rs:47-59)
+    def policy_eval(self, my_bb, op_bb):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        if my.size != op.size:
+            raise ValueError("my_bb and op_bb must have the same length")
+        logits = np.zeros((my.size, 9), np.float32)
+        value = np.zeros((my.size, 3), np.float32)
+        self._check(self._lib.syn_policy_eval_batch(self._h, _p(my), _p(op), int(my.size), _p(logits), _p(value)))
+        return logits, value
+
+    def policy_eval_device(self, d_my, d_op, n, d_logits, d_value, sync=True):
+        """Device-pointer form (ints = raw device addresses, e.g. torch tensor .data_ptr())."""
+        self._check(self._lib.syn_policy_eval_batch_device(self._h, C.c_void_p(d_my), C.c_void_p(d_op), int(n),
+                                                           C.c_void_p(d_logits), C.c_void_p(d_value), int(sync)))
+
+    # ---- Game::features (connect4.rs:235-258)
+    def features(self, my_bb, op_bb):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        out = np.zeros((my.size, 63), np.float32)
+        self._check(self._lib.syn_features_batch(self._h, _p(my), _p(op), int(my.size), _p(out)))
+        return out
+
+    # ---- slimnn layers
+    def linear(self, W, b, x, relu=False):
+        W = np.ascontiguousarray(W, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, W.shape[1])
+        y = np.zeros((x.shape[0], W.shape[0]), np.float32)
+        self._check(self._lib.syn_linear_forward(self._h, W.shape[1], W.shape[0], _p(W), _p(b), _p(x), x.shape[0],
+                                                 _p(y), int(relu)))
+        return y
+
+    def conv2d(self, W, b, x, row_pad=0, col_pad=0, stride=1, relu=False, out_hw=None):
+        W = np.ascontiguousarray(W, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim == 3:
+            x = x[None]
+        cout, cin, k, _ = W.shape
+        n, _, h_in, w_in = x.shape
+        if out_hw is None:
+            out_hw = ((h_in + 2 * row_pad - k) // stride + 1, (w_in + 2 * col_pad - k) // stride + 1)
+        h_out, w_out = out_hw
+        y = np.zeros((n, cout, max(h_out, 0), max(w_out, 0)), np.float32)
+        self._check(self._lib.syn_conv2d_forward(self._h, cin, cout, k, row_pad, col_pad, stride, h_in, w_in, h_out,
+                                                 w_out, _p(W), _p(b), _p(x), n, _p(y), int(relu)))
+        return y
+
+    # ---- MCTS::with_capacity + explore_n on n roots (mcts.rs:123-147)
+    def mcts_search(self, cfg: MCTSConfig, my_bb, op_bb, explores, action_selection=1):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        n = int(my.size)
+        res = (CSearchResult * max(n, 1))()
+        c = cfg.to_c()
+        self._check(self._lib.syn_mcts_search(self._h, C.byref(c), _p(my), _p(op), n, int(explores),
+                                              int(action_selection), C.cast(res, C.c_void_p)))
+        raw = np.frombuffer(res, dtype=np.uint8).reshape(max(n, 1), C.sizeof(CSearchResult))[:n]
+        dt = np.dtype([("child_N", np.float32, (9,)), ("child_W", np.float32, (9, 3)), ("child_P", np.float32, (9,)),
+                       ("child_sol", np.int32, (9, 3)), ("root_N", np.float32), ("root_W", np.float32, (3,)),
+                       ("root_sol", np.int32, (3,)), ("num_nodes", np.uint32), ("best_action", np.int32),
+                       ("target_pi", np.float32, (9,)), ("target_q", np.float32, (3,))])
+        assert dt.itemsize == C.sizeof(CSearchResult)
+        rec = raw.copy().view(dt).reshape(n)
+        out = {k: rec[k].copy() for k in dt.names}
+        out["root_stat"] = np.concatenate([out.pop("root_N")[:, None], out.pop("root_W")], axis=1)
+        return out
+
+    # ---- run_n_games (alpha_zero.rs:181-209)
+    def selfplay(self, cfg: RolloutConfig, base_seed, n_games, first_game=0, outputs=True, counters=False):
+        n = int(n_games)
+        r = dict(plies=np.zeros(n, np.int32))
+        if outputs:
+            r.update(states_bb=np.zeros((n, 63, 2), np.uint64), pis=np.zeros((n, 63, 9), np.float32),
+                     vs=np.zeros((n, 63, 3), np.float32), actions=np.zeros((n, 63), np.uint8),
+                     root_nodes=np.zeros((n, 63), np.uint32), final_kind=np.zeros(n, np.uint8))
+        ctr = CCounters() if counters else None
+        c = cfg.to_c()
+        self._check(self._lib.syn_selfplay_run(
+            self._h, C.byref(c), int(base_seed), int(first_game), n, _p(r["plies"]), _p(r.get("states_bb")),
+            _p(r.get("pis")), _p(r.get("vs")), _p(r.get("actions")), _p(r.get("root_nodes")), _p(r.get("final_kind")),
+            C.cast(C.byref(ctr), C.c_void_p) if ctr is not None else None))
+        if ctr is not None:
+            r["counters"] = {name: int(getattr(ctr, name)) for name, _ in CCounters._fields_ if name != "reserved"}
+        r["kernel_ms"] = self.last_kernel_ms()
+        return r
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        nl = C.c_int()
+        self._check(self._lib.syn_last_timing(self._h, C.byref(ms), C.byref(nl)))
+        return float(ms.value)
+
+    # ---- parity probes
+    def debug_stdrng_u32(self, seed, n):
+        out = np.zeros(int(n), np.uint32)
+        self._check(self._lib.syn_debug_stdrng_u32(self._h, int(seed), int(n), _p(out)))
+        return out
+
+    def debug_math(self, a, b):
+        a = np.ascontiguousarray(a, np.float32).ravel()
+        b = np.ascontiguousarray(b, np.float32).ravel()
+        e = np.zeros_like(a); d = np.zeros_like(a); s = np.zeros_like(a)
+        self._check(self._lib.syn_debug_math(self._h, _p(a), _p(b), int(a.size), _p(e), _p(d), _p(s)))
+        return e, d, s

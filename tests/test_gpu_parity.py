@@ -1,0 +1,346 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star):
+  * integer / index / visit-count work: bit-exact (np.array_equal on f32 visit counts, W sums, priors, solutions);
+  * policy/value network: within 1e-5 of the canonical slimnn-order oracle, and EXACTLY equal to the oracle's ACC_FMA
+    mode (the fused-multiply-add chain the f32 MFMA computes), which is what makes visit-exact MCTS parity testable.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NN_TOL = 1e-5  # north_star: "policy/value outputs within 1e-5 fp32"
+
+
+@pytest.fixture(scope="module")
+def blob(golden_dir):
+    return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+
+
+@pytest.fixture(scope="module")
+def engine(blob):
+    import synthesis_amd as sa
+
+    eng = sa.Engine(concurrent_games=256, max_explores=800, device=0)
+    eng.load_weights(blob)
+    yield eng
+    eng.close()
+
+
+def random_positions(oracle, n, seed, max_moves=45):
+    """Random reachable non-terminal positions (uniform random legal playouts of random length)."""
+    rng = np.random.RandomState(seed)
+    my, op = [], []
+    while len(my) < n:
+        moves = []
+        h = [0] * 9
+        ok = True
+        for _ in range(rng.randint(0, max_moves)):
+            legal = [c for c in range(9) if h[c] < 7]
+            if not legal:
+                ok = False
+                break
+            c = legal[rng.randint(len(legal))]
+            moves.append(c)
+            h[c] += 1
+        r = oracle.c4_play(moves) if moves else dict(over=np.zeros(0, bool), my_bb=0, op_bb=0)
+        if ok and not np.any(r["over"]):
+            my.append(r["my_bb"])
+            op.append(r["op_bb"])
+    return np.array(my, np.uint64), np.array(op, np.uint64)
+
+
+# ------------------------------------------------------------------------------------------------ primitives
+def test_device_math_is_ieee_exact(engine, oracle):
+    rng = np.random.RandomState(1)
+    a = np.concatenate([rng.uniform(-104, 1, 200000), rng.uniform(0, 2000, 100000), [0.0, -0.0, 1.0, 800.0, 1601.0]]).astype(np.float32)
+    b = np.concatenate([rng.uniform(0.5, 1700, 300000), [1.0, 3.0, 7.0, 1601.0, 0.1]]).astype(np.float32)
+    e, d, s = engine.debug_math(a, b)
+    assert np.array_equal(e.view(np.uint32), oracle.det_expf(a).view(np.uint32))  # det_expf bit for bit
+    assert np.array_equal(d.view(np.uint32), (a / b).view(np.uint32))            # correctly rounded divide
+    pos = a >= 0
+    assert np.array_equal(s[pos].view(np.uint32), np.sqrt(a[pos]).view(np.uint32))  # correctly rounded sqrt
+
+
+def test_device_stdrng_matches_oracle(engine, oracle):
+    for seed in (0, 1, 12345, 2**63 + 17):
+        assert np.array_equal(engine.debug_stdrng_u32(seed, 200), oracle.stdrng_u32(seed, 200))
+
+
+# ------------------------------------------------------------------------------------------------ leaf evaluation
+def test_features_match_oracle(engine, oracle):
+    my, op = random_positions(oracle, 300, seed=2, max_moves=63)
+    assert np.array_equal(engine.features(my, op), oracle.c4_features(my, op))
+
+
+def test_policy_eval_parity(engine, oracle, blob):
+    my, op = random_positions(oracle, 1000, seed=3)
+    logits, value = engine.policy_eval(my, op)
+    ref_l, ref_v = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_SLIMNN)
+    assert np.abs(logits - ref_l).max() < NN_TOL and np.abs(value - ref_v).max() < NN_TOL
+    fma_l, fma_v = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    assert np.array_equal(logits, fma_l)   # MFMA == k-ordered fmaf chain
+    assert np.array_equal(value, fma_v)
+
+
+def test_policy_eval_torch_goldens_and_ragged_sizes(engine, golden_dir, oracle, blob):
+    g = json.load(open(os.path.join(golden_dir, "c4net_torch_goldens.json")))
+    logits, value = engine.policy_eval(g["my_bb"], g["op_bb"])
+    assert np.abs(logits - np.array(g["logits_f64"])).max() < NN_TOL
+    assert np.abs(value - np.array(g["value_f64"])).max() < NN_TOL
+    my, op = random_positions(oracle, 70, seed=4)
+    full = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    for n in (0, 1, 15, 16, 17, 33, 70):  # empty, partial tiles, tile boundaries
+        l, v = engine.policy_eval(my[:n], op[:n])
+        assert l.shape == (n, 9) and np.array_equal(l, full[0][:n]) and np.array_equal(v, full[1][:n])
+
+
+def test_policy_eval_large_batch_consistency(engine, oracle, blob):
+    """Full-size property: 65,536 positions (4096 games x 16) — every tile of the grid-stride loop gives the same
+    answer as the first, and a sample is checked against the oracle."""
+    my, op = random_positions(oracle, 512, seed=5)
+    big_my, big_op = np.tile(my, 128), np.tile(op, 128)
+    logits, value = engine.policy_eval(big_my, big_op)
+    assert np.array_equal(logits.reshape(128, 512, 9), np.broadcast_to(logits[:512], (128, 512, 9)))
+    assert np.array_equal(value.reshape(128, 512, 3), np.broadcast_to(value[:512], (128, 512, 3)))
+    fl, fv = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    assert np.array_equal(logits[:512], fl) and np.array_equal(value[:512], fv)
+
+
+# ------------------------------------------------------------------------------------------------ slimnn layers
+def test_slimnn_layer_kats_on_gpu(engine, oracle, golden_dir):
+    """slimnn/src/conv.rs:92-602, linear.rs:105-112 through the GPU kernels; also bit-exact vs the oracle's slimnn mode."""
+    for k in json.load(open(os.path.join(golden_dir, "slimnn_conv_kats.json"))):
+        W = np.array(k["weight"], np.float32)
+        x = np.array(k["x"], np.float32)
+        y = engine.conv2d(W, k["bias"], x, k["row_pad"], k["col_pad"], k["stride"])[0]
+        assert np.abs(y - np.array(k["expected"], np.float32)).max() < k["tolerance"], k["name"]
+        assert np.array_equal(y, oracle.conv2d(W, k["bias"], x, k["row_pad"], k["col_pad"], k["stride"])[0])
+    lk = json.load(open(os.path.join(golden_dir, "slimnn_linear_relu_kats.json")))
+    for case in lk["linear"]["cases"]:
+        assert engine.linear(lk["linear"]["weight"], lk["linear"]["bias"], case["x"])[0].tolist() == case["expected"]
+    rng = np.random.RandomState(6)
+    W = rng.randn(96, 128).astype(np.float32); b = rng.randn(96).astype(np.float32); x = rng.randn(37, 128).astype(np.float32)
+    assert np.array_equal(engine.linear(W, b, x), oracle.linear(W, b, x))
+    assert np.array_equal(engine.linear(W, b, x, relu=True), np.maximum(oracle.linear(W, b, x), 0))
+    Wc = rng.randn(8, 2, 3, 3).astype(np.float32); bc = rng.randn(8).astype(np.float32); xc = rng.randn(5, 2, 7, 9).astype(np.float32)
+    assert np.array_equal(engine.conv2d(Wc, bc, xc, 1, 0, 3), oracle.conv2d(Wc, bc, xc, 1, 0, 3))
+    assert np.array_equal(engine.conv2d(Wc, bc, xc, 1, 1, 1), oracle.conv2d(Wc, bc, xc, 1, 1, 1))
+    import synthesis_amd as sa
+    with pytest.raises(sa.SynthesisAmdError):  # conv.rs:50-51 asserts on inconsistent output dims
+        engine.conv2d(Wc, bc, xc, 1, 0, 3, out_hw=(4, 3))
+
+
+# ------------------------------------------------------------------------------------------------ MCTS
+SEARCH_KEYS = ("child_N", "child_W", "child_P", "child_sol", "root_stat", "root_sol", "num_nodes", "best_action",
+               "target_pi", "target_q")
+
+
+def assert_search_equal(got, ref, ctx=""):
+    for k in SEARCH_KEYS:
+        a, b = np.asarray(got[k]), np.asarray(ref[k])
+        assert a.shape == b.shape, (ctx, k, a.shape, b.shape)
+        if not np.array_equal(a, b):
+            bad = np.argwhere(a != b)
+            raise AssertionError(f"{ctx}: {k} differs at {bad[:5].tolist()} got {a[tuple(bad[0])]} ref {b[tuple(bad[0])]}")
+
+
+def test_mcts_search_visit_exact(engine, oracle, blob):
+    """Visit counts, W sums, priors, solver marks, node counts, best action and both targets are identical to the
+    oracle MCTS on the same roots (parity config of study-connect4/src/main.rs:58-66)."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config
+
+    my, op = random_positions(oracle, 96, seed=7)
+    my[0] = 0; op[0] = 0  # the empty board
+    for explores in (0, 1, 37, 200):
+        got = engine.mcts_search(sa.parity_mcts_config(), my, op, explores)
+        ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, explores, nn_mode=oracle.ACC_FMA)
+        assert_search_equal(got, ref, f"explores={explores}")
+    got = engine.mcts_search(sa.parity_mcts_config(), my[:24], op[:24], 800)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my[:24], op[:24], 800, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, "explores=800")
+    assert got["num_nodes"].max() <= 1 + 9 * 801
+
+
+def test_mcts_search_late_game_solver_and_auto_extend(engine, oracle, blob):
+    """Nearly full boards: few legal columns (auto-extend chains), many terminal children (solver + value correction),
+    roots that get solved before the explore budget is used."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config
+
+    rng = np.random.RandomState(8)
+    my, op = [], []
+    while len(my) < 64:
+        h = [0] * 9
+        moves = []
+        target = rng.randint(50, 62)
+        for _ in range(target):
+            legal = [c for c in range(9) if h[c] < 7]
+            c = legal[rng.randint(len(legal))]
+            moves.append(c); h[c] += 1
+        r = oracle.c4_play(moves)
+        if not r["over"].any():
+            my.append(r["my_bb"]); op.append(r["op_bb"])
+    my = np.array(my, np.uint64); op = np.array(op, np.uint64)
+    got = engine.mcts_search(sa.parity_mcts_config(), my, op, 300)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 300, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, "late game")
+    assert ref["root_sol"][:, 0].sum() > 10  # the case really exercises solved roots
+
+
+def test_mcts_config_variants(engine, oracle, blob):
+    """Remaining deterministic MCTSConfig variants: Fpu::ParentQ, no solver, no value correction, no auto-extend,
+    select_solved_nodes = false, ActionSelection::Q, other c."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config
+
+    my, op = random_positions(oracle, 48, seed=9, max_moves=60)
+    variants = [
+        dict(fpu=1), dict(solve=0), dict(correct_values_on_solve=0), dict(auto_extend=0), dict(select_solved_nodes=0),
+        dict(c=1.25, fpu_value=0.0),
+    ]
+    for v in variants:
+        ocfg = parity_mcts_config(**v)
+        scfg = sa.MCTSConfig(exploration=sa.Exploration.PolynomialUct, c=ocfg.c, solve=bool(ocfg.solve),
+                             correct_values_on_solve=bool(ocfg.correct_values_on_solve),
+                             select_solved_nodes=bool(ocfg.select_solved_nodes), auto_extend=bool(ocfg.auto_extend),
+                             fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value)
+        for sel in (0, 1):
+            got = engine.mcts_search(scfg, my, op, 150, action_selection=sel)
+            ref = oracle.c4_mcts_search(ocfg, blob, my, op, 150, action_selection=sel, nn_mode=oracle.ACC_FMA)
+            assert_search_equal(got, ref, f"variant {v} sel {sel}")
+
+
+def test_engine_error_behaviour(blob):
+    """Errors are codes + messages, never a silent fallback (SURVEY §8b 'Errors')."""
+    import synthesis_amd as sa
+
+    eng = sa.Engine(concurrent_games=16, max_explores=32)
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.policy_eval([0], [0])
+    assert e.value.code == -4  # SYN_ERR_NO_WEIGHTS
+    with pytest.raises(sa.SynthesisAmdError):
+        eng.load_weights(blob[:-1])
+    eng.load_weights(blob)
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.mcts_search(sa.parity_mcts_config(), [0], [0], 33)
+    assert e.value.code == -6  # SYN_ERR_CAPACITY
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.mcts_search(sa.MCTSConfig(fpu=sa.Fpu.Func), [0], [0], 8)
+    assert e.value.code == -5  # SYN_ERR_UNSUPPORTED
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.mcts_search(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet), [0], [0], 8)
+    assert e.value.code == -5
+    r = eng.selfplay(sa.parity_rollout_config(8), 0, 0)
+    assert r["plies"].size == 0
+    eng.close()
+
+
+# ------------------------------------------------------------------------------------------------ self-play
+SELFPLAY_KEYS = ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind")
+
+
+def assert_selfplay_equal(got, ref, ctx=""):
+    assert np.array_equal(got["plies"], ref["plies"]), (ctx, got["plies"], ref["plies"])
+    for g in range(len(ref["plies"])):
+        n = ref["plies"][g]
+        for k in ("states_bb", "pis", "vs", "actions", "root_nodes"):
+            if not np.array_equal(got[k][g, :n], ref[k][g, :n]):
+                ply = int(np.argwhere((got[k][g, :n] != ref[k][g, :n]).reshape(n, -1).any(axis=1))[0][0])
+                raise AssertionError(f"{ctx}: game {g} {k} differs first at ply {ply}: {got[k][g, ply]} vs {ref[k][g, ply]}")
+    assert np.array_equal(got["final_kind"], ref["final_kind"])
+
+
+def test_selfplay_matches_oracle_800_explores(engine, oracle, blob):
+    """BASELINE config (800 explores, parity MCTS config): whole games — every position, visit distribution, value
+    target, sampled action and tree size — identical to the oracle's run_game with the same per-game StdRng."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+
+    got = engine.selfplay(sa.parity_rollout_config(800), base_seed=11, n_games=12, counters=True)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 11, 12, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, "800 explores")
+    for k in ("explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals",
+              "backprop_levels", "solver_children", "solved_hits"):
+        assert got["counters"][k] == ref["counters"][k], k
+    assert got["counters"]["games"] == 12 and got["counters"]["moves"] == int(ref["plies"].sum())
+
+
+def test_selfplay_many_games_and_refill(engine, oracle, blob):
+    """More games than tree slots (256 slots, 700 games): finished games hand their slot to the next game index;
+    results depend only on the game index. Also first_game offsets (the multi-GPU shard parameter)."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+
+    cfg = sa.parity_rollout_config(40)
+    got = engine.selfplay(cfg, base_seed=3, n_games=700)
+    ref = oracle.c4_selfplay(parity_rollout_config(40), blob, 3, 700, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, "700 games")
+    part = engine.selfplay(cfg, base_seed=3, n_games=100, first_game=350)
+    for k in SELFPLAY_KEYS:
+        assert np.array_equal(part[k], got[k][350:450]), k
+
+
+def test_selfplay_value_targets_and_action_variants(engine, oracle, blob):
+    """ValueTarget::{Z, QZaverage, QtoZ}, stop_games_when_solved, ActionSelection::Q, other sampling horizons
+    (alpha_zero.rs:270-338)."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+
+    variants = [
+        (dict(value_target=sa.ValueTarget.Z), dict(value_target=0)),
+        (dict(value_target=sa.ValueTarget.QZaverage, value_target_p=0.3), dict(value_target=2, vt_p=0.3)),
+        (dict(value_target=sa.ValueTarget.QtoZ, value_target_from=0.1, value_target_to=0.9), dict(value_target=3, vt_from=0.1, vt_to=0.9)),
+        (dict(stop_games_when_solved=True), dict(stop_games_when_solved=1)),
+        (dict(action=sa.ActionSelection.Q, random_actions_until=3, sample_actions_until=10),
+         dict(action=0, random_actions_until=3, sample_actions_until=10)),
+        (dict(random_actions_until=0, sample_actions_until=0), dict(random_actions_until=0, sample_actions_until=0)),
+    ]
+    for sv, ov in variants:
+        got = engine.selfplay(sa.parity_rollout_config(60, **sv), base_seed=21, n_games=40)
+        ref = oracle.c4_selfplay(parity_rollout_config(60, **ov), blob, 21, 40, threads=8, nn_mode=oracle.ACC_FMA)
+        assert_selfplay_equal(got, ref, str(sv))
+
+
+def test_selfplay_full_size_properties(blob, oracle):
+    """BASELINE full size: 4096 concurrent games x 800 explores. Too big for the oracle, so size-independent
+    properties: replaying the recorded actions with the oracle's Connect4 reproduces every recorded position and ends
+    exactly at the recorded ply; visit distributions sum to 1 and are zero on illegal columns; value targets are
+    distributions; tree sizes respect 1 + 9*(explores+1); counters are self-consistent; a re-run is bit-identical."""
+    import synthesis_amd as sa
+
+    eng = sa.Engine(concurrent_games=4096, max_explores=800)
+    eng.load_weights(blob)
+    cfg = sa.parity_rollout_config(800)
+    r = eng.selfplay(cfg, base_seed=2024, n_games=4096, counters=True)
+    plies = r["plies"]
+    assert plies.min() >= 7 and plies.max() <= 63
+    mask = np.arange(63)[None, :] < plies[:, None]
+    np.testing.assert_allclose(r["pis"].sum(axis=2)[mask], 1.0, atol=2e-6)
+    np.testing.assert_allclose(r["vs"].sum(axis=2)[mask], 1.0, atol=2e-6)
+    assert r["root_nodes"][mask].max() <= 1 + 9 * 801
+    occ = r["states_bb"][..., 0] | r["states_bb"][..., 1]
+    for c in range(9):  # full column => zero visit probability
+        full = ((occ >> np.uint64(7 * c)) & np.uint64(0x7F)) == np.uint64(0x7F)
+        assert np.all(r["pis"][..., c][mask & full] == 0)
+    for g in range(0, 4096, 37):  # replay a sample of games on the oracle's rules
+        n = plies[g]
+        rep = oracle.c4_play(list(r["actions"][g, :n]))
+        assert rep["over"][-1] and not rep["over"][:-1].any()
+        assert (rep["my_bb"], rep["op_bb"]) != (0, 0)
+        pre = oracle.c4_play(list(r["actions"][g, : n - 1]))
+        assert (pre["my_bb"], pre["op_bb"]) == (int(r["states_bb"][g, n - 1, 0]), int(r["states_bb"][g, n - 1, 1]))
+    c = r["counters"]
+    assert c["games"] == 4096 and c["moves"] == int(plies.sum())
+    assert c["policy_evals"] <= c["expansions"] <= c["explores"]
+    assert c["new_nodes"] <= 9 * c["expansions"]
+    r2 = eng.selfplay(cfg, base_seed=2024, n_games=4096)
+    for k in SELFPLAY_KEYS:
+        assert np.array_equal(r[k][mask] if r[k].ndim > 1 and r[k].shape[:2] == mask.shape else r[k],
+                              r2[k][mask] if r2[k].ndim > 1 and r2[k].shape[:2] == mask.shape else r2[k]), k
+    eng.close()
