@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — self-play throughput of the MI355X engine on BASELINE.json's metric.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7 Connect4, 800 explores per move,
+           deterministic parity MCTS config (study-connect4/src/main.rs:58-66), 4096 concurrent games per GPU.
+Step     : one pass of the hot path over one batch = GAMES_PER_STEP self-play games per GPU played to completion by
+           the fused kernel (finished games hand their tree slot to the next game index, so the 4096 slots stay busy).
+Scaling  : weak — every rank plays its own GAMES_PER_STEP games per step (games share nothing; no collective on the
+           data path). Timed region = barrier + device sync on both sides, max over ranks.
+Roofline : the fused kernel's achieved rate against both roofs — f32 MFMA (60,288 FLOP per leaf evaluation,
+           SURVEY.md §8d) and HBM (event-counted algorithmic bytes, formula of SURVEY.md §8d) — the nearer roof is
+           reported as "roofline", the other under "roofline_other". Kernel time = HIP events on the engine's stream.
+CPU side : the oracle (restated reference CPU path, thread-per-worker with PolicyWithCache like gather_experience)
+           timed on this box's host cores on a bounded sample of the same workload — rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_EVAL = 60288           # 2 * (63*128 + 128*96 + 96*64 + 64*48 + 48*12)  
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+
+
+def make_weights(seed=20211003):
+    """Connect4Net shapes (policies.rs:20-24), fixed-seed U(+-1/sqrt(fan_in)) init — the same blob as
+    tests/golden/c4net_blob_f32.npy (tests/golden/make_golden.py)."""
+    dims = [63, 128, 96, 64, 48, 12]
+    rng = np.random.RandomState(seed)
+    parts = []
+    for i in range(5):
+        bound = 1.0 / np.sqrt(dims[i])
+        parts.append(rng.uniform(-bound, bound, size=(dims[i + 1], dims[i])).astype(np.float32).ravel())
+        parts.append(rng.uniform(-bound, bound, size=(dims[i + 1],)).astype(np.float32).ravel())
+    return np.concatenate(parts)
+
+
+def algorithmic_bytes(c):
+    """SURVEY.md §8(d), per event: select level = 12 B parent + 20 B per child scanned; expand = 16 B state +
+    48 B per new node + 8 B parent update; NN I/O = 64 B per leaf evaluation (0 when fused — counted as 0 here);
+    backprop level = 40 B + 4 B per child solution read by the solver."""
+    return (12 * c["select_levels"] + 20 * c["children_scanned"] + 16 * c["expansions"] + 48 * c["new_nodes"]
+            + 8 * c["expansions"] + 40 * c["backprop_levels"] + 4 * c["solver_children"])
+
+
+def cpu_baseline(blob, explores, sample_games, threads):
+    from tests import oracle_lib
+
+    oracle = oracle_lib.load()
+    cfg = oracle_lib.parity_rollout_config(explores)
+    r = oracle.c4_selfplay(cfg, blob, base_seed=0, n_games=sample_games, threads=threads, use_cache=True,
+                           nn_mode=oracle.ACC_SLIMNN, outputs=False)
+    secs = r["seconds"]
+    c = r["counters"]
+    return {
+        "value": sample_games / secs, "unit": "games/s", "cores": threads, "kind": "port",
+        "sample": f"{sample_games} games of the same workload (800-explore self-play, parity config, PolicyWithCache on, "
+                  f"one policy+cache per thread) in {secs:.2f} s wall on {threads} host threads",
+        "leaf_evals_per_s": c["policy_evals"] / secs, "explores_per_s": c["explores"] / secs,
+        "cache_hit_rate": c["cache_hits"] / max(1, c["cache_hits"] + c["cache_misses"]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--concurrent", type=int, default=4096, help="concurrent games per GPU (BASELINE: 4096)")
+    ap.add_argument("--games-per-step", type=int, default=16384, help="self-play games per GPU per step")
+    ap.add_argument("--explores", type=int, default=800)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 4 games per host thread")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch  # device sync + (N > 1) the RCCL barrier / max-reduce; the engine itself does not use torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import synthesis_amd as sa
+
+    blob = make_weights()
+    eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
+    eng.load_weights(blob)
+    cfg = sa.parity_rollout_config(args.explores)
+    gps = args.games_per_step
+
+    def barrier():
+        torch.cuda.synchronize(local_rank)
+        if dist is not None:
+            dist.barrier()
+
+    def step(i, **kw):
+        # global game index space: step i, rank r plays [ (i*world + r)*gps, +gps )
+        return eng.selfplay(cfg, base_seed=0, n_games=gps, first_game=(i * world + rank) * gps, outputs=False, **kw)
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    plies = 0
+    for i in range(args.steps):
+        r = step(args.warmup + i)
+        kernel_ms.append(r["kernel_ms"])
+        plies += int(r["plies"].sum())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        p = torch.tensor([plies], dtype=torch.int64, device=f"cuda:{local_rank}")
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        plies = int(p.item())
+
+    # Event counts of exactly the games of the last timed step (trajectories are deterministic, so an instrumented
+    # re-run outside the timed region gives the counts of the timed run).
+    rc = step(args.warmup + args.steps - 1, counters=True)
+    c = rc["counters"]
+    last_ms = kernel_ms[-1]
+    avg_ms = float(np.mean(kernel_ms))
+
+    if rank == 0:
+        total_games = gps * world * args.steps
+        games_per_s = total_games / elapsed
+        evals_per_game = c["policy_evals"] / gps
+        explores_per_game = c["explores"] / gps
+        tflops = c["policy_evals"] * FLOP_PER_EVAL / (last_ms * 1e-3) / 1e12
+        gbs = algorithmic_bytes(c) / (last_ms * 1e-3) / 1e9
+        mfma = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "selfplay_kernel (fused select/expand + Connect4Net f32 MFMA + backprop)",
+                "kernel_ms_avg": avg_ms, "flop_per_leaf_eval": FLOP_PER_EVAL}
+        hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+               "traffic": None, "algorithmic_bytes_per_explore": algorithmic_bytes(c) / max(1, c["explores"]),
+               "kernel_ms_avg": avg_ms}
+        near, other = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
+        out = {
+            "metric": "self-play games/sec, 9x7 Connect4", "value": games_per_s, "unit": "games/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"9x7 Connect4 self-play, {args.concurrent} concurrent games per GPU, "
+                                   f"{args.explores} explores/move, device-resident SoA MCTS node pool + fused f32-MFMA "
+                                   f"Connect4Net leaf inference (BASELINE configs[1]/[2]); fixed-seed random-init weights",
+                       "games_per_step_per_gpu": gps, "concurrent_games_per_gpu": args.concurrent,
+                       "explores_per_move": args.explores, "parallelism": f"games sharded over {world} GPU(s), no collective"},
+            "leaf_evals_per_s": games_per_s * evals_per_game, "explores_per_s": games_per_s * explores_per_game,
+            "plies_per_game": plies / total_games,
+            "roofline": near, "roofline_other": other,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = os.cpu_count() or 1
+            sample = args.cpu_sample_games or 4 * threads
+            out["cpu_baseline"] = cpu_baseline(blob, args.explores, sample, threads)
+        print(json.dumps(out), flush=True)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

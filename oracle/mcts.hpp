@@ -49,7 +49,7 @@ struct MCTSConfig {
 
 // Event counters for the bench's algorithmic-bytes accounting; not part of the reference.
 struct MCTSCounters {
-    uint64_t explores = 0, select_levels = 0, children_scanned = 0, expansions = 0, new_nodes = 0;
+    uint64_t explores = 0 /* explore() calls + root visits */, select_levels = 0, children_scanned = 0, expansions = 0, new_nodes = 0;
     uint64_t policy_evals = 0, backprop_levels = 0, solver_children = 0, solved_hits = 0;
 };
 
@@ -94,10 +94,16 @@ struct MCTS {
     MCTSCounters* ctr = nullptr;
 
     // mcts.rs:123-137
-    MCTS(size_t capacity, const MCTSConfig& cfg_, P* policy_, const G& game, MCTSCounters* ctr_ = nullptr)
+    // `storage`: an empty vector whose capacity is reused (the reference allocates a fresh Vec::with_capacity per
+    // move, mcts.rs:124; reusing the allocation changes no result and keeps the multi-threaded CPU baseline from
+    // serialising on mmap/munmap of ~700 KB vectors).
+    MCTS(size_t capacity, const MCTSConfig& cfg_, P* policy_, const G& game, MCTSCounters* ctr_ = nullptr,
+         std::vector<Node<G>>* storage = nullptr)
         : policy(policy_), cfg(cfg_), ctr(ctr_) {
+        if (storage) { nodes = std::move(*storage); nodes.clear(); }
         nodes.reserve(capacity);
         nodes.push_back(unvisited(0, game, OptOutcome::none(), 0, 0.0f));
+        if (ctr) ctr->explores++;  // the root visit is one select/expand/backprop pass like any explore
         float probs[3];
         bool any_solved;
         uint32_t node_id = visit(root, probs, any_solved);

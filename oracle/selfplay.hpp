@@ -134,8 +134,9 @@ void run_game(const RolloutConfig& cfg, P& policy, ChaChaRng& rng, GameRecord& r
     infos.reserve(Connect4::MAX_TURNS);
     rec.plies = 0;
 
+    std::vector<Node<Connect4>> storage;
     while (!solution.some) {
-        MCTS<Connect4, P> mcts((size_t)cfg.num_explores + 1, cfg.mcts_cfg, &policy, game, ctr);
+        MCTS<Connect4, P> mcts((size_t)cfg.num_explores + 1, cfg.mcts_cfg, &policy, game, ctr, &storage);
         mcts.explore_n((size_t)cfg.num_explores);
 
         mcts.target_policy(search_policy);
@@ -160,6 +161,7 @@ void run_game(const RolloutConfig& cfg, P& policy, ChaChaRng& rng, GameRecord& r
         if (is_over) solution = OptOutcome::of(outcome_from_reward(game.reward(game.player_id())));
         else if (!cfg.stop_games_when_solved) solution = OptOutcome::none();
         num_turns++;
+        storage = std::move(mcts.nodes);
     }
     rec.final_kind = (uint8_t)solution.o.kind;
 

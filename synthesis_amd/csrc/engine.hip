@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -137,8 +138,9 @@ static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) 
 }
 
 // ------------------------------------------------------------------------------------------------ launches
-template <int MODE, bool COUNT>
-static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs) {
+template <int MODE, bool COUNT, bool PROF = false>
+static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, int* out_grid = nullptr,
+                                int* out_nt = nullptr) {
     // workgroup size: 16 trees per 256 threads; grow the block (not the grid) past one workgroup per CU, because
     // the 123 KB weight image allows exactly one resident workgroup per CU.
     int want_slots = h->slots;
@@ -150,7 +152,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs) 
     hipError_t e;
 #define SYN_LAUNCH(NT)                                                                                            \
     {                                                                                                             \
-        auto k = selfplay_kernel<MODE, COUNT, NT>;                                                                \
+        auto k = selfplay_kernel<MODE, COUNT, NT, PROF>;                                                               \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                 (int)EngineLds<NT>::BYTES);                                                       \
         if (e != hipSuccess) return e;                                                                            \
@@ -160,6 +162,8 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs) 
     else if (nt == 512) SYN_LAUNCH(512)
     else SYN_LAUNCH(1024)
 #undef SYN_LAUNCH
+    if (out_grid) *out_grid = grid;
+    if (out_nt) *out_nt = nt;
     return hipGetLastError();
 }
 
@@ -527,10 +531,38 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     P.final_kind = h->d_final;
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), h->stream));
+    // SYN_PROFILE=1: diagnostic build of the kernel with s_memtime stamps around each phase (never timed/benched)
+    const bool prof = !counters && std::getenv("SYN_PROFILE") != nullptr;
+    int pgrid = 0, pnt = 0;
+    unsigned long long* d_prof = nullptr;
+    if (prof) {
+        HIP_TRY(h, hipMalloc(&d_prof, (size_t)4096 * 16 * 6 * 8));
+        HIP_TRY(h, hipMemsetAsync(d_prof, 0, (size_t)4096 * 16 * 6 * 8, h->stream));
+        P.prof = d_prof;
+    }
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    if (counters) HIP_TRY(h, (launch_engine<MODE_SELFPLAY, true>(h, P, n_games)));
+    if (prof) HIP_TRY(h, (launch_engine<MODE_SELFPLAY, false, true>(h, P, n_games, &pgrid, &pnt)));
+    else if (counters) HIP_TRY(h, (launch_engine<MODE_SELFPLAY, true>(h, P, n_games)));
     else HIP_TRY(h, (launch_engine<MODE_SELFPLAY, false>(h, P, n_games)));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    if (prof) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        int nw = pgrid * (pnt / 64);
+        std::vector<unsigned long long> hp((size_t)nw * 6);
+        HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipFree(d_prof));
+        double sum[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long max_it = 0;
+        for (int w = 0; w < nw; w++) {
+            for (int j = 0; j < 6; j++) sum[j] += (double)hp[(size_t)w * 6 + j];
+            if (hp[(size_t)w * 6 + 5] > max_it) max_it = hp[(size_t)w * 6 + 5];
+        }
+        double its = sum[5] / nw;
+        fprintf(stderr, "[syn profile] grid=%d nt=%d waves=%d iterations avg=%.0f max=%llu | cycles/iteration per wave (100 MHz s_memtime ticks x?): "
+                        "A=%.0f wait1=%.0f B=%.0f wait2=%.0f C=%.0f total=%.0f\n",
+                pgrid, pnt, nw, its, max_it, sum[0] / sum[5], sum[1] / sum[5], sum[2] / sum[5], sum[3] / sum[5],
+                sum[4] / sum[5], (sum[0] + sum[1] + sum[2] + sum[3] + sum[4]) / sum[5]);
+    }
     size_t g = (size_t)n_games, p = g * 63;
     if (plies) HIP_TRY(h, hipMemcpyAsync(plies, h->d_plies, g * 4, hipMemcpyDeviceToHost, h->stream));
     if (states_bb) HIP_TRY(h, hipMemcpyAsync(states_bb, h->d_states, p * 16, hipMemcpyDeviceToHost, h->stream));

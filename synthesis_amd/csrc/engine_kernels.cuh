@@ -42,6 +42,7 @@ struct EngineParams {
     int n_jobs;              // games (self-play) or roots (search)
     int* job_next;           // global job counter
     unsigned long long* counters;  // DevCounters (may be null)
+    unsigned long long* prof;      // PROF builds: per-wave cycle sums [A, wait1, B, wait2, C, iterations]
     // self-play
     unsigned long long base_seed;  // game g uses StdRng::seed_from_u64(base_seed + first_game + g)
     unsigned long long first_game;
@@ -342,7 +343,7 @@ struct EngineLds {
     static constexpr size_t BYTES = (size_t)MlpGeom::IMG_FLOATS * 4 + (size_t)TPW * 16 + (size_t)TPW * 64 + 128;
 };
 
-template <int MODE, bool COUNT, int NT>
+template <int MODE, bool COUNT, int NT, bool PROF = false>
 __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TPW = NT / 16;
@@ -376,7 +377,10 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
 
     const int n_explores = P.roll.num_explores;
     int it = 0;
+    unsigned long long pA = 0, pW1 = 0, pB = 0, pW2 = 0, pC = 0, pT = 0;
+#define SYN_STAMP() (PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
     for (;;) {
+        pT = SYN_STAMP();
         const bool active = G.job >= 0;
         ExploreCtx X = {};
         if (active) {
@@ -390,7 +394,9 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
                 if (COUNT) ctr[CTR_POLICY_EVALS]++;
             }
         }
+        if (PROF) { unsigned long long n = SYN_STAMP(); pA += n - pT; pT = n; }
         if (!__syncthreads_or(active ? 1 : 0)) break;  // barrier 1: leaf boards visible; exit when every row is idle
+        if (PROF) { unsigned long long n = SYN_STAMP(); pW1 += n - pT; pT = n; }
 
         // ---- phase B: one wave per 16-position tile
         if (wave < NTILES) {
@@ -408,7 +414,9 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
             }
             if (lane == 0) tileflag[((it + 1) & 1) * 16 + wave] = 0;
         }
+        if (PROF) { unsigned long long n = SYN_STAMP(); pB += n - pT; pT = n; }
         __syncthreads();
+        if (PROF) { unsigned long long n = SYN_STAMP(); pW2 += n - pT; pT = n; }
 
         // ---- phase C
         if (active) {
@@ -432,7 +440,15 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
                 else search_finish(P, T, G, gl);
             }
         }
+        if (PROF) { unsigned long long n = SYN_STAMP(); pC += n - pT; pT = n; }
         it++;
+    }
+#undef SYN_STAMP
+    if (PROF) {
+        if (P.prof && lane == 0) {
+            unsigned long long* o = P.prof + ((size_t)blockIdx.x * (NT / 64) + wave) * 6;
+            o[0] = pA; o[1] = pW1; o[2] = pB; o[3] = pW2; o[4] = pC; o[5] = (unsigned long long)it;
+        }
     }
 
     if (COUNT) {
