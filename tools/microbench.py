@@ -7,6 +7,7 @@ import sys
 import time
 
 import numpy as np
+import torch  # noqa: F401  (import BEFORE the engine library: one HIP runtime per process, torch's bundled one)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
