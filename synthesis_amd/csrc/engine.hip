@@ -141,29 +141,21 @@ static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) 
 template <int MODE, bool COUNT, bool PROF = false>
 static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, int* out_grid = nullptr,
                                 int* out_nt = nullptr) {
-    // workgroup size: 16 trees per 256 threads; grow the block (not the grid) past one workgroup per CU, because
-    // the 123 KB weight image allows exactly one resident workgroup per CU.
+    // one 256-thread workgroup per 16 tree slots; the kernel needs ~17 KB of LDS and <= 256 VGPRs, so up to two
+    // workgroups are resident per CU (concurrency beyond 2 x 16 x CUs queues behind resident workgroups)
     int want_slots = h->slots;
     if (jobs < want_slots) want_slots = ((jobs + 15) / 16) * 16;
-    int nt = 256;
-    while (nt < 1024 && want_slots / (nt / 16) > h->num_cus) nt *= 2;
-    int grid = (want_slots + nt / 16 - 1) / (nt / 16);
+    int grid = want_slots / 16;
     if (grid < 1) grid = 1;
-    hipError_t e;
-#define SYN_LAUNCH(NT)                                                                                            \
-    {                                                                                                             \
-        auto k = selfplay_kernel<MODE, COUNT, NT, PROF>;                                                               \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                (int)EngineLds<NT>::BYTES);                                                       \
-        if (e != hipSuccess) return e;                                                                            \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), EngineLds<NT>::BYTES, h->stream, P);                          \
+    if (grid <= h->num_cus) {
+        auto k = selfplay_kernel<MODE, COUNT, 1, PROF>;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), EngineLds::BYTES, h->stream, P);
+    } else {
+        auto k = selfplay_kernel<MODE, COUNT, 2, PROF>;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), EngineLds::BYTES, h->stream, P);
     }
-    if (nt == 256) SYN_LAUNCH(256)
-    else if (nt == 512) SYN_LAUNCH(512)
-    else SYN_LAUNCH(1024)
-#undef SYN_LAUNCH
     if (out_grid) *out_grid = grid;
-    if (out_nt) *out_nt = nt;
+    if (out_nt) *out_nt = 256;
     return hipGetLastError();
 }
 

@@ -1,9 +1,9 @@
 // synthesis_amd — the fused self-play / search kernel and the stand-alone batched kernels.
 //
-// selfplay_kernel: ONE launch plays whole games. A workgroup owns TPW = blockDim/16 trees (one per DPP row) for its
-// entire life and keeps the 123 KB weight image in LDS; per explore it runs
+// selfplay_kernel: ONE launch plays whole games. A workgroup (4 waves) owns 16 trees (one per DPP row) for its entire
+// life and keeps its share of the network weights in registers; per explore it runs
 //     phase A  (all rows)   select + expand                       [node pool: HBM/L2, latency-bound gathers]
-//     phase B  (tile waves) Connect4Net on 16-position tiles      [f32 MFMA, weights from LDS]
+//     phase B  (all waves)  Connect4Net on the 16-position tile   [f32 MFMA, layers split over the 4 waves]
 //     phase C  (all rows)   legal softmax -> priors, backprop, and — when a search finishes — the whole move step
 //                           of run_game (targets, action sampling, game step, next root / next game)
 // separated by two workgroup barriers. Trees never communicate across workgroups, so there is no grid barrier, no
@@ -168,6 +168,8 @@ SYN_DEV void start_job(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl) {
     G.turn = 0;
     G.rng_index = 0;
     T.next_node = 0;
+    T.root_fc = 0;
+    T.root_nc = 0;
     T.iter = 0;
     T.root_solved = false;
     if (MODE == MODE_SELFPLAY) {
@@ -335,24 +337,32 @@ SYN_DEV void search_finish(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl
     start_job<MODE_SEARCH>(P, T, G, gl);
 }
 
-// LDS: [weight image 123,264 B][leaf boards: TPW x 16 B][net outputs: TPW x 64 B][tile flags 2 x 16 x 4 B]
-template <int NT>
+// LDS per workgroup (16 trees): [bias image 1,408 B][exA 8 KB][exB 6 KB][leaf boards 16 x 16 B][net outputs 16 x 64 B]
+// = 17,024 B, so several workgroups fit one CU; the weights themselves live in registers (mlp.cuh, split variant).
 struct EngineLds {
-    static constexpr int TPW = NT / 16;
-    static constexpr int NTILES = TPW / 16;
-    static constexpr size_t BYTES = (size_t)MlpGeom::IMG_FLOATS * 4 + (size_t)TPW * 16 + (size_t)TPW * 64 + 128;
+    static constexpr int TPW = 16;
+    static constexpr size_t BIAS_OFF = 0;
+    static constexpr size_t EXA_OFF = (size_t)MlpGeom::B_FLOATS * 4;
+    static constexpr size_t EXB_OFF = EXA_OFF + 8 * 64 * 16;
+    static constexpr size_t LEAF_OFF = EXB_OFF + 6 * 64 * 16;
+    static constexpr size_t OUT_OFF = LEAF_OFF + TPW * 16;
+    static constexpr size_t FLAG_OFF = OUT_OFF + TPW * 64;
+    static constexpr size_t BYTES = FLAG_OFF + 16;
 };
 
-template <int MODE, bool COUNT, int NT, bool PROF = false>
-__global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TPW = NT / 16;
-    constexpr int NTILES = TPW / 16;
-    float* wimg = smem;
-    float* bimg = smem + MlpGeom::W_FLOATS;
-    uint4* leafbuf = reinterpret_cast<uint4*>(smem + MlpGeom::IMG_FLOATS);
-    float* outbuf = reinterpret_cast<float*>(leafbuf + TPW);
-    int* tileflag = reinterpret_cast<int*>(outbuf + TPW * 16);
+// One workgroup = 256 threads = 4 waves = 16 trees (one per DPP row) = one 16-position MFMA tile.
+// WPS = waves per SIMD the register allocation must allow: 1 -> up to 512 VGPRs, one workgroup (16 trees) per CU;
+// 2 -> at most 256 VGPRs so two workgroups (32 trees) share a CU.
+template <int MODE, bool COUNT, int WPS, bool PROF = false>
+__global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = 256;
+    float* bimg = reinterpret_cast<float*>(smem_raw + EngineLds::BIAS_OFF);
+    f32x4* exA = reinterpret_cast<f32x4*>(smem_raw + EngineLds::EXA_OFF);
+    f32x4* exB = reinterpret_cast<f32x4*>(smem_raw + EngineLds::EXB_OFF);
+    uint4* leafbuf = reinterpret_cast<uint4*>(smem_raw + EngineLds::LEAF_OFF);
+    float* outbuf = reinterpret_cast<float*>(smem_raw + EngineLds::OUT_OFF);
+    int* evalflag = reinterpret_cast<int*>(smem_raw + EngineLds::FLAG_OFF);  // [2]: double-buffered "tile needs eval"
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -360,15 +370,18 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
     const int gl = tid & 15;
     const int t = tid >> 4;  // tree (row) index inside the workgroup
 
-    stage_weight_image(smem, P.wimg, tid, NT);
-    if (tid < 32) tileflag[tid] = 0;
+    // this wave's share of the network -> registers, for the lifetime of the kernel
+    MlpSplitWeights W;
+    mlp_split_load_weights(P.wimg, wave, lane, W);
+    for (int i = tid; i < MlpGeom::B_FLOATS; i += NT) bimg[i] = P.wimg[MlpGeom::W_FLOATS + i];
+    if (tid < 2) evalflag[tid] = 0;
 
     uint32_t ctr[COUNT ? CTR_COUNT : 1];
 #pragma unroll
     for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) ctr[i] = 0;
 
     TreeCtx T;
-    const size_t slot = (size_t)blockIdx.x * TPW + (size_t)t;
+    const size_t slot = (size_t)blockIdx.x * EngineLds::TPW + (size_t)t;
     T.stat = P.stat + slot * P.cap;
     T.edge = P.edge + slot * P.cap;
     GameCtx G;
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
                 if (gl == 0) {
                     leafbuf[t] = make_uint4((uint32_t)X.leaf_my, (uint32_t)(X.leaf_my >> 32), (uint32_t)X.leaf_op,
                                             (uint32_t)(X.leaf_op >> 32));
-                    tileflag[(it & 1) * 16 + (t >> 4)] = 1;
+                    evalflag[it & 1] = 1;
                 }
                 if (COUNT) ctr[CTR_POLICY_EVALS]++;
             }
@@ -398,22 +411,23 @@ __global__ __launch_bounds__(NT) void selfplay_kernel(EngineParams P) {
         if (!__syncthreads_or(active ? 1 : 0)) break;  // barrier 1: leaf boards visible; exit when every row is idle
         if (PROF) { unsigned long long n = SYN_STAMP(); pW1 += n - pT; pT = n; }
 
-        // ---- phase B: one wave per 16-position tile
-        if (wave < NTILES) {
-            if (tileflag[(it & 1) * 16 + wave]) {
-                const int j = lane & 15, q = lane >> 4;
-                uint4 b = leafbuf[wave * 16 + j];
-                uint64_t my = (uint64_t)b.x | ((uint64_t)b.y << 32), op = (uint64_t)b.z | ((uint64_t)b.w << 32);
-                f32x4 o = mlp_tile16(wimg, bimg, lane, my, op);
+        // ---- phase B: the four waves evaluate the tile together (4 internal barriers); skipped (uniformly) when no
+        //      tree of the workgroup needs the network this round
+        if (evalflag[it & 1]) {
+            const int j = lane & 15, q = lane >> 4;
+            uint4 b = leafbuf[j];
+            uint64_t my = (uint64_t)b.x | ((uint64_t)b.y << 32), op = (uint64_t)b.z | ((uint64_t)b.w << 32);
+            f32x4 o = mlp_split_tile16(W, bimg, exA, exB, wave, lane, my, op);
+            if (wave == 0) {
                 if (q == 2) {
                     float v0 = o[1], v1 = o[2], v2 = o[3];
                     value_softmax(v0, v1, v2);
                     o[1] = v0; o[2] = v1; o[3] = v2;
                 }
-                if (q < 3) *reinterpret_cast<f32x4*>(outbuf + (wave * 16 + j) * 16 + q * 4) = o;
+                if (q < 3) *reinterpret_cast<f32x4*>(outbuf + j * 16 + q * 4) = o;
             }
-            if (lane == 0) tileflag[((it + 1) & 1) * 16 + wave] = 0;
         }
+        if (tid == 0) evalflag[(it + 1) & 1] = 0;
         if (PROF) { unsigned long long n = SYN_STAMP(); pB += n - pT; pT = n; }
         __syncthreads();
         if (PROF) { unsigned long long n = SYN_STAMP(); pW2 += n - pT; pT = n; }

@@ -91,7 +91,9 @@ struct TreeCtx {
     // root position of the current search
     uint64_t root_my, root_op;
     uint32_t next_node;   // nodes.len()
-    int iter;             // explores done on this tree (root visit counts as 1)
+    uint32_t root_fc;     // first child / child count of the root, mirrored in registers so a descent never has
+    uint32_t root_nc;     // to re-read the root record (its N is `iter`, its solution ends the search)
+    int iter;             // explores done on this tree (root visit counts as 1) == root.num_visits
     bool root_solved;
 };
 
@@ -154,13 +156,16 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
         meta = 0;
         pN = pW0 = pW2 = 0.0f;
     } else {
-        uint4 e = T.edge[0];
-        float4 s = T.stat[0];
-        fc = e.x;
-        meta = e.y;
-        pN = s.x;
-        pW0 = s.y;
-        pW2 = s.w;
+        // the root was expanded by this tree's first pass; it is never entered once solved (explore_n stops first)
+        fc = T.root_fc;
+        meta = T.root_nc;
+        pN = (float)T.iter;
+        pW0 = pW2 = 0.0f;
+        if (cfg.fpu == 1) {  // Fpu::ParentQ needs the root's W as well
+            float4 s = T.stat[0];
+            pW0 = s.y;
+            pW2 = s.w;
+        }
     }
 
     for (;;) {
@@ -200,6 +205,7 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
                 bool any_solved = row_ballot(over) != 0u;
                 meta = (meta & ~META_NC_MASK) | n_new;
                 if (gl == 0) *reinterpret_cast<uint2*>(&T.edge[node]) = make_uint2(first, meta);
+                if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
                 if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
 
                 if (cfg.auto_extend && n_new == 1u) {

@@ -133,4 +133,148 @@ SYN_DEV void stage_weight_image(float* __restrict__ lds_img, const float* __rest
     for (int i = tid; i < MlpGeom::IMG_FLOATS / 4; i += nthreads) dst[i] = src[i];
 }
 
+
+// ====================================================================================================================
+// Register-resident, wave-split variant used by the fused self-play kernel.
+//
+// At 16 trees per CU there is exactly ONE 16-position tile per explore, so a single-wave evaluation (476 dependent-ish
+// MFMAs, ~20k cycles) leaves three of the CU's four matrix pipes idle while everybody waits. Here the four waves of a
+// workgroup split every layer by 16-unit output blocks and exchange activations through a 14 KB LDS buffer:
+//     layer   blocks   wave 0   wave 1   wave 2   wave 3      MFMAs on the critical path
+//     L1        8      0,4      1,5      2,6      3,7         32
+//     L2        6      0,4      1,5      2        3           64
+//     L3        4      0        1        2        3           24
+//     L4        3      -        0        1        2           16
+//     L5        1      0        -        -        -           12      = 148 instead of 476
+// Because an f32 MFMA's A operand is ONE VGPR per k-step, a wave's share of the network is at most 148 registers: the
+// weights are loaded once per kernel and then live in VGPRs — no LDS weight image, no per-MFMA ds_read, and the LDS
+// budget drops from 123 KB to ~16 KB (which also lets two workgroups share a CU).
+// The exchange keeps the fragment trick of the single-wave path: with the permuted unit order a lane's four D registers
+// of block ob are exactly the B operands of the next layer's steps 4*ob..4*ob+3 on the SAME lane, so a lane writes one
+// 16-byte record ex[ob][lane] and reads ex[s4][lane] back — lane-linear, conflict-free, no transposition.
+// Accumulation order per output is unchanged (ascending k, bias first), so results stay bit-identical to mlp_tile16.
+struct MlpSplitWeights {
+    f32x4 w1[2][4];   // [slot][s4]
+    f32x4 w2[2][8];
+    f32x4 w3[6];
+    f32x4 w4[4];
+    f32x4 w5[3];
+};
+
+SYN_DEV f32x4 ldg_f32x4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// mw = wave index inside the workgroup (0..3)
+SYN_DEV void mlp_split_load_weights(const float* __restrict__ g_img, int mw, int lane, MlpSplitWeights& W) {
+    const float* base = g_img + lane * 4;
+#pragma unroll
+    for (int slot = 0; slot < 2; slot++)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++)
+            W.w1[slot][s4] = ldg_f32x4(base + MlpGeom::W_OFF[0] + (s4 * 8 + (mw + 4 * slot)) * 256);
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+        W.w2[0][s4] = ldg_f32x4(base + MlpGeom::W_OFF[1] + (s4 * 6 + mw) * 256);
+        W.w2[1][s4] = ldg_f32x4(base + MlpGeom::W_OFF[1] + (s4 * 6 + (mw < 2 ? 4 + mw : mw)) * 256);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 6; s4++) W.w3[s4] = ldg_f32x4(base + MlpGeom::W_OFF[2] + (s4 * 4 + mw) * 256);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) W.w4[s4] = ldg_f32x4(base + MlpGeom::W_OFF[3] + (s4 * 3 + (mw > 0 ? mw - 1 : 0)) * 256);
+#pragma unroll
+    for (int s4 = 0; s4 < 3; s4++) W.w5[s4] = ldg_f32x4(base + MlpGeom::W_OFF[4] + s4 * 256);
+}
+
+SYN_DEV f32x4 relu4(f32x4 v) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.0f);
+    return v;
+}
+
+// One 16-position tile, evaluated cooperatively by the 4 waves of the workgroup. `exA`/`exB`: LDS exchange buffers of
+// 8 KB and 6 KB (f32x4 per [block][lane]); `bimg`: bias image in LDS (MlpGeom::B_FLOATS floats).
+// Contains 4 workgroup barriers; must be called by all 256 threads. Returns the last layer's D registers on wave 0
+// (lane (j,q) register r = raw output 4*q + r of position j); other waves return zeros.
+SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict__ bimg, f32x4* exA, f32x4* exB,
+                               int mw, int lane, uint64_t my, uint64_t op) {
+    const int q = lane >> 4;
+    const uint64_t nextfree = c4::next_free_cells(my | op);
+    auto bias = [&](int layer, int ob) {
+        return *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[layer] + (ob * 4 + q) * 4);
+    };
+    // ---- L1: blocks mw and mw+4, B = features
+    {
+        f32x4 a0 = bias(0, mw), a1 = bias(0, mw + 4);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            f32x4 b;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int f = 16 * s4 + 4 * r + q;
+                b[r] = f < 63 ? c4::feature(my, op, nextfree, f) : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[0][s4][r], b[r], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[1][s4][r], b[r], a1, 0, 0, 0);
+            }
+        }
+        exA[mw * 64 + lane] = relu4(a0);
+        exA[(mw + 4) * 64 + lane] = relu4(a1);
+    }
+    __syncthreads();
+    // ---- L2: block mw (all waves) and block 4+mw (waves 0,1); B = exA[0..7]
+    {
+        const bool two = mw < 2;
+        f32x4 a0 = bias(1, mw), a1 = bias(1, two ? 4 + mw : mw);
+#pragma unroll
+        for (int s4 = 0; s4 < 8; s4++) {
+            f32x4 b = exA[s4 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[0][s4][r], b[r], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w2[1][s4][r], b[r], a1, 0, 0, 0);
+            }
+        }
+        exB[mw * 64 + lane] = relu4(a0);
+        if (two) exB[(4 + mw) * 64 + lane] = relu4(a1);
+    }
+    __syncthreads();
+    // ---- L3: block mw; B = exB[0..5]
+    {
+        f32x4 a0 = bias(2, mw);
+#pragma unroll
+        for (int s4 = 0; s4 < 6; s4++) {
+            f32x4 b = exB[s4 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w3[s4][r], b[r], a0, 0, 0, 0);
+        }
+        exA[mw * 64 + lane] = relu4(a0);
+    }
+    __syncthreads();
+    // ---- L4: waves 1..3 compute block mw-1; B = exA[0..3]
+    if (mw > 0) {
+        f32x4 a0 = bias(3, mw - 1);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            f32x4 b = exA[s4 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w4[s4][r], b[r], a0, 0, 0, 0);
+        }
+        exB[(mw - 1) * 64 + lane] = relu4(a0);
+    }
+    __syncthreads();
+    // ---- L5: wave 0; B = exB[0..2]
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (mw == 0) {
+        out = bias(4, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 3; s4++) {
+            f32x4 b = exB[s4 * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; r++) out = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w5[s4][r], b[r], out, 0, 0, 0);
+        }
+    }
+    return out;
+}
+
 }  // namespace syn
