@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
     // this wave's share of the network -> registers, for the lifetime of the kernel
     MlpSplitWeights W;
     mlp_split_load_weights(P.wimg, wave, lane, W);
+    const FeatureTable FT = make_feature_table(lane >> 4);
     for (int i = tid; i < MlpGeom::B_FLOATS; i += NT) bimg[i] = P.wimg[MlpGeom::W_FLOATS + i];
     if (tid < 2) evalflag[tid] = 0;
 
@@ -400,8 +401,9 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
             tree_select_expand<COUNT>(P.mcts, T, X, gl, ctr);
             if (X.needs_eval) {
                 if (gl == 0) {
-                    leafbuf[t] = make_uint4((uint32_t)X.leaf_my, (uint32_t)(X.leaf_my >> 32), (uint32_t)X.leaf_op,
-                                            (uint32_t)(X.leaf_op >> 32));
+                    uint64_t hi, lo;  // the two derived boards layer 1 reads (mlp.cuh: feature_boards)
+                    feature_boards(X.leaf_my, X.leaf_op, hi, lo);
+                    leafbuf[t] = make_uint4((uint32_t)hi, (uint32_t)(hi >> 32), (uint32_t)lo, (uint32_t)(lo >> 32));
                     evalflag[it & 1] = 1;
                 }
                 if (COUNT) ctr[CTR_POLICY_EVALS]++;
@@ -416,8 +418,8 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
         if (evalflag[it & 1]) {
             const int j = lane & 15, q = lane >> 4;
             uint4 b = leafbuf[j];
-            uint64_t my = (uint64_t)b.x | ((uint64_t)b.y << 32), op = (uint64_t)b.z | ((uint64_t)b.w << 32);
-            f32x4 o = mlp_split_tile16(W, bimg, exA, exB, wave, lane, my, op);
+            uint64_t hi = (uint64_t)b.x | ((uint64_t)b.y << 32), lo = (uint64_t)b.z | ((uint64_t)b.w << 32);
+            f32x4 o = mlp_split_tile16(W, bimg, exA, exB, wave, lane, FT, hi, lo);
             if (wave == 0) {
                 if (q == 2) {
                     float v0 = o[1], v1 = o[2], v2 = o[3];
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(NT) void policy_eval_kernel(const float* __restrict
     const float* bimg = smem + MlpGeom::W_FLOATS;
     const int ntiles = (n + 15) >> 4;
     const int j = lane & 15, q = lane >> 4;
+    const FeatureTable FT = make_feature_table(q);
     for (int tile = blockIdx.x * (NT / 64) + wave; tile < ntiles; tile += gridDim.x * (NT / 64)) {
         // the weight fragments do not depend on the tile: make the LDS base opaque per iteration so their ~500 reads
         // stay next to the MFMAs that consume them instead of being hoisted out of the loop into spilled registers
@@ -497,7 +500,9 @@ __global__ __launch_bounds__(NT) void policy_eval_kernel(const float* __restrict
         int pos = tile * 16 + j;
         bool valid = pos < n;
         uint64_t my = valid ? my_bb[pos] : 0ull, op = valid ? op_bb[pos] : 0ull;
-        f32x4 o = mlp_tile16(wimg, bimg, lane, my, op);
+        uint64_t hi, lo;
+        feature_boards(my, op, hi, lo);
+        f32x4 o = mlp_tile16(wimg, bimg, lane, FT, hi, lo);
         if (valid) {
             if (q < 2) {
 #pragma unroll

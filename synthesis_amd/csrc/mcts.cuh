@@ -168,79 +168,16 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
         }
     }
 
+    // ---- descent (mcts.rs:310-341). The loop body is ONLY the child scan: the four trees of a wave run it in
+    // lockstep and a tree that has reached its leaf just idles (exec-masked) until the deepest one is done, so the
+    // long expansion code below is executed once per wave instead of once per tree.
+    bool hit_solved = false;
     for (;;) {
-        if (meta_some(meta)) {
-            // explore(): node already solved -> backprop its one-hot outcome (mcts.rs:314-316)
-            uint32_t k = meta_kind(meta);
-            X.p0 = k == 0u ? 1.0f : 0.0f;
-            X.p1 = k == 1u ? 1.0f : 0.0f;
-            X.p2 = k == 2u ? 1.0f : 0.0f;
-            X.solved = true;
-            if (COUNT) ctr[CTR_SOLVED_HITS]++;
-            break;
-        }
+        if (meta_some(meta)) { hit_solved = true; break; }
         uint32_t nc = meta_nc(meta);
-        if (nc == 0) {
-            // visit(): expansion, possibly repeated by auto-extend (mcts.rs:374-406)
-            for (;;) {
-                uint64_t occ = my | op;
-                int h = c4::col_height(occ, gl < 9 ? gl : 0);
-                bool legal = gl < 9 && h < c4::HEIGHT;
-                uint32_t lmask = row_ballot(legal);
-                uint32_t n_new = (uint32_t)__popc(lmask);
-                uint32_t idx = (uint32_t)__popc(lmask & ((1u << gl) - 1u));
-                uint32_t first = T.next_node;
-                T.next_node += n_new;
-                uint64_t bit = 1ull << (h + 7 * (gl < 9 ? gl : 0));
-                uint64_t cop = my | bit;  // child.op_bb = the mover's stones (connect4.rs:224-229)
-                bool w = c4::won(cop);
-                bool full = (occ | bit) == c4::FULL;
-                bool over = legal && (w || full);
-                // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost
-                uint32_t cmeta = meta_make(0, (uint32_t)gl, over, w ? 0u : 1u, 0u);
-                if (legal) {
-                    T.stat[first + idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    T.edge[first + idx] = make_uint4(0u, cmeta, f32_bits(1.0f), node);
-                }
-                bool any_solved = row_ballot(over) != 0u;
-                meta = (meta & ~META_NC_MASK) | n_new;
-                if (gl == 0) *reinterpret_cast<uint2*>(&T.edge[node]) = make_uint2(first, meta);
-                if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
-                if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
+        if (nc == 0) break;
 
-                if (cfg.auto_extend && n_new == 1u) {
-                    // recurse into the only child without calling the policy (mcts.rs:404-405)
-                    int a = __ffs((int)lmask) - 1;
-                    int ha = c4::col_height(occ, a);
-                    uint64_t abit = 1ull << (ha + 7 * a);
-                    uint64_t nmy = op, nop = my | abit;
-                    bool aw = c4::won(nop);
-                    bool afull = (occ | abit) == c4::FULL;
-                    node = first;
-                    depth++;
-                    path_set(X, gl, depth, node);
-                    my = nmy;
-                    op = nop;
-                    meta = meta_make(0, (uint32_t)a, aw || afull, aw ? 0u : 1u, 0u);
-                    if (aw || afull) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
-                        X.p0 = aw ? 1.0f : 0.0f;
-                        X.p1 = aw ? 0.0f : 1.0f;
-                        X.p2 = 0.0f;
-                        X.solved = true;
-                        break;
-                    }
-                    continue;
-                }
-                X.needs_eval = true;
-                X.solved = any_solved;
-                X.fc = first;
-                X.legal_mask = lmask;
-                break;
-            }
-            break;
-        }
-
-        // select_best_child (mcts.rs:327-341): lane i scores child i
+        // select_best_child: lane i scores child i
         bool active = (uint32_t)gl < nc;
         uint32_t cid = fc + (active ? (uint32_t)gl : 0u);
         float4 cs = T.stat[cid];
@@ -287,6 +224,73 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
         pN = row_bcast_f32(cs.x, best);
         pW0 = row_bcast_f32(cs.y, best);
         pW2 = row_bcast_f32(cs.w, best);
+    }
+
+    if (hit_solved) {
+        // explore(): node already solved -> backprop its one-hot outcome (mcts.rs:314-316)
+        uint32_t k = meta_kind(meta);
+        X.p0 = k == 0u ? 1.0f : 0.0f;
+        X.p1 = k == 1u ? 1.0f : 0.0f;
+        X.p2 = k == 2u ? 1.0f : 0.0f;
+        X.solved = true;
+        if (COUNT) ctr[CTR_SOLVED_HITS]++;
+    } else {
+        // visit(): expansion, possibly repeated by auto-extend (mcts.rs:374-406)
+        for (;;) {
+            uint64_t occ = my | op;
+            int h = c4::col_height(occ, gl < 9 ? gl : 0);
+            bool legal = gl < 9 && h < c4::HEIGHT;
+            uint32_t lmask = row_ballot(legal);
+            uint32_t n_new = (uint32_t)__popc(lmask);
+            uint32_t idx = (uint32_t)__popc(lmask & ((1u << gl) - 1u));
+            uint32_t first = T.next_node;
+            T.next_node += n_new;
+            uint64_t bit = 1ull << (h + 7 * (gl < 9 ? gl : 0));
+            uint64_t cop = my | bit;  // child.op_bb = the mover's stones (connect4.rs:224-229)
+            bool w = c4::won(cop);
+            bool full = (occ | bit) == c4::FULL;
+            bool over = legal && (w || full);
+            // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost
+            uint32_t cmeta = meta_make(0, (uint32_t)gl, over, w ? 0u : 1u, 0u);
+            if (legal) {
+                T.stat[first + idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+                T.edge[first + idx] = make_uint4(0u, cmeta, f32_bits(1.0f), node);
+            }
+            bool any_solved = row_ballot(over) != 0u;
+            meta = (meta & ~META_NC_MASK) | n_new;
+            if (gl == 0) *reinterpret_cast<uint2*>(&T.edge[node]) = make_uint2(first, meta);
+            if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
+            if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
+
+            if (cfg.auto_extend && n_new == 1u) {
+                // recurse into the only child without calling the policy (mcts.rs:404-405)
+                int a = __ffs((int)lmask) - 1;
+                int ha = c4::col_height(occ, a);
+                uint64_t abit = 1ull << (ha + 7 * a);
+                uint64_t nmy = op, nop = my | abit;
+                bool aw = c4::won(nop);
+                bool afull = (occ | abit) == c4::FULL;
+                node = first;
+                depth++;
+                path_set(X, gl, depth, node);
+                my = nmy;
+                op = nop;
+                meta = meta_make(0, (uint32_t)a, aw || afull, aw ? 0u : 1u, 0u);
+                if (aw || afull) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
+                    X.p0 = aw ? 1.0f : 0.0f;
+                    X.p1 = aw ? 0.0f : 1.0f;
+                    X.p2 = 0.0f;
+                    X.solved = true;
+                    break;
+                }
+                continue;
+            }
+            X.needs_eval = true;
+            X.solved = any_solved;
+            X.fc = first;
+            X.legal_mask = lmask;
+            break;
+        }
     }
     X.depth = depth;
     X.leaf = node;

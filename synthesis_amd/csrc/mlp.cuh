@@ -41,6 +41,49 @@ __host__ __device__ inline int mlp_unit_of_row(int layer, int ob, int i) {
     return layer == MlpGeom::NL - 1 ? 16 * ob + i : 16 * ob + 4 * (i & 3) + (i >> 2);
 }
 
+// ---- layer-1 B operands straight from the bitboards ------------------------------------------------------------------
+// Lane (j,q) consumes features f = 4*m + q, m = 0..15 (k = 63 is padding: its weight column is zero, so any finite
+// value is fine). Cell values (connect4.rs:235-258) from two derived boards: hi = occupied, lo = mine | next-free:
+//   (hi,lo) = (1,1) mine +1.0 | (1,0) theirs -1.0 | (0,1) lowest empty cell +0.1 | (0,0) empty -0.1
+// i.e. magnitude = hi ? 1.0 : 0.1, sign = lo ? + : -. Per feature: two 64-bit shifts by a per-lane bit position taken
+// from a 16-entry table packed into 4 registers (built once per kernel), instead of ~25 instructions of div/mod/test.
+struct FeatureTable { uint32_t t[4]; };
+SYN_DEV FeatureTable make_feature_table(int q) {
+    FeatureTable T;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int f = 4 * (4 * w + b) + q;
+            int row = f / 9, col = f - 9 * row;
+            uint32_t pos = f < 63 ? (uint32_t)(row + 7 * col) : 63u;
+            packed |= pos << (8 * b);
+        }
+        T.t[w] = packed;
+    }
+    return T;
+}
+SYN_DEV void feature_boards(uint64_t my, uint64_t op, uint64_t& hi, uint64_t& lo) {
+    hi = my | op;
+    lo = my | c4::next_free_cells(hi);
+}
+template <int M>
+SYN_DEV float feature_from_boards(const FeatureTable& T, uint64_t hi, uint64_t lo) {
+    uint32_t pos = (T.t[M >> 2] >> (8 * (M & 3))) & 0xFFu;
+    uint32_t h = (uint32_t)(hi >> pos) & 1u, l = (uint32_t)(lo >> pos) & 1u;
+    return bits_f32((h ? 0x3F800000u : 0x3DCCCCCDu) | ((l ^ 1u) << 31));
+}
+template <int S4>
+SYN_DEV f32x4 feature_quad(const FeatureTable& T, uint64_t hi, uint64_t lo) {
+    f32x4 b;
+    b[0] = feature_from_boards<4 * S4 + 0>(T, hi, lo);
+    b[1] = feature_from_boards<4 * S4 + 1>(T, hi, lo);
+    b[2] = feature_from_boards<4 * S4 + 2>(T, hi, lo);
+    b[3] = feature_from_boards<4 * S4 + 3>(T, hi, lo);
+    return b;
+}
+
 // One layer: acc[ob] (NOB blocks) = bias; for every group of 4 k-steps: 4*NOB MFMAs, interleaved over the blocks
 // so consecutive MFMAs never depend on each other (dependent latency 40 cycles > 32-cycle issue).
 template <int LAYER, int NOB, int S4, class BOperand>
@@ -76,20 +119,13 @@ SYN_DEV void relu_inplace(f32x4 (&acc)[NOB]) {
 // Evaluates the network for the 16 positions of this wave's tile. Lane l = (j = l&15, q = l>>4) must pass the
 // bitboards of position j. Returns the last layer's D registers: lane (j,q) register r = raw output 4*q + r of
 // position j (outputs 0..8 = policy logits, 9..11 = outcome logits, 12..15 = padding).
-SYN_DEV f32x4 mlp_tile16(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane, uint64_t my,
-                         uint64_t op) {
-    const int q = lane >> 4;
-    const uint64_t nextfree = c4::next_free_cells(my | op);
-
+SYN_DEV f32x4 mlp_tile16(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane,
+                         const FeatureTable& FT, uint64_t hi, uint64_t lo) {
     f32x4 h1[8];
     mlp_layer<0, 8, 4>(wimg, bimg, lane, [&](int s4) {
-        f32x4 b;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int f = 16 * s4 + 4 * r + q;  // feature index consumed by this lane in step 4*s4 + r
-            b[r] = f < 63 ? c4::feature(my, op, nextfree, f) : 0.0f;
-        }
-        return b;
+        // s4 is a compile-time constant after unrolling; dispatch to the templated quad
+        return s4 == 0 ? feature_quad<0>(FT, hi, lo) : s4 == 1 ? feature_quad<1>(FT, hi, lo)
+             : s4 == 2 ? feature_quad<2>(FT, hi, lo) : feature_quad<3>(FT, hi, lo);
     }, h1);
     relu_inplace(h1);
 
@@ -195,27 +231,22 @@ SYN_DEV f32x4 relu4(f32x4 v) {
 // Contains 4 workgroup barriers; must be called by all 256 threads. Returns the last layer's D registers on wave 0
 // (lane (j,q) register r = raw output 4*q + r of position j); other waves return zeros.
 SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict__ bimg, f32x4* exA, f32x4* exB,
-                               int mw, int lane, uint64_t my, uint64_t op) {
+                               int mw, int lane, const FeatureTable& FT, uint64_t hi, uint64_t lo) {
     const int q = lane >> 4;
-    const uint64_t nextfree = c4::next_free_cells(my | op);
     auto bias = [&](int layer, int ob) {
         return *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[layer] + (ob * 4 + q) * 4);
     };
     // ---- L1: blocks mw and mw+4, B = features
     {
         f32x4 a0 = bias(0, mw), a1 = bias(0, mw + 4);
+        f32x4 bq[4] = {feature_quad<0>(FT, hi, lo), feature_quad<1>(FT, hi, lo), feature_quad<2>(FT, hi, lo),
+                       feature_quad<3>(FT, hi, lo)};
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
-            f32x4 b;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                int f = 16 * s4 + 4 * r + q;
-                b[r] = f < 63 ? c4::feature(my, op, nextfree, f) : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[0][s4][r], b[r], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[1][s4][r], b[r], a1, 0, 0, 0);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[0][s4][r], bq[s4][r], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w1[1][s4][r], bq[s4][r], a1, 0, 0, 0);
             }
         }
         exA[mw * 64 + lane] = relu4(a0);
