@@ -54,6 +54,20 @@ def algorithmic_bytes(c):
             + 8 * c["expansions"] + 40 * c["backprop_levels"] + 4 * c["solver_children"])
 
 
+def measured_traffic(args):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json,
+    produced by tools/collect_profiles.sh on this exact bench command); None if the run is not that configuration."""
+    import glob
+
+    if (args.concurrent, args.games_per_step, args.explores) != (4096, 16384, 800):
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline(blob, explores, sample_games, threads):
     from tests import oracle_lib
 
@@ -84,24 +98,16 @@ def main():
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 4 games per host thread")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-
     import torch  # device sync + (N > 1) the RCCL barrier / max-reduce; the engine itself does not use torch
-
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+                  # (import it BEFORE the engine library so the process holds one HIP runtime: torch's)
 
     import synthesis_amd as sa
+    from synthesis_amd import dist_util
+
+    rank, local_rank, world = dist_util.rank_info()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = dist_util.init_process_group("nccl", local_rank) if world > 1 else None
 
     blob = make_weights()
     eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
@@ -115,8 +121,8 @@ def main():
             dist.barrier()
 
     def step(i, **kw):
-        # global game index space: step i, rank r plays [ (i*world + r)*gps, +gps )
-        return eng.selfplay(cfg, base_seed=0, n_games=gps, first_game=(i * world + rank) * gps, outputs=False, **kw)
+        first, count = dist_util.step_game_range(i, rank, world, gps)
+        return eng.selfplay(cfg, base_seed=0, n_games=count, first_game=first, outputs=False, **kw)
 
     for i in range(args.warmup):
         step(i)
@@ -130,13 +136,7 @@ def main():
         plies += int(r["plies"].sum())
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        p = torch.tensor([plies], dtype=torch.int64, device=f"cuda:{local_rank}")
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        plies = int(p.item())
+    elapsed, (plies,) = dist_util.reduce_scalars(dist, f"cuda:{local_rank}", elapsed, [plies])
 
     # Event counts of exactly the games of the last timed step (trajectories are deterministic, so an instrumented
     # re-run outside the timed region gives the counts of the timed run).
@@ -159,6 +159,11 @@ def main():
         hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                "traffic": None, "algorithmic_bytes_per_explore": algorithmic_bytes(c) / max(1, c["explores"]),
                "kernel_ms_avg": avg_ms}
+        traffic, src = measured_traffic(args)
+        for rf in (mfma, hbm):
+            rf["traffic"] = traffic            # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, guide §HBM), PMC passes
+            rf["traffic_source"] = src
+        hbm["algorithmic_bytes_per_launch"] = algorithmic_bytes(c)
         near, other = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
         out = {
             "metric": "self-play games/sec, 9x7 Connect4", "value": games_per_s, "unit": "games/s",

@@ -1,0 +1,161 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol include/synthesis_amd.h declares (no compute calls
+without a GPU), struct layouts agree between the header, the ctypes mirrors and the device structs, host-side config
+mirrors carry the reference's values, and the N>1 sharding / reduce plumbing works under gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_text():
+    return open(os.path.join(ROOT, "include", "synthesis_amd.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    from synthesis_amd.engine import ABI_SYMBOLS, load_library
+
+    declared = set(re.findall(r"\b(syn_[a-z0-9_]+)\s*\(", header_text()))
+    declared -= {"syn_status"}
+    assert declared == set(ABI_SYMBOLS), declared ^ set(ABI_SYMBOLS)
+    lib = load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    # exported with C linkage from the in-tree .so (what the reference-side FFI would bind)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "synthesis_amd", "libsynthesis_amd.so")]).decode()
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), name
+
+
+def test_struct_layouts_match_header():
+    from synthesis_amd.config import CEngineConfig, CMctsConfig, CRolloutConfig
+    from synthesis_amd.engine import CCounters, CSearchResult
+
+    h = header_text()
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), h, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [m.group(1) for m in re.finditer(r"\b([a-z_A-Z0-9]+)(?:\[\d+\])*;", body)]
+
+    assert fields("syn_mcts_config") == [f[0] for f in CMctsConfig._fields_]
+    assert fields("syn_rollout_config") == [f[0] for f in CRolloutConfig._fields_]
+    assert fields("syn_engine_config") == [f[0] for f in CEngineConfig._fields_]
+    assert fields("syn_search_result") == [f[0] for f in CSearchResult._fields_]
+    assert fields("syn_counters") == [f[0] for f in CCounters._fields_]
+    assert C.sizeof(CMctsConfig) == 44 and C.sizeof(CRolloutConfig) == 36 + 44
+    assert C.sizeof(CSearchResult) == 4 * (9 + 27 + 9 + 27 + 1 + 3 + 3 + 1 + 1 + 9 + 3)
+    assert C.sizeof(CCounters) == 96
+
+
+def test_default_config_is_the_reference_parity_config():
+    """syn_default_rollout_config == study-connect4/src/main.rs:28-36 + policy_mcts_cfg (58-66), explores per BASELINE."""
+    import synthesis_amd as sa
+    from synthesis_amd.config import CRolloutConfig
+    from synthesis_amd.engine import load_library
+
+    c = CRolloutConfig()
+    load_library().syn_default_rollout_config(C.byref(c))
+    p = sa.parity_rollout_config().to_c()
+    for name, _ in CRolloutConfig._fields_:
+        if name == "mcts_cfg":
+            for n2, _ in type(c.mcts_cfg)._fields_:
+                assert getattr(c.mcts_cfg, n2) == getattr(p.mcts_cfg, n2), n2
+        else:
+            assert getattr(c, name) == getattr(p, name), name
+    assert (c.num_explores, c.random_actions_until, c.sample_actions_until, c.stop_games_when_solved) == (800, 1, 30, 0)
+    assert c.value_target == sa.ValueTarget.Q and c.action == sa.ActionSelection.NumVisits
+    m = c.mcts_cfg
+    assert (m.exploration, m.c, m.solve, m.correct_values_on_solve, m.select_solved_nodes, m.auto_extend, m.fpu,
+            m.fpu_value, m.root_policy_noise) == (1, 3.0, 1, 1, 1, 1, 0, 1.0, 0)
+
+
+def test_engine_create_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without an MI355X, creating an engine raises with SYN_ERR_NO_DEVICE."""
+    import torch
+
+    import synthesis_amd as sa
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        sa.Engine(concurrent_games=16, max_explores=8)
+    assert e.value.code == -2
+
+
+def test_weight_image_is_a_permutation_of_the_blob():
+    """Host logic: the fragment-order weight image (engine.hip build_weight_image) must contain every parameter exactly
+    once at the position the MFMA lane map expects. Rebuilt here in numpy from the documented formula and checked for
+    consistency properties (the device result itself is covered by the GPU parity tests)."""
+    dims = [63, 128, 96, 64, 48, 12]
+    S4 = [4, 8, 6, 4, 3]; NOB = [8, 6, 4, 3, 1]
+    total = 0
+    for l in range(5):
+        K, O = dims[l], dims[l + 1]
+        seen = np.zeros((O, K), np.int32)
+        for s4 in range(S4[l]):
+            for ob in range(NOB[l]):
+                for lane in range(64):
+                    for r in range(4):
+                        i, q = lane & 15, lane >> 4
+                        unit = 16 * ob + i if l == 4 else 16 * ob + 4 * (i & 3) + (i >> 2)
+                        k = 16 * s4 + 4 * r + q
+                        if unit < O and k < K:
+                            seen[unit, k] += 1
+        assert np.all(seen == 1), l
+        total += S4[l] * NOB[l] * 256
+    assert total == 30464
+    # unit permutation is a bijection on each 16-block: D register r of lane-quad q holds unit 16*ob + 4*r + q
+    assert sorted(4 * (i & 3) + (i >> 2) for i in range(16)) == list(range(16))
+
+
+def test_shard_and_step_ranges_cover_every_game_once():
+    from synthesis_amd import dist_util, shard_games
+
+    for world in (1, 2, 4, 8):
+        seen = []
+        for step in range(3):
+            for rank in range(world):
+                first, count = dist_util.step_game_range(step, rank, world, 1000)
+                seen += list(range(first, first + count))
+        assert sorted(seen) == list(range(3 * world * 1000))
+        for n in (0, 1, 7, 4096, 4099):
+            parts = [shard_games(n, r, world) for r in range(world)]
+            cover = [g for f, c in parts for g in range(f, f + c)]
+            assert cover == list(range(n))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from synthesis_amd import dist_util
+rank, local_rank, world = dist_util.rank_info()
+dist = dist_util.init_process_group("gloo")
+first, count = dist_util.step_game_range(2, rank, world, 500)
+elapsed, (games, lo) = dist_util.reduce_scalars(dist, "cpu", 1.0 + rank, [count, first])
+dist.barrier()
+if rank == 0:
+    print("RESULT", elapsed, games, lo)
+dist.destroy_process_group()
+'''
+
+
+def test_multi_rank_reduce_under_gloo(tmp_path):
+    """The N>1 path of bench.py (barrier, MAX of elapsed, SUM of counters) with world_size 2 on CPU (gloo)."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", "29533", str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
+    line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) == 2.0          # MAX over ranks of (1.0, 2.0)
+    assert int(line[2]) == 1000           # SUM of per-rank game counts
+    assert int(line[3]) == (2 * 2 + 0) * 500 + (2 * 2 + 1) * 500  # SUM of the two shard offsets
