@@ -79,21 +79,26 @@ SYN_DEV float row_max_f32(float v) {
 
 // Argmax with "first index wins ties": returns the winning index on every lane of the row.
 // Caller guarantees no NaN in v (see select: NaN is pre-mapped to the sequential-scan semantics).
+// (value, index) is packed into one 64-bit key — order-preserving image of the float in the high word, 255 - index
+// in the low word — so each butterfly step is two DPP moves, one 64-bit compare and two selects, no branches.
 SYN_DEV int row_argmax_first(float v, int idx) {
-#define SYN_ARGMAX_STEP(CTRL)                                              \
-    {                                                                      \
-        float ov = dpp_f32<CTRL>(v);                                       \
-        int oi = (int)dpp_u32<CTRL>((uint32_t)idx);                        \
-        bool take = (ov > v) || (ov == v && oi < idx);                     \
-        v = take ? ov : v;                                                 \
-        idx = take ? oi : idx;                                             \
+    v = v + 0.0f;  // -0.0 -> +0.0 so the integer image orders exactly like the float compare
+    uint32_t u = f32_bits(v);
+    u ^= (uint32_t)((int32_t)u >> 31) | 0x80000000u;
+    uint32_t lo = (uint32_t)(255 - idx);
+#define SYN_ARGMAX_STEP(CTRL)                                                        \
+    {                                                                                \
+        uint32_t ou = dpp_u32<CTRL>(u), ol = dpp_u32<CTRL>(lo);                      \
+        bool take = (((uint64_t)ou << 32) | ol) > (((uint64_t)u << 32) | lo);        \
+        u = take ? ou : u;                                                           \
+        lo = take ? ol : lo;                                                         \
     }
     SYN_ARGMAX_STEP(DPP_XOR1)
     SYN_ARGMAX_STEP(DPP_XOR2)
     SYN_ARGMAX_STEP(DPP_HALF_MIRROR)
     SYN_ARGMAX_STEP(DPP_MIRROR)
 #undef SYN_ARGMAX_STEP
-    return idx;
+    return 255 - (int)lo;
 }
 
 // value of lane `src` (0..15) of this lane's row

@@ -147,13 +147,19 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     if (jobs < want_slots) want_slots = ((jobs + 15) / 16) * 16;
     int grid = want_slots / 16;
     if (grid < 1) grid = 1;
-    if (grid <= h->num_cus) {
-        auto k = selfplay_kernel<MODE, COUNT, 1, PROF>;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), EngineLds::BYTES, h->stream, P);
-    } else {
-        auto k = selfplay_kernel<MODE, COUNT, 2, PROF>;
-        hipLaunchKernelGGL(k, dim3(grid), dim3(256), EngineLds::BYTES, h->stream, P);
+    const bool fast = cfg_is_fast(P.mcts);  // compile-time-folded config family (mcts.cuh CfgView)
+#define SYN_LAUNCH(WPS, FAST)                                                                                      \
+    {                                                                                                              \
+        auto k = selfplay_kernel<MODE, COUNT, WPS, FAST, PROF>;                                                    \
+        size_t lds = WPS == 1 ? EngineLds::BYTES_WPS1 : EngineLds::BYTES_WPS2;                                     \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->stream, P);                                           \
     }
+    if (grid <= h->num_cus) {
+        if (fast) SYN_LAUNCH(1, true) else SYN_LAUNCH(1, false)
+    } else {
+        if (fast) SYN_LAUNCH(2, true) else SYN_LAUNCH(2, false)
+    }
+#undef SYN_LAUNCH
     if (out_grid) *out_grid = grid;
     if (out_nt) *out_nt = 256;
     return hipGetLastError();

@@ -347,13 +347,16 @@ struct EngineLds {
     static constexpr size_t LEAF_OFF = EXB_OFF + 6 * 64 * 16;
     static constexpr size_t OUT_OFF = LEAF_OFF + TPW * 16;
     static constexpr size_t FLAG_OFF = OUT_OFF + TPW * 64;
-    static constexpr size_t BYTES = FLAG_OFF + 16;
+    static constexpr size_t W345_OFF = FLAG_OFF + 16;
+    static constexpr size_t W345_FLOATS = MlpGeom::W_FLOATS - MlpGeom::W_OFF[2];  // layers 3-5: 9,984 floats
+    static constexpr size_t BYTES_WPS1 = W345_OFF;                                // all weights in registers
+    static constexpr size_t BYTES_WPS2 = W345_OFF + W345_FLOATS * 4;              // + 39,936 B
 };
 
 // One workgroup = 256 threads = 4 waves = 16 trees (one per DPP row) = one 16-position MFMA tile.
 // WPS = waves per SIMD the register allocation must allow: 1 -> up to 512 VGPRs, one workgroup (16 trees) per CU;
 // 2 -> at most 256 VGPRs so two workgroups (32 trees) share a CU.
-template <int MODE, bool COUNT, int WPS, bool PROF = false>
+template <int MODE, bool COUNT, int WPS, bool FAST, bool PROF = false>
 __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 256;
@@ -371,8 +374,15 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
     const int t = tid >> 4;  // tree (row) index inside the workgroup
 
     // this wave's share of the network -> registers, for the lifetime of the kernel
+    constexpr bool W345_LDS = WPS >= 2;
+    const float* w345 = reinterpret_cast<const float*>(smem_raw + EngineLds::W345_OFF);
     MlpSplitWeights W;
-    mlp_split_load_weights(P.wimg, wave, lane, W);
+    mlp_split_load_weights<W345_LDS>(P.wimg, wave, lane, W);
+    if (W345_LDS) {
+        f32x4* dst = reinterpret_cast<f32x4*>(smem_raw + EngineLds::W345_OFF);
+        const f32x4* src = reinterpret_cast<const f32x4*>(P.wimg + MlpGeom::W_OFF[2]);
+        for (int i = tid; i < (int)(EngineLds::W345_FLOATS / 4); i += NT) dst[i] = src[i];
+    }
     const FeatureTable FT = make_feature_table(lane >> 4);
     for (int i = tid; i < MlpGeom::B_FLOATS; i += NT) bimg[i] = P.wimg[MlpGeom::W_FLOATS + i];
     if (tid < 2) evalflag[tid] = 0;
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
         const bool active = G.job >= 0;
         ExploreCtx X = {};
         if (active) {
-            tree_select_expand<COUNT>(P.mcts, T, X, gl, ctr);
+            tree_select_expand<COUNT, FAST>(P.mcts, T, X, gl, ctr);
             if (X.needs_eval) {
                 if (gl == 0) {
                     uint64_t hi, lo;  // the two derived boards layer 1 reads (mlp.cuh: feature_boards)
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
             const int j = lane & 15, q = lane >> 4;
             uint4 b = leafbuf[j];
             uint64_t hi = (uint64_t)b.x | ((uint64_t)b.y << 32), lo = (uint64_t)b.z | ((uint64_t)b.w << 32);
-            f32x4 o = mlp_split_tile16(W, bimg, exA, exB, wave, lane, FT, hi, lo);
+            f32x4 o = mlp_split_tile16<W345_LDS>(W, bimg, w345, exA, exB, wave, lane, FT, hi, lo);
             if (wave == 0) {
                 if (q == 2) {
                     float v0 = o[1], v1 = o[2], v2 = o[3];
@@ -448,7 +458,7 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
                 d1 = ov[2];
                 d2 = ov[3];
             }
-            tree_backprop<COUNT>(P.mcts, T, X, gl, d0, d1, d2, X.solved, ctr);
+            tree_backprop<COUNT, FAST>(P.mcts, T, X, gl, d0, d1, d2, X.solved, ctr);
             T.iter += 1;
             // explore_n (mcts.rs:139-147): the root visit, then up to n explores unless the root is solved
             if (T.iter > n_explores || T.root_solved) {

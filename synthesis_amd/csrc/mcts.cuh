@@ -44,6 +44,25 @@ struct DevRolloutCfg {
     int action;  // 0 Q, 1 NumVisits
 };
 
+// Compile-time view of the MCTS config. FAST = the reference's own configuration family (PolynomialUct, Fpu::Const,
+// solver + value correction + select_solved_nodes + auto_extend, study-connect4/src/main.rs:37-66): every switch folds
+// away and only `c` and `fpu_value` stay runtime. The generic view serves every other combination with the same code.
+template <bool FAST>
+struct CfgView {
+    const DevMctsCfg& c;
+    SYN_DEV bool puct() const { return FAST ? true : c.exploration == 1; }
+    SYN_DEV bool fpu_const() const { return FAST ? true : c.fpu == 0; }
+    SYN_DEV bool select_solved() const { return FAST ? true : c.select_solved != 0; }
+    SYN_DEV bool solve() const { return FAST ? true : c.solve != 0; }
+    SYN_DEV bool correct_values() const { return FAST ? true : c.correct_values != 0; }
+    SYN_DEV bool auto_extend() const { return FAST ? true : c.auto_extend != 0; }
+    SYN_DEV float cc() const { return c.c; }
+    SYN_DEV float fpu_value() const { return c.fpu_value; }
+};
+inline bool cfg_is_fast(const DevMctsCfg& c) {
+    return c.exploration == 1 && c.fpu == 0 && c.select_solved && c.solve && c.correct_values && c.auto_extend;
+}
+
 struct DevCounters {  // index order = syn_counters
     unsigned long long v[12];
 };
@@ -130,8 +149,9 @@ SYN_DEV uint32_t path_get(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, in
 
 // ---------------------------------------------------------------------------------------------- phase A
 // explore() up to the point where the policy is needed: descend by PUCT, expand, auto-extend.  (mcts.rs:310-427)
-template <bool COUNT>
-SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X, int gl, uint32_t* ctr) {
+template <bool COUNT, bool FAST>
+SYN_DEV void tree_select_expand(const DevMctsCfg& cfg_, TreeCtx& T, ExploreCtx& X, int gl, uint32_t* ctr) {
+    const CfgView<FAST> cfg{cfg_};
     uint32_t node = 0;
     int depth = 0;
     X.path0 = X.path1 = X.path2 = X.path3 = 0;
@@ -161,7 +181,7 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
         meta = T.root_nc;
         pN = (float)T.iter;
         pW0 = pW2 = 0.0f;
-        if (cfg.fpu == 1) {  // Fpu::ParentQ needs the root's W as well
+        if (!cfg.fpu_const()) {  // Fpu::ParentQ needs the root's W as well
             float4 s = T.stat[0];
             pW0 = s.y;
             pW2 = s.w;
@@ -177,28 +197,26 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
         uint32_t nc = meta_nc(meta);
         if (nc == 0) break;
 
-        // select_best_child: lane i scores child i
+        // select_best_child: lane i scores child i (branch-free: every lane evaluates all three exploit forms)
         bool active = (uint32_t)gl < nc;
         uint32_t cid = fc + (active ? (uint32_t)gl : 0u);
         float4 cs = T.stat[cid];
         uint4 ce = T.edge[cid];
-        float q;
-        if (meta_some(ce.y)) {
-            // outcome.reversed().value(): child Win -> -1, Draw -> 0, Lose -> +1 (game.rs:29-43)
-            uint32_t k = meta_kind(ce.y);
-            float rv = k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f);
-            q = cfg.select_solved ? rv : -__builtin_inff();
-        } else if (meta_nc(ce.y) == 0u) {
-            q = cfg.fpu == 0 ? cfg.fpu_value : (pW2 - pW0) / pN;
-        } else {
-            q = -((cs.w - cs.y) / cs.x);
-        }
+        // exploit_value (mcts.rs:343-359)
+        float q_visited = -((cs.w - cs.y) / cs.x);
+        float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : (pW2 - pW0) / pN;
+        uint32_t k = meta_kind(ce.y);
+        // outcome.reversed().value(): child Win -> -1, Draw -> 0, Lose -> +1 (game.rs:29-43)
+        float q_solved = cfg.select_solved() ? (k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
+        float q = meta_nc(ce.y) == 0u ? q_fpu : q_visited;
+        q = meta_some(ce.y) ? q_solved : q;
+        // explore_value (mcts.rs:361-372)
         float u;
-        if (cfg.exploration == 1) {
+        if (cfg.puct()) {
             float visits = sqrtf(pN);
-            u = cfg.c * bits_f32(ce.z) * visits / (1.0f + cs.x);
+            u = cfg.cc() * bits_f32(ce.z) * visits / (1.0f + cs.x);
         } else {
-            float visits = sqrtf(cfg.c * logf(pN));
+            float visits = sqrtf(cfg.cc() * logf(pN));
             u = visits / sqrtf(cs.x);
         }
         float v = q + u;
@@ -222,8 +240,10 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
         fc = row_bcast_u32(ce.x, best);
         meta = bmeta;
         pN = row_bcast_f32(cs.x, best);
-        pW0 = row_bcast_f32(cs.y, best);
-        pW2 = row_bcast_f32(cs.w, best);
+        if (!cfg.fpu_const()) {
+            pW0 = row_bcast_f32(cs.y, best);
+            pW2 = row_bcast_f32(cs.w, best);
+        }
     }
 
     if (hit_solved) {
@@ -262,7 +282,7 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg, TreeCtx& T, ExploreCtx& X
             if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
             if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
 
-            if (cfg.auto_extend && n_new == 1u) {
+            if (cfg.auto_extend() && n_new == 1u) {
                 // recurse into the only child without calling the policy (mcts.rs:404-405)
                 int a = __ffs((int)lmask) - 1;
                 int ha = c4::col_height(occ, a);
@@ -317,14 +337,15 @@ SYN_DEV void tree_write_priors(TreeCtx& T, const ExploreCtx& X, int gl, float lo
 }
 
 // backprop (mcts.rs:429-488). (d0,d1,d2) = outcome distribution from the leaf's point of view.
-template <bool COUNT>
-SYN_DEV void tree_backprop(const DevMctsCfg& cfg, TreeCtx& T, const ExploreCtx& X, int gl, float d0, float d1,
+template <bool COUNT, bool FAST>
+SYN_DEV void tree_backprop(const DevMctsCfg& cfg_, TreeCtx& T, const ExploreCtx& X, int gl, float d0, float d1,
                            float d2, bool solved, uint32_t* ctr) {
+    const CfgView<FAST> cfg{cfg_};
     int level = X.depth;
     const uint32_t xp0 = X.path0, xp1 = X.path1, xp2 = X.path2, xp3 = X.path3;
     if (COUNT) ctr[CTR_BACKPROP_LEVELS] += (uint32_t)(X.depth + 1);
     // --- solver walk: level by level while the subtree below is proven
-    while (cfg.solve && solved && level >= 0) {
+    while (cfg.solve() && solved && level >= 0) {
         uint32_t nd = path_get(xp0, xp1, xp2, xp3, level);
         uint4 e = T.edge[nd];
         float4 s = T.stat[nd];
@@ -341,7 +362,7 @@ SYN_DEV void tree_backprop(const DevMctsCfg& cfg, TreeCtx& T, const ExploreCtx& 
         outcome_from_key(key, bsome, bkind, bturns);
         if (bsome && bkind == 2u) {
             e.y = (e.y & 0xFFu) | (meta_make(0, 0, true, 2u, bturns) & ~0xFFu);
-            if (cfg.correct_values) {
+            if (cfg.correct_values()) {
                 d0 = -s.y;
                 d1 = -s.z;
                 d2 = -s.w;
@@ -349,7 +370,7 @@ SYN_DEV void tree_backprop(const DevMctsCfg& cfg, TreeCtx& T, const ExploreCtx& 
             }
         } else if (bsome && all_solved) {
             e.y = (e.y & 0xFFu) | (meta_make(0, 0, true, bkind, bturns) & ~0xFFu);
-            if (cfg.correct_values) {
+            if (cfg.correct_values()) {
                 d0 = -s.y;
                 d1 = -s.z;
                 d2 = -s.w;

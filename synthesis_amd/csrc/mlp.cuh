@@ -200,6 +200,7 @@ struct MlpSplitWeights {
 SYN_DEV f32x4 ldg_f32x4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // mw = wave index inside the workgroup (0..3)
+template <bool W345_LDS>
 SYN_DEV void mlp_split_load_weights(const float* __restrict__ g_img, int mw, int lane, MlpSplitWeights& W) {
     const float* base = g_img + lane * 4;
 #pragma unroll
@@ -212,6 +213,7 @@ SYN_DEV void mlp_split_load_weights(const float* __restrict__ g_img, int mw, int
         W.w2[0][s4] = ldg_f32x4(base + MlpGeom::W_OFF[1] + (s4 * 6 + mw) * 256);
         W.w2[1][s4] = ldg_f32x4(base + MlpGeom::W_OFF[1] + (s4 * 6 + (mw < 2 ? 4 + mw : mw)) * 256);
     }
+    if (W345_LDS) return;
 #pragma unroll
     for (int s4 = 0; s4 < 6; s4++) W.w3[s4] = ldg_f32x4(base + MlpGeom::W_OFF[2] + (s4 * 4 + mw) * 256);
 #pragma unroll
@@ -230,9 +232,20 @@ SYN_DEV f32x4 relu4(f32x4 v) {
 // 8 KB and 6 KB (f32x4 per [block][lane]); `bimg`: bias image in LDS (MlpGeom::B_FLOATS floats).
 // Contains 4 workgroup barriers; must be called by all 256 threads. Returns the last layer's D registers on wave 0
 // (lane (j,q) register r = raw output 4*q + r of position j); other waves return zeros.
-SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict__ bimg, f32x4* exA, f32x4* exB,
-                               int mw, int lane, const FeatureTable& FT, uint64_t hi, uint64_t lo) {
+//
+// W345_LDS: layers 3-5 take their A operands from an LDS copy of the weight image (`w345` = image floats starting at
+// MlpGeom::W_OFF[2]) instead of 52 registers. Those layers run one dependent accumulator chain per wave (40-cycle MFMA
+// latency), so a ds_read_b128 per 4 MFMAs hides completely; it brings the kernel under 256 VGPRs so that two
+// workgroups can share a CU.
+template <bool W345_LDS>
+SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict__ bimg, const float* __restrict__ w345,
+                               f32x4* exA, f32x4* exB, int mw, int lane, const FeatureTable& FT, uint64_t hi,
+                               uint64_t lo) {
     const int q = lane >> 4;
+    auto wlds = [&](int layer, int nob, int s4, int ob) {
+        return *reinterpret_cast<const f32x4*>(w345 + (MlpGeom::W_OFF[layer] - MlpGeom::W_OFF[2]) +
+                                               (s4 * nob + ob) * 256 + lane * 4);
+    };
     auto bias = [&](int layer, int ob) {
         return *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[layer] + (ob * 4 + q) * 4);
     };
@@ -276,8 +289,9 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
 #pragma unroll
         for (int s4 = 0; s4 < 6; s4++) {
             f32x4 b = exB[s4 * 64 + lane];
+            f32x4 w = W345_LDS ? wlds(2, 4, s4, mw) : W.w3[s4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w3[s4][r], b[r], a0, 0, 0, 0);
+            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], a0, 0, 0, 0);
         }
         exA[mw * 64 + lane] = relu4(a0);
     }
@@ -288,8 +302,9 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
             f32x4 b = exA[s4 * 64 + lane];
+            f32x4 w = W345_LDS ? wlds(3, 3, s4, mw - 1) : W.w4[s4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w4[s4][r], b[r], a0, 0, 0, 0);
+            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], a0, 0, 0, 0);
         }
         exB[(mw - 1) * 64 + lane] = relu4(a0);
     }
@@ -301,8 +316,9 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
 #pragma unroll
         for (int s4 = 0; s4 < 3; s4++) {
             f32x4 b = exB[s4 * 64 + lane];
+            f32x4 w = W345_LDS ? wlds(4, 1, s4, 0) : W.w5[s4];
 #pragma unroll
-            for (int r = 0; r < 4; r++) out = __builtin_amdgcn_mfma_f32_16x16x4f32(W.w5[s4][r], b[r], out, 0, 0, 0);
+            for (int r = 0; r < 4; r++) out = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], out, 0, 0, 0);
         }
     }
     return out;
