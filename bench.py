@@ -5,9 +5,11 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7 Connect4, 800 explores per move,
-           deterministic parity MCTS config (study-connect4/src/main.rs:58-66), 4096 concurrent games per GPU.
+           deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
+           SoA MCTS node pool) at 16,384 concurrent games per GPU; configs[1]'s 4096 concurrent games is measured in the
+           same run and reported under "at_4096_concurrent_games".
 Step     : one pass of the hot path over one batch = GAMES_PER_STEP self-play games per GPU played to completion by
-           the fused kernel (finished games hand their tree slot to the next game index, so the 4096 slots stay busy).
+           ONE launch of the fused kernel (finished games hand their tree slot to the next game index, so the slots stay busy).
 Scaling  : weak — every rank plays its own GAMES_PER_STEP games per step (games share nothing; no collective on the
            data path). Timed region = barrier + device sync on both sides, max over ranks.
 Roofline : the fused kernel's achieved rate against both roofs — f32 MFMA (60,288 FLOP per leaf evaluation,
@@ -59,7 +61,7 @@ def measured_traffic(args):
     produced by tools/collect_profiles.sh on this exact bench command); None if the run is not that configuration."""
     import glob
 
-    if (args.concurrent, args.games_per_step, args.explores) != (4096, 16384, 800):
+    if (args.concurrent, args.games_per_step, args.explores) != (16384, 98304, 800):
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
@@ -91,8 +93,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--concurrent", type=int, default=4096, help="concurrent games per GPU (BASELINE: 4096)")
-    ap.add_argument("--games-per-step", type=int, default=16384, help="self-play games per GPU per step")
+    ap.add_argument("--concurrent", type=int, default=16384,
+                    help="concurrent games (tree slots) per GPU; BASELINE configs[1] names 4096, reported as extra")
+    ap.add_argument("--games-per-step", type=int, default=98304, help="self-play games per GPU per step")
+    ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 4 games per host thread")
@@ -154,7 +158,7 @@ def main():
         gbs = algorithmic_bytes(c) / (last_ms * 1e-3) / 1e9
         mfma = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "selfplay_kernel (fused select/expand + Connect4Net f32 MFMA + backprop)",
+                "kernel": "selfplay_kernel_quads (fused select/expand + Connect4Net f32 MFMA + backprop)",
                 "kernel_ms_avg": avg_ms, "flop_per_leaf_eval": FLOP_PER_EVAL}
         hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                "traffic": None, "algorithmic_bytes_per_explore": algorithmic_bytes(c) / max(1, c["explores"]),
@@ -170,15 +174,28 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"9x7 Connect4 self-play, {args.concurrent} concurrent games per GPU, "
-                                   f"{args.explores} explores/move, device-resident SoA MCTS node pool + fused f32-MFMA "
-                                   f"Connect4Net leaf inference (BASELINE configs[1]/[2]); fixed-seed random-init weights",
+            "config": {"workload": f"9x7 Connect4 self-play, 1 MI355X per rank, GPU-resident SoA MCTS node pool "
+                                   f"(BASELINE configs[2]) + fused f32-MFMA Connect4Net leaf inference, {args.concurrent} "
+                                   f"concurrent games per GPU, {args.explores} explores/move, parity MCTS config; "
+                                   f"fixed-seed random-init weights",
                        "games_per_step_per_gpu": gps, "concurrent_games_per_gpu": args.concurrent,
                        "explores_per_move": args.explores, "parallelism": f"games sharded over {world} GPU(s), no collective"},
             "leaf_evals_per_s": games_per_s * evals_per_game, "explores_per_s": games_per_s * explores_per_game,
             "plies_per_game": plies / total_games,
             "roofline": near, "roofline_other": other,
         }
+        if world == 1 and not args.no_4096:
+            # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
+            # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
+            e2 = sa.Engine(concurrent_games=4096, max_explores=args.explores, device=local_rank)
+            e2.load_weights(blob)
+            e2.selfplay(cfg, base_seed=1, n_games=4096, outputs=False)
+            t1 = time.perf_counter()
+            r2 = e2.selfplay(cfg, base_seed=1, n_games=16384, first_game=4096, outputs=False)
+            dt = time.perf_counter() - t1
+            out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
+                                               "games": 16384, "plies_per_game": float(r2["plies"].mean())}
+            e2.close()
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             sample = args.cpu_sample_games or 4 * threads

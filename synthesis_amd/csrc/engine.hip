@@ -154,6 +154,34 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         size_t lds = WPS == 1 ? EngineLds::BYTES_WPS1 : EngineLds::BYTES_WPS2;                                     \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->stream, P);                                           \
     }
+    // Kernel choice by trees per CU: <= 16 -> one 16-tree workgroup per CU, weights in registers (latency-optimal);
+    // <= 32 -> two such workgroups per CU (hybrid register/LDS weights); more -> the quad-async kernel (NQ quads of 16
+    // trees per workgroup sharing one LDS weight image). SYN_QUADS=0..4 overrides (0 = never use the quad kernel).
+    int nq = 0;
+    {
+        int per_cu = (grid + h->num_cus - 1) / h->num_cus;
+        nq = per_cu <= 2 ? 0 : (per_cu >= 4 ? 4 : 3);
+        if (const char* ev = std::getenv("SYN_QUADS")) nq = std::atoi(ev);
+        if (nq < 0 || nq == 1 || nq > 4) nq = 0;
+    }
+    if (nq >= 2) {
+        int qgrid = (grid + nq - 1) / nq;
+#define SYN_LAUNCH_Q(NQ, FAST)                                                                                     \
+    {                                                                                                              \
+        auto k = selfplay_kernel_quads<MODE, COUNT, FAST, NQ, PROF>;                                                    \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)QuadLds<NQ>::BYTES);   \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(qgrid), dim3(256 * NQ), QuadLds<NQ>::BYTES, h->stream, P);                      \
+    }
+        if (nq == 2) { if (fast) SYN_LAUNCH_Q(2, true) else SYN_LAUNCH_Q(2, false) }
+        else if (nq == 3) { if (fast) SYN_LAUNCH_Q(3, true) else SYN_LAUNCH_Q(3, false) }
+        else { if (fast) SYN_LAUNCH_Q(4, true) else SYN_LAUNCH_Q(4, false) }
+#undef SYN_LAUNCH_Q
+        if (out_grid) *out_grid = qgrid;
+        if (out_nt) *out_nt = 256 * nq;
+        return hipGetLastError();
+    }
     if (grid <= h->num_cus) {
         if (fast) SYN_LAUNCH(1, true) else SYN_LAUNCH(1, false)
     } else {
@@ -227,7 +255,8 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     // the launch may round the slot count up to a whole workgroup (<= 64 trees)
-    size_t nodes = (size_t)(((h->slots + 63) / 64) * 64) * h->cap;
+    // + 48: the 3-quad launch rounds to multiples of 48 slots
+    size_t nodes = (size_t)(((h->slots + 63) / 64) * 64 + 48) * h->cap;
     if ((e = hipMalloc(&h->d_stat, nodes * sizeof(float4))) != hipSuccess) return bail("hipMalloc(stat)", e);
     if ((e = hipMalloc(&h->d_edge, nodes * sizeof(uint4))) != hipSuccess) return bail("hipMalloc(edge)", e);
     if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
@@ -426,6 +455,7 @@ static int common_params(syn_engine* h, EngineParams& P, int explores) {
     P.edge = h->d_edge;
     P.cap = h->cap;
     P.job_next = h->d_job_next;
+    P.error = h->d_job_next + 8;  // same 64-byte block, zeroed before every launch
     P.counters = h->d_counters;
     return SYN_OK;
 }
@@ -463,7 +493,10 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
     HIP_TRY(h, (launch_engine<MODE_SEARCH, false>(h, P, n)));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(results, d_res, nb * sizeof(DevSearchResult), hipMemcpyDeviceToHost, h->stream));
+    int kerr = 0;
+    HIP_TRY(h, hipMemcpyAsync(&kerr, h->d_job_next + 8, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
     return SYN_OK;
@@ -571,7 +604,10 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (final_kind) HIP_TRY(h, hipMemcpyAsync(final_kind, h->d_final, g, hipMemcpyDeviceToHost, h->stream));
     if (counters)
         HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
+    int kerr = 0;
+    HIP_TRY(h, hipMemcpyAsync(&kerr, h->d_job_next + 8, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
     return SYN_OK;

@@ -43,6 +43,7 @@ struct EngineParams {
     int* job_next;           // global job counter
     unsigned long long* counters;  // DevCounters (may be null)
     unsigned long long* prof;      // PROF builds: per-wave cycle sums [A, wait1, B, wait2, C, iterations]
+    int* error;                    // set to 1 by a quad whose bounded spin gave up (quad-async kernel)
     // self-play
     unsigned long long base_seed;  // game g uses StdRng::seed_from_u64(base_seed + first_game + g)
     unsigned long long first_game;
@@ -185,6 +186,16 @@ SYN_DEV void start_job(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl) {
 template <bool COUNT>
 SYN_DEV void selfplay_move_step(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl, uint32_t* ctr) {
     const DevRolloutCfg& rc = P.roll;
+    // sample_action consumes exactly one StdRng word in the common case (gen_range's rejection zone is 4 / 2^32):
+    // generate it FIRST, while nothing but the tree handle is live (ChaCha12 needs ~32 registers of its own).
+    const bool want_random = G.turn < rc.random_until;
+    const bool maybe_sample = !want_random && G.turn < rc.sample_until;
+    uint32_t rnd = 0;
+    if (want_random || maybe_sample) {
+        StdRng rng;
+        rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)G.job);
+        rnd = rng.word(G.rng_index);
+    }
     RootView R = load_root_view(T, gl);
     float pi = target_policy(R, gl);
     float q0, q1, q2;
@@ -203,21 +214,24 @@ SYN_DEV void selfplay_move_step(const EngineParams& P, TreeCtx& T, GameCtx& G, i
     int best = best_action(R, rc.action);
     uint32_t best_meta = row_bcast_u32(R.meta, best);
     int action;
-    if (G.turn < rc.random_until) {
-        StdRng rng;
-        rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)G.job);
-        rng.index = G.rng_index;
+    if (want_random) {
+        // Rng::gen_range(0..n) for u8 (device_common.cuh StdRng::gen_range_u8), first candidate = rnd
         uint32_t n = (uint32_t)__popc(R.lmask);
-        uint32_t r = rng.gen_range_u8(n);
-        G.rng_index = rng.index;
+        uint32_t zone = 0xFFFFFFFFu - (0xFFFFFFFFu - n + 1u) % n;
+        uint64_t mm = (uint64_t)rnd * (uint64_t)n;
+        G.rng_index += 1;
+        while ((uint32_t)mm > zone) {  // rejected (probability ~1e-9): draw again
+            StdRng rng;
+            rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)G.job);
+            mm = (uint64_t)rng.word(G.rng_index) * (uint64_t)n;
+            G.rng_index += 1;
+        }
+        uint32_t r = (uint32_t)(mm >> 32);
         uint32_t m = R.lmask;
         for (uint32_t i = 0; i < r; i++) m &= m - 1u;  // iter_actions().nth(r)
         action = __ffs((int)m) - 1;
-    } else if (G.turn < rc.sample_until && (!meta_some(best_meta) || !rc.stop_when_solved)) {
+    } else if (maybe_sample && (!meta_some(best_meta) || !rc.stop_when_solved)) {
         // WeightedIndex::new(search_policy).sample(rng): 9 weights by column
-        StdRng rng;
-        rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)G.job);
-        rng.index = G.rng_index;
         float cum[8];
         float total = row_bcast_f32(pi, 0);
 #pragma unroll
@@ -225,8 +239,9 @@ SYN_DEV void selfplay_move_step(const EngineParams& P, TreeCtx& T, GameCtx& G, i
             cum[c - 1] = total;
             total += row_bcast_f32(pi, c);
         }
-        float chosen = rng.uniform_0_to(total);
-        G.rng_index = rng.index;
+        // Uniform<f32>::new(0, total).sample: [1,2) from the top 23 bits, minus 1, times total
+        float chosen = (bits_f32((rnd >> 9) | 0x3F800000u) - 1.0f) * total + 0.0f;
+        G.rng_index += 1;
         int idx = 0;
 #pragma unroll
         for (int c = 0; c < 8; c++) idx = cum[c] <= chosen ? c + 1 : idx;
@@ -476,6 +491,210 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
             o[0] = pA; o[1] = pW1; o[2] = pB; o[3] = pW2; o[4] = pC; o[5] = (unsigned long long)it;
         }
     }
+
+    if (COUNT) {
+        if (P.counters && gl == 0) {
+#pragma unroll
+            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++)
+                if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- quad-async kernel
+// Many trees per CU. One workgroup = NQ quads; a quad = 4 waves = 16 trees = one MFMA tile, exactly the unit of the
+// kernel above — but here the quads of a workgroup share ONE LDS copy of the weight image (123 KB, which is what limits
+// a CU to one such workgroup) and are otherwise independent: each quad runs its own A -> B -> C loop and synchronises
+// only with itself through an LDS spin barrier, so while one quad's waves issue MFMAs another quad's waves are
+// chasing pointers or back-propagating on the same SIMDs. The 14 KB activation-exchange buffers are a pool of NEX sets
+// handed out with an LDS compare-and-swap token (a quad holds one only during phase B).
+// Spins are bounded: if a barrier or token wait exceeds SPIN_LIMIT polls the quad raises P.error and leaves.
+template <int NQ>
+struct QuadLds {
+    static constexpr int NEX = NQ >= 3 ? 2 : NQ;                     // exchange sets (2 x 14 KB fit beside the weights)
+    static constexpr size_t WIMG_OFF = 0;
+    static constexpr size_t EX_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;            // [NEX][exA 8 KB | exB 6 KB]
+    static constexpr size_t EX_BYTES = 14 * 1024;
+    static constexpr size_t LEAF_OFF = EX_OFF + NEX * EX_BYTES;                  // [NQ][16] uint4
+    static constexpr size_t OUT_OFF = LEAF_OFF + (size_t)NQ * 256;               // [NQ][16][16] float
+    static constexpr size_t SYNC_OFF = OUT_OFF + (size_t)NQ * 1024;              // [NQ][8] int + [NEX] int
+    static constexpr size_t BYTES = SYNC_OFF + (size_t)NQ * 32 + 16;
+};
+enum { QS_BAR = 0, QS_ACT0 = 1, QS_ACT1 = 2, QS_EVAL0 = 3, QS_EVAL1 = 4, QS_SET = 5 };
+
+template <int MODE, bool COUNT, bool FAST, int NQ, bool PROF = false>
+__global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    using L = QuadLds<NQ>;
+    constexpr int NT = 256 * NQ;
+    constexpr int SPIN_LIMIT = 1 << 22;
+    const float* wimg = reinterpret_cast<const float*>(smem_raw + L::WIMG_OFF);
+    const float* bimg = wimg + MlpGeom::W_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int quad = wave >> 2;
+    const int mw = wave & 3;
+    const int gl = tid & 15;
+    const int t = (tid >> 4) & 15;  // tree (row) index inside the quad
+
+    uint4* leafbuf = reinterpret_cast<uint4*>(smem_raw + L::LEAF_OFF) + quad * 16;
+    float* outbuf = reinterpret_cast<float*>(smem_raw + L::OUT_OFF) + quad * 256;
+    int* qs = reinterpret_cast<int*>(smem_raw + L::SYNC_OFF) + quad * 8;
+    int* ex_owner = reinterpret_cast<int*>(smem_raw + L::SYNC_OFF) + NQ * 8;
+
+    stage_weight_image(reinterpret_cast<float*>(smem_raw + L::WIMG_OFF), P.wimg, tid, NT);
+    if (tid < NQ * 8 + L::NEX) reinterpret_cast<int*>(smem_raw + L::SYNC_OFF)[tid] = 0;
+    uint32_t ft_mw;  // this wave's quarter of the layer-1 shift table (features 16*mw + 4*r + q)
+    {
+        const FeatureTable FT = make_feature_table(lane >> 4);
+        ft_mw = mw == 0 ? FT.t[0] : (mw == 1 ? FT.t[1] : (mw == 2 ? FT.t[2] : FT.t[3]));
+    }
+
+    uint32_t ctr[COUNT ? CTR_COUNT : 1];
+#pragma unroll
+    for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) ctr[i] = 0;
+
+    TreeCtx T;
+    const size_t slot = ((size_t)blockIdx.x * NQ + quad) * 16 + (size_t)t;
+    T.stat = P.stat + slot * P.cap;
+    T.edge = P.edge + slot * P.cap;
+    GameCtx G;
+    start_job<MODE>(P, T, G, gl);
+    __syncthreads();  // weights staged; the only workgroup-wide barrier of the kernel
+
+    int gen = 0;
+    bool failed = false;
+    // LDS spin barrier of this quad: monotonic arrival counter, one arrival per wave
+    // Only LDS traffic is exchanged between the waves of a quad (leaf boards, activations, network outputs): wait for
+    // this wave's LDS operations only. A full workgroup release fence would also drain vmcnt, i.e. expose the latency
+    // of the node-pool stores (expansion, backprop) that nobody else ever reads, at every barrier.
+    auto quad_sync = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        gen += 4;
+        if (lane == 0) {
+            __hip_atomic_fetch_add(&qs[QS_BAR], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int spins = 0;
+            while (__hip_atomic_load(&qs[QS_BAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { failed = true; break; }
+            }
+        }
+        asm volatile("" ::: "memory");  // LDS is coherent inside the CU: only stop the compiler from hoisting reads
+    };
+
+    const int n_explores = P.roll.num_explores;
+    int it = 0;
+    unsigned long long pA = 0, pW1 = 0, pB = 0, pW2 = 0, pC = 0, pT = 0;
+#define SYN_STAMP() (PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#define SYN_LAP(acc) if (PROF) { unsigned long long n_ = SYN_STAMP(); acc += n_ - pT; pT = n_; }
+    for (;;) {
+        pT = SYN_STAMP();
+        const bool active = G.job >= 0;
+        ExploreCtx X = {};
+        if (active) {
+            tree_select_expand<COUNT, FAST>(P.mcts, T, X, gl, ctr);
+            if (X.needs_eval) {
+                if (gl == 0) {
+                    uint64_t hi, lo;
+                    feature_boards(X.leaf_my, X.leaf_op, hi, lo);
+                    leafbuf[t] = make_uint4((uint32_t)hi, (uint32_t)(hi >> 32), (uint32_t)lo, (uint32_t)(lo >> 32));
+                    qs[QS_EVAL0 + (it & 1)] = 1;
+                }
+                if (COUNT) ctr[CTR_POLICY_EVALS]++;
+            }
+        }
+        // wave-level "any tree active" -> quad flag (double-buffered by iteration parity)
+        if (__ballot(active) != 0ull && lane == 0) qs[QS_ACT0 + (it & 1)] = 1;
+        SYN_LAP(pA)
+        quad_sync();  // barrier 1: leaf boards + flags visible to the quad
+        SYN_LAP(pW1)
+        const bool alive = __hip_atomic_load(&qs[QS_ACT0 + (it & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        const bool need_eval = __hip_atomic_load(&qs[QS_EVAL0 + (it & 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+        if (!alive || __any(failed)) break;
+
+        // ---- phase B
+        if (need_eval) {
+            // wave 0 takes an exchange set from the pool, the quad learns which through barrier 1b
+            if (mw == 0 && lane == 0) {
+                int got = -1, spins = 0;
+                while (got < 0) {
+#pragma unroll
+                    for (int s = 0; s < L::NEX; s++) {
+                        int expected = 0;
+                        if (got < 0 && __hip_atomic_compare_exchange_strong(&ex_owner[s], &expected, quad + 1,
+                                                                            __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                            __HIP_MEMORY_SCOPE_WORKGROUP))
+                            got = s;
+                    }
+                    if (got < 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > SPIN_LIMIT) { failed = true; got = 0; }
+                    }
+                }
+                qs[QS_SET] = got;
+            }
+            quad_sync();
+            SYN_LAP(pW1)  // token wait is booked with barrier 1
+            const int set = __hip_atomic_load(&qs[QS_SET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            f32x4* exA = reinterpret_cast<f32x4*>(smem_raw + L::EX_OFF + (size_t)set * L::EX_BYTES);
+            f32x4* exB = exA + 8 * 64;
+            const int j = lane & 15, q = lane >> 4;
+            uint4 b = leafbuf[j];
+            uint64_t hi = (uint64_t)b.x | ((uint64_t)b.y << 32), lo = (uint64_t)b.z | ((uint64_t)b.w << 32);
+            f32x4 o = mlp_quad_tile16(wimg, bimg, exA, exB, mw, lane, ft_mw, hi, lo, quad_sync);
+            if (mw == 0) {
+                // L5 has consumed exB: nobody touches the exchange set any more -> hand it back
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&ex_owner[set], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (q == 2) {
+                    float v0 = o[1], v1 = o[2], v2 = o[3];
+                    value_softmax(v0, v1, v2);
+                    o[1] = v0; o[2] = v1; o[3] = v2;
+                }
+                if (q < 3) *reinterpret_cast<f32x4*>(outbuf + j * 16 + q * 4) = o;
+            }
+        }
+        if (mw == 0 && lane == 0) {  // reset next iteration's flags (their writers run after barrier 2)
+            qs[QS_ACT0 + ((it + 1) & 1)] = 0;
+            qs[QS_EVAL0 + ((it + 1) & 1)] = 0;
+        }
+        SYN_LAP(pB)
+        quad_sync();  // barrier 2: network outputs visible
+        SYN_LAP(pW2)
+
+        // ---- phase C
+        if (active) {
+            float d0 = X.p0, d1 = X.p1, d2 = X.p2;
+            if (X.needs_eval) {
+                const float* o = outbuf + t * 16;
+                float logit = o[gl < 9 ? gl : 0];
+                tree_write_priors(T, X, gl, logit);
+                f32x4 ov = *reinterpret_cast<const f32x4*>(o + 8);
+                d0 = ov[1];
+                d1 = ov[2];
+                d2 = ov[3];
+            }
+            tree_backprop<COUNT, FAST>(P.mcts, T, X, gl, d0, d1, d2, X.solved, ctr);
+            T.iter += 1;
+            if (T.iter > n_explores || T.root_solved) {
+                if (MODE == MODE_SELFPLAY) selfplay_move_step<COUNT>(P, T, G, gl, ctr);
+                else search_finish(P, T, G, gl);
+            }
+        }
+        SYN_LAP(pC)
+        it++;
+    }
+#undef SYN_STAMP
+#undef SYN_LAP
+    if (PROF) {
+        if (P.prof && lane == 0) {
+            unsigned long long* o = P.prof + ((size_t)blockIdx.x * (NT / 64) + wave) * 6;
+            o[0] = pA; o[1] = pW1; o[2] = pB; o[3] = pW2; o[4] = pC; o[5] = (unsigned long long)it;
+        }
+    }
+    if (__any(failed) && lane == 0 && P.error) atomicExch(P.error, 1);
 
     if (COUNT) {
         if (P.counters && gl == 0) {

@@ -74,6 +74,12 @@ SYN_DEV float feature_from_boards(const FeatureTable& T, uint64_t hi, uint64_t l
     uint32_t h = (uint32_t)(hi >> pos) & 1u, l = (uint32_t)(lo >> pos) & 1u;
     return bits_f32((h ? 0x3F800000u : 0x3DCCCCCDu) | ((l ^ 1u) << 31));
 }
+// runtime-indexed form: `packed` = FT.t[w] (4 positions), b = 0..3
+SYN_DEV float feature_from_boards_rt(uint32_t packed, int b, uint64_t hi, uint64_t lo) {
+    uint32_t pos = (packed >> (8 * b)) & 0xFFu;
+    uint32_t h = (uint32_t)(hi >> pos) & 1u, l = (uint32_t)(lo >> pos) & 1u;
+    return bits_f32((h ? 0x3F800000u : 0x3DCCCCCDu) | ((l ^ 1u) << 31));
+}
 template <int S4>
 SYN_DEV f32x4 feature_quad(const FeatureTable& T, uint64_t hi, uint64_t lo) {
     f32x4 b;
@@ -317,6 +323,130 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
         for (int s4 = 0; s4 < 3; s4++) {
             f32x4 b = exB[s4 * 64 + lane];
             f32x4 w = W345_LDS ? wlds(4, 1, s4, 0) : W.w5[s4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) out = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], out, 0, 0, 0);
+        }
+    }
+    return out;
+}
+
+}  // namespace syn
+
+namespace syn {
+
+// ====================================================================================================================
+// LDS-weight, wave-split variant for the quad-asynchronous kernel: same block assignment and accumulation order as
+// mlp_split_tile16, but every A operand comes from the shared LDS weight image (one ds_read_b128 per 4 MFMAs) and the
+// four waves of the quad synchronise through `sync()` (an LDS spin barrier private to the quad) instead of the
+// workgroup barrier, so other quads of the workgroup keep running their own phases.
+template <class Sync>
+SYN_DEV f32x4 mlp_quad_tile16(const float* __restrict__ wimg, const float* __restrict__ bimg, f32x4* exA, f32x4* exB,
+                              int mw, int lane, uint32_t ft_mw /* FeatureTable::t[mw] */, uint64_t hi, uint64_t lo,
+                              Sync sync) {
+    const int q = lane >> 4;
+    auto bias = [&](int layer, int ob) {
+        return *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[layer] + (ob * 4 + q) * 4);
+    };
+    // The s4 loops are deliberately NOT unrolled and fetch their LDS operands one step ahead: fully unrolled, the
+    // compiler hoists every ds_read of a layer to its top (60+ live registers), which is what pushed the 3- and
+    // 4-quad workgroups (168 / 128 VGPR budgets) into scratch spills.
+    // ---- features: wave mw builds the B operands of k-steps 4*mw..4*mw+3 (one f32x4 per lane) for the whole quad;
+    //      exB is free until the end of L2, so it carries them to the other waves (one extra quad barrier, but 4x less
+    //      feature arithmetic per wave and ~40 fewer live registers than computing all 16 features everywhere)
+    {
+        f32x4 f;
+        f[0] = feature_from_boards_rt(ft_mw, 0, hi, lo);
+        f[1] = feature_from_boards_rt(ft_mw, 1, hi, lo);
+        f[2] = feature_from_boards_rt(ft_mw, 2, hi, lo);
+        f[3] = feature_from_boards_rt(ft_mw, 3, hi, lo);
+        exB[mw * 64 + lane] = f;
+    }
+    sync();
+    // ---- L1: blocks mw and mw+4; B = features from exB[0..3]
+    {
+        f32x4 a0 = bias(0, mw), a1 = bias(0, mw + 4);
+        const float* w0p = wimg + MlpGeom::W_OFF[0] + mw * 256 + lane * 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            f32x4 b = exB[s4 * 64 + lane];
+            f32x4 w0 = *reinterpret_cast<const f32x4*>(w0p + s4 * 8 * 256);
+            f32x4 w1 = *reinterpret_cast<const f32x4*>(w0p + (s4 * 8 + 4) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], b[r], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], b[r], a1, 0, 0, 0);
+            }
+        }
+        exA[mw * 64 + lane] = relu4(a0);
+        exA[(mw + 4) * 64 + lane] = relu4(a1);
+    }
+    sync();
+    // ---- L2: block mw (all waves) and block 4+mw (waves 0,1); B = exA[0..7]
+    {
+        const bool two = mw < 2;
+        f32x4 a0 = bias(1, mw), a1 = bias(1, two ? 4 + mw : mw);
+        const float* w0p = wimg + MlpGeom::W_OFF[1] + mw * 256 + lane * 4;
+        const float* w1p = wimg + MlpGeom::W_OFF[1] + (two ? 4 + mw : mw) * 256 + lane * 4;
+        f32x4 b = exA[lane];
+        f32x4 w0 = *reinterpret_cast<const f32x4*>(w0p), w1 = *reinterpret_cast<const f32x4*>(w1p);
+#pragma unroll 1
+        for (int s4 = 0; s4 < 8; s4++) {
+            int nx = s4 < 7 ? s4 + 1 : 7;
+            f32x4 bn = exA[nx * 64 + lane];
+            f32x4 w0n = *reinterpret_cast<const f32x4*>(w0p + nx * 6 * 256);
+            f32x4 w1n = *reinterpret_cast<const f32x4*>(w1p + nx * 6 * 256);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], b[r], a0, 0, 0, 0);
+                if (two) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], b[r], a1, 0, 0, 0);
+            }
+            b = bn; w0 = w0n; w1 = w1n;
+        }
+        exB[mw * 64 + lane] = relu4(a0);
+        if (two) exB[(4 + mw) * 64 + lane] = relu4(a1);
+    }
+    sync();
+    // ---- L3: block mw; B = exB[0..5]
+    {
+        f32x4 a0 = bias(2, mw);
+        const float* wp = wimg + MlpGeom::W_OFF[2] + mw * 256 + lane * 4;
+        f32x4 b = exB[lane];
+        f32x4 w = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll 1
+        for (int s4 = 0; s4 < 6; s4++) {
+            int nx = s4 < 5 ? s4 + 1 : 5;
+            f32x4 bn = exB[nx * 64 + lane];
+            f32x4 wn = *reinterpret_cast<const f32x4*>(wp + nx * 4 * 256);
+#pragma unroll
+            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], a0, 0, 0, 0);
+            b = bn; w = wn;
+        }
+        exA[mw * 64 + lane] = relu4(a0);
+    }
+    sync();
+    // ---- L4: waves 1..3 compute block mw-1; B = exA[0..3]
+    if (mw > 0) {
+        f32x4 a0 = bias(3, mw - 1);
+        const float* wp = wimg + MlpGeom::W_OFF[3] + (mw - 1) * 256 + lane * 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+            f32x4 b = exA[s4 * 64 + lane];
+            f32x4 w = *reinterpret_cast<const f32x4*>(wp + s4 * 3 * 256);
+#pragma unroll
+            for (int r = 0; r < 4; r++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], a0, 0, 0, 0);
+        }
+        exB[(mw - 1) * 64 + lane] = relu4(a0);
+    }
+    sync();
+    // ---- L5: wave 0; B = exB[0..2]
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (mw == 0) {
+        out = bias(4, 0);
+        const float* wp = wimg + MlpGeom::W_OFF[4] + lane * 4;
+#pragma unroll
+        for (int s4 = 0; s4 < 3; s4++) {
+            f32x4 b = exB[s4 * 64 + lane];
+            f32x4 w = *reinterpret_cast<const f32x4*>(wp + s4 * 256);
 #pragma unroll
             for (int r = 0; r < 4; r++) out = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r], b[r], out, 0, 0, 0);
         }

@@ -307,6 +307,31 @@ def test_selfplay_value_targets_and_action_variants(engine, oracle, blob):
         assert_selfplay_equal(got, ref, str(sv))
 
 
+@pytest.mark.parametrize("quads", [2, 3, 4])
+def test_quad_async_kernel_matches_oracle(blob, oracle, monkeypatch, quads):
+    """The many-trees-per-CU kernel (NQ quads of 16 trees per workgroup sharing one LDS weight image, quad-level spin
+    barriers, pooled exchange buffers) is normally chosen above 32 trees per CU; force it on a small engine and hold it
+    to the same bit-exact bar: searches incl. late-game solver positions, and whole self-play games with refill."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    monkeypatch.setenv("SYN_QUADS", str(quads))
+    eng = sa.Engine(concurrent_games=208, max_explores=800)  # 13 quads: partial last workgroup for every NQ
+    eng.load_weights(blob)
+    my, op = random_positions(oracle, 300, seed=31, max_moves=60)
+    got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, f"quads={quads} search")
+    got = eng.selfplay(sa.parity_rollout_config(50), base_seed=77, n_games=500, counters=True)
+    ref = oracle.c4_selfplay(parity_rollout_config(50), blob, 77, 500, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"quads={quads} self-play")
+    assert got["counters"]["policy_evals"] == ref["counters"]["policy_evals"]
+    got = eng.selfplay(sa.parity_rollout_config(800), base_seed=5, n_games=6)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 5, 6, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"quads={quads} 800 explores")
+    eng.close()
+
+
 def test_selfplay_full_size_properties(blob, oracle):
     """BASELINE full size: 4096 concurrent games x 800 explores. Too big for the oracle, so size-independent
     properties: replaying the recorded actions with the oracle's Connect4 reproduces every recorded position and ends
@@ -342,3 +367,9 @@ def test_selfplay_full_size_properties(blob, oracle):
     r2 = eng.selfplay(cfg, base_seed=2024, n_games=4096)
     assert_selfplay_equal(r2, r, "re-run")
     eng.close()
+    # the same games on the 16,384-slot engine (quad-async kernel): results depend only on the game index
+    big = sa.Engine(concurrent_games=16384, max_explores=800)
+    big.load_weights(blob)
+    r3 = big.selfplay(cfg, base_seed=2024, n_games=4096)
+    assert_selfplay_equal(r3, r, "16384-slot engine")
+    big.close()

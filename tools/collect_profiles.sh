@@ -9,7 +9,7 @@ R=$PWD
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT $R/gpurun_out/prof_trace $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
 export TMPDIR=/tmp
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $BENCH > $OUT/bench_under_trace.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $BENCH > $OUT/bench_under_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $BENCH > $OUT/bench_under_write.log 2>&1
@@ -27,14 +27,14 @@ import csv, json, sys
 out, tag = sys.argv[1], sys.argv[2]
 def rows(path):
     return list(csv.DictReader(open(path)))
-def timed(rs):  # the un-instrumented kernel <.., false, ..> launches (timed steps + warm-up)
-    return [r for r in rs if "false, 1, false" in r["Kernel_Name"] or "false, 2, false" in r["Kernel_Name"]]
+def timed(rs):  # the un-instrumented (COUNT = false) launches of the headline kernel (timed steps + warm-up)
+    return [r for r in rs if "selfplay_kernel_quads<0, false" in r["Kernel_Name"]]
 f = timed(rows(f"{out}/{tag}_pmc_fetch.csv")); w = timed(rows(f"{out}/{tag}_pmc_write.csv"))
 fetch_kb = sum(float(r["Counter_Value"]) for r in f) / max(1, len(f))
 write_kb = sum(float(r["Counter_Value"]) for r in w) / max(1, len(w))
-ks = [r for r in rows(f"{out}/{tag}_kernel_stats.csv") if "selfplay_kernel" in r["Name"] and "false, " in r["Name"].split("selfplay_kernel")[1][:12]]
+ks = [r for r in rows(f"{out}/{tag}_kernel_stats.csv") if "selfplay_kernel_quads<0, false" in r["Name"]]
 summary = {
-    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline",
+    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096",
     "kernel": ks[0]["Name"] if ks else None,
     "kernel_calls": int(ks[0]["Calls"]) if ks else None,
     "kernel_avg_ms": float(ks[0]["AverageNs"]) / 1e6 if ks else None,
