@@ -352,6 +352,26 @@ SYN_DEV void search_finish(const EngineParams& P, TreeCtx& T, GameCtx& G, int gl
     start_job<MODE_SEARCH>(P, T, G, gl);
 }
 
+// Out-of-line forms of the cold end-of-search code (once per ~570 explores): used by the 4-quad kernel, whose 128-VGPR
+// budget must be set by the hot loop, not by the root view / targets / ChaCha12; the caller-saved spills then happen
+// only around the rare call. State goes in and out BY VALUE: passing TreeCtx by reference would park its node-pool
+// pointers in memory, and the hot loop's loads would degrade from global_load to flat_load (which also tick the LDS
+// counter). Inlined everywhere else: with registers to spare the call only costs.
+struct TreeGame {
+    TreeCtx T;
+    GameCtx G;
+};
+template <bool COUNT>
+__device__ __attribute__((noinline)) TreeGame selfplay_move_step_call(const EngineParams& P, TreeGame s, int gl,
+                                                                      uint32_t* ctr) {
+    selfplay_move_step<COUNT>(P, s.T, s.G, gl, ctr);
+    return s;
+}
+__device__ __attribute__((noinline)) TreeGame search_finish_call(const EngineParams& P, TreeGame s, int gl) {
+    search_finish(P, s.T, s.G, gl);
+    return s;
+}
+
 // LDS per workgroup (16 trees): [bias image 1,408 B][exA 8 KB][exB 6 KB][leaf boards 16 x 16 B][net outputs 16 x 64 B]
 // = 17,024 B, so several workgroups fit one CU; the weights themselves live in registers (mlp.cuh, split variant).
 struct EngineLds {
@@ -636,6 +656,9 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
                 qs[QS_SET] = got;
             }
             quad_sync();
+            // the quad now holds one of the scarce exchange sets: let its MFMA chains win issue arbitration against
+            // the other quads' pointer-chasing on the same SIMDs until the set is handed back
+            __builtin_amdgcn_s_setprio(3);
             SYN_LAP(pW1)  // token wait is booked with barrier 1
             const int set = __hip_atomic_load(&qs[QS_SET], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             f32x4* exA = reinterpret_cast<f32x4*>(smem_raw + L::EX_OFF + (size_t)set * L::EX_BYTES);
@@ -656,6 +679,7 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
                 if (q < 3) *reinterpret_cast<f32x4*>(outbuf + j * 16 + q * 4) = o;
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (mw == 0 && lane == 0) {  // reset next iteration's flags (their writers run after barrier 2)
             qs[QS_ACT0 + ((it + 1) & 1)] = 0;
             qs[QS_EVAL0 + ((it + 1) & 1)] = 0;
@@ -679,8 +703,23 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
             tree_backprop<COUNT, FAST>(P.mcts, T, X, gl, d0, d1, d2, X.solved, ctr);
             T.iter += 1;
             if (T.iter > n_explores || T.root_solved) {
-                if (MODE == MODE_SELFPLAY) selfplay_move_step<COUNT>(P, T, G, gl, ctr);
-                else search_finish(P, T, G, gl);
+                if (NQ >= 4) {
+                    TreeGame s{T, G};
+                    // a private copy goes to the callee: taking the address of the kernel-argument struct itself
+                    // would demote every pointer loaded from it to the generic address space
+                    EngineParams Pc = P;
+                    if (MODE == MODE_SELFPLAY) s = selfplay_move_step_call<COUNT>(Pc, s, gl, ctr);
+                    else s = search_finish_call(Pc, s, gl);
+                    T = s.T;
+                    G = s.G;
+                    // re-derive the node-pool pointers from the kernel arguments so they never come back from
+                    // memory (keeps the hot loop on global_load / global_store)
+                    T.stat = P.stat + slot * P.cap;
+                    T.edge = P.edge + slot * P.cap;
+                } else {
+                    if (MODE == MODE_SELFPLAY) selfplay_move_step<COUNT>(P, T, G, gl, ctr);
+                    else search_finish(P, T, G, gl);
+                }
             }
         }
         SYN_LAP(pC)

@@ -2,16 +2,18 @@
 # Developer tool (GPU box): SQ counter passes over one quad_sweep configuration, e.g. tools/pmc_probe.sh 12288:3
 set -u
 CFG=${1:-12288:3}
+PASSES=${2:-"P1 P2 P3 P4"}
 R=$PWD
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS"
 P2="SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"
 P3="SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH"
+P4="SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_INST_CYCLES_SMEM SQ_WAVES SQ_LEVEL_WAVES SQ_BUSY_CU_CYCLES"
 i=0
-for P in "$P1" "$P2" "$P3"; do
+for P in $PASSES; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $P --output-format csv -d $R/gpurun_out/pmc/p$i -- python3 tools/quad_sweep.py $CFG > $R/gpurun_out/pmc/p$i.log 2>&1
+  timeout 600 rocprofv3 --pmc ${!P} --output-format csv -d $R/gpurun_out/pmc/p$i -- python3 tools/quad_sweep.py $CFG > $R/gpurun_out/pmc/p$i.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
