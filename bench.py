@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
+                                                           "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 4 games per host thread")
     args = ap.parse_args()
 
@@ -111,7 +113,10 @@ def main():
     rank, local_rank, world = dist_util.rank_info()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = dist_util.init_process_group("nccl", local_rank) if world > 1 else None
+    dist = dist_util.init_process_group(args.dist_backend, local_rank) if world > 1 else None
+    reduce_device = f"cuda:{local_rank}"
+    if args.dist_backend != "nccl":
+        local_rank, reduce_device = 0, "cpu"   # dry run: all ranks share GPU 0, scalars reduced over gloo
 
     blob = make_weights()
     eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
@@ -140,7 +145,7 @@ def main():
         plies += int(r["plies"].sum())
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, (plies,) = dist_util.reduce_scalars(dist, f"cuda:{local_rank}", elapsed, [plies])
+    elapsed, (plies,) = dist_util.reduce_scalars(dist, reduce_device, elapsed, [plies])
 
     # Event counts of exactly the games of the last timed step (trajectories are deterministic, so an instrumented
     # re-run outside the timed region gives the counts of the timed run).

@@ -44,7 +44,8 @@ enum { SYN_EXPLORATION_UCT = 0, SYN_EXPLORATION_POLYNOMIAL_UCT = 1 };
 enum { SYN_ACTION_Q = 0, SYN_ACTION_NUM_VISITS = 1 };
 /* config.rs:21-26 Fpu (Func(fn()->f32) is a host closure: rejected with SYN_ERR_UNSUPPORTED) */
 enum { SYN_FPU_CONST = 0, SYN_FPU_PARENT_Q = 1 };
-/* config.rs:39-44 PolicyNoise (Dirichlet needs rand_distr's gamma sampler: SYN_ERR_UNSUPPORTED for now) */
+/* config.rs:39-44 PolicyNoise (None and Equal run on the device; Dirichlet needs rand_distr's gamma sampler:
+ * SYN_ERR_UNSUPPORTED for now) */
 enum { SYN_NOISE_NONE = 0, SYN_NOISE_EQUAL = 1, SYN_NOISE_DIRICHLET = 2 };
 /* config.rs:1-7 ValueTarget */
 enum { SYN_VALUE_Z = 0, SYN_VALUE_Q = 1, SYN_VALUE_QZ_AVERAGE = 2, SYN_VALUE_Q_TO_Z = 3 };

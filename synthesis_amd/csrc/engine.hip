@@ -122,8 +122,10 @@ static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) 
         return fail(h, SYN_ERR_UNSUPPORTED, "Fpu::Func is a host closure and cannot run on the device");
     if (c->root_policy_noise == SYN_NOISE_DIRICHLET)
         return fail(h, SYN_ERR_UNSUPPORTED, "PolicyNoise::Dirichlet is not implemented on the device yet");
-    if (c->root_policy_noise != SYN_NOISE_NONE)
-        return fail(h, SYN_ERR_UNSUPPORTED, "root policy noise is not implemented on the device yet");
+    if (c->root_policy_noise != SYN_NOISE_NONE && c->root_policy_noise != SYN_NOISE_EQUAL)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown root policy noise %d", c->root_policy_noise);
+    if (c->root_policy_noise == SYN_NOISE_EQUAL && !(c->noise_weight >= 0.0f))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "PolicyNoise::Equal weight must be >= 0");
     d.exploration = c->exploration;
     d.c = c->c;
     d.solve = c->solve != 0;

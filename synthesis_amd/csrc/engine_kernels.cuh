@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
             if (X.needs_eval) {
                 const float* o = outbuf + t * 16;
                 float logit = o[gl < 9 ? gl : 0];
-                tree_write_priors(T, X, gl, logit);
+                tree_write_priors(T, X, gl, logit, (P.mcts.noise == 1 && T.iter == 0 && X.leaf == 0u) ? P.mcts.noise_weight : -1.0f);
                 // one 16-byte LDS read (also keeps these loads from being merged with the X.p* loads above into a
                 // pointer phi, which would pin X in scratch)
                 f32x4 ov = *reinterpret_cast<const f32x4*>(o + 8);
@@ -593,13 +593,16 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
     auto quad_sync = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         gen += 4;
-        if (lane == 0) {
-            __hip_atomic_fetch_add(&qs[QS_BAR], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            int spins = 0;
-            while (__hip_atomic_load(&qs[QS_BAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < gen) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > SPIN_LIMIT) { failed = true; break; }
-            }
+        if (lane == 0) __hip_atomic_fetch_add(&qs[QS_BAR], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // every lane polls the same LDS word (a broadcast read); readfirstlane makes the exit test a scalar branch, so
+        // the spin is ds_read / s_waitcnt / v_readfirstlane / s_cmp / s_cbranch / s_sleep with no exec-mask bookkeeping
+        const int target = __builtin_amdgcn_readfirstlane(gen);
+        int spins = 0;
+        for (;;) {
+            int v = __hip_atomic_load(&qs[QS_BAR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { failed = true; break; }
         }
         asm volatile("" ::: "memory");  // LDS is coherent inside the CU: only stop the compiler from hoisting reads
     };
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
             if (X.needs_eval) {
                 const float* o = outbuf + t * 16;
                 float logit = o[gl < 9 ? gl : 0];
-                tree_write_priors(T, X, gl, logit);
+                tree_write_priors(T, X, gl, logit, (P.mcts.noise == 1 && T.iter == 0 && X.leaf == 0u) ? P.mcts.noise_weight : -1.0f);
                 f32x4 ov = *reinterpret_cast<const f32x4*>(o + 8);
                 d0 = ov[1];
                 d1 = ov[2];

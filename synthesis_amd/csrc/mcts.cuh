@@ -320,7 +320,9 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg_, TreeCtx& T, ExploreCtx& 
 
 // ---------------------------------------------------------------------------------------------- phase C
 // Legal-move softmax of visit() (mcts.rs:409-423) for the node expanded in phase A. lane c = column c.
-SYN_DEV void tree_write_priors(TreeCtx& T, const ExploreCtx& X, int gl, float logit) {
+// `equal_noise_weight` >= 0: this is the root's first visit and PolicyNoise::Equal applies (mcts.rs:258-269):
+// prior = prior * (1 - w) + w * (1 / num_children), for roots with at least two children.
+SYN_DEV void tree_write_priors(TreeCtx& T, const ExploreCtx& X, int gl, float logit, float equal_noise_weight) {
     uint32_t lmask = X.legal_mask;
     bool legal = (lmask >> gl) & 1u;
     float mx = row_max_f32(legal ? logit : -__builtin_inff());
@@ -332,6 +334,11 @@ SYN_DEV void tree_write_priors(TreeCtx& T, const ExploreCtx& X, int gl, float lo
         if ((lmask >> c) & 1u) total += ec;  // summed in child (= ascending column) order
     }
     float p = e / total;
+    uint32_t nc = (uint32_t)__popc(lmask);
+    if (equal_noise_weight >= 0.0f && nc >= 2u) {
+        float noise = 1.0f / (float)nc;
+        p = p * (1.0f - equal_noise_weight) + equal_noise_weight * noise;
+    }
     uint32_t idx = (uint32_t)__popc(lmask & ((1u << gl) - 1u));
     if (legal) T.edge[X.fc + idx].z = f32_bits(p);
 }

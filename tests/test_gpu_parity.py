@@ -195,21 +195,22 @@ def test_mcts_search_late_game_solver_and_auto_extend(engine, oracle, blob):
 
 def test_mcts_config_variants(engine, oracle, blob):
     """Remaining deterministic MCTSConfig variants: Fpu::ParentQ, no solver, no value correction, no auto-extend,
-    select_solved_nodes = false, ActionSelection::Q, other c."""
+    select_solved_nodes = false, ActionSelection::Q, other c, PolicyNoise::Equal (mcts.rs:258-269)."""
     import synthesis_amd as sa
     from tests.oracle_lib import parity_mcts_config
 
     my, op = random_positions(oracle, 48, seed=9, max_moves=60)
     variants = [
         dict(fpu=1), dict(solve=0), dict(correct_values_on_solve=0), dict(auto_extend=0), dict(select_solved_nodes=0),
-        dict(c=1.25, fpu_value=0.0),
+        dict(c=1.25, fpu_value=0.0), dict(noise=1, noise_weight=0.25), dict(noise=1, noise_weight=0.6, fpu=1),
     ]
     for v in variants:
         ocfg = parity_mcts_config(**v)
         scfg = sa.MCTSConfig(exploration=sa.Exploration.PolynomialUct, c=ocfg.c, solve=bool(ocfg.solve),
                              correct_values_on_solve=bool(ocfg.correct_values_on_solve),
                              select_solved_nodes=bool(ocfg.select_solved_nodes), auto_extend=bool(ocfg.auto_extend),
-                             fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value)
+                             fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value,
+                             root_policy_noise=sa.PolicyNoise(ocfg.noise), noise_weight=ocfg.noise_weight)
         for sel in (0, 1):
             got = engine.mcts_search(scfg, my, op, 150, action_selection=sel)
             ref = oracle.c4_mcts_search(ocfg, blob, my, op, 150, action_selection=sel, nn_mode=oracle.ACC_FMA)
