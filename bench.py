@@ -61,7 +61,7 @@ def measured_traffic(args):
     produced by tools/collect_profiles.sh on this exact bench command); None if the run is not that configuration."""
     import glob
 
-    if (args.concurrent, args.games_per_step, args.explores) != (16384, 98304, 800):
+    if (args.concurrent, args.games_per_step, args.explores) != (16384, 131072, 800):
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--concurrent", type=int, default=16384,
                     help="concurrent games (tree slots) per GPU; BASELINE configs[1] names 4096, reported as extra")
-    ap.add_argument("--games-per-step", type=int, default=98304, help="self-play games per GPU per step")
+    ap.add_argument("--games-per-step", type=int, default=131072, help="self-play games per GPU per step")
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -259,8 +259,8 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     // the launch may round the slot count up to a whole workgroup (<= 64 trees)
     // + 48: the 3-quad launch rounds to multiples of 48 slots
     size_t nodes = (size_t)(((h->slots + 63) / 64) * 64 + 48) * h->cap;
-    if ((e = hipMalloc(&h->d_stat, nodes * sizeof(float4))) != hipSuccess) return bail("hipMalloc(stat)", e);
-    if ((e = hipMalloc(&h->d_edge, nodes * sizeof(uint4))) != hipSuccess) return bail("hipMalloc(edge)", e);
+    if ((e = hipMalloc(&h->d_stat, nodes * 32)) != hipSuccess) return bail("hipMalloc(node pool)", e);
+    h->d_edge = reinterpret_cast<uint4*>(h->d_stat);  // same records, edge half = odd 16-byte elements
     if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
     if ((e = hipMalloc(&h->d_job_next, 64)) != hipSuccess) return bail("hipMalloc(job)", e);
     if ((e = hipMalloc(&h->d_counters, sizeof(DevCounters))) != hipSuccess) return bail("hipMalloc(counters)", e);
@@ -273,7 +273,6 @@ int syn_engine_destroy(syn_engine* h) {
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_stat);
-    hipFree(h->d_edge);
     hipFree(h->d_wimg);
     hipFree(h->d_job_next);
     hipFree(h->d_counters);

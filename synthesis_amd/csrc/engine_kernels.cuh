@@ -36,7 +36,7 @@ struct EngineParams {
     DevMctsCfg mcts;
     DevRolloutCfg roll;
     const float* wimg;       // weight image, fragment order (MlpGeom::IMG_FLOATS floats)
-    float4* stat;            // node pool
+    float4* stat;            // node pool: 32-byte records; stat and edge are the same base address (two typed views)
     uint4* edge;
     uint32_t cap;            // nodes per tree slab
     int n_jobs;              // games (self-play) or roots (search)
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
 
     TreeCtx T;
     const size_t slot = (size_t)blockIdx.x * EngineLds::TPW + (size_t)t;
-    T.stat = P.stat + slot * P.cap;
-    T.edge = P.edge + slot * P.cap;
+    T.stat.base = P.stat + 2 * slot * P.cap;
+    T.edge.base = P.edge + 2 * slot * P.cap;
     GameCtx G;
     start_job<MODE>(P, T, G, gl);
     __syncthreads();
@@ -578,8 +578,8 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
 
     TreeCtx T;
     const size_t slot = ((size_t)blockIdx.x * NQ + quad) * 16 + (size_t)t;
-    T.stat = P.stat + slot * P.cap;
-    T.edge = P.edge + slot * P.cap;
+    T.stat.base = P.stat + 2 * slot * P.cap;
+    T.edge.base = P.edge + 2 * slot * P.cap;
     GameCtx G;
     start_job<MODE>(P, T, G, gl);
     __syncthreads();  // weights staged; the only workgroup-wide barrier of the kernel
@@ -717,8 +717,8 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
                     G = s.G;
                     // re-derive the node-pool pointers from the kernel arguments so they never come back from
                     // memory (keeps the hot loop on global_load / global_store)
-                    T.stat = P.stat + slot * P.cap;
-                    T.edge = P.edge + slot * P.cap;
+                    T.stat.base = P.stat + 2 * slot * P.cap;
+                    T.edge.base = P.edge + 2 * slot * P.cap;
                 } else {
                     if (MODE == MODE_SELFPLAY) selfplay_move_step<COUNT>(P, T, G, gl, ctr);
                     else search_finish(P, T, G, gl);

@@ -13,12 +13,12 @@
 //     select = one 2x16-byte gather per level + a 4-step DPP arg-max (first index wins ties); no LDS, no atomics.
 //     A tree has exactly one leaf in flight (the reference is sequential per tree, mcts.rs:139-147), so its f32
 //     sums are order-exact; throughput comes from thousands of independent trees, never from intra-tree races.
-//   * Node pool (HBM): two arrays of 16-byte records per node, slab of `cap` nodes per tree slot:
-//       stat[node] = {N, W_lose, W_draw, W_win}            read by select, read-modify-written by backprop
-//       edge[node] = {first_child, meta, P, parent}        written at expansion; meta rewritten when solved
+//   * Node pool (HBM): one 32-byte record per node = two 16-byte halves, slab of `cap` nodes per tree slot:
+//       stat half = {N, W_lose, W_draw, W_win}            read by select, read-modify-written by backprop
+//       edge half = {first_child, meta, P, parent}        written at expansion; meta rewritten when solved
 //     meta = num_children[0:3] | action[4:7] | sol_some[8] | sol_kind[9:10] | sol_turns[16:31].
-//     Children of a node are contiguous (ids first_child..first_child+n), so a row's 9 lanes read 144 contiguous
-//     bytes per array. The reference also keeps the Game in every node (mcts.rs:33); here positions are re-derived
+//     Children of a node are contiguous (ids first_child..first_child+n), so a row's 9 lanes read one 288-byte
+//     span (two 16-byte loads per lane). The reference also keeps the Game in every node (mcts.rs:33); here positions are re-derived
 //     in registers while descending (my' = op, op' = my | bit), so no board array is read or written on the hot path.
 //   * The descent path is kept in registers (lane L&15 of register L>>4 holds level L), so backprop touches all
 //     its nodes with ONE parallel gather/scatter; only the (rare) solver branch walks level by level.
@@ -103,10 +103,22 @@ SYN_DEV uint32_t outcome_key_reversed(uint32_t meta) {
 }
 
 // ---------------------------------------------------------------------------------------------- per-tree registers
+// A node is one 32-byte record {stat (16 B), edge (16 B)}; stat[i] / edge[i] are views on record i. Interleaving the
+// two halves keeps a sibling scan (<= 9 consecutive nodes) inside one contiguous 288-byte span instead of two 144-byte
+// spans in different arrays: fewer cache lines and DRAM pages per level for the same two 16-byte loads per lane.
+struct StatView {
+    float4* base;
+    SYN_DEV float4& operator[](uint32_t i) const { return base[2u * i]; }
+};
+struct EdgeView {
+    uint4* base;
+    SYN_DEV uint4& operator[](uint32_t i) const { return base[2u * i + 1u]; }
+};
+
 struct TreeCtx {
     // node pool slab of this tree (already offset by slot * cap)
-    float4* stat;
-    uint4* edge;
+    StatView stat;
+    EdgeView edge;
     // root position of the current search
     uint64_t root_my, root_op;
     uint32_t next_node;   // nodes.len()

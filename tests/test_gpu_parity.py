@@ -167,6 +167,26 @@ def test_mcts_search_visit_exact(engine, oracle, blob):
     assert got["num_nodes"].max() <= 1 + 9 * 801
 
 
+def test_mcts_search_reference_default_1600_explores(oracle, blob):
+    """The reference's own default budget (num_explores: 1600, study-connect4/src/main.rs:30): slab of 1 + 9*1601 nodes
+    per tree, still visit-exact; plus one full self-play game at 1600 explores."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    eng = sa.Engine(concurrent_games=64, max_explores=1600)
+    eng.load_weights(blob)
+    my, op = random_positions(oracle, 12, seed=41, max_moves=30)
+    my[0] = 0; op[0] = 0
+    got = eng.mcts_search(sa.parity_mcts_config(), my, op, 1600)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 1600, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, "explores=1600")
+    assert got["num_nodes"].max() <= 1 + 9 * 1601 and got["num_nodes"].max() > 7210
+    sp = eng.selfplay(sa.parity_rollout_config(1600), base_seed=9, n_games=2)
+    rf = oracle.c4_selfplay(parity_rollout_config(1600), blob, 9, 2, threads=2, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(sp, rf, "1600 explores")
+    eng.close()
+
+
 def test_mcts_search_late_game_solver_and_auto_extend(engine, oracle, blob):
     """Nearly full boards: few legal columns (auto-extend chains), many terminal children (solver + value correction),
     roots that get solved before the explore budget is used."""
