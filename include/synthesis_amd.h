@@ -170,7 +170,7 @@ typedef struct syn_counters {
     uint64_t solved_hits;       /* explores that ended on an already solved node */
     uint64_t moves;             /* plies played */
     uint64_t games;             /* games finished */
-    uint64_t reserved;
+    uint64_t max_depth;         /* longest root-to-leaf chain (levels) any backprop walked */
 } syn_counters;
 
 /* Replaces: run_n_games (alpha_zero.rs:181-209) for games [first_game, first_game + n_games). Game g uses its own

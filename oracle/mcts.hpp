@@ -51,6 +51,7 @@ struct MCTSConfig {
 struct MCTSCounters {
     uint64_t explores = 0 /* explore() calls + root visits */, select_levels = 0, children_scanned = 0, expansions = 0, new_nodes = 0;
     uint64_t policy_evals = 0, backprop_levels = 0, solver_children = 0, solved_hits = 0;
+    uint64_t max_depth = 0;  // deepest backprop chain (levels) seen
 };
 
 template <class G>
@@ -351,9 +352,11 @@ struct MCTS {
     // mcts.rs:429-488
     void backprop(uint32_t leaf_node_id, float outcome_probs[3], bool solved) {
         uint32_t node_id = leaf_node_id;
+        uint64_t levels = 0;
         for (;;) {
             uint32_t parent = nodes[node_id].parent;
-            if (ctr) ctr->backprop_levels++;
+            levels++;
+            if (ctr) { ctr->backprop_levels++; if (levels > ctr->max_depth) ctr->max_depth = levels; }
             if (cfg.solve && solved) {
                 bool all_solved = true;
                 OptOutcome best = nodes[node_id].solution;

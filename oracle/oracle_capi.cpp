@@ -287,8 +287,8 @@ void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn
 // `threads` OS threads the way gather_experience splits workers (alpha_zero.rs:132-154): each thread owns its
 // policy copy and, if use_cache, its own PolicyWithCache (alpha_zero.rs:196-198).
 // Outputs are indexed by (game - first_game): plies[n], states_bb[n][63][2], pis[n][63][9], vs[n][63][3],
-// actions[n][63], root_nodes[n][63], final_kind[n]. counters[9] = MCTSCounters fields summed; counters[9..11] =
-// cache hits, misses. Returns wall seconds.
+// actions[n][63], root_nodes[n][63], final_kind[n]. counters[9] = MCTSCounters fields summed; counters[9..10] =
+// cache hits, misses; counters[11] = max backprop depth. Returns wall seconds.
 double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
                        uint64_t first_game, int n_games, int threads, int use_cache, int* plies, uint64_t* states_bb,
                        float* pis, float* vs, uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind,
@@ -335,7 +335,7 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
     for (auto& t : pool) t.join();
     auto t1 = std::chrono::steady_clock::now();
     if (counters) {
-        for (int i = 0; i < 11; i++) counters[i] = 0;
+        for (int i = 0; i < 12; i++) counters[i] = 0;
         for (int w = 0; w < threads; w++) {
             const MCTSCounters& c = ctrs[w];
             uint64_t v[9] = {c.explores, c.select_levels, c.children_scanned, c.expansions, c.new_nodes,
@@ -343,6 +343,7 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
             for (int i = 0; i < 9; i++) counters[i] += v[i];
             counters[9] += hits[w];
             counters[10] += misses[w];
+            if (c.max_depth > counters[11]) counters[11] = c.max_depth;
         }
     }
     return std::chrono::duration<double>(t1 - t0).count();

@@ -515,8 +515,10 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
     if (COUNT) {
         if (P.counters && gl == 0) {
 #pragma unroll
-            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++)
-                if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) {
+                if (i == CTR_MAX_DEPTH) atomicMax(&P.counters[i], (unsigned long long)ctr[i]);
+                else if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+            }
         }
     }
 }
@@ -741,8 +743,10 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
     if (COUNT) {
         if (P.counters && gl == 0) {
 #pragma unroll
-            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++)
-                if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) {
+                if (i == CTR_MAX_DEPTH) atomicMax(&P.counters[i], (unsigned long long)ctr[i]);
+                else if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+            }
         }
     }
 }

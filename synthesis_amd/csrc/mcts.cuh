@@ -67,7 +67,7 @@ struct DevCounters {  // index order = syn_counters
     unsigned long long v[12];
 };
 enum { CTR_EXPLORES, CTR_SELECT_LEVELS, CTR_CHILDREN_SCANNED, CTR_EXPANSIONS, CTR_NEW_NODES, CTR_POLICY_EVALS,
-       CTR_BACKPROP_LEVELS, CTR_SOLVER_CHILDREN, CTR_SOLVED_HITS, CTR_MOVES, CTR_GAMES, CTR_RESERVED, CTR_COUNT };
+       CTR_BACKPROP_LEVELS, CTR_SOLVER_CHILDREN, CTR_SOLVED_HITS, CTR_MOVES, CTR_GAMES, CTR_MAX_DEPTH, CTR_COUNT };
 
 // ---------------------------------------------------------------------------------------------- meta / outcome
 constexpr uint32_t META_NC_MASK = 0xFu;
@@ -362,7 +362,10 @@ SYN_DEV void tree_backprop(const DevMctsCfg& cfg_, TreeCtx& T, const ExploreCtx&
     const CfgView<FAST> cfg{cfg_};
     int level = X.depth;
     const uint32_t xp0 = X.path0, xp1 = X.path1, xp2 = X.path2, xp3 = X.path3;
-    if (COUNT) ctr[CTR_BACKPROP_LEVELS] += (uint32_t)(X.depth + 1);
+    if (COUNT) {
+        ctr[CTR_BACKPROP_LEVELS] += (uint32_t)(X.depth + 1);
+        if ((uint32_t)(X.depth + 1) > ctr[CTR_MAX_DEPTH]) ctr[CTR_MAX_DEPTH] = (uint32_t)(X.depth + 1);
+    }
     // --- solver walk: level by level while the subtree below is proven
     while (cfg.solve() && solved && level >= 0) {
         uint32_t nd = path_get(xp0, xp1, xp2, xp3, level);

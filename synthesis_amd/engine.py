@@ -41,7 +41,7 @@ class CSearchResult(C.Structure):  # struct syn_search_result
 class CCounters(C.Structure):  # struct syn_counters
     _fields_ = [(n, C.c_uint64) for n in (
         "explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals", "backprop_levels",
-        "solver_children", "solved_hits", "moves", "games", "reserved")]
+        "solver_children", "solved_hits", "moves", "games", "max_depth")]
 
 
 def library_path():
@@ -227,7 +227,7 @@ class Engine:
             _p(r.get("pis")), _p(r.get("vs")), _p(r.get("actions")), _p(r.get("root_nodes")), _p(r.get("final_kind")),
             C.cast(C.byref(ctr), C.c_void_p) if ctr is not None else None))
         if ctr is not None:
-            r["counters"] = {name: int(getattr(ctr, name)) for name, _ in CCounters._fields_ if name != "reserved"}
+            r["counters"] = {name: int(getattr(ctr, name)) for name, _ in CCounters._fields_}
         r["kernel_ms"] = self.last_kernel_ms()
         return r
 

@@ -209,7 +209,7 @@ class Oracle:
                     outputs=True):
         blob = np.ascontiguousarray(blob, np.float32)
         r = dict(plies=np.zeros(n_games, np.int32), final_kind=np.zeros(n_games, np.uint8),
-                 counters=np.zeros(11, np.uint64))
+                 counters=np.zeros(12, np.uint64))
         if outputs:
             r.update(states_bb=np.zeros((n_games, 63, 2), np.uint64), pis=np.zeros((n_games, 63, 9), np.float32),
                      vs=np.zeros((n_games, 63, 3), np.float32), actions=np.zeros((n_games, 63), np.uint8),
@@ -220,7 +220,7 @@ class Oracle:
                                         g("vs"), g("actions"), g("root_nodes"), _p(r["final_kind"]), _p(r["counters"]))
         r["seconds"] = secs
         names = ["explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals",
-                 "backprop_levels", "solver_children", "solved_hits", "cache_hits", "cache_misses"]
+                 "backprop_levels", "solver_children", "solved_hits", "cache_hits", "cache_misses", "max_depth"]
         r["counters"] = {k: int(v) for k, v in zip(names, r["counters"])}
         return r
 

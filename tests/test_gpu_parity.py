@@ -237,6 +237,29 @@ def test_mcts_config_variants(engine, oracle, blob):
             assert_search_equal(got, ref, f"variant {v} sel {sel}")
 
 
+def test_deep_narrow_trees_exercise_long_paths(oracle, blob):
+    """Low FPU + small c make the search dive: descent paths far longer than one 16-lane register chunk (the path lives
+    on lane L&15 of register L>>4) must still select / backprop exactly like the oracle."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    eng = sa.Engine(concurrent_games=128, max_explores=800)
+    eng.load_weights(blob)
+    kw = dict(c=0.35, fpu_value=-1.0)
+    my, op = random_positions(oracle, 40, seed=51, max_moves=12)
+    my[0] = 0; op[0] = 0
+    got = eng.mcts_search(sa.MCTSConfig(**kw), my, op, 800)
+    ref = oracle.c4_mcts_search(parity_mcts_config(**kw), blob, my, op, 800, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, "deep trees")
+    sp = eng.selfplay(sa.parity_rollout_config(300, mcts_cfg=sa.MCTSConfig(**kw)), base_seed=13, n_games=48, counters=True)
+    rf = oracle.c4_selfplay(parity_rollout_config(300, mcts=parity_mcts_config(**kw)), blob, 13, 48, threads=8,
+                            nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(sp, rf, "deep trees self-play")
+    assert sp["counters"]["max_depth"] == rf["counters"]["max_depth"]
+    assert sp["counters"]["max_depth"] > 34, sp["counters"]["max_depth"]  # more than two register chunks deep
+    eng.close()
+
+
 def test_engine_error_behaviour(blob):
     """Errors are codes + messages, never a silent fallback (SURVEY §8b 'Errors')."""
     import synthesis_amd as sa
