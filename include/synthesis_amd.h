@@ -190,7 +190,8 @@ int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches);
 /* Device-side RNG / math primitives exposed for parity tests against the oracle (no reference counterpart):
  * out[i] = i-th u32 of StdRng::seed_from_u64(seed) as generated on the GPU. */
 int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out);
-/* y[i] = device det_expf(x[i]); q[i] = a[i] / b[i]; s[i] = sqrtf(a[i])  (IEEE-exactness checks) */
+/* y[i] = device det_expf(a[i]); q[i] = a[i] / b[i]; s[i] = sqrtf(a[i]), or det_logf(a[i]) where b[i] < 0
+ * (IEEE-exactness checks) */
 int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
                    float* out_sqrt_a);
 

@@ -53,4 +53,46 @@ inline float det_expf(float x) {
     return z * bits_to_float((uint32_t)(127 - 64) << 23);
 }
 
+
+// Deterministic f32 natural log for Exploration::Uct (synthesis/src/mcts.rs:364 calls Rust's f32::ln -> platform libm,
+// unpinned). Same contract as det_expf: IEEE-exact operations only, identical on CPU and GPU. Cephes logf scheme:
+// x = m * 2^e with m in (sqrt(1/2), sqrt(2)], f = m - 1, degree-8 polynomial in f with fma, ln2 split in two parts.
+// ln(1) is exactly 0 (a parent with one visit gives a zero exploration term, as in the reference).
+inline float det_logf(float x) {
+    if (x != x || x < 0.0f) return bits_to_float(0x7FC00000u);
+    if (x == 0.0f) return bits_to_float(0xFF800000u);
+    uint32_t bits = float_to_bits(x);
+    if (bits == 0x7F800000u) return x;
+    int e = 0;
+    if (bits < 0x00800000u) {  // subnormal: scale into the normal range first
+        x = x * 8388608.0f;
+        bits = float_to_bits(x);
+        e = -23;
+    }
+    e += (int)(bits >> 23) - 127;
+    float m = bits_to_float((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float f = m - 1.0f;
+    float z = f * f;
+    float y = 7.0376836292e-2f;
+    y = std::fmaf(y, f, -1.1514610310e-1f);
+    y = std::fmaf(y, f, 1.1676998740e-1f);
+    y = std::fmaf(y, f, -1.2420140846e-1f);
+    y = std::fmaf(y, f, 1.4249322787e-1f);
+    y = std::fmaf(y, f, -1.6668057665e-1f);
+    y = std::fmaf(y, f, 2.0000714765e-1f);
+    y = std::fmaf(y, f, -2.4999993993e-1f);
+    y = std::fmaf(y, f, 3.3333331174e-1f);
+    y = y * f;
+    y = y * z;
+    float fe = (float)e;
+    y = std::fmaf(fe, -2.12194440e-4f, y);
+    y = std::fmaf(-0.5f, z, y);
+    float r = f + y;
+    return std::fmaf(fe, 0.693359375f, r);
+}
+
 }  // namespace oracle

@@ -13,7 +13,7 @@
 //   synthesis/src/config.rs:9-44   Exploration / ActionSelection / Fpu / MCTSConfig / PolicyNoise
 // Transcendentals: the reference calls Rust's f32::exp / sqrt / ln (platform libm for exp/ln — unpinned). sqrt
 // and division are IEEE-exact; exp is replaced by the deterministic oracle::det_expf (det_math.hpp) so that a
-// device implementation can match bit for bit; ln (Uct only) stays std::log.
+// device implementation can match bit for bit; ln (Uct only) is the deterministic oracle::det_logf likewise.
 // Parity: pinned by the reference's KATs mcts.rs:691-868 as far as they are reproducible (tests/test_oracle_kats.py).
 #pragma once
 #include <cmath>
@@ -281,7 +281,7 @@ struct MCTS {
     // mcts.rs:361-372
     float explore_value(const Node<G>& parent, const Node<G>& child) const {
         if (cfg.exploration == UCT) {
-            float visits = std::sqrt(cfg.c * std::log(parent.num_visits));
+            float visits = std::sqrt(cfg.c * det_logf(parent.num_visits));
             return visits / std::sqrt(child.num_visits);
         } else {
             float visits = std::sqrt(parent.num_visits);

@@ -88,6 +88,9 @@ void orc_softmax_stable(const float* x, float* y, int n) { softmax_stable(x, y, 
 void orc_det_expf(const float* x, float* y, int n) {
     for (int i = 0; i < n; i++) y[i] = det_expf(x[i]);
 }
+void orc_det_logf(const float* x, float* y, int n) {
+    for (int i = 0; i < n; i++) y[i] = det_logf(x[i]);
+}
 
 // ---------------------------------------------------------------- Connect4Net (policies.rs)
 size_t orc_c4net_num_params() { return Connect4Net::NUM_PARAMS; }

@@ -42,6 +42,44 @@ SYN_DEV float det_expf(float x) {
     return z * bits_f32((uint32_t)(127 - 64) << 23);
 }
 
+// Deterministic f32 natural log (Exploration::Uct); same algorithm as oracle/det_math.hpp det_logf, bit for bit.
+SYN_DEV float det_logf(float x) {
+    if (x != x || x < 0.0f) return bits_f32(0x7FC00000u);
+    if (x == 0.0f) return bits_f32(0xFF800000u);
+    uint32_t bits = f32_bits(x);
+    if (bits == 0x7F800000u) return x;
+    int e = 0;
+    if (bits < 0x00800000u) {
+        x = x * 8388608.0f;
+        bits = f32_bits(x);
+        e = -23;
+    }
+    e += (int)(bits >> 23) - 127;
+    float m = bits_f32((bits & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) {
+        m = m * 0.5f;
+        e += 1;
+    }
+    float f = m - 1.0f;
+    float z = f * f;
+    float y = 7.0376836292e-2f;
+    y = __builtin_fmaf(y, f, -1.1514610310e-1f);
+    y = __builtin_fmaf(y, f, 1.1676998740e-1f);
+    y = __builtin_fmaf(y, f, -1.2420140846e-1f);
+    y = __builtin_fmaf(y, f, 1.4249322787e-1f);
+    y = __builtin_fmaf(y, f, -1.6668057665e-1f);
+    y = __builtin_fmaf(y, f, 2.0000714765e-1f);
+    y = __builtin_fmaf(y, f, -2.4999993993e-1f);
+    y = __builtin_fmaf(y, f, 3.3333331174e-1f);
+    y = y * f;
+    y = y * z;
+    float fe = (float)e;
+    y = __builtin_fmaf(fe, -2.12194440e-4f, y);
+    y = __builtin_fmaf(-0.5f, z, y);
+    float r = f + y;
+    return __builtin_fmaf(fe, 0.693359375f, r);
+}
+
 // ------------------------------------------------------------------------------------------------ row16 primitives
 SYN_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 

@@ -869,7 +869,7 @@ __global__ void debug_math_kernel(const float* a, const float* b, int n, float* 
     if (i < n) {
         e[i] = det_expf(a[i]);
         d[i] = a[i] / b[i];
-        s[i] = sqrtf(a[i]);
+        s[i] = b[i] < 0.0f ? det_logf(a[i]) : sqrtf(a[i]);  // b < 0 selects the log probe
     }
 }
 

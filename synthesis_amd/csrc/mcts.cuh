@@ -228,7 +228,7 @@ SYN_DEV void tree_select_expand(const DevMctsCfg& cfg_, TreeCtx& T, ExploreCtx& 
             float visits = sqrtf(pN);
             u = cfg.cc() * bits_f32(ce.z) * visits / (1.0f + cs.x);
         } else {
-            float visits = sqrtf(cfg.cc() * logf(pN));
+            float visits = sqrtf(cfg.cc() * det_logf(pN));
             u = visits / sqrtf(cs.x);
         }
         float v = q + u;

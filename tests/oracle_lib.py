@@ -129,6 +129,12 @@ class Oracle:
         self.lib.orc_det_expf(_p(x), _p(y), int(x.size))
         return y
 
+    def det_logf(self, x):
+        x = np.ascontiguousarray(x, np.float32).ravel()
+        y = np.zeros_like(x)
+        self.lib.orc_det_logf(_p(x), _p(y), int(x.size))
+        return y
+
     def softmax_stable(self, x):
         x = np.ascontiguousarray(x, np.float32).ravel()
         y = np.zeros_like(x)

@@ -66,6 +66,14 @@ def test_device_math_is_ieee_exact(engine, oracle):
     assert np.array_equal(s[pos].view(np.uint32), np.sqrt(a[pos]).view(np.uint32))  # correctly rounded sqrt
 
 
+def test_device_logf_matches_oracle(engine, oracle):
+    a = np.concatenate([np.arange(1, 5000), np.random.RandomState(2).uniform(1e-30, 1e30, 100000)]).astype(np.float32)
+    _, _, s = engine.debug_math(a, -np.ones_like(a))
+    assert np.array_equal(s.view(np.uint32), oracle.det_logf(a).view(np.uint32))
+    assert oracle.det_logf([1.0])[0] == 0.0
+    np.testing.assert_allclose(oracle.det_logf(a).astype(np.float64), np.log(a.astype(np.float64)), rtol=3e-7, atol=1e-7)
+
+
 def test_device_stdrng_matches_oracle(engine, oracle):
     for seed in (0, 1, 12345, 2**63 + 17):
         assert np.array_equal(engine.debug_stdrng_u32(seed, 200), oracle.stdrng_u32(seed, 200))
@@ -223,10 +231,12 @@ def test_mcts_config_variants(engine, oracle, blob):
     variants = [
         dict(fpu=1), dict(solve=0), dict(correct_values_on_solve=0), dict(auto_extend=0), dict(select_solved_nodes=0),
         dict(c=1.25, fpu_value=0.0), dict(noise=1, noise_weight=0.25), dict(noise=1, noise_weight=0.6, fpu=1),
+        # Exploration::Uct as the reference configures its rollout MCTS (study-connect4/src/main.rs:74-82)
+        dict(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf")), dict(exploration=0, c=0.7, fpu_value=0.5),
     ]
     for v in variants:
         ocfg = parity_mcts_config(**v)
-        scfg = sa.MCTSConfig(exploration=sa.Exploration.PolynomialUct, c=ocfg.c, solve=bool(ocfg.solve),
+        scfg = sa.MCTSConfig(exploration=sa.Exploration(ocfg.exploration), c=ocfg.c, solve=bool(ocfg.solve),
                              correct_values_on_solve=bool(ocfg.correct_values_on_solve),
                              select_solved_nodes=bool(ocfg.select_solved_nodes), auto_extend=bool(ocfg.auto_extend),
                              fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value,

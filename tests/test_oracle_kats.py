@@ -215,6 +215,14 @@ def test_det_expf_accuracy(oracle):
     np.testing.assert_allclose(sm, np.exp([1.0, 2, 3]) / np.exp([1.0, 2, 3]).sum(), rtol=3e-7)
 
 
+def test_det_logf_accuracy(oracle):
+    x = np.concatenate([np.arange(1, 100000), np.geomspace(1e-38, 1e38, 200001)]).astype(np.float32)
+    y = oracle.det_logf(x).astype(np.float64)
+    t = np.log(x.astype(np.float64))
+    assert np.max(np.abs(y - t) / np.maximum(np.abs(t), 1e-3)) < 4e-7
+    assert oracle.det_logf([1.0])[0] == 0.0 and np.isneginf(oracle.det_logf([0.0])[0]) and np.isnan(oracle.det_logf([-1.0])[0])
+
+
 def test_c4net_matches_torch_goldens(oracle, golden_dir):
     """Connect4Net has no test in the reference (parity unpinned there): check both accumulation modes against
     torch float32/float64 outputs generated by make_golden.py. Tolerance = north_star's 1e-5."""
