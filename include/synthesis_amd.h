@@ -195,6 +195,10 @@ int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out);
 int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
                    float* out_sqrt_a);
 
+/* PMC calibration probe (tools/calibrate_pmc.py): gathers n_spans 288-byte sibling spans of 32-byte node records at
+ * record offsets d_span_off[i] from d_base (device pointers), optionally rewriting 16 bytes per touched record. */
+int syn_debug_calibrate(syn_engine* h, const void* d_base, const uint32_t* d_span_off, int n_spans, int do_write);
+
 #ifdef __cplusplus
 }
 #endif

@@ -621,6 +621,22 @@ int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches) {
     return SYN_OK;
 }
 
+int syn_debug_calibrate(syn_engine* h, const void* d_base, const uint32_t* d_span_off, int n_spans, int do_write) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!d_base || !d_span_off || n_spans < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_scratch(h, 1 << 20);
+    if (rc != SYN_OK) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(calib_gather_kernel, dim3(2048), dim3(256), 0, h->stream, static_cast<const float4*>(d_base),
+                       d_span_off, n_spans, static_cast<float4*>(h->d_scratch), do_write);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    return SYN_OK;
+}
+
 int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (n < 0 || (n > 0 && !out)) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");

@@ -855,6 +855,27 @@ __global__ void conv2d_kernel(int CIN, int COUT, int K, int RP, int CP, int S, i
     }
 }
 
+// PMC calibration probe (MI355X guide §HBM: FETCH_SIZE / WRITE_SIZE are only calibrated for wide streaming accesses):
+// reproduces the node pool's access shape — every 16-lane row gathers one 288-byte sibling span (9 lanes x two 16-byte
+// loads) at span_off[i] and optionally rewrites 16 bytes per lane — over a buffer far larger than the caches, so the
+// counters can be compared with exactly known byte / cache-line counts (tools/calibrate_pmc.py).
+__global__ void calib_gather_kernel(const float4* __restrict__ base, const unsigned* __restrict__ span_off, int n_spans,
+                                    float4* __restrict__ sink, int do_write) {
+    int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int gl = threadIdx.x & 15;
+    int nrows = (gridDim.x * blockDim.x) >> 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = row; i < n_spans; i += nrows) {
+        if (gl < 9) {
+            size_t rec = (size_t)span_off[i] + (size_t)gl;  // 32-byte records
+            float4 a = base[2 * rec], b = base[2 * rec + 1];
+            acc.x += a.x + b.x; acc.y += a.y + b.y; acc.z += a.z + b.z; acc.w += a.w + b.w;
+            if (do_write) const_cast<float4*>(base)[2 * rec] = make_float4(acc.x, a.y, a.z, a.w);
+        }
+    }
+    if (acc.x == 123.456f) sink[row] = acc;  // keep the loads alive
+}
+
 // parity probes for the device primitives
 __global__ void debug_rng_kernel(unsigned long long seed, int n, uint32_t* out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

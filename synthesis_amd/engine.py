@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_debug_stdrng_u32",
-    "syn_debug_math",
+    "syn_debug_math", "syn_debug_calibrate",
 ]
 
 
@@ -82,6 +82,7 @@ def load_library():
     lib.syn_debug_stdrng_u32.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
+    lib.syn_debug_calibrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     _lib = lib
     return lib
 
