@@ -445,6 +445,21 @@ int syn_conv2d_forward(syn_engine* h, int CIN, int COUT, int K, int RP, int CP, 
     return SYN_OK;
 }
 
+// A searchable Connect4 position (connect4.rs:3-13): disjoint bitboards inside the 63 cells, every column filled
+// from the bottom without holes, at least one free column. (The reference would panic in best_action().unwrap() on a
+// root without legal moves, mcts.rs:293.)
+static bool valid_root(uint64_t my, uint64_t op) {
+    if ((my & op) != 0 || ((my | op) >> 63) != 0) return false;
+    uint64_t occ = my | op;
+    bool any_free = false;
+    for (int c = 0; c < 9; c++) {
+        unsigned col = (unsigned)((occ >> (7 * c)) & 0x7F);
+        if ((col & (col + 1)) != 0) return false;  // must be 0b0..01..1
+        any_free |= col != 0x7F;
+    }
+    return any_free;
+}
+
 static int common_params(syn_engine* h, EngineParams& P, int explores) {
     if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
     if (explores < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "explores must be >= 0");
@@ -474,6 +489,10 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
     rc = convert_mcts(h, cfg, P.mcts);
     if (rc != SYN_OK) return rc;
     if (n == 0) return SYN_OK;
+    for (int i = 0; i < n; i++)
+        if (!valid_root(my_bb[i], op_bb[i]))
+            return fail(h, SYN_ERR_INVALID_ARGUMENT, "root %d is not a searchable Connect4 position "
+                        "(overlapping / floating stones, bit 63 set, or no free column)", i);
     HIP_TRY(h, hipSetDevice(h->device));
     size_t nb = (size_t)n;
     rc = ensure_scratch(h, nb * (16 + sizeof(DevSearchResult)) + 256);
@@ -532,6 +551,8 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown value target %d", cfg->value_target);
     if (cfg->action != SYN_ACTION_Q && cfg->action != SYN_ACTION_NUM_VISITS)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection %d", cfg->action);
+    if (cfg->random_actions_until < 0 || cfg->sample_actions_until < 0)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "random_actions_until / sample_actions_until must be >= 0");
     EngineParams P;
     int rc = common_params(h, P, cfg->num_explores);
     if (rc != SYN_OK) return rc;

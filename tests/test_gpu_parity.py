@@ -292,6 +292,11 @@ def test_engine_error_behaviour(blob):
     assert e.value.code == -5
     r = eng.selfplay(sa.parity_rollout_config(8), 0, 0)
     assert r["plies"].size == 0
+    # roots the reference itself could not search: overlapping stones, a floating stone, a full board
+    for my, op in ((1, 1), (2, 0), ((1 << 63) - 1 - 0x2AAAAAAAAAAAAAAA & ((1 << 63) - 1), 0x2AAAAAAAAAAAAAAA)):
+        with pytest.raises(sa.SynthesisAmdError) as e:
+            eng.mcts_search(sa.parity_mcts_config(), [my], [op], 8)
+        assert e.value.code == -1
     eng.close()
 
 
