@@ -183,6 +183,43 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
                      int n_games, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
                      uint32_t* root_nodes, uint8_t* final_kind, syn_counters* counters);
 
+/* ---- learner step and replay de-duplication (the step right after the self-play path) ---------- */
+
+/* LearningConfig's optimiser fields (config.rs:76-94) + Adam::default() (alpha_zero.rs:33-36) */
+typedef struct syn_train_config {
+    float weight_decay;    /* LearningConfig::weight_decay (study-connect4/src/main.rs:20: 1e-6) */
+    float policy_weight;   /* LearningConfig::policy_weight */
+    float value_weight;    /* LearningConfig::value_weight */
+    float beta1;           /* 0.9 */
+    float beta2;           /* 0.999 */
+    float eps;             /* 1e-8 */
+} syn_train_config;
+
+/* Replaces: P::new(&vs) + Adam::default().build(&vs, lr) (alpha_zero.rs:31-36): parameters (same blob order as
+ * syn_load_weights) and zeroed Adam moments on the device. */
+int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg);
+/* Replaces: one iteration of the minibatch loop alpha_zero.rs:76-92 (forward, log_softmax, kl_div(Sum)/batch for both
+ * heads, loss, backward_step). States are given as bitboards; losses[2] = {pi_loss, v_loss} (may be NULL). */
+int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
+                   const float* target_v, int batch, float lr, float* losses);
+/* Data-parallel form (BASELINE configs[4]): gradients of this rank's minibatch into a caller-owned DEVICE buffer of
+ * 30,492 floats (all other pointers are device pointers too), to be all-reduced by the caller (RCCL), then applied with
+ * syn_train_apply_device(grad_scale = 1/ranks). losses is a host pointer (may be NULL). */
+int syn_train_gradients_device(syn_engine* h, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,
+                               const float* d_target_v, int batch, float* d_grads, float* losses);
+int syn_train_apply_device(syn_engine* h, const float* d_grads, float lr, float grad_scale);
+/* Copies out parameters / Adam moments / last gradient (each may be NULL) and the optimiser step count. */
+int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long long* step, float* grads);
+/* Replaces: vs.save(model_{i+1}.ot) + the workers' vs.load (alpha_zero.rs:97,194): the trained parameters become the
+ * engine's policy for syn_policy_eval_batch / syn_mcts_search / syn_selfplay_run. */
+int syn_trainer_publish_weights(syn_engine* h);
+/* Replaces: ReplayBuffer::deduplicate (data.rs:196-235): identical states are merged, their targets summed in buffer
+ * order and divided by the count. Outputs are sized for n entries; *out_count = number of unique states, emitted in
+ * ascending (my_bb, op_bb) order (the reference's order is HashMap iteration order, i.e. unspecified). */
+int syn_replay_deduplicate(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* pis,
+                           const float* vs, size_t n, uint64_t* out_my, uint64_t* out_op, float* out_pi, float* out_v,
+                           uint32_t* out_num, size_t* out_count);
+
 /* Timing of the last syn_selfplay_run / syn_mcts_search / *_device call on this handle, measured with HIP events on
  * the engine stream: kernel_ms = device time of the dominant kernel launch(es), n_launches = how many. */
 int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches);

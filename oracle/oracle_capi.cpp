@@ -17,6 +17,7 @@
 #include "rng.hpp"
 #include "selfplay.hpp"
 #include "tictactoe.hpp"
+#include "train.hpp"
 
 using namespace oracle;
 
@@ -350,6 +351,71 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
         }
     }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---------------------------------------------------------------- training step + replay de-duplication
+struct orc_train_hyper {
+    float weight_decay, policy_weight, value_weight, beta1, beta2, eps;
+};
+static TrainHyper to_hyper(const orc_train_hyper& h) {
+    TrainHyper t;
+    t.weight_decay = h.weight_decay;
+    t.policy_weight = h.policy_weight;
+    t.value_weight = h.value_weight;
+    t.beta1 = h.beta1;
+    t.beta2 = h.beta2;
+    t.eps = h.eps;
+    return t;
+}
+// Gradients of one minibatch (features X[B][63]); grad_out[30492]; losses[2].
+void orc_train_gradients(const float* blob, const orc_train_hyper* hp, const float* X, const float* tpi,
+                         const float* tv, int B, float* grad_out, float* losses) {
+    Trainer t(blob, to_hyper(*hp));
+    t.gradients(X, tpi, tv, B, losses);
+    std::memcpy(grad_out, t.grad.data(), t.grad.size() * sizeof(float));
+}
+// n_steps optimiser steps on consecutive minibatches X[n_steps][B][63] ...; state (m, v, step) starts at zero unless
+// m_io / v_io / step_io are given (then they are read and written back). losses[n_steps][2].
+void orc_train_steps(float* blob_io, const orc_train_hyper* hp, const float* X, const float* tpi, const float* tv,
+                     int B, int n_steps, const float* lrs, float* m_io, float* v_io, long long* step_io,
+                     float* losses) {
+    Trainer t(blob_io, to_hyper(*hp));
+    if (m_io) std::memcpy(t.m.data(), m_io, t.m.size() * sizeof(float));
+    if (v_io) std::memcpy(t.v.data(), v_io, t.v.size() * sizeof(float));
+    if (step_io) t.step = *step_io;
+    for (int s = 0; s < n_steps; s++)
+        t.train_step(X + (size_t)s * B * 63, tpi + (size_t)s * B * 9, tv + (size_t)s * B * 3, B, lrs[s], losses + 2 * s);
+    std::memcpy(blob_io, t.w.data(), t.w.size() * sizeof(float));
+    if (m_io) std::memcpy(m_io, t.m.data(), t.m.size() * sizeof(float));
+    if (v_io) std::memcpy(v_io, t.v.data(), t.v.size() * sizeof(float));
+    if (step_io) *step_io = t.step;
+}
+// Adam only (after an external gradient all-reduce)
+void orc_train_adam(float* blob_io, const orc_train_hyper* hp, const float* grad, float lr, float* m_io, float* v_io,
+                    long long* step_io) {
+    Trainer t(blob_io, to_hyper(*hp));
+    std::memcpy(t.m.data(), m_io, t.m.size() * sizeof(float));
+    std::memcpy(t.v.data(), v_io, t.v.size() * sizeof(float));
+    std::memcpy(t.grad.data(), grad, t.grad.size() * sizeof(float));
+    t.step = *step_io;
+    t.adam(lr);
+    std::memcpy(blob_io, t.w.data(), t.w.size() * sizeof(float));
+    std::memcpy(m_io, t.m.data(), t.m.size() * sizeof(float));
+    std::memcpy(v_io, t.v.data(), t.v.size() * sizeof(float));
+    *step_io = t.step;
+}
+// data.rs:196-235. Outputs sized for n entries; returns the number of unique states (ascending (my, op)).
+size_t orc_dedup(const uint64_t* my_bb, const uint64_t* op_bb, const float* pis, const float* vs, size_t n,
+                 uint64_t* out_my, uint64_t* out_op, float* out_pi, float* out_v, uint32_t* out_num) {
+    std::vector<DedupEntry> d = deduplicate(my_bb, op_bb, pis, vs, n);
+    for (size_t i = 0; i < d.size(); i++) {
+        out_my[i] = d[i].my_bb;
+        out_op[i] = d[i].op_bb;
+        for (int j = 0; j < 9; j++) out_pi[i * 9 + j] = d[i].pi[j];
+        for (int j = 0; j < 3; j++) out_v[i * 3 + j] = d[i].v[j];
+        out_num[i] = d[i].num;
+    }
+    return d.size();
 }
 
 }  // extern "C"

@@ -1,0 +1,188 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+//
+// CPU restatement of the step that follows the self-play path in the reference's learner:
+//   synthesis/src/data.rs:196-235        ReplayBuffer::deduplicate (average the targets of identical states)
+//   synthesis/src/alpha_zero.rs:72-94    one optimiser step: forward, log_softmax, kl_div(Sum) * (1/batch) for the
+//                                        policy and the outcome head, loss = policy_weight*pi + value_weight*v, Adam
+//   synthesis/src/alpha_zero.rs:33-36    Adam::default() + set_weight_decay
+// The arithmetic lives in libtorch (tch 0.4.1, not in /root/reference): Linear / relu / log_softmax / kl_div / Adam.
+// What is restated is their published semantics:
+//   kl_div(input = log p, target t, Sum, log_target = false) = sum t * (log t - log p), with 0 * log 0 = 0
+//   d/dlogits = scale * (softmax * sum(t) - t)                       (kl_div backward, then log_softmax backward)
+//   Adam (torch::optim::Adam, amsgrad off): g += wd * p; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g g;
+//                                           p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)
+// No reference test exercises this step -> PARITY UNPINNED against the reference; an independent second opinion
+// (this container's torch, float64) is committed as tests/golden/train_torch_goldens.json and checked to 1e-5.
+// Every f32 operation below is written in a fixed order (fma chains, ascending indices) so the HIP implementation
+// can match bit for bit.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <utility>
+#include <vector>
+
+#include "det_math.hpp"
+#include "nn.hpp"
+
+namespace oracle {
+
+struct TrainHyper {
+    float weight_decay = 1e-6f;   // study-connect4/src/main.rs:20
+    float policy_weight = 1.0f;   // main.rs:23
+    float value_weight = 1.0f;    // main.rs:24
+    float beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;  // Adam::default()
+};
+
+struct Trainer {
+    static constexpr int NL = 5;
+    std::vector<float> w, m, v, grad;
+    int64_t step = 0;
+    TrainHyper hp;
+
+    explicit Trainer(const float* blob, TrainHyper h = TrainHyper())
+        : w(blob, blob + Connect4Net::NUM_PARAMS), m(Connect4Net::NUM_PARAMS, 0.0f), v(Connect4Net::NUM_PARAMS, 0.0f),
+          grad(Connect4Net::NUM_PARAMS, 0.0f), hp(h) {}
+
+    static size_t w_off(int l) {
+        size_t off = 0;
+        for (int i = 0; i < l; i++) off += (size_t)Connect4Net::DIMS[i] * Connect4Net::DIMS[i + 1] + Connect4Net::DIMS[i + 1];
+        return off;
+    }
+    static size_t b_off(int l) { return w_off(l) + (size_t)Connect4Net::DIMS[l] * Connect4Net::DIMS[l + 1]; }
+
+    // Gradients of loss = pw * (1/B) * KL(pi) + vw * (1/B) * KL(v) for one minibatch; losses[0..1] = pi_loss, v_loss.
+    // X[B][63] features, tpi[B][9], tv[B][3].
+    void gradients(const float* X, const float* tpi, const float* tv, int B, float losses[2]) {
+        const int* D = Connect4Net::DIMS;
+        std::vector<std::vector<float>> A(NL + 1), dZ(NL + 1);
+        A[0].assign(X, X + (size_t)B * 63);
+        for (int l = 0; l < NL; l++) {
+            int K = D[l], O = D[l + 1];
+            A[l + 1].resize((size_t)B * O);
+            const float* W = w.data() + w_off(l);
+            const float* bias = w.data() + b_off(l);
+            for (int b = 0; b < B; b++)
+                for (int o = 0; o < O; o++) {
+                    float acc = bias[o];
+                    for (int k = 0; k < K; k++) acc = std::fmaf(A[l][(size_t)b * K + k], W[(size_t)o * K + k], acc);
+                    if (l < NL - 1) acc = acc > 0.0f ? acc : 0.0f;
+                    A[l + 1][(size_t)b * O + o] = acc;
+                }
+        }
+        // heads: out[b][0..9) policy logits, out[b][9..12) outcome logits
+        const float bm = 1.0f / (float)B;  // batch_mean (alpha_zero.rs:44)
+        dZ[NL].assign((size_t)B * 12, 0.0f);
+        float pi_loss = 0.0f, v_loss = 0.0f;
+        for (int b = 0; b < B; b++) {
+            for (int head = 0; head < 2; head++) {
+                const int off = head == 0 ? 0 : 9, n = head == 0 ? 9 : 3;
+                const float* x = &A[NL][(size_t)b * 12 + off];
+                const float* t = head == 0 ? tpi + (size_t)b * 9 : tv + (size_t)b * 3;
+                const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
+                float mx = x[0];
+                for (int j = 1; j < n; j++) mx = x[j] > mx ? x[j] : mx;
+                float se = 0.0f;
+                for (int j = 0; j < n; j++) se += det_expf(x[j] - mx);
+                const float lse = mx + det_logf(se);
+                float kl = 0.0f, tsum = 0.0f;
+                for (int j = 0; j < n; j++) {
+                    float logp = x[j] - lse;
+                    if (t[j] > 0.0f) kl += t[j] * (det_logf(t[j]) - logp);
+                    tsum += t[j];
+                }
+                (head == 0 ? pi_loss : v_loss) += kl;
+                const float s = weight * bm;
+                for (int j = 0; j < n; j++) {
+                    float p = det_expf(x[j] - lse);
+                    dZ[NL][(size_t)b * 12 + off + j] = s * (p * tsum - t[j]);
+                }
+            }
+        }
+        losses[0] = bm * pi_loss;
+        losses[1] = bm * v_loss;
+        // backward
+        for (int l = NL - 1; l >= 0; l--) {
+            int K = D[l], O = D[l + 1];
+            const float* W = w.data() + w_off(l);
+            float* gW = grad.data() + w_off(l);
+            float* gb = grad.data() + b_off(l);
+            for (int o = 0; o < O; o++) {
+                float acc = 0.0f;
+                for (int b = 0; b < B; b++) acc += dZ[l + 1][(size_t)b * O + o];
+                gb[o] = acc;
+                for (int k = 0; k < K; k++) {
+                    float a = 0.0f;
+                    for (int b = 0; b < B; b++) a = std::fmaf(dZ[l + 1][(size_t)b * O + o], A[l][(size_t)b * K + k], a);
+                    gW[(size_t)o * K + k] = a;
+                }
+            }
+            if (l > 0) {
+                dZ[l].resize((size_t)B * K);
+                for (int b = 0; b < B; b++)
+                    for (int k = 0; k < K; k++) {
+                        float a = 0.0f;
+                        for (int o = 0; o < O; o++) a = std::fmaf(dZ[l + 1][(size_t)b * O + o], W[(size_t)o * K + k], a);
+                        dZ[l][(size_t)b * K + k] = A[l][(size_t)b * K + k] > 0.0f ? a : 0.0f;  // relu'
+                    }
+            }
+        }
+    }
+
+    // torch::optim::Adam step on `grad` (already summed/averaged over ranks if data-parallel)
+    void adam(float lr) {
+        step += 1;
+        const double bc1 = 1.0 - std::pow((double)hp.beta1, (double)step);
+        const double bc2 = 1.0 - std::pow((double)hp.beta2, (double)step);
+        const float step_size = (float)((double)lr / bc1);
+        const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+        for (size_t i = 0; i < w.size(); i++) {
+            float g = hp.weight_decay != 0.0f ? std::fmaf(hp.weight_decay, w[i], grad[i]) : grad[i];
+            m[i] = std::fmaf(1.0f - hp.beta1, g, hp.beta1 * m[i]);
+            v[i] = std::fmaf((1.0f - hp.beta2) * g, g, hp.beta2 * v[i]);
+            float denom = std::sqrt(v[i]) * inv_sqrt_bc2 + hp.eps;
+            w[i] = w[i] - step_size * (m[i] / denom);
+        }
+    }
+
+    void train_step(const float* X, const float* tpi, const float* tv, int B, float lr, float losses[2]) {
+        gradients(X, tpi, tv, B, losses);
+        adam(lr);
+    }
+};
+
+// data.rs:196-235: average the targets of identical states. Output order of the reference is HashMap iteration order
+// (unspecified); here: ascending (my_bb, op_bb). Sums run in buffer order, then one division by the count.
+struct DedupEntry {
+    uint64_t my_bb, op_bb;
+    float pi[9], v[3];
+    uint32_t num;
+};
+inline std::vector<DedupEntry> deduplicate(const uint64_t* my_bb, const uint64_t* op_bb, const float* pis,
+                                           const float* vs, size_t n) {
+    std::map<std::pair<uint64_t, uint64_t>, DedupEntry> stats;
+    for (size_t i = 0; i < n; i++) {
+        auto key = std::make_pair(my_bb[i], op_bb[i]);
+        auto it = stats.find(key);
+        if (it == stats.end()) {
+            DedupEntry e{};
+            e.my_bb = my_bb[i];
+            e.op_bb = op_bb[i];
+            it = stats.emplace(key, e).first;
+        }
+        for (int j = 0; j < 9; j++) it->second.pi[j] += pis[i * 9 + j];
+        for (int j = 0; j < 3; j++) it->second.v[j] += vs[i * 3 + j];
+        it->second.num += 1;
+    }
+    std::vector<DedupEntry> out;
+    out.reserve(stats.size());
+    for (auto& kv : stats) {
+        DedupEntry e = kv.second;
+        for (int j = 0; j < 9; j++) e.pi[j] = e.pi[j] / (float)e.num;
+        for (int j = 0; j < 3; j++) e.v[j] = e.v[j] / (float)e.num;
+        out.push_back(e);
+    }
+    return out;
+}
+
+}  // namespace oracle

@@ -16,6 +16,10 @@
 
 #include "../../include/synthesis_amd.h"
 #include "engine_kernels.cuh"
+#include "train_kernels.cuh"
+
+#include <hipcub/hipcub.hpp>
+#include <cmath>
 
 using namespace syn;
 
@@ -53,6 +57,15 @@ struct syn_engine {
     std::string err;
     float last_kernel_ms = 0.0f;
     int last_launches = 0;
+    // learner state (syn_trainer_init): parameters, Adam moments, gradient + loss scratch
+    float* d_tw = nullptr;
+    float* d_tm = nullptr;
+    float* d_tv = nullptr;
+    float* d_tgrad = nullptr;
+    float* d_tloss = nullptr;
+    long long train_step = 0;
+    DevTrainHyper train_hp{};
+    bool has_trainer = false;
 };
 
 static int fail(syn_engine* h, int code, const char* fmt, ...) {
@@ -284,6 +297,11 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_root_nodes);
     hipFree(h->d_final);
     hipFree(h->d_scratch);
+    hipFree(h->d_tw);
+    hipFree(h->d_tm);
+    hipFree(h->d_tv);
+    hipFree(h->d_tgrad);
+    hipFree(h->d_tloss);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -632,6 +650,205 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
+    return SYN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ learner step
+int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!blob || !cfg) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob/cfg is NULL");
+    if (n_floats != (size_t)TrainGeom::NUM_PARAMS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4Net has %d parameters, got %zu", TrainGeom::NUM_PARAMS, n_floats);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
+    if (!h->d_tw) {
+        HIP_TRY(h, hipMalloc(&h->d_tw, bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tm, bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tv, bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tgrad, bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tloss, 64));
+    }
+    HIP_TRY(h, hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tm, 0, bytes, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tv, 0, bytes, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->train_hp = DevTrainHyper{cfg->weight_decay, cfg->policy_weight, cfg->value_weight, cfg->beta1, cfg->beta2, cfg->eps};
+    h->train_step = 0;
+    h->has_trainer = true;
+    return SYN_OK;
+}
+
+static int launch_grads(syn_engine* h, const unsigned long long* d_my, const unsigned long long* d_op,
+                        const float* d_tpi, const float* d_tv, int batch, float* d_grads) {
+    auto k = train_grad_kernel;
+    const size_t lds = (size_t)TrainGeom::LDS_FLOATS * 4;
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3(1), dim3(1024), lds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
+                       d_grads, h->d_tloss);
+    HIP_TRY(h, hipGetLastError());
+    return SYN_OK;
+}
+
+static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad_scale) {
+    h->train_step += 1;
+    const double bc1 = 1.0 - std::pow((double)h->train_hp.beta1, (double)h->train_step);
+    const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, (double)h->train_step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+    const int n = TrainGeom::NUM_PARAMS;
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads,
+                       n, h->train_hp, step_size, inv_sqrt_bc2, grad_scale);
+    HIP_TRY(h, hipGetLastError());
+    return SYN_OK;
+}
+
+int syn_train_gradients_device(syn_engine* h, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,
+                               const float* d_target_v, int batch, float* d_grads, float* losses) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (batch < 1 || !d_my_bb || !d_op_bb || !d_target_pi || !d_target_v || !d_grads)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_train_gradients_device");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = launch_grads(h, reinterpret_cast<const unsigned long long*>(d_my_bb),
+                          reinterpret_cast<const unsigned long long*>(d_op_bb), d_target_pi, d_target_v, batch, d_grads);
+    if (rc != SYN_OK) return rc;
+    if (losses) HIP_TRY(h, hipMemcpyAsync(losses, h->d_tloss, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_train_apply_device(syn_engine* h, const float* d_grads, float lr, float grad_scale) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (!d_grads) return fail(h, SYN_ERR_INVALID_ARGUMENT, "d_grads is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = launch_adam(h, d_grads, lr, grad_scale);
+    if (rc != SYN_OK) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
+                   const float* target_v, int batch, float lr, float* losses) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (batch < 1 || !my_bb || !op_bb || !target_pi || !target_v)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_train_step");
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nb = (size_t)batch;
+    int rc = ensure_scratch(h, nb * (16 + 36 + 12) + 256);
+    if (rc != SYN_OK) return rc;
+    unsigned long long* d_my = static_cast<unsigned long long*>(h->d_scratch);
+    unsigned long long* d_op = d_my + nb;
+    float* d_tpi = reinterpret_cast<float*>(d_op + nb);
+    float* d_tv = d_tpi + nb * 9;
+    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_tpi, target_pi, nb * 36, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_tv, target_v, nb * 12, hipMemcpyHostToDevice, h->stream));
+    rc = launch_grads(h, d_my, d_op, d_tpi, d_tv, batch, h->d_tgrad);
+    if (rc != SYN_OK) return rc;
+    rc = launch_adam(h, h->d_tgrad, lr, 1.0f);
+    if (rc != SYN_OK) return rc;
+    if (losses) HIP_TRY(h, hipMemcpyAsync(losses, h->d_tloss, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long long* step, float* grads) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
+    if (blob) HIP_TRY(h, hipMemcpyAsync(blob, h->d_tw, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (m) HIP_TRY(h, hipMemcpyAsync(m, h->d_tm, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (v) HIP_TRY(h, hipMemcpyAsync(v, h->d_tv, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (grads) HIP_TRY(h, hipMemcpyAsync(grads, h->d_tgrad, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (step) *step = h->train_step;
+    return SYN_OK;
+}
+
+// weight hand-off learner -> self-play (the reference does it through models/model_i.ot, alpha_zero.rs:97,194)
+int syn_trainer_publish_weights(syn_engine* h) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    std::vector<float> blob(TrainGeom::NUM_PARAMS);
+    int rc = syn_trainer_get_state(h, blob.data(), nullptr, nullptr, nullptr, nullptr);
+    if (rc != SYN_OK) return rc;
+    return syn_load_weights(h, blob.data(), blob.size());
+}
+
+// ------------------------------------------------------------------------------------------------ deduplicate
+int syn_replay_deduplicate(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* pis,
+                           const float* vs, size_t n, uint64_t* out_my, uint64_t* out_op, float* out_pi, float* out_v,
+                           uint32_t* out_num, size_t* out_count) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!out_count) return fail(h, SYN_ERR_INVALID_ARGUMENT, "out_count is NULL");
+    *out_count = 0;
+    if (n == 0) return SYN_OK;
+    if (!my_bb || !op_bb || !pis || !vs || !out_my || !out_op || !out_pi || !out_v || !out_num || n > 0x7FFFFFFFu)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_replay_deduplicate");
+    HIP_TRY(h, hipSetDevice(h->device));
+    const int ni = (int)n;
+    // device layout: inputs | sort keys/values (double buffers) | heads | scan | seg_start | outputs | cub temp
+    size_t tmp_sort = 0, tmp_scan = 0;
+    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, (const unsigned long long*)nullptr,
+                                                  (unsigned long long*)nullptr, (const unsigned*)nullptr,
+                                                  (unsigned*)nullptr, ni, 0, 64, h->stream));
+    HIP_TRY(h, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, (const unsigned*)nullptr, (unsigned*)nullptr, ni,
+                                                h->stream));
+    size_t tmp = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    size_t o_my = take(n * 8), o_op = take(n * 8), o_pi = take(n * 36), o_v = take(n * 12);
+    size_t o_k0 = take(n * 8), o_k1 = take(n * 8), o_i0 = take(n * 4), o_i1 = take(n * 4);
+    size_t o_head = take(n * 4), o_scan = take(n * 4), o_start = take(n * 4);
+    size_t o_omy = take(n * 8), o_oop = take(n * 8), o_opi = take(n * 36), o_ov = take(n * 12), o_on = take(n * 4);
+    size_t o_tmp = take(tmp);
+    int rc = ensure_scratch(h, off + 256);
+    if (rc != SYN_OK) return rc;
+    char* base = static_cast<char*>(h->d_scratch);
+    auto P8 = [&](size_t o) { return reinterpret_cast<unsigned long long*>(base + o); };
+    auto P4 = [&](size_t o) { return reinterpret_cast<unsigned*>(base + o); };
+    auto PF = [&](size_t o) { return reinterpret_cast<float*>(base + o); };
+    HIP_TRY(h, hipMemcpyAsync(P8(o_my), my_bb, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(P8(o_op), op_bb, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(PF(o_pi), pis, n * 36, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(PF(o_v), vs, n * 12, hipMemcpyHostToDevice, h->stream));
+    const int blocks = (ni + 255) / 256;
+    // stable LSD sort of the buffer indices by the 128-bit key: first by op_bb, then by my_bb
+    hipLaunchKernelGGL(iota_kernel, dim3(blocks), dim3(256), 0, h->stream, P4(o_i0), ni);
+    size_t t1 = tmp;
+    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(base + o_tmp, t1, P8(o_op), P8(o_k0), P4(o_i0), P4(o_i1), ni, 0, 64,
+                                                  h->stream));
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks), dim3(256), 0, h->stream, P8(o_my), P4(o_i1), ni, P8(o_k1));
+    t1 = tmp;
+    HIP_TRY(h, hipcub::DeviceRadixSort::SortPairs(base + o_tmp, t1, P8(o_k1), P8(o_k0), P4(o_i1), P4(o_i0), ni, 0, 64,
+                                                  h->stream));
+    // o_k0 = my_bb sorted, o_i0 = buffer indices in (my, op, index) order; op_bb in that order:
+    hipLaunchKernelGGL(gather_u64_kernel, dim3(blocks), dim3(256), 0, h->stream, P8(o_op), P4(o_i0), ni, P8(o_k1));
+    hipLaunchKernelGGL(dedup_heads_kernel, dim3(blocks), dim3(256), 0, h->stream, P8(o_k0), P8(o_k1), ni, P4(o_head));
+    t1 = tmp;
+    HIP_TRY(h, hipcub::DeviceScan::InclusiveSum(base + o_tmp, t1, P4(o_head), P4(o_scan), ni, h->stream));
+    hipLaunchKernelGGL(dedup_starts_kernel, dim3(blocks), dim3(256), 0, h->stream, P4(o_head), P4(o_scan), ni,
+                       P4(o_start));
+    unsigned m_u = 0;
+    HIP_TRY(h, hipMemcpyAsync(&m_u, P4(o_scan) + (ni - 1), 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int m = (int)m_u;
+    hipLaunchKernelGGL(dedup_reduce_kernel, dim3((m * 16 + 255) / 256), dim3(256), 0, h->stream, P4(o_i0), P4(o_start),
+                       m, ni, P8(o_my), P8(o_op), PF(o_pi), PF(o_v), P8(o_omy), P8(o_oop), PF(o_opi), PF(o_ov),
+                       P4(o_on));
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_my, P8(o_omy), (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_op, P8(o_oop), (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_pi, PF(o_opi), (size_t)m * 36, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_v, PF(o_ov), (size_t)m * 12, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_num, P4(o_on), (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    *out_count = (size_t)m;
     return SYN_OK;
 }
 

@@ -18,7 +18,8 @@ ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_debug_stdrng_u32",
-    "syn_debug_math", "syn_debug_calibrate",
+    "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
+    "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate",
 ]
 
 
@@ -36,6 +37,11 @@ class CSearchResult(C.Structure):  # struct syn_search_result
         ("num_nodes", C.c_uint32), ("best_action", C.c_int32),
         ("target_pi", C.c_float * 9), ("target_q", C.c_float * 3),
     ]
+
+
+class CTrainConfig(C.Structure):  # struct syn_train_config
+    _fields_ = [("weight_decay", C.c_float), ("policy_weight", C.c_float), ("value_weight", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
 
 
 class CCounters(C.Structure):  # struct syn_counters
@@ -83,6 +89,18 @@ def load_library():
     lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
     lib.syn_debug_calibrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.syn_trainer_init.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(CTrainConfig)]
+    lib.syn_train_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
+                                   C.c_void_p]
+    lib.syn_train_gradients_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_void_p, C.c_void_p]
+    lib.syn_train_apply_device.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    lib.syn_trainer_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong),
+                                          C.c_void_p]
+    lib.syn_trainer_publish_weights.argtypes = [C.c_void_p]
+    lib.syn_replay_deduplicate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_size_t)]
     _lib = lib
     return lib
 
@@ -237,6 +255,56 @@ class Engine:
         nl = C.c_int()
         self._check(self._lib.syn_last_timing(self._h, C.byref(ms), C.byref(nl)))
         return float(ms.value)
+
+    # ---- learner step (alpha_zero.rs:31-36,72-94) and replay de-duplication (data.rs:196-235)
+    def trainer_init(self, blob, weight_decay=1e-6, policy_weight=1.0, value_weight=1.0, beta1=0.9, beta2=0.999,
+                     eps=1e-8):
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        cfg = CTrainConfig(weight_decay, policy_weight, value_weight, beta1, beta2, eps)
+        self._check(self._lib.syn_trainer_init(self._h, _p(blob), blob.size, C.byref(cfg)))
+
+    def train_step(self, my_bb, op_bb, target_pi, target_v, lr):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        tpi = np.ascontiguousarray(target_pi, dtype=np.float32).reshape(my.size, 9)
+        tv = np.ascontiguousarray(target_v, dtype=np.float32).reshape(my.size, 3)
+        losses = np.zeros(2, np.float32)
+        self._check(self._lib.syn_train_step(self._h, _p(my), _p(op), _p(tpi), _p(tv), int(my.size), float(lr),
+                                             _p(losses)))
+        return losses
+
+    def train_gradients_device(self, d_my, d_op, d_tpi, d_tv, batch, d_grads):
+        losses = np.zeros(2, np.float32)
+        self._check(self._lib.syn_train_gradients_device(self._h, C.c_void_p(d_my), C.c_void_p(d_op),
+                                                         C.c_void_p(d_tpi), C.c_void_p(d_tv), int(batch),
+                                                         C.c_void_p(d_grads), _p(losses)))
+        return losses
+
+    def train_apply_device(self, d_grads, lr, grad_scale=1.0):
+        self._check(self._lib.syn_train_apply_device(self._h, C.c_void_p(d_grads), float(lr), float(grad_scale)))
+
+    def trainer_state(self):
+        blob = np.zeros(NUM_PARAMS, np.float32); m = np.zeros_like(blob); v = np.zeros_like(blob); g = np.zeros_like(blob)
+        step = C.c_longlong()
+        self._check(self._lib.syn_trainer_get_state(self._h, _p(blob), _p(m), _p(v), C.byref(step), _p(g)))
+        return dict(weights=blob, m=m, v=v, step=int(step.value), grads=g)
+
+    def trainer_publish_weights(self):
+        self._check(self._lib.syn_trainer_publish_weights(self._h))
+
+    def replay_deduplicate(self, my_bb, op_bb, pis, vs):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        n = int(my.size)
+        pis = np.ascontiguousarray(pis, dtype=np.float32).reshape(n, 9)
+        vs = np.ascontiguousarray(vs, dtype=np.float32).reshape(n, 3)
+        o = dict(my_bb=np.zeros(n, np.uint64), op_bb=np.zeros(n, np.uint64), pis=np.zeros((n, 9), np.float32),
+                 vs=np.zeros((n, 3), np.float32), num=np.zeros(n, np.uint32))
+        cnt = C.c_size_t()
+        self._check(self._lib.syn_replay_deduplicate(self._h, _p(my), _p(op), _p(pis), _p(vs), n, _p(o["my_bb"]),
+                                                     _p(o["op_bb"]), _p(o["pis"]), _p(o["vs"]), _p(o["num"]),
+                                                     C.byref(cnt)))
+        return {k: a[: cnt.value] for k, a in o.items()}
 
     # ---- parity probes
     def debug_stdrng_u32(self, seed, n):

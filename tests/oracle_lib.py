@@ -51,8 +51,20 @@ def parity_rollout_config(num_explores=800, **kw):
     return RolloutConfig(**d)
 
 
+class TrainHyper(C.Structure):
+    _fields_ = [("weight_decay", C.c_float), ("policy_weight", C.c_float), ("value_weight", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
+
+
+def default_train_hyper(**kw):
+    """study-connect4/src/main.rs:20-24 + Adam::default()."""
+    d = dict(weight_decay=1e-6, policy_weight=1.0, value_weight=1.0, beta1=0.9, beta2=0.999, eps=1e-8)
+    d.update(kw)
+    return TrainHyper(**d)
+
+
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 class Oracle:
@@ -209,6 +221,46 @@ class Oracle:
                                     _p(r["root_stat"]), _p(r["root_sol"]), _p(r["num_nodes"]), _p(r["best_action"]),
                                     _p(r["target_pi"]), _p(r["target_q"]))
         return r
+
+    # ---- training step / dedup
+    def train_gradients(self, blob, hp, X, tpi, tv):
+        blob = np.ascontiguousarray(blob, np.float32)
+        X = np.ascontiguousarray(X, np.float32); tpi = np.ascontiguousarray(tpi, np.float32); tv = np.ascontiguousarray(tv, np.float32)
+        grad = np.zeros_like(blob); losses = np.zeros(2, np.float32)
+        self.lib.orc_train_gradients(_p(blob), C.byref(hp), _p(X), _p(tpi), _p(tv), int(X.shape[0]), _p(grad), _p(losses))
+        return grad, losses
+
+    def train_steps(self, blob, hp, X, tpi, tv, lrs, m=None, v=None, step=0):
+        """X[n_steps][B][63] ...; returns (blob', m', v', step', losses[n_steps][2])."""
+        blob = np.array(blob, np.float32).copy()
+        X = np.ascontiguousarray(X, np.float32); tpi = np.ascontiguousarray(tpi, np.float32); tv = np.ascontiguousarray(tv, np.float32)
+        n_steps, B = X.shape[0], X.shape[1]
+        lrs = np.ascontiguousarray(np.broadcast_to(np.asarray(lrs, np.float32), (n_steps,)))
+        m = np.zeros_like(blob) if m is None else np.array(m, np.float32).copy()
+        v = np.zeros_like(blob) if v is None else np.array(v, np.float32).copy()
+        st = C.c_longlong(step)
+        losses = np.zeros((n_steps, 2), np.float32)
+        self.lib.orc_train_steps(_p(blob), C.byref(hp), _p(X), _p(tpi), _p(tv), B, n_steps, _p(lrs), _p(m), _p(v),
+                                 C.byref(st), _p(losses))
+        return blob, m, v, st.value, losses
+
+    def train_adam(self, blob, hp, grad, lr, m, v, step):
+        blob = np.array(blob, np.float32).copy(); m = np.array(m, np.float32).copy(); v = np.array(v, np.float32).copy()
+        grad = np.ascontiguousarray(grad, np.float32)
+        st = C.c_longlong(step)
+        self.lib.orc_train_adam(_p(blob), C.byref(hp), _p(grad), C.c_float(lr), _p(m), _p(v), C.byref(st))
+        return blob, m, v, st.value
+
+    def dedup(self, my_bb, op_bb, pis, vs):
+        my = np.ascontiguousarray(my_bb, np.uint64); op = np.ascontiguousarray(op_bb, np.uint64)
+        pis = np.ascontiguousarray(pis, np.float32); vs = np.ascontiguousarray(vs, np.float32)
+        n = int(my.size)
+        o = dict(my_bb=np.zeros(n, np.uint64), op_bb=np.zeros(n, np.uint64), pis=np.zeros((n, 9), np.float32),
+                 vs=np.zeros((n, 3), np.float32), num=np.zeros(n, np.uint32))
+        self.lib.orc_dedup.restype = C.c_size_t
+        m = self.lib.orc_dedup(_p(my), _p(op), _p(pis), _p(vs), C.c_size_t(n), _p(o["my_bb"]), _p(o["op_bb"]),
+                               _p(o["pis"]), _p(o["vs"]), _p(o["num"]))
+        return {k: a[:m] for k, a in o.items()}
 
     # ---- self-play
     def c4_selfplay(self, cfg, blob, base_seed, n_games, first_game=0, threads=1, use_cache=False, nn_mode=1,

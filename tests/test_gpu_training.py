@@ -1,0 +1,138 @@
+"""GPU parity of the learner step and the replay de-duplication against the oracle (bit-exact: same
+fixed-order f32 arithmetic) and against the torch float64 goldens (1e-5; no reference test covers this step)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def blob(golden_dir):
+    return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "train_torch_goldens.npz"))
+
+
+@pytest.fixture(scope="module")
+def engine(blob):
+    import synthesis_amd as sa
+
+    eng = sa.Engine(concurrent_games=256, max_explores=64)
+    eng.load_weights(blob)
+    yield eng
+    eng.close()
+
+
+def test_train_steps_match_oracle_and_torch(engine, oracle, blob, gold):
+    from tests.oracle_lib import default_train_hyper
+
+    S, B = gold["my_bb"].shape
+    X = np.stack([oracle.c4_features(gold["my_bb"][s], gold["op_bb"][s]) for s in range(S)])
+    engine.trainer_init(blob)
+    losses = np.stack([engine.train_step(gold["my_bb"][s], gold["op_bb"][s], gold["target_pi"][s], gold["target_v"][s],
+                                         float(gold["lrs"][s])) for s in range(S)])
+    st = engine.trainer_state()
+    wo, mo, vo, step, lo = oracle.train_steps(blob, default_train_hyper(), X, gold["target_pi"], gold["target_v"], gold["lrs"])
+    assert st["step"] == step == S
+    assert np.array_equal(losses, lo)
+    assert np.array_equal(st["weights"], wo) and np.array_equal(st["m"], mo) and np.array_equal(st["v"], vo)
+    # independent second opinion (torch float64): losses, final weights
+    assert np.abs(losses - gold["losses_f64"]).max() < 1e-5
+    assert np.abs(st["weights"] - gold["weights_f64"]).max() < 1e-5
+    # first-step gradient vs torch
+    engine.trainer_init(blob)
+    engine.train_step(gold["my_bb"][0], gold["op_bb"][0], gold["target_pi"][0], gold["target_v"][0], 1e-3)
+    assert np.abs(engine.trainer_state()["grads"] - gold["grad0_f64"]).max() < 1e-6
+
+
+def test_train_ragged_batches_and_hyper(engine, oracle, blob, gold):
+    """Batch sizes around the 32-sample LDS chunk (1, 31, 33, 64, 100) and non-default weights / weight decay."""
+    from tests.oracle_lib import default_train_hyper
+
+    my = gold["my_bb"].reshape(-1); op = gold["op_bb"].reshape(-1)
+    tpi = gold["target_pi"].reshape(-1, 9); tv = gold["target_v"].reshape(-1, 3)
+    X = oracle.c4_features(my, op)
+    hp = default_train_hyper(weight_decay=1e-3, policy_weight=0.7, value_weight=1.9)
+    for B in (1, 31, 32, 33, 64, 100):
+        engine.trainer_init(blob, weight_decay=1e-3, policy_weight=0.7, value_weight=1.9)
+        l = engine.train_step(my[:B], op[:B], tpi[:B], tv[:B], 2e-3)
+        st = engine.trainer_state()
+        g, lo = oracle.train_gradients(blob, hp, X[:B], tpi[:B], tv[:B])
+        assert np.array_equal(st["grads"], g), B
+        assert np.array_equal(l, lo), B
+        wo, mo, vo, _, _ = oracle.train_steps(blob, hp, X[:B][None], tpi[:B][None], tv[:B][None], [2e-3])
+        assert np.array_equal(st["weights"], wo), B
+
+
+def test_data_parallel_gradient_path(engine, oracle, blob, gold):
+    """configs[4] plumbing on one GPU: two 'ranks' compute gradients of their half-batches into caller-owned device
+    buffers, the sum is applied with grad_scale = 1/2 — equals (to f32 rounding) one step on the combined batch, and is
+    bit-identical to the oracle doing the same two-gradient average."""
+    import torch
+    from tests.oracle_lib import default_train_hyper
+
+    B = 32
+    my = torch.from_numpy(gold["my_bb"][:2].astype(np.int64)).cuda()
+    op = torch.from_numpy(gold["op_bb"][:2].astype(np.int64)).cuda()
+    tpi = torch.from_numpy(gold["target_pi"][:2]).cuda()
+    tv = torch.from_numpy(gold["target_v"][:2]).cuda()
+    g = [torch.zeros(30492, dtype=torch.float32, device="cuda") for _ in range(2)]
+    engine.trainer_init(blob)
+    for r in range(2):
+        engine.train_gradients_device(my[r].data_ptr(), op[r].data_ptr(), tpi[r].data_ptr(), tv[r].data_ptr(), B, g[r].data_ptr())
+    total = g[0] + g[1]  # what an all-reduce(sum) leaves on every rank
+    engine.train_apply_device(total.data_ptr(), 1e-3, grad_scale=0.5)
+    st = engine.trainer_state()
+    hp = default_train_hyper()
+    X = np.stack([oracle.c4_features(gold["my_bb"][s], gold["op_bb"][s]) for s in range(2)])
+    g0, _ = oracle.train_gradients(blob, hp, X[0], gold["target_pi"][0], gold["target_v"][0])
+    g1, _ = oracle.train_gradients(blob, hp, X[1], gold["target_pi"][1], gold["target_v"][1])
+    assert np.array_equal(g[0].cpu().numpy(), g0) and np.array_equal(g[1].cpu().numpy(), g1)
+    wo, mo, vo, _ = oracle.train_adam(blob, hp, (g0 + g1) * np.float32(0.5), 1e-3, np.zeros_like(blob), np.zeros_like(blob), 0)
+    assert np.array_equal(st["weights"], wo)
+    # the same update as one 64-sample step, up to f32 summation order
+    engine.trainer_init(blob)
+    engine.train_step(gold["my_bb"][:2].reshape(-1), gold["op_bb"][:2].reshape(-1), gold["target_pi"][:2].reshape(-1, 9),
+                      gold["target_v"][:2].reshape(-1, 3), 1e-3)
+    assert np.abs(engine.trainer_state()["weights"] - wo).max() < 1e-5
+
+
+def test_publish_weights_feeds_selfplay(engine, oracle, blob, gold):
+    engine.trainer_init(blob)
+    for s in range(4):
+        engine.train_step(gold["my_bb"][s], gold["op_bb"][s], gold["target_pi"][s], gold["target_v"][s], 1e-3)
+    w = engine.trainer_state()["weights"]
+    engine.trainer_publish_weights()
+    logits, value = engine.policy_eval(gold["my_bb"][5], gold["op_bb"][5])
+    fl, fv = oracle.c4net_eval(w, gold["my_bb"][5], gold["op_bb"][5], mode=oracle.ACC_FMA)
+    assert np.array_equal(logits, fl) and np.array_equal(value, fv)
+    engine.load_weights(blob)
+
+
+def test_replay_deduplicate_matches_oracle(engine, oracle, blob):
+    """data.rs:196-235 on real self-play output: openings repeat across games (the empty board appears in every game),
+    targets of identical states are averaged in buffer order."""
+    import synthesis_amd as sa
+
+    r = engine.selfplay(sa.parity_rollout_config(24), base_seed=77, n_games=400)
+    my, op, pi, v = [], [], [], []
+    for g in range(400):
+        n = r["plies"][g]
+        my.append(r["states_bb"][g, :n, 0]); op.append(r["states_bb"][g, :n, 1]); pi.append(r["pis"][g, :n]); v.append(r["vs"][g, :n])
+    my = np.concatenate(my); op = np.concatenate(op); pi = np.concatenate(pi); v = np.concatenate(v)
+    got = engine.replay_deduplicate(my, op, pi, v)
+    ref = oracle.dedup(my, op, pi, v)
+    assert got["num"].size == ref["num"].size < my.size
+    assert int(ref["num"].max()) == 400  # the empty board
+    for k in ("my_bb", "op_bb", "num", "pis", "vs"):
+        assert np.array_equal(got[k], ref[k]), k
+    assert int(got["num"].sum()) == my.size
+    empty = engine.replay_deduplicate(my[:0], op[:0], pi[:0], v[:0])
+    assert empty["num"].size == 0
+    one = engine.replay_deduplicate(my[:1], op[:1], pi[:1], v[:1])
+    assert one["num"].tolist() == [1] and np.array_equal(one["pis"][0], pi[0])
