@@ -57,6 +57,24 @@ def library_path():
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """A process must hold ONE HIP runtime. PyTorch-ROCm wheels bundle their own libamdhip64.so.7; if this library pulled
+    in /opt/rocm's copy first, a later `import torch` (device buffers, torch.distributed/RCCL) finds no GPU. When a torch
+    with a bundled runtime is installed, bind to that copy (same soname, so our DT_NEEDED resolves to it); otherwise the
+    RUNPATH copy under /opt/rocm is used. torch itself is not imported here."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Loads libsynthesis_amd.so; raises (never falls back) if it has not been built."""
     global _lib
@@ -66,6 +84,7 @@ def load_library():
     if not os.path.exists(path):
         raise SynthesisAmdError(-100, f"{path} not found: build it with `make -C synthesis_amd/csrc` "
                                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(path)
     lib.syn_last_error.restype = C.c_char_p
     lib.syn_last_error.argtypes = [C.c_void_p]
