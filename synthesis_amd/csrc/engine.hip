@@ -16,6 +16,7 @@
 
 #include "../../include/synthesis_amd.h"
 #include "engine_kernels.cuh"
+#include "lane_kernel.cuh"
 #include "train_kernels.cuh"
 
 #include <hipcub/hipcub.hpp>
@@ -34,6 +35,7 @@ struct syn_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int slots = 0;
+    int pool_slots = 0;  // tree slabs actually allocated (slots rounded up to the largest workgroup + slack)
     int max_explores = 0;
     uint32_t cap = 0;
     float4* d_stat = nullptr;
@@ -172,6 +174,34 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // Kernel choice by trees per CU: <= 16 -> one 16-tree workgroup per CU, weights in registers (latency-optimal);
     // <= 32 -> two such workgroups per CU (hybrid register/LDS weights); more -> the quad-async kernel (NQ quads of 16
     // trees per workgroup sharing one LDS weight image). SYN_QUADS=0..4 overrides (0 = never use the quad kernel).
+    // Lane-per-tree kernel (lane_kernel.cuh): one tree per lane, NW waves per workgroup, one workgroup per CU.
+    // SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it; by default it takes over once every CU can be given at
+    // least 512 trees.
+    {
+        int nw = 0;
+        if (want_slots >= h->num_cus * 512) nw = want_slots >= h->num_cus * 1024 ? 16 : 8;
+        if (const char* ev = std::getenv("SYN_LANES")) nw = std::atoi(ev);
+        if (nw == 4 || nw == 8 || nw == 12 || nw == 16) {
+            int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
+            // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
+#define SYN_LAUNCH_L(NW, FAST)                                                                                     \
+    {                                                                                                              \
+        auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneLds<NW>::BYTES);   \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, P);                       \
+    }
+            if (nw == 4) { if (fast) SYN_LAUNCH_L(4, true) else SYN_LAUNCH_L(4, false) }
+            else if (nw == 8) { if (fast) SYN_LAUNCH_L(8, true) else SYN_LAUNCH_L(8, false) }
+            else if (nw == 12) { if (fast) SYN_LAUNCH_L(12, true) else SYN_LAUNCH_L(12, false) }
+            else { if (fast) SYN_LAUNCH_L(16, true) else SYN_LAUNCH_L(16, false) }
+#undef SYN_LAUNCH_L
+            if (out_grid) *out_grid = -lgrid;  // negative: lane kernel (profile layout differs)
+            if (out_nt) *out_nt = 64 * nw;
+            return hipGetLastError();
+        }
+    }
     int nq = 0;
     {
         int per_cu = (grid + h->num_cus - 1) / h->num_cus;
@@ -269,9 +299,10 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    // the launch may round the slot count up to a whole workgroup (<= 64 trees)
+    // the launch may round the slot count up to a whole workgroup (<= 1024 trees: lane kernel)
     // + 48: the 3-quad launch rounds to multiples of 48 slots
-    size_t nodes = (size_t)(((h->slots + 63) / 64) * 64 + 48) * h->cap;
+    h->pool_slots = ((h->slots + 1023) / 1024) * 1024 + 48;
+    size_t nodes = (size_t)h->pool_slots * h->cap;
     if ((e = hipMalloc(&h->d_stat, nodes * 32)) != hipSuccess) return bail("hipMalloc(node pool)", e);
     h->d_edge = reinterpret_cast<uint4*>(h->d_stat);  // same records, edge half = odd 16-byte elements
     if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
@@ -618,6 +649,22 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     if (prof) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (pgrid < 0) {  // lane kernel: per wave [A, B, C, move, rounds, tiles, active lanes, evals]
+            int nwv = -pgrid * (pnt / 64);
+            std::vector<unsigned long long> hp((size_t)nwv * 8);
+            HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipFree(d_prof));
+            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int w = 0; w < nwv; w++)
+                for (int j = 0; j < 8; j++) s[j] += (double)hp[(size_t)w * 8 + j];
+            fprintf(stderr, "[syn profile lanes] grid=%d nt=%d waves=%d rounds/wave=%.0f | ticks per round (100 MHz): A=%.1f B=%.1f C=%.1f "
+                            "move=%.1f total=%.1f | tiles/round=%.3f active lanes/round=%.2f evals/round=%.2f evals/tile=%.2f\n",
+                    -pgrid, pnt, nwv, s[4] / nwv, s[0] / s[4], s[1] / s[4], s[2] / s[4], s[3] / s[4],
+                    (s[0] + s[1] + s[2] + s[3]) / s[4], s[5] / s[4], s[6] / s[4], s[7] / s[4], s[7] / s[5]);
+            d_prof = nullptr;
+        }
+    }
+    if (prof && d_prof) {
         int nw = pgrid * (pnt / 64);
         std::vector<unsigned long long> hp((size_t)nw * 6);
         HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));

@@ -1,0 +1,747 @@
+// synthesis_amd — lane-per-tree self-play / search kernel (the high-concurrency launch shape).
+//
+// Same algorithm, node records and results as the row-per-tree kernels (engine_kernels.cuh, mcts.cuh) — the reference's
+//   synthesis/src/mcts.rs:310-488       explore / select_best_child / visit / backprop
+//   synthesis/src/alpha_zero.rs:229-338 run_game / sample_action / fill_state_info / store_rewards
+// — but with ONE TREE PER LANE: a wave64 owns 64 independent trees, a 1024-thread workgroup 1024, the chip 262,144.
+//
+// Why a second shape: with one tree per 16-lane DPP row at most 9 of 16 lanes do useful work and a wave amortises every
+// scalar/vector instruction of select/expand/backprop over only 4 trees; at 16 k concurrent games that kernel is
+// SIMD-issue bound. Here every VALU instruction serves 64 trees (the per-tree code is the sequential
+// algorithm, children scanned in a 9-step unrolled loop), each wave evaluates its own four 16-position MFMA tiles out of
+// the workgroup's shared LDS weight image, and NOTHING synchronises across waves after the weights are staged: no
+// barriers, no exchange buffers, every wave free-runs, so one wave's matrix-core phase overlaps its neighbours'
+// pointer-chasing phases on the same SIMD. The price is concurrency (a CU wants 1024 games) and divergence (a wave
+// descends until its deepest tree is done), which is why the row kernels stay for <= 16 k concurrent games.
+//
+//   phase A (per lane)   select + expand (global loads of 32-byte child records, 9 per level)
+//   phase B (per wave)   up to four mlp_tile16 evaluations; leaf boards reach the tile layout by ds_bpermute, the 12
+//                        outputs per position return through a 1 KB per-wave LDS patch
+//   phase C (per lane)   legal softmax -> priors, backprop along parent links, move step when the search is over
+#pragma once
+#include "engine_kernels.cuh"
+
+namespace syn {
+
+struct LaneTree {
+    unsigned char* slab;      // this lane's node records (32 B each: stat half, edge half)
+    uint64_t root_my, root_op;
+    uint32_t next_node;       // nodes.len()
+    uint32_t root_fc, root_nc;
+    int iter;                 // passes done on this tree (root visit = 1) == root.num_visits
+    bool root_solved;
+    int job;                  // game / root index, -1 = idle
+    int turn;
+    uint32_t rng_index;
+};
+
+struct LaneLeaf {             // phase A -> phase C
+    uint32_t leaf;            // node the backprop starts from
+    uint32_t fc;              // first child of the node that needs priors
+    uint32_t legal_mask;
+    bool needs_eval, solved;
+    float p0, p1, p2;
+    uint64_t leaf_my, leaf_op;
+};
+
+SYN_DEV float4 ln_stat(const unsigned char* slab, uint32_t i) {
+    return *reinterpret_cast<const float4*>(slab + (size_t)i * 32u);
+}
+SYN_DEV uint4 ln_edge(const unsigned char* slab, uint32_t i) {
+    return *reinterpret_cast<const uint4*>(slab + (size_t)i * 32u + 16u);
+}
+SYN_DEV void st_stat(unsigned char* slab, uint32_t i, float4 v) { *reinterpret_cast<float4*>(slab + (size_t)i * 32u) = v; }
+SYN_DEV void st_edge(unsigned char* slab, uint32_t i, uint4 v) {
+    *reinterpret_cast<uint4*>(slab + (size_t)i * 32u + 16u) = v;
+}
+
+template <int MODE>
+SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
+    int j = atomicAdd(P.job_next, 1);
+    T.job = j < P.n_jobs ? j : -1;
+    T.turn = 0;
+    T.rng_index = 0;
+    T.next_node = 0;
+    T.root_fc = 0;
+    T.root_nc = 0;
+    T.iter = 0;
+    T.root_solved = false;
+    T.root_my = 0;
+    T.root_op = 0;
+    if (MODE == MODE_SEARCH && T.job >= 0) {
+        T.root_my = P.in_my[T.job];
+        T.root_op = P.in_op[T.job];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- phase A
+template <bool COUNT, bool FAST>
+SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X, bool active, uint32_t* ctr) {
+    const CfgView<FAST> cfg{cfg_};
+    unsigned char* const slab = T.slab;
+    uint32_t node = 0;
+    uint64_t my = T.root_my, op = T.root_op;
+    X.needs_eval = false;
+    X.solved = false;
+    X.p0 = X.p1 = X.p2 = 0.0f;
+    X.fc = 0;
+    X.legal_mask = 0;
+    uint32_t fc = 0, meta = 0;
+    float pN = 0.0f, pW0 = 0.0f, pW2 = 0.0f;
+    if (active) {
+        if (COUNT) ctr[CTR_EXPLORES]++;
+        if (T.next_node == 0) {
+            // MCTS::with_capacity: push the root (mcts.rs:125) — unvisited, parent 0, action 0, prior 0
+            st_stat(slab, 0, make_float4(0.f, 0.f, 0.f, 0.f));
+            st_edge(slab, 0, make_uint4(0u, meta_make(0, 0, false, 0, 0), f32_bits(0.0f), 0u));
+            T.next_node = 1;
+        } else {
+            fc = T.root_fc;
+            meta = T.root_nc;
+            pN = (float)T.iter;
+            if (!cfg.fpu_const()) {
+                float4 s = ln_stat(slab, 0);
+                pW0 = s.y;
+                pW2 = s.w;
+            }
+        }
+    }
+
+    // ---- descent (mcts.rs:310-341): every lane walks its own tree; the wave iterates until its deepest lane is done
+    bool hit_solved = false;
+    bool go = active;
+    while (go) {
+        if (meta_some(meta)) { hit_solved = true; break; }
+        const uint32_t nc = meta_nc(meta);
+        if (nc == 0) break;
+        const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : (pW2 - pW0) / pN;
+        const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
+        // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces)
+        float best_v = 0.0f, bN = 0.0f, bW0 = 0.0f, bW2 = 0.0f;
+        uint32_t best_i = 0, bmeta = 0, bfc = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            // indices past the last child re-read the last child (valid address, no predicate in front of the loads,
+            // so the nine record loads of a level can be in flight together)
+            const uint32_t ci = fc + (i < nc ? i : nc - 1u);
+            const float4 cs = ln_stat(slab, ci);
+            const uint4 ce = ln_edge(slab, ci);
+            const float q_visited = -((cs.w - cs.y) / cs.x);
+            const uint32_t k = meta_kind(ce.y);
+            const float q_solved = cfg.select_solved() ? (k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
+            float q = meta_nc(ce.y) == 0u ? q_fpu : q_visited;
+            q = meta_some(ce.y) ? q_solved : q;
+            float u;
+            if (cfg.puct()) u = cfg.cc() * bits_f32(ce.z) * visits / (1.0f + cs.x);
+            else u = visits / sqrtf(cs.x);
+            const float v = q + u;
+            const bool take = i == 0u || (i < nc && v > best_v);
+            best_v = take ? v : best_v;
+            best_i = take ? i : best_i;
+            bmeta = take ? ce.y : bmeta;
+            bfc = take ? ce.x : bfc;
+            bN = take ? cs.x : bN;
+            bW0 = take ? cs.y : bW0;
+            bW2 = take ? cs.w : bW2;
+        }
+        if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
+        const int a = (int)meta_action(bmeta);
+        const int ha = c4::col_height(my | op, a);
+        const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
+        my = nmy;
+        op = nop;
+        node = fc + best_i;
+        fc = bfc;
+        meta = bmeta;
+        pN = bN;
+        pW0 = bW0;
+        pW2 = bW2;
+    }
+
+    if (active) {
+        if (hit_solved) {
+            const uint32_t k = meta_kind(meta);
+            X.p0 = k == 0u ? 1.0f : 0.0f;
+            X.p1 = k == 1u ? 1.0f : 0.0f;
+            X.p2 = k == 2u ? 1.0f : 0.0f;
+            X.solved = true;
+            if (COUNT) ctr[CTR_SOLVED_HITS]++;
+        } else {
+            // visit(): expansion, possibly repeated by auto-extend (mcts.rs:374-406)
+            for (;;) {
+                const uint64_t occ = my | op;
+                const uint32_t first = T.next_node;
+                uint32_t n_new = 0, lmask = 0;
+                bool any_solved = false;
+#pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    const int h = c4::col_height(occ, c);
+                    if (h < c4::HEIGHT) {
+                        const uint64_t bit = 1ull << (h + 7 * c);
+                        const uint64_t cop = my | bit;  // child.op_bb = the mover's stones (connect4.rs:224-229)
+                        const bool w = c4::won(cop);
+                        const bool full = (occ | bit) == c4::FULL;
+                        const bool over = w || full;
+                        st_stat(slab, first + n_new, make_float4(0.f, 0.f, 0.f, 0.f));
+                        st_edge(slab, first + n_new,
+                                make_uint4(0u, meta_make(0, (uint32_t)c, over, w ? 0u : 1u, 0u), f32_bits(1.0f), node));
+                        n_new++;
+                        lmask |= 1u << c;
+                        any_solved = any_solved || over;
+                    }
+                }
+                T.next_node = first + n_new;
+                meta = (meta & ~META_NC_MASK) | n_new;
+                *reinterpret_cast<uint2*>(slab + (size_t)node * 32u + 16u) = make_uint2(first, meta);
+                if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
+                if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
+
+                if (cfg.auto_extend() && n_new == 1u) {
+                    const int a = __ffs((int)lmask) - 1;
+                    const int ha = c4::col_height(occ, a);
+                    const uint64_t abit = 1ull << (ha + 7 * a);
+                    const uint64_t nmy = op, nop = my | abit;
+                    const bool aw = c4::won(nop);
+                    const bool afull = (occ | abit) == c4::FULL;
+                    node = first;
+                    my = nmy;
+                    op = nop;
+                    meta = meta_make(0, (uint32_t)a, aw || afull, aw ? 0u : 1u, 0u);
+                    if (aw || afull) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
+                        X.p0 = aw ? 1.0f : 0.0f;
+                        X.p1 = aw ? 0.0f : 1.0f;
+                        X.p2 = 0.0f;
+                        X.solved = true;
+                        break;
+                    }
+                    continue;
+                }
+                X.needs_eval = true;
+                X.solved = any_solved;
+                X.fc = first;
+                X.legal_mask = lmask;
+                break;
+            }
+        }
+    }
+    X.leaf = node;
+    X.leaf_my = my;
+    X.leaf_op = op;
+}
+
+// ---------------------------------------------------------------------------------------------- phase C
+// legal-move softmax of visit() (mcts.rs:409-423): lg = the nine raw policy logits of the expanded node
+SYN_DEV void lane_write_priors(unsigned char* slab, const LaneLeaf& X, const float (&lg)[9], float equal_noise_weight) {
+    const uint32_t lmask = X.legal_mask;
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+        if ((lmask >> c) & 1u) mx = lg[c] > mx ? lg[c] : mx;
+    float e[9];
+    float total = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        e[c] = det_expf(lg[c] - mx);
+        if ((lmask >> c) & 1u) total += e[c];  // summed in child (= ascending column) order
+    }
+    const uint32_t nc = (uint32_t)__popc(lmask);
+    const float noise = 1.0f / (float)nc;
+    uint32_t idx = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        if ((lmask >> c) & 1u) {
+            float p = e[c] / total;
+            if (equal_noise_weight >= 0.0f && nc >= 2u) p = p * (1.0f - equal_noise_weight) + equal_noise_weight * noise;
+            *reinterpret_cast<uint32_t*>(slab + (size_t)(X.fc + idx) * 32u + 24u) = f32_bits(p);
+            idx++;
+        }
+    }
+}
+
+// backprop (mcts.rs:429-488) along the parent links of the records
+template <bool COUNT, bool FAST>
+SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, uint32_t leaf, float d0, float d1, float d2, bool solved,
+                           bool active, uint32_t* ctr) {
+    const CfgView<FAST> cfg{cfg_};
+    unsigned char* const slab = T.slab;
+    uint32_t node = leaf;
+    uint32_t levels = 0;
+    bool go = active;
+    while (go) {
+        uint4 e = ln_edge(slab, node);
+        float4 s = ln_stat(slab, node);
+        levels++;
+        if (cfg.solve() && solved) {
+            const uint32_t nc = meta_nc(e.y);
+            bool all_solved = true;
+            uint32_t key = outcome_key(meta_some(e.y), meta_kind(e.y), meta_turns(e.y));
+            if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) {
+                if (i < nc) {
+                    const uint32_t cmeta = *reinterpret_cast<const uint32_t*>(slab + (size_t)(e.x + i) * 32u + 20u);
+                    all_solved = all_solved && meta_some(cmeta);
+                    const uint32_t ck = outcome_key_reversed(cmeta);
+                    key = ck > key ? ck : key;
+                }
+            }
+            bool bsome;
+            uint32_t bkind, bturns;
+            outcome_from_key(key, bsome, bkind, bturns);
+            if (bsome && bkind == 2u) {
+                e.y = (e.y & 0xFFu) | (meta_make(0, 0, true, 2u, bturns) & ~0xFFu);
+                if (cfg.correct_values()) {
+                    d0 = -s.y;
+                    d1 = -s.z;
+                    d2 = -s.w;
+                    d2 += s.x + 1.0f;
+                }
+            } else if (bsome && all_solved) {
+                e.y = (e.y & 0xFFu) | (meta_make(0, 0, true, bkind, bturns) & ~0xFFu);
+                if (cfg.correct_values()) {
+                    d0 = -s.y;
+                    d1 = -s.z;
+                    d2 = -s.w;
+                    if (bkind == 1u) d1 += s.x + 1.0f;
+                    else d0 += s.x + 1.0f;
+                }
+            } else {
+                solved = false;
+            }
+            if (solved) {
+                *reinterpret_cast<uint32_t*>(slab + (size_t)node * 32u + 20u) = e.y;
+                if (node == 0u) T.root_solved = true;
+            }
+        }
+        s.y += d0;
+        s.z += d1;
+        s.w += d2;
+        s.x += 1.0f;
+        st_stat(slab, node, s);
+        if (node == 0u) break;
+        const float t = d0;
+        d0 = d2;
+        d2 = t;
+        node = e.w;
+    }
+    if (COUNT && active) {
+        ctr[CTR_BACKPROP_LEVELS] += levels;
+        if (levels > ctr[CTR_MAX_DEPTH]) ctr[CTR_MAX_DEPTH] = levels;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- end of a search
+// The root's children by column, streamed (the cold path must not set the kernel's register budget).
+struct LaneRoot {
+    uint32_t fc, nc, root_meta, lmask;
+    float rootN, rW0, rW1, rW2;
+};
+SYN_DEV LaneRoot lane_root(const LaneTree& T) {
+    LaneRoot R;
+    const uint4 e = ln_edge(T.slab, 0);
+    const float4 s = ln_stat(T.slab, 0);
+    R.fc = e.x;
+    R.root_meta = e.y;
+    R.nc = meta_nc(e.y);
+    R.rootN = s.x; R.rW0 = s.y; R.rW1 = s.z; R.rW2 = s.w;
+    const uint64_t occ = T.root_my | T.root_op;
+    uint32_t lm = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+        if (c4::col_height(occ, c) < c4::HEIGHT) lm |= 1u << c;
+    // a root that was never expanded (solved at once) has no children
+    R.lmask = R.nc == 0u ? 0u : lm;
+    return R;
+}
+
+// MCTS::target_policy numerators (mcts.rs:174-211) per column (0 for non-children) and their sum in child order
+SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&w)[9]) {
+    const bool first_visit = R.rootN == 1.0f;
+    const bool root_win = meta_some(R.root_meta) && meta_kind(R.root_meta) == 2u;
+    float total = 0.0f;
+    uint32_t idx = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        w[c] = 0.0f;
+        if ((R.lmask >> c) & 1u) {
+            const float4 cs = ln_stat(T.slab, R.fc + idx);
+            const uint32_t cm = ln_edge(T.slab, R.fc + idx).y;
+            float v;
+            if (first_visit) v = root_win ? ((meta_some(cm) && meta_kind(cm) == 0u) ? 1.0f : 0.0f) : 1.0f;
+            else v = cs.x;
+            w[c] = v;
+            total += v;
+            idx++;
+        }
+    }
+    return total;
+}
+
+SYN_DEV void lane_target_q(const LaneRoot& R, float& q0, float& q1, float& q2) {
+    if (meta_some(R.root_meta)) {
+        const uint32_t k = meta_kind(R.root_meta);
+        q0 = k == 0u ? 1.0f : 0.0f;
+        q1 = k == 1u ? 1.0f : 0.0f;
+        q2 = k == 2u ? 1.0f : 0.0f;
+    } else {
+        q0 = R.rW0 / R.rootN;
+        q1 = R.rW1 / R.rootN;
+        q2 = R.rW2 / R.rootN;
+    }
+}
+
+// MCTS::best_action (mcts.rs:273-294); also returns the meta of the chosen child
+SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_selection, uint32_t& best_meta) {
+    int best = -1;
+    float b0 = 0.0f, b1 = 0.0f;
+    best_meta = 0;
+    uint32_t idx = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        if ((R.lmask >> c) & 1u) {
+            const float4 cs = ln_stat(T.slab, R.fc + idx);
+            const uint32_t cm = ln_edge(T.slab, R.fc + idx).y;
+            float k0, k1;
+            if (meta_some(cm)) {
+                const uint32_t kind = meta_kind(cm);
+                const float t = (float)meta_turns(cm);
+                if (kind == 2u) { k0 = 0.0f; k1 = t; }
+                else if (kind == 1u) { k0 = 2.0f; k1 = -t; }
+                else { k0 = 3.0f; k1 = -t; }
+            } else {
+                k0 = 1.0f;
+                k1 = action_selection == 0 ? -((cs.w - cs.y) / cs.x) : cs.x;
+            }
+            const bool gt = best < 0 || (k0 > b0) || (k0 == b0 && k1 > b1);
+            if (gt) { best = c; b0 = k0; b1 = k1; best_meta = cm; }
+            idx++;
+        }
+    }
+    return best;
+}
+
+SYN_DEV uint32_t lane_child_meta(const LaneTree& T, const LaneRoot& R, int action, bool& is_child) {
+    is_child = ((R.lmask >> action) & 1u) != 0u;
+    const uint32_t idx = (uint32_t)__popc(R.lmask & ((1u << action) - 1u));
+    return is_child ? ln_edge(T.slab, R.fc + idx).y : 0u;
+}
+
+// run_game's per-move tail (alpha_zero.rs:243-264) + game end (fill_state_info / store_rewards, 296-338)
+template <bool COUNT>
+SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
+    const DevRolloutCfg& rc = P.roll;
+    const bool want_random = T.turn < rc.random_until;
+    const bool maybe_sample = !want_random && T.turn < rc.sample_until;
+    uint32_t rnd = 0;
+    if (want_random || maybe_sample) {
+        StdRng rng;
+        rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)T.job);
+        rnd = rng.word(T.rng_index);
+    }
+    const LaneRoot R = lane_root(T);
+    float pi[9];
+    const float wtotal = lane_policy_weights(T, R, pi);
+#pragma unroll
+    for (int c = 0; c < 9; c++) pi[c] = pi[c] / wtotal;
+    float q0, q1, q2;
+    lane_target_q(R, q0, q1, q2);
+    const size_t pos = (size_t)T.job * 63 + (size_t)T.turn;
+    P.states_bb[pos * 2 + 0] = T.root_my;
+    P.states_bb[pos * 2 + 1] = T.root_op;
+    P.root_nodes[pos] = T.next_node;
+#pragma unroll
+    for (int c = 0; c < 9; c++) P.pis[pos * 9 + c] = pi[c];
+    P.vs[pos * 3 + 0] = q0;
+    P.vs[pos * 3 + 1] = q1;
+    P.vs[pos * 3 + 2] = q2;
+
+    // sample_action (alpha_zero.rs:270-294)
+    uint32_t best_meta;
+    const int best = lane_best_action(T, R, rc.action, best_meta);
+    int action;
+    if (want_random) {
+        const uint32_t n = (uint32_t)__popc(R.lmask);
+        const uint32_t zone = 0xFFFFFFFFu - (0xFFFFFFFFu - n + 1u) % n;
+        uint64_t mm = (uint64_t)rnd * (uint64_t)n;
+        T.rng_index += 1;
+        while ((uint32_t)mm > zone) {
+            StdRng rng;
+            rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)T.job);
+            mm = (uint64_t)rng.word(T.rng_index) * (uint64_t)n;
+            T.rng_index += 1;
+        }
+        const uint32_t r = (uint32_t)(mm >> 32);
+        uint32_t m = R.lmask;
+        for (uint32_t i = 0; i < r; i++) m &= m - 1u;
+        action = __ffs((int)m) - 1;
+    } else if (maybe_sample && (!meta_some(best_meta) || !rc.stop_when_solved)) {
+        float total = pi[0];
+        const float chosen_unit = bits_f32((rnd >> 9) | 0x3F800000u) - 1.0f;
+        float cum[8];
+#pragma unroll
+        for (int c = 1; c < 9; c++) {
+            cum[c - 1] = total;
+            total += pi[c];
+        }
+        const float chosen = chosen_unit * total + 0.0f;
+        T.rng_index += 1;
+        int idx = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) idx = cum[c] <= chosen ? c + 1 : idx;
+        action = idx;
+    } else {
+        action = best;
+    }
+    P.actions[pos] = (unsigned char)action;
+
+    bool a_child;
+    const uint32_t a_meta = lane_child_meta(T, R, action, a_child);
+    bool sol_some = a_child && meta_some(a_meta);
+    uint32_t sol_kind = meta_kind(a_meta);
+
+    const uint64_t occ = T.root_my | T.root_op;
+    const int h = c4::col_height(occ, action);
+    const uint64_t bit = 1ull << (h + 7 * action);
+    const uint64_t nmy = T.root_op, nop = T.root_my | bit;
+    const bool w = c4::won(nop);
+    const bool full = (occ | bit) == c4::FULL;
+    if (w || full) {
+        sol_some = true;
+        sol_kind = w ? 0u : 1u;
+    } else if (!rc.stop_when_solved) {
+        sol_some = false;
+    }
+    T.turn += 1;
+    if (COUNT) ctr[CTR_MOVES]++;
+
+    if (!sol_some) {
+        T.root_my = nmy;
+        T.root_op = nop;
+        T.next_node = 0;
+        T.iter = 0;
+        T.root_solved = false;
+        return;
+    }
+
+    const int n = T.turn;
+    const uint32_t last_kind = sol_kind == 1u ? 1u : 2u - sol_kind;
+    for (int i = 0; i < n; i++) {
+        const bool flip = ((n - 1 - i) & 1) != 0;
+        const uint32_t zk = (flip && last_kind != 1u) ? 2u - last_kind : last_kind;
+        const float z0 = zk == 0u ? 1.0f : 0.0f, z1 = zk == 1u ? 1.0f : 0.0f, z2 = zk == 2u ? 1.0f : 0.0f;
+        const float t = (float)(i + 1) / (float)n;
+        float* v = P.vs + ((size_t)T.job * 63 + (size_t)i) * 3;
+        const float a0 = v[0], a1 = v[1], a2 = v[2];
+        float o0, o1, o2;
+        if (rc.value_target == 1) { o0 = a0; o1 = a1; o2 = a2; }
+        else if (rc.value_target == 0) { o0 = z0; o1 = z1; o2 = z2; }
+        else if (rc.value_target == 2) {
+            const float p = rc.vt_p;
+            o0 = a0 * p + z0 * (1.0f - p);
+            o1 = a1 * p + z1 * (1.0f - p);
+            o2 = a2 * p + z2 * (1.0f - p);
+        } else {
+            const float p = (1.0f - t) * rc.vt_from + t * rc.vt_to;
+            o0 = a0 * (1.0f - p) + z0 * p;
+            o1 = a1 * (1.0f - p) + z1 * p;
+            o2 = a2 * (1.0f - p) + z2 * p;
+        }
+        v[0] = o0; v[1] = o1; v[2] = o2;
+    }
+    P.plies[T.job] = n;
+    P.final_kind[T.job] = (unsigned char)sol_kind;
+    if (COUNT) ctr[CTR_GAMES]++;
+    lane_start_job<MODE_SELFPLAY>(P, T);
+}
+
+SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
+    const LaneRoot R = lane_root(T);
+    float pi[9];
+    const float wtotal = lane_policy_weights(T, R, pi);
+    float q0, q1, q2;
+    lane_target_q(R, q0, q1, q2);
+    uint32_t bm;
+    const int best = lane_best_action(T, R, P.action_selection, bm);
+    DevSearchResult* out = P.results + T.job;
+    uint32_t idx = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const bool ch = ((R.lmask >> c) & 1u) != 0u;
+        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint4 ce = make_uint4(0u, 0u, 0u, 0u);
+        if (ch) {
+            cs = ln_stat(T.slab, R.fc + idx);
+            ce = ln_edge(T.slab, R.fc + idx);
+            idx++;
+        }
+        out->child_N[c] = cs.x;
+        out->child_W[c][0] = cs.y;
+        out->child_W[c][1] = cs.z;
+        out->child_W[c][2] = cs.w;
+        out->child_P[c] = ch ? bits_f32(ce.z) : 0.0f;
+        const bool some = ch && meta_some(ce.y);
+        out->child_sol[c][0] = some ? 1 : 0;
+        out->child_sol[c][1] = some ? (int)meta_kind(ce.y) : 0;
+        out->child_sol[c][2] = some ? (int)meta_turns(ce.y) : 0;
+        out->target_pi[c] = pi[c] / wtotal;
+    }
+    out->root_N = R.rootN;
+    out->root_W[0] = R.rW0; out->root_W[1] = R.rW1; out->root_W[2] = R.rW2;
+    const bool some = meta_some(R.root_meta);
+    out->root_sol[0] = some ? 1 : 0;
+    out->root_sol[1] = some ? (int)meta_kind(R.root_meta) : 0;
+    out->root_sol[2] = some ? (int)meta_turns(R.root_meta) : 0;
+    out->num_nodes = T.next_node;
+    out->best_action = best;
+    out->target_q[0] = q0; out->target_q[1] = q1; out->target_q[2] = q2;
+    lane_start_job<MODE_SEARCH>(P, T);
+}
+
+// cold path out of line, state by value (see engine_kernels.cuh: TreeGame)
+template <bool COUNT>
+__device__ __attribute__((noinline)) LaneTree lane_move_step_call(const EngineParams& P, LaneTree t, uint32_t* ctr) {
+    lane_move_step<COUNT>(P, t, ctr);
+    return t;
+}
+__device__ __attribute__((noinline)) LaneTree lane_search_finish_call(const EngineParams& P, LaneTree t) {
+    lane_search_finish(P, t);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------- the kernel
+template <int NW>
+struct LaneLds {
+    static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
+    static constexpr size_t BYTES = OUT_OFF + (size_t)NW * 1024;       // + 1 KB result patch per wave
+};
+
+SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
+    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+template <int MODE, bool COUNT, bool FAST, int NW, bool PROF = false>
+__global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int NT = 64 * NW;
+    float* wimg = reinterpret_cast<float*>(smem_raw);
+    const float* bimg = wimg + MlpGeom::W_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    float* outw = reinterpret_cast<float*>(smem_raw + LaneLds<NW>::OUT_OFF) + wave * 256;
+
+    stage_weight_image(wimg, P.wimg, tid, NT);
+    const FeatureTable FT = make_feature_table(lane >> 4);
+
+    uint32_t ctr[COUNT ? CTR_COUNT : 1];
+#pragma unroll
+    for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) ctr[i] = 0;
+
+    LaneTree T;
+    const size_t slot = (size_t)blockIdx.x * NT + (size_t)tid;
+    T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
+    lane_start_job<MODE>(P, T);
+    __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
+
+    const int n_explores = P.roll.num_explores;
+    unsigned long long pA = 0, pB = 0, pC = 0, pM = 0, pT = 0, pTiles = 0, pRounds = 0, pLanes = 0, pEvals = 0;
+#define SYN_STAMP() (PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
+#define SYN_LAP(acc) if (PROF) { unsigned long long n_ = SYN_STAMP(); acc += n_ - pT; pT = n_; }
+    for (;;) {
+        const bool active = T.job >= 0;
+        if (__ballot(active) == 0ull) break;
+        pT = SYN_STAMP();
+        LaneLeaf X;
+        lane_select_expand<COUNT, FAST>(P.mcts, T, X, active, ctr);
+        SYN_LAP(pA)
+        const bool need = active && X.needs_eval;
+        if (COUNT && need) ctr[CTR_POLICY_EVALS]++;
+
+        // ---- phase B: this wave's (up to) four 16-position tiles
+        const unsigned long long need_mask = __ballot(need);
+        uint64_t hi, lo;
+        feature_boards(X.leaf_my, X.leaf_op, hi, lo);
+        float lg[9];
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; c++) lg[c] = 0.0f;
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+            if (((need_mask >> (16 * j)) & 0xFFFFull) == 0ull) continue;  // wave-uniform
+            if (PROF) pTiles++;
+            const int src = 16 * j + (lane & 15);
+            const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
+            f32x4 o = mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+            const int q = lane >> 4;
+            if (q == 2) {
+                float a = o[1], b = o[2], c = o[3];
+                value_softmax(a, b, c);
+                o[1] = a; o[2] = b; o[3] = c;
+            }
+            if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 16 + q * 4) = o;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (q == j) {
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(outw + (lane & 15) * 16);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(outw + (lane & 15) * 16 + 4);
+                const f32x4 r2 = *reinterpret_cast<const f32x4*>(outw + (lane & 15) * 16 + 8);
+                lg[0] = r0[0]; lg[1] = r0[1]; lg[2] = r0[2]; lg[3] = r0[3];
+                lg[4] = r1[0]; lg[5] = r1[1]; lg[6] = r1[2]; lg[7] = r1[3];
+                lg[8] = r2[0]; v0 = r2[1]; v1 = r2[2]; v2 = r2[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+
+        SYN_LAP(pB)
+        if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(active)); pEvals += (unsigned long long)__popcll(need_mask); }
+
+        // ---- phase C
+        float d0 = X.p0, d1 = X.p1, d2 = X.p2;
+        if (need) {
+            lane_write_priors(T.slab, X, lg,
+                              (P.mcts.noise == 1 && T.iter == 0 && X.leaf == 0u) ? P.mcts.noise_weight : -1.0f);
+            d0 = v0;
+            d1 = v1;
+            d2 = v2;
+        }
+        lane_backprop<COUNT, FAST>(P.mcts, T, X.leaf, d0, d1, d2, X.solved, active, ctr);
+        SYN_LAP(pC)
+        if (active) {
+            T.iter += 1;
+            if (T.iter > n_explores || T.root_solved) {
+                // a private copy of the arguments goes to the callee and the slab pointer is re-derived afterwards, so
+                // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
+                EngineParams Pc = P;
+                if (MODE == MODE_SELFPLAY) T = lane_move_step_call<COUNT>(Pc, T, ctr);
+                else T = lane_search_finish_call(Pc, T);
+                T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
+            }
+        }
+        SYN_LAP(pM)
+    }
+#undef SYN_STAMP
+#undef SYN_LAP
+    if (PROF) {
+        if (P.prof && lane == 0) {
+            unsigned long long* o = P.prof + ((size_t)blockIdx.x * NW + wave) * 8;
+            o[0] = pA; o[1] = pB; o[2] = pC; o[3] = pM; o[4] = pRounds; o[5] = pTiles; o[6] = pLanes; o[7] = pEvals;
+        }
+    }
+
+    if (COUNT) {
+        if (P.counters) {
+#pragma unroll
+            for (int i = 0; i < (COUNT ? CTR_COUNT : 1); i++) {
+                if (i == CTR_MAX_DEPTH) atomicMax(&P.counters[i], (unsigned long long)ctr[i]);
+                else if (ctr[i]) atomicAdd(&P.counters[i], (unsigned long long)ctr[i]);
+            }
+        }
+    }
+}
+
+}  // namespace syn

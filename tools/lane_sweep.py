@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Developer tool: throughput of the lane-per-tree kernel. Args: conc:nw[:games] ... (nw = waves per workgroup, 0 = row kernels)"""
+import os, sys, time
+import numpy as np
+import torch  # noqa
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import synthesis_amd as sa
+from bench import make_weights
+blob = make_weights()
+combos = [tuple(map(int, a.split(":"))) for a in sys.argv[1:]] or [(65536, 16), (131072, 16), (262144, 16)]
+cfg = sa.parity_rollout_config(800)
+for c in combos:
+    conc, nw = c[0], c[1]
+    n = c[2] if len(c) > 2 else 2 * conc
+    if nw: os.environ["SYN_LANES"] = str(nw)
+    else: os.environ.pop("SYN_LANES", None)
+    eng = sa.Engine(concurrent_games=conc, max_explores=800)
+    eng.load_weights(blob)
+    eng.selfplay(cfg, 0, 256, outputs=False)
+    t0 = time.perf_counter()
+    r = eng.selfplay(cfg, 0, n, first_game=conc, outputs=False)
+    dt = time.perf_counter() - t0
+    print(f"concurrent={conc} lanes_nw={nw}: {n} games in {dt:.3f} s = {n / dt:.0f} games/s  (mean plies {r['plies'].mean():.2f})", flush=True)
+    eng.close()
