@@ -43,6 +43,8 @@ struct syn_engine {
     float* d_wimg = nullptr;
     bool has_weights = false;
     int* d_job_next = nullptr;
+    uint2* d_path = nullptr;   // lane kernel's per-wave descent logs
+    size_t path_bytes = 0;
     unsigned long long* d_counters = nullptr;
     // self-play output buffers (device), grown on demand
     int out_games = 0;
@@ -184,13 +186,24 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (nw == 4 || nw == 8 || nw == 12 || nw == 16) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
+            const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint2);
+            if (need_path > h->path_bytes) {
+                if (h->d_path) (void)hipFree(h->d_path);
+                h->d_path = nullptr;
+                h->path_bytes = 0;
+                hipError_t pe = hipMalloc(&h->d_path, need_path);
+                if (pe != hipSuccess) return pe;
+                h->path_bytes = need_path;
+            }
+            EngineParams PL = P;
+            PL.path = h->d_path;
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneLds<NW>::BYTES);   \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, P);                       \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                       \
     }
             if (nw == 4) { if (fast) SYN_LAUNCH_L(4, true) else SYN_LAUNCH_L(4, false) }
             else if (nw == 8) { if (fast) SYN_LAUNCH_L(8, true) else SYN_LAUNCH_L(8, false) }
@@ -301,7 +314,8 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     // the launch may round the slot count up to a whole workgroup (<= 1024 trees: lane kernel)
     // + 48: the 3-quad launch rounds to multiples of 48 slots
-    h->pool_slots = ((h->slots + 1023) / 1024) * 1024 + 48;
+    // (768: the 12-wave lane kernel rounds to multiples of 768 slots)
+    h->pool_slots = ((h->slots + 1023) / 1024) * 1024 + 768;
     size_t nodes = (size_t)h->pool_slots * h->cap;
     if ((e = hipMalloc(&h->d_stat, nodes * 32)) != hipSuccess) return bail("hipMalloc(node pool)", e);
     h->d_edge = reinterpret_cast<uint4*>(h->d_stat);  // same records, edge half = odd 16-byte elements
@@ -319,6 +333,7 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_stat);
     hipFree(h->d_wimg);
     hipFree(h->d_job_next);
+    hipFree(h->d_path);
     hipFree(h->d_counters);
     hipFree(h->d_plies);
     hipFree(h->d_states);
@@ -521,6 +536,7 @@ static int common_params(syn_engine* h, EngineParams& P, int explores) {
     P.cap = h->cap;
     P.job_next = h->d_job_next;
     P.error = h->d_job_next + 8;  // same 64-byte block, zeroed before every launch
+    P.path = nullptr;
     P.counters = h->d_counters;
     return SYN_OK;
 }

@@ -23,8 +23,31 @@
 
 namespace syn {
 
+// Node records of this launch shape (private to it: the pool's contents never outlive a launch). A tree slab of `cap`
+// nodes is two arrays of 16-byte records:
+//   sel[node] = { N, q | turns, P, packed }      everything select_best_child needs about a child: ONE 16-byte load
+//       q       = -((W_win - W_lose) / N), rewritten by every backprop (the value exploit_value would recompute,
+//                 mcts.rs:343-359); once the node is solved the slot holds the solution's turn count instead (a solved
+//                 child is scored from its outcome kind alone)
+//       packed  = first_child[0:19] | num_children[20:23] | action[24:27] | solved[28] | kind[29:30]
+//   aux[node] = { W_lose, W_draw, W_win, - }     touched only by backprop (never read while N == 0: no initialisation)
+// Children of a node are contiguous, so a level of the descent is nine 16-byte loads from one 144-byte span (two cache
+// lines) — half the requests and lines of the 32-byte records, which is what the per-CU vector-memory pipeline (the
+// bottleneck of this shape) charges for. There are no parent links: the descent logs (node, N) per level into
+// a per-wave path buffer [level][lane] (coalesced 512-byte rows) and backprop replays it from the leaf's level down to
+// 0, all lanes of a wave on the same level, so backprop has no dependent pointer chase at all.
+constexpr uint32_t PW_FC_MASK = 0xFFFFFu, PW_NC_SHIFT = 20, PW_ACT_SHIFT = 24, PW_SOME_BIT = 1u << 28, PW_KIND_SHIFT = 29;
+SYN_DEV uint32_t pw_make(uint32_t fc, uint32_t nc, uint32_t action, bool some, uint32_t kind) {
+    return fc | (nc << PW_NC_SHIFT) | (action << PW_ACT_SHIFT) | (some ? PW_SOME_BIT : 0u) | (kind << PW_KIND_SHIFT);
+}
+SYN_DEV uint32_t pw_fc(uint32_t w) { return w & PW_FC_MASK; }
+SYN_DEV uint32_t pw_nc(uint32_t w) { return (w >> PW_NC_SHIFT) & 0xFu; }
+SYN_DEV uint32_t pw_action(uint32_t w) { return (w >> PW_ACT_SHIFT) & 0xFu; }
+SYN_DEV bool pw_some(uint32_t w) { return (w & PW_SOME_BIT) != 0u; }
+SYN_DEV uint32_t pw_kind(uint32_t w) { return (w >> PW_KIND_SHIFT) & 3u; }
+
 struct LaneTree {
-    unsigned char* slab;      // this lane's node records (32 B each: stat half, edge half)
+    unsigned char* slab;      // this lane's records: sel[cap] then aux[cap]
     uint64_t root_my, root_op;
     uint32_t next_node;       // nodes.len()
     uint32_t root_fc, root_nc;
@@ -36,23 +59,28 @@ struct LaneTree {
 };
 
 struct LaneLeaf {             // phase A -> phase C
-    uint32_t leaf;            // node the backprop starts from
-    uint32_t fc;              // first child of the node that needs priors
+    int depth;                // level of the node the backprop starts from (root = 0)
+    uint32_t fc;              // first child of the node that needs its children created (valid if needs_eval)
     uint32_t legal_mask;
     bool needs_eval, solved;
     float p0, p1, p2;
     uint64_t leaf_my, leaf_op;
 };
 
-SYN_DEV float4 ln_stat(const unsigned char* slab, uint32_t i) {
-    return *reinterpret_cast<const float4*>(slab + (size_t)i * 32u);
+SYN_DEV float4 ln_sel(const unsigned char* slab, uint32_t i) {
+    return *reinterpret_cast<const float4*>(slab + (size_t)i * 16u);
 }
-SYN_DEV uint4 ln_edge(const unsigned char* slab, uint32_t i) {
-    return *reinterpret_cast<const uint4*>(slab + (size_t)i * 32u + 16u);
+SYN_DEV void st_sel(unsigned char* slab, uint32_t i, float N, uint32_t y, float P, uint32_t w) {
+    *reinterpret_cast<float4*>(slab + (size_t)i * 16u) = make_float4(N, bits_f32(y), P, bits_f32(w));
 }
-SYN_DEV void st_stat(unsigned char* slab, uint32_t i, float4 v) { *reinterpret_cast<float4*>(slab + (size_t)i * 32u) = v; }
-SYN_DEV void st_edge(unsigned char* slab, uint32_t i, uint4 v) {
-    *reinterpret_cast<uint4*>(slab + (size_t)i * 32u + 16u) = v;
+SYN_DEV void st_sel_w(unsigned char* slab, uint32_t i, uint32_t w) {
+    *reinterpret_cast<uint32_t*>(slab + (size_t)i * 16u + 12u) = w;
+}
+SYN_DEV float4 ln_aux(const unsigned char* slab, uint32_t cap, uint32_t i) {
+    return *reinterpret_cast<const float4*>(slab + (size_t)(cap + i) * 16u);
+}
+SYN_DEV void st_aux(unsigned char* slab, uint32_t cap, uint32_t i, float4 v) {
+    *reinterpret_cast<float4*>(slab + (size_t)(cap + i) * 16u) = v;
 }
 
 template <int MODE>
@@ -75,124 +103,108 @@ SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
 }
 
 // ---------------------------------------------------------------------------------------------- phase A
+// pl = this lane's column of the wave's path buffer: level L lives at pl[L * 64]
 template <bool COUNT, bool FAST>
-SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X, bool active, uint32_t* ctr) {
+SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X, bool active, uint2* pl, uint32_t cap,
+                                uint32_t* ctr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     uint32_t node = 0;
+    int level = 0;
     uint64_t my = T.root_my, op = T.root_op;
     X.needs_eval = false;
     X.solved = false;
     X.p0 = X.p1 = X.p2 = 0.0f;
     X.fc = 0;
     X.legal_mask = 0;
-    uint32_t fc = 0, meta = 0;
-    float pN = 0.0f, pW0 = 0.0f, pW2 = 0.0f;
+    uint32_t wcur = 0;  // packed word of the current node (the root has action 0 and no solution while it is searched)
+    float pN = 0.0f, pq = 0.0f;
     if (active) {
         if (COUNT) ctr[CTR_EXPLORES]++;
         if (T.next_node == 0) {
-            // MCTS::with_capacity: push the root (mcts.rs:125) — unvisited, parent 0, action 0, prior 0
-            st_stat(slab, 0, make_float4(0.f, 0.f, 0.f, 0.f));
-            st_edge(slab, 0, make_uint4(0u, meta_make(0, 0, false, 0, 0), f32_bits(0.0f), 0u));
-            T.next_node = 1;
+            T.next_node = 1;  // MCTS::with_capacity pushes the root (mcts.rs:125); its record is written by backprop
         } else {
-            fc = T.root_fc;
-            meta = T.root_nc;
+            wcur = pw_make(T.root_fc, T.root_nc, 0, false, 0);
             pN = (float)T.iter;
-            if (!cfg.fpu_const()) {
-                float4 s = ln_stat(slab, 0);
-                pW0 = s.y;
-                pW2 = s.w;
+            if (!cfg.fpu_const()) {  // Fpu::ParentQ at the first level needs the root's q
+                const float4 a = ln_aux(slab, cap, 0);
+                pq = -((a.z - a.x) / pN);
             }
         }
+        pl[0] = make_uint2(0u, f32_bits(pN));
     }
 
     // ---- descent (mcts.rs:310-341): every lane walks its own tree; the wave iterates until its deepest lane is done
     bool hit_solved = false;
     bool go = active;
     while (go) {
-        if (meta_some(meta)) { hit_solved = true; break; }
-        const uint32_t nc = meta_nc(meta);
+        if (pw_some(wcur)) { hit_solved = true; break; }
+        const uint32_t nc = pw_nc(wcur);
         if (nc == 0) break;
-        const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : (pW2 - pW0) / pN;
+        const uint32_t fc = pw_fc(wcur);
+        const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -pq;  // parent.q() = -(stored q)
         const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
         // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces)
-        float best_v = 0.0f, bN = 0.0f, bW0 = 0.0f, bW2 = 0.0f;
-        uint32_t best_i = 0, bmeta = 0, bfc = 0;
+        float best_v = 0.0f, bN = 0.0f, bq = 0.0f;
+        uint32_t best_i = 0, bw = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 9; i++) {
             // indices past the last child re-read the last child (valid address, no predicate in front of the loads,
-            // so the nine record loads of a level can be in flight together)
-            const uint32_t ci = fc + (i < nc ? i : nc - 1u);
-            const float4 cs = ln_stat(slab, ci);
-            const uint4 ce = ln_edge(slab, ci);
-            const float q_visited = -((cs.w - cs.y) / cs.x);
-            const uint32_t k = meta_kind(ce.y);
+            // so the nine loads of a level are in flight together)
+            const float4 s = ln_sel(slab, fc + (i < nc ? i : nc - 1u));
+            const uint32_t w = f32_bits(s.w);
+            const uint32_t k = pw_kind(w);
+            // outcome.reversed().value(): child Win -> -1, Draw -> 0, Lose -> +1 (game.rs:29-43)
             const float q_solved = cfg.select_solved() ? (k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
-            float q = meta_nc(ce.y) == 0u ? q_fpu : q_visited;
-            q = meta_some(ce.y) ? q_solved : q;
+            float q = pw_nc(w) == 0u ? q_fpu : s.y;
+            q = pw_some(w) ? q_solved : q;
             float u;
-            if (cfg.puct()) u = cfg.cc() * bits_f32(ce.z) * visits / (1.0f + cs.x);
-            else u = visits / sqrtf(cs.x);
+            if (cfg.puct()) u = cfg.cc() * s.z * visits / (1.0f + s.x);
+            else u = visits / sqrtf(s.x);
             const float v = q + u;
             const bool take = i == 0u || (i < nc && v > best_v);
             best_v = take ? v : best_v;
             best_i = take ? i : best_i;
-            bmeta = take ? ce.y : bmeta;
-            bfc = take ? ce.x : bfc;
-            bN = take ? cs.x : bN;
-            bW0 = take ? cs.y : bW0;
-            bW2 = take ? cs.w : bW2;
+            bw = take ? w : bw;
+            bN = take ? s.x : bN;
+            bq = take ? s.y : bq;
         }
         if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
-        const int a = (int)meta_action(bmeta);
+        const int a = (int)pw_action(bw);
         const int ha = c4::col_height(my | op, a);
         const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
         my = nmy;
         op = nop;
         node = fc + best_i;
-        fc = bfc;
-        meta = bmeta;
+        wcur = bw;
         pN = bN;
-        pW0 = bW0;
-        pW2 = bW2;
+        pq = bq;
+        level++;
+        pl[level * 64] = make_uint2(node, f32_bits(pN));
     }
 
     if (active) {
         if (hit_solved) {
-            const uint32_t k = meta_kind(meta);
+            const uint32_t k = pw_kind(wcur);
             X.p0 = k == 0u ? 1.0f : 0.0f;
             X.p1 = k == 1u ? 1.0f : 0.0f;
             X.p2 = k == 2u ? 1.0f : 0.0f;
             X.solved = true;
             if (COUNT) ctr[CTR_SOLVED_HITS]++;
         } else {
-            // visit(): expansion, possibly repeated by auto-extend (mcts.rs:374-406)
+            // visit() (mcts.rs:374-406): allocate the children; their records are written in phase C together with
+            // their priors. Only an auto-extended single child is written here (prior 1.0, no policy call).
             for (;;) {
                 const uint64_t occ = my | op;
-                const uint32_t first = T.next_node;
-                uint32_t n_new = 0, lmask = 0;
-                bool any_solved = false;
+                uint32_t lmask = 0;
 #pragma unroll
-                for (int c = 0; c < 9; c++) {
-                    const int h = c4::col_height(occ, c);
-                    if (h < c4::HEIGHT) {
-                        const uint64_t bit = 1ull << (h + 7 * c);
-                        const uint64_t cop = my | bit;  // child.op_bb = the mover's stones (connect4.rs:224-229)
-                        const bool w = c4::won(cop);
-                        const bool full = (occ | bit) == c4::FULL;
-                        const bool over = w || full;
-                        st_stat(slab, first + n_new, make_float4(0.f, 0.f, 0.f, 0.f));
-                        st_edge(slab, first + n_new,
-                                make_uint4(0u, meta_make(0, (uint32_t)c, over, w ? 0u : 1u, 0u), f32_bits(1.0f), node));
-                        n_new++;
-                        lmask |= 1u << c;
-                        any_solved = any_solved || over;
-                    }
-                }
+                for (int c = 0; c < 9; c++)
+                    if (c4::col_height(occ, c) < c4::HEIGHT) lmask |= 1u << c;
+                const uint32_t n_new = (uint32_t)__popc(lmask);
+                const uint32_t first = T.next_node;
                 T.next_node = first + n_new;
-                meta = (meta & ~META_NC_MASK) | n_new;
-                *reinterpret_cast<uint2*>(slab + (size_t)node * 32u + 16u) = make_uint2(first, meta);
+                wcur = (wcur & ~(PW_FC_MASK | (0xFu << PW_NC_SHIFT))) | first | (n_new << PW_NC_SHIFT);
+                st_sel_w(slab, node, wcur);
                 if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
                 if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
 
@@ -203,10 +215,13 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X
                     const uint64_t nmy = op, nop = my | abit;
                     const bool aw = c4::won(nop);
                     const bool afull = (occ | abit) == c4::FULL;
+                    wcur = pw_make(0, 0, (uint32_t)a, aw || afull, aw ? 0u : 1u);
+                    st_sel(slab, first, 0.0f, 0u, 1.0f, wcur);
                     node = first;
                     my = nmy;
                     op = nop;
-                    meta = meta_make(0, (uint32_t)a, aw || afull, aw ? 0u : 1u, 0u);
+                    level++;
+                    pl[level * 64] = make_uint2(node, f32_bits(0.0f));
                     if (aw || afull) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
                         X.p0 = aw ? 1.0f : 0.0f;
                         X.p1 = aw ? 0.0f : 1.0f;
@@ -217,21 +232,21 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X
                     continue;
                 }
                 X.needs_eval = true;
-                X.solved = any_solved;
                 X.fc = first;
                 X.legal_mask = lmask;
                 break;
             }
         }
     }
-    X.leaf = node;
+    X.depth = level;
     X.leaf_my = my;
     X.leaf_op = op;
 }
 
 // ---------------------------------------------------------------------------------------------- phase C
-// legal-move softmax of visit() (mcts.rs:409-423): lg = the nine raw policy logits of the expanded node
-SYN_DEV void lane_write_priors(unsigned char* slab, const LaneLeaf& X, const float (&lg)[9], float equal_noise_weight) {
+// The rest of visit() for the node expanded in phase A (mcts.rs:389-423): creates its children (terminal ones already
+// solved) with the legal-move softmax of the nine raw logits as priors. Returns any_solved.
+SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, const float (&lg)[9], float equal_noise_weight) {
     const uint32_t lmask = X.legal_mask;
     float mx = -__builtin_inff();
 #pragma unroll
@@ -246,130 +261,189 @@ SYN_DEV void lane_write_priors(unsigned char* slab, const LaneLeaf& X, const flo
     }
     const uint32_t nc = (uint32_t)__popc(lmask);
     const float noise = 1.0f / (float)nc;
+    const uint64_t my = X.leaf_my, occ = X.leaf_my | X.leaf_op;
     uint32_t idx = 0;
+    bool any_solved = false;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         if ((lmask >> c) & 1u) {
             float p = e[c] / total;
             if (equal_noise_weight >= 0.0f && nc >= 2u) p = p * (1.0f - equal_noise_weight) + equal_noise_weight * noise;
-            *reinterpret_cast<uint32_t*>(slab + (size_t)(X.fc + idx) * 32u + 24u) = f32_bits(p);
+            const int h = c4::col_height(occ, c);
+            const uint64_t bit = 1ull << (h + 7 * c);
+            const bool w = c4::won(my | bit);  // child.op_bb = the mover's stones (connect4.rs:224-229)
+            const bool over = w || (occ | bit) == c4::FULL;
+            // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost
+            st_sel(slab, X.fc + idx, 0.0f, 0u, p, pw_make(0, 0, (uint32_t)c, over, w ? 0u : 1u));
+            any_solved = any_solved || over;
             idx++;
         }
     }
+    return any_solved;
 }
 
-// backprop (mcts.rs:429-488) along the parent links of the records
+SYN_DEV int wave_max_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// backprop (mcts.rs:429-488) replayed from the path buffer.
+//   phase 1 (per lane, rare): the MCTS-Solver walk, level by level while the subtree below stays proven.
+//   phase 2 (whole wave, four levels per step): every remaining level just adds the leaf's outcome distribution
+//            (win/lose swapped once per level climbed) and one visit, so the levels are independent: the four path rows
+//            and then the four aux records are fetched together — two memory round trips per four levels.
+// `leaf_solved`: the backprop starts at a node that already carries a solution (explore() hit a solved node, or an
+// auto-extended terminal child); its q slot holds the turn count and must stay that way even with the solver off.
 template <bool COUNT, bool FAST>
-SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, uint32_t leaf, float d0, float d1, float d2, bool solved,
-                           bool active, uint32_t* ctr) {
+SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
+                           bool leaf_solved, bool active, const uint2* pl, uint32_t cap, uint32_t* ctr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
-    uint32_t node = leaf;
-    uint32_t levels = 0;
-    bool go = active;
-    while (go) {
-        uint4 e = ln_edge(slab, node);
-        float4 s = ln_stat(slab, node);
-        levels++;
-        if (cfg.solve() && solved) {
-            const uint32_t nc = meta_nc(e.y);
-            bool all_solved = true;
-            uint32_t key = outcome_key(meta_some(e.y), meta_kind(e.y), meta_turns(e.y));
-            if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+    if (COUNT && active) {
+        ctr[CTR_BACKPROP_LEVELS] += (uint32_t)(depth + 1);
+        if ((uint32_t)(depth + 1) > ctr[CTR_MAX_DEPTH]) ctr[CTR_MAX_DEPTH] = (uint32_t)(depth + 1);
+    }
+    int L = active ? depth : -1;
+    bool keep_turns = leaf_solved;  // only ever true for the first level handled
+    // ---- phase 1
+    while (cfg.solve() && solved && L >= 0) {
+        const uint2 pe = pl[L * 64];
+        const uint32_t node = pe.x;
+        float N = bits_f32(pe.y);
+        const float4 a = ln_aux(slab, cap, node);
+        // a node that was never backpropagated into has no aux record yet
+        float W0 = N == 0.0f ? 0.0f : a.x, W1 = N == 0.0f ? 0.0f : a.y, W2 = N == 0.0f ? 0.0f : a.z;
+        const float4 s = ln_sel(slab, node);
+        uint32_t w = f32_bits(s.w);
+        const uint32_t nc = pw_nc(w), fc = pw_fc(w);
+        bool all_solved = true;
+        uint32_t key = outcome_key(pw_some(w), pw_kind(w), f32_bits(s.y));
+        if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
 #pragma unroll
-            for (uint32_t i = 0; i < 9; i++) {
-                if (i < nc) {
-                    const uint32_t cmeta = *reinterpret_cast<const uint32_t*>(slab + (size_t)(e.x + i) * 32u + 20u);
-                    all_solved = all_solved && meta_some(cmeta);
-                    const uint32_t ck = outcome_key_reversed(cmeta);
-                    key = ck > key ? ck : key;
-                }
-            }
-            bool bsome;
-            uint32_t bkind, bturns;
-            outcome_from_key(key, bsome, bkind, bturns);
-            if (bsome && bkind == 2u) {
-                e.y = (e.y & 0xFFu) | (meta_make(0, 0, true, 2u, bturns) & ~0xFFu);
-                if (cfg.correct_values()) {
-                    d0 = -s.y;
-                    d1 = -s.z;
-                    d2 = -s.w;
-                    d2 += s.x + 1.0f;
-                }
-            } else if (bsome && all_solved) {
-                e.y = (e.y & 0xFFu) | (meta_make(0, 0, true, bkind, bturns) & ~0xFFu);
-                if (cfg.correct_values()) {
-                    d0 = -s.y;
-                    d1 = -s.z;
-                    d2 = -s.w;
-                    if (bkind == 1u) d1 += s.x + 1.0f;
-                    else d0 += s.x + 1.0f;
-                }
-            } else {
-                solved = false;
-            }
-            if (solved) {
-                *reinterpret_cast<uint32_t*>(slab + (size_t)node * 32u + 20u) = e.y;
-                if (node == 0u) T.root_solved = true;
+        for (uint32_t i = 0; i < 9; i++) {
+            if (i < nc) {
+                const float4 cs = ln_sel(slab, fc + i);
+                const uint32_t cw = f32_bits(cs.w);
+                all_solved = all_solved && pw_some(cw);
+                // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
+                const uint32_t ck = pw_kind(cw);
+                const uint32_t rk = pw_some(cw) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, f32_bits(cs.y) + 1u) : 0u;
+                key = rk > key ? rk : key;
             }
         }
-        s.y += d0;
-        s.z += d1;
-        s.w += d2;
-        s.x += 1.0f;
-        st_stat(slab, node, s);
-        if (node == 0u) break;
+        bool bsome;
+        uint32_t bkind, bturns;
+        outcome_from_key(key, bsome, bkind, bturns);
+        if (bsome && bkind == 2u) {
+            if (cfg.correct_values()) {
+                d0 = -W0;
+                d1 = -W1;
+                d2 = -W2;
+                d2 += N + 1.0f;
+            }
+        } else if (bsome && all_solved) {
+            if (cfg.correct_values()) {
+                d0 = -W0;
+                d1 = -W1;
+                d2 = -W2;
+                if (bkind == 1u) d1 += N + 1.0f;
+                else d0 += N + 1.0f;
+            }
+        } else {
+            solved = false;
+            break;  // this level and everything above belongs to phase 2
+        }
+        w = (w & ~(PW_SOME_BIT | (3u << PW_KIND_SHIFT))) | PW_SOME_BIT | (bkind << PW_KIND_SHIFT);
+        st_sel_w(slab, node, w);
+        if (L == 0) T.root_solved = true;
+        W0 += d0;
+        W1 += d1;
+        W2 += d2;
+        N += 1.0f;
+        st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
+        *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, bits_f32(bturns));
         const float t = d0;
         d0 = d2;
         d2 = t;
-        node = e.w;
+        keep_turns = false;
+        L--;
     }
-    if (COUNT && active) {
-        ctr[CTR_BACKPROP_LEVELS] += levels;
-        if (levels > ctr[CTR_MAX_DEPTH]) ctr[CTR_MAX_DEPTH] = levels;
+    // ---- phase 2: levels L..0 of this lane; (d0,d1,d2) is the delta for level L
+    for (int base = wave_max_i32(L); base >= 0; base -= 4) {
+        uint2 pe[4];
+        float4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int Lj = base - j;
+            pe[j] = pl[(Lj < 0 ? 0 : Lj) * 64];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int Lj = base - j;
+            const bool ok = Lj >= 0 && Lj <= L;
+            a[j] = ln_aux(slab, cap, ok ? pe[j].x : 0u);  // (idle lanes re-read their root's record: a valid address)
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int Lj = base - j;
+            if (Lj >= 0 && Lj <= L) {
+                const uint32_t node = pe[j].x;
+                float N = bits_f32(pe[j].y);
+                const bool flip = ((L - Lj) & 1) != 0;  // delta[0] <-> delta[2] once per level climbed
+                const float W0 = (N == 0.0f ? 0.0f : a[j].x) + (flip ? d2 : d0);
+                const float W1 = (N == 0.0f ? 0.0f : a[j].y) + d1;
+                const float W2 = (N == 0.0f ? 0.0f : a[j].z) + (flip ? d0 : d2);
+                N += 1.0f;
+                st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
+                const float q = -((W2 - W0) / N);
+                if (keep_turns && Lj == L) *reinterpret_cast<float*>(slab + (size_t)node * 16u) = N;
+                else *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, q);
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------- end of a search
-// The root's children by column, streamed (the cold path must not set the kernel's register budget).
 struct LaneRoot {
-    uint32_t fc, nc, root_meta, lmask;
-    float rootN, rW0, rW1, rW2;
+    uint32_t fc, nc, root_w, lmask;
+    float rootN;
 };
 SYN_DEV LaneRoot lane_root(const LaneTree& T) {
     LaneRoot R;
-    const uint4 e = ln_edge(T.slab, 0);
-    const float4 s = ln_stat(T.slab, 0);
-    R.fc = e.x;
-    R.root_meta = e.y;
-    R.nc = meta_nc(e.y);
-    R.rootN = s.x; R.rW0 = s.y; R.rW1 = s.z; R.rW2 = s.w;
+    const float4 s = ln_sel(T.slab, 0);
+    R.root_w = f32_bits(s.w);
+    R.fc = pw_fc(R.root_w);
+    R.nc = pw_nc(R.root_w);
+    R.rootN = s.x;
     const uint64_t occ = T.root_my | T.root_op;
     uint32_t lm = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++)
         if (c4::col_height(occ, c) < c4::HEIGHT) lm |= 1u << c;
-    // a root that was never expanded (solved at once) has no children
-    R.lmask = R.nc == 0u ? 0u : lm;
+    R.lmask = R.nc == 0u ? 0u : lm;  // the children of the root are its legal columns in ascending order
     return R;
 }
 
 // MCTS::target_policy numerators (mcts.rs:174-211) per column (0 for non-children) and their sum in child order
-SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&w)[9]) {
+SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&wts)[9]) {
     const bool first_visit = R.rootN == 1.0f;
-    const bool root_win = meta_some(R.root_meta) && meta_kind(R.root_meta) == 2u;
+    const bool root_win = pw_some(R.root_w) && pw_kind(R.root_w) == 2u;
     float total = 0.0f;
     uint32_t idx = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
-        w[c] = 0.0f;
+        wts[c] = 0.0f;
         if ((R.lmask >> c) & 1u) {
-            const float4 cs = ln_stat(T.slab, R.fc + idx);
-            const uint32_t cm = ln_edge(T.slab, R.fc + idx).y;
+            const float4 cs = ln_sel(T.slab, R.fc + idx);
+            const uint32_t cw = f32_bits(cs.w);
             float v;
-            if (first_visit) v = root_win ? ((meta_some(cm) && meta_kind(cm) == 0u) ? 1.0f : 0.0f) : 1.0f;
+            if (first_visit) v = root_win ? ((pw_some(cw) && pw_kind(cw) == 0u) ? 1.0f : 0.0f) : 1.0f;
             else v = cs.x;
-            w[c] = v;
+            wts[c] = v;
             total += v;
             idx++;
         }
@@ -377,53 +451,56 @@ SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&
     return total;
 }
 
-SYN_DEV void lane_target_q(const LaneRoot& R, float& q0, float& q1, float& q2) {
-    if (meta_some(R.root_meta)) {
-        const uint32_t k = meta_kind(R.root_meta);
+SYN_DEV void lane_target_q(const LaneTree& T, const LaneRoot& R, uint32_t cap, float& q0, float& q1, float& q2) {
+    if (pw_some(R.root_w)) {
+        const uint32_t k = pw_kind(R.root_w);
         q0 = k == 0u ? 1.0f : 0.0f;
         q1 = k == 1u ? 1.0f : 0.0f;
         q2 = k == 2u ? 1.0f : 0.0f;
     } else {
-        q0 = R.rW0 / R.rootN;
-        q1 = R.rW1 / R.rootN;
-        q2 = R.rW2 / R.rootN;
+        const float4 a = ln_aux(T.slab, cap, 0);
+        q0 = a.x / R.rootN;
+        q1 = a.y / R.rootN;
+        q2 = a.z / R.rootN;
     }
 }
 
-// MCTS::best_action (mcts.rs:273-294); also returns the meta of the chosen child
-SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_selection, uint32_t& best_meta) {
+// MCTS::best_action (mcts.rs:273-294); also returns the packed word of the chosen child
+SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_selection, uint32_t& best_w) {
     int best = -1;
     float b0 = 0.0f, b1 = 0.0f;
-    best_meta = 0;
+    best_w = 0;
     uint32_t idx = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         if ((R.lmask >> c) & 1u) {
-            const float4 cs = ln_stat(T.slab, R.fc + idx);
-            const uint32_t cm = ln_edge(T.slab, R.fc + idx).y;
+            const float4 cs = ln_sel(T.slab, R.fc + idx);
+            const uint32_t cw = f32_bits(cs.w);
             float k0, k1;
-            if (meta_some(cm)) {
-                const uint32_t kind = meta_kind(cm);
-                const float t = (float)meta_turns(cm);
+            if (pw_some(cw)) {
+                const uint32_t kind = pw_kind(cw);
+                const float t = (float)f32_bits(cs.y);
                 if (kind == 2u) { k0 = 0.0f; k1 = t; }
                 else if (kind == 1u) { k0 = 2.0f; k1 = -t; }
                 else { k0 = 3.0f; k1 = -t; }
             } else {
                 k0 = 1.0f;
-                k1 = action_selection == 0 ? -((cs.w - cs.y) / cs.x) : cs.x;
+                // -child.q(): the stored q, except for a never-visited child where the reference divides 0 by 0
+                const float nq = cs.x == 0.0f ? -((0.0f - 0.0f) / cs.x) : cs.y;
+                k1 = action_selection == 0 ? nq : cs.x;
             }
             const bool gt = best < 0 || (k0 > b0) || (k0 == b0 && k1 > b1);
-            if (gt) { best = c; b0 = k0; b1 = k1; best_meta = cm; }
+            if (gt) { best = c; b0 = k0; b1 = k1; best_w = cw; }
             idx++;
         }
     }
     return best;
 }
 
-SYN_DEV uint32_t lane_child_meta(const LaneTree& T, const LaneRoot& R, int action, bool& is_child) {
+SYN_DEV uint32_t lane_child_w(const LaneTree& T, const LaneRoot& R, int action, bool& is_child) {
     is_child = ((R.lmask >> action) & 1u) != 0u;
     const uint32_t idx = (uint32_t)__popc(R.lmask & ((1u << action) - 1u));
-    return is_child ? ln_edge(T.slab, R.fc + idx).y : 0u;
+    return is_child ? f32_bits(ln_sel(T.slab, R.fc + idx).w) : 0u;
 }
 
 // run_game's per-move tail (alpha_zero.rs:243-264) + game end (fill_state_info / store_rewards, 296-338)
@@ -444,7 +521,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
 #pragma unroll
     for (int c = 0; c < 9; c++) pi[c] = pi[c] / wtotal;
     float q0, q1, q2;
-    lane_target_q(R, q0, q1, q2);
+    lane_target_q(T, R, P.cap, q0, q1, q2);
     const size_t pos = (size_t)T.job * 63 + (size_t)T.turn;
     P.states_bb[pos * 2 + 0] = T.root_my;
     P.states_bb[pos * 2 + 1] = T.root_op;
@@ -456,8 +533,8 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     P.vs[pos * 3 + 2] = q2;
 
     // sample_action (alpha_zero.rs:270-294)
-    uint32_t best_meta;
-    const int best = lane_best_action(T, R, rc.action, best_meta);
+    uint32_t best_w;
+    const int best = lane_best_action(T, R, rc.action, best_w);
     int action;
     if (want_random) {
         const uint32_t n = (uint32_t)__popc(R.lmask);
@@ -474,7 +551,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
         uint32_t m = R.lmask;
         for (uint32_t i = 0; i < r; i++) m &= m - 1u;
         action = __ffs((int)m) - 1;
-    } else if (maybe_sample && (!meta_some(best_meta) || !rc.stop_when_solved)) {
+    } else if (maybe_sample && (!pw_some(best_w) || !rc.stop_when_solved)) {
         float total = pi[0];
         const float chosen_unit = bits_f32((rnd >> 9) | 0x3F800000u) - 1.0f;
         float cum[8];
@@ -495,9 +572,9 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     P.actions[pos] = (unsigned char)action;
 
     bool a_child;
-    const uint32_t a_meta = lane_child_meta(T, R, action, a_child);
-    bool sol_some = a_child && meta_some(a_meta);
-    uint32_t sol_kind = meta_kind(a_meta);
+    const uint32_t a_w = lane_child_w(T, R, action, a_child);
+    bool sol_some = a_child && pw_some(a_w);
+    uint32_t sol_kind = pw_kind(a_w);
 
     const uint64_t occ = T.root_my | T.root_op;
     const int h = c4::col_height(occ, action);
@@ -559,38 +636,40 @@ SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
     float pi[9];
     const float wtotal = lane_policy_weights(T, R, pi);
     float q0, q1, q2;
-    lane_target_q(R, q0, q1, q2);
-    uint32_t bm;
-    const int best = lane_best_action(T, R, P.action_selection, bm);
+    lane_target_q(T, R, P.cap, q0, q1, q2);
+    uint32_t bw;
+    const int best = lane_best_action(T, R, P.action_selection, bw);
     DevSearchResult* out = P.results + T.job;
     uint32_t idx = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const bool ch = ((R.lmask >> c) & 1u) != 0u;
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-        uint4 ce = make_uint4(0u, 0u, 0u, 0u);
+        float4 ca = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ch) {
-            cs = ln_stat(T.slab, R.fc + idx);
-            ce = ln_edge(T.slab, R.fc + idx);
+            cs = ln_sel(T.slab, R.fc + idx);
+            if (cs.x != 0.0f) ca = ln_aux(T.slab, P.cap, R.fc + idx);
             idx++;
         }
+        const uint32_t cw = f32_bits(cs.w);
         out->child_N[c] = cs.x;
-        out->child_W[c][0] = cs.y;
-        out->child_W[c][1] = cs.z;
-        out->child_W[c][2] = cs.w;
-        out->child_P[c] = ch ? bits_f32(ce.z) : 0.0f;
-        const bool some = ch && meta_some(ce.y);
+        out->child_W[c][0] = ca.x;
+        out->child_W[c][1] = ca.y;
+        out->child_W[c][2] = ca.z;
+        out->child_P[c] = ch ? cs.z : 0.0f;
+        const bool some = ch && pw_some(cw);
         out->child_sol[c][0] = some ? 1 : 0;
-        out->child_sol[c][1] = some ? (int)meta_kind(ce.y) : 0;
-        out->child_sol[c][2] = some ? (int)meta_turns(ce.y) : 0;
+        out->child_sol[c][1] = some ? (int)pw_kind(cw) : 0;
+        out->child_sol[c][2] = some ? (int)f32_bits(cs.y) : 0;
         out->target_pi[c] = pi[c] / wtotal;
     }
+    const float4 ra = ln_aux(T.slab, P.cap, 0);
     out->root_N = R.rootN;
-    out->root_W[0] = R.rW0; out->root_W[1] = R.rW1; out->root_W[2] = R.rW2;
-    const bool some = meta_some(R.root_meta);
+    out->root_W[0] = ra.x; out->root_W[1] = ra.y; out->root_W[2] = ra.z;
+    const bool some = pw_some(R.root_w);
     out->root_sol[0] = some ? 1 : 0;
-    out->root_sol[1] = some ? (int)meta_kind(R.root_meta) : 0;
-    out->root_sol[2] = some ? (int)meta_turns(R.root_meta) : 0;
+    out->root_sol[1] = some ? (int)pw_kind(R.root_w) : 0;
+    out->root_sol[2] = some ? (int)f32_bits(ln_sel(T.slab, 0).y) : 0;
     out->num_nodes = T.next_node;
     out->best_action = best;
     out->target_q[0] = q0; out->target_q[1] = q1; out->target_q[2] = q2;
@@ -642,6 +721,9 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     LaneTree T;
     const size_t slot = (size_t)blockIdx.x * NT + (size_t)tid;
     T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
+    // this lane's column of its wave's path buffer ([level 0..63][lane 0..63] entries of 8 bytes)
+    uint2* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * 4096 + (size_t)lane;
+    const uint32_t cap = P.cap;
     lane_start_job<MODE>(P, T);
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
 
@@ -654,7 +736,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, X, active, ctr);
+        lane_select_expand<COUNT, FAST>(P.mcts, T, X, active, pl, cap, ctr);
         SYN_LAP(pA)
         const bool need = active && X.needs_eval;
         if (COUNT && need) ctr[CTR_POLICY_EVALS]++;
@@ -702,14 +784,16 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 
         // ---- phase C
         float d0 = X.p0, d1 = X.p1, d2 = X.p2;
+        bool solved = X.solved;
         if (need) {
-            lane_write_priors(T.slab, X, lg,
-                              (P.mcts.noise == 1 && T.iter == 0 && X.leaf == 0u) ? P.mcts.noise_weight : -1.0f);
+            // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
+            solved = lane_create_children(T.slab, X, lg,
+                                          (P.mcts.noise == 1 && T.iter == 0 && X.depth == 0) ? P.mcts.noise_weight : -1.0f);
             d0 = v0;
             d1 = v1;
             d2 = v2;
         }
-        lane_backprop<COUNT, FAST>(P.mcts, T, X.leaf, d0, d1, d2, X.solved, active, ctr);
+        lane_backprop<COUNT, FAST>(P.mcts, T, X.depth, d0, d1, d2, solved, X.solved && !need, active, pl, cap, ctr);
         SYN_LAP(pC)
         if (active) {
             T.iter += 1;
