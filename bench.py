@@ -6,8 +6,8 @@
 
 Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7 Connect4, 800 explores per move,
            deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
-           SoA MCTS node pool) at 16,384 concurrent games per GPU; configs[1]'s 4096 concurrent games is measured in the
-           same run and reported under "at_4096_concurrent_games".
+           SoA MCTS node pool) at 196,608 concurrent games per GPU (768 per CU: the lane-per-tree kernel); configs[1]'s
+           4096 concurrent games is measured in the same run and reported under "at_4096_concurrent_games".
 Step     : one pass of the hot path over one batch = GAMES_PER_STEP self-play games per GPU played to completion by
            ONE launch of the fused kernel (finished games hand their tree slot to the next game index, so the slots stay busy).
 Scaling  : weak — every rank plays its own GAMES_PER_STEP games per step (games share nothing; no collective on the
@@ -61,7 +61,7 @@ def measured_traffic(args):
     produced by tools/collect_profiles.sh on this exact bench command); None if the run is not that configuration."""
     import glob
 
-    if (args.concurrent, args.games_per_step, args.explores) != (16384, 131072, 800):
+    if (args.concurrent, args.games_per_step, args.explores) != (196608, 1572864, 800):
         return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
@@ -91,11 +91,11 @@ def cpu_baseline(blob, explores, sample_games, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--concurrent", type=int, default=16384,
+    ap.add_argument("--concurrent", type=int, default=196608,
                     help="concurrent games (tree slots) per GPU; BASELINE configs[1] names 4096, reported as extra")
-    ap.add_argument("--games-per-step", type=int, default=131072, help="self-play games per GPU per step")
+    ap.add_argument("--games-per-step", type=int, default=1572864, help="self-play games per GPU per step")
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,6 +151,9 @@ def main():
     # re-run outside the timed region gives the counts of the timed run).
     rc = step(args.warmup + args.steps - 1, counters=True)
     c = rc["counters"]
+    shape, sgrid, sthreads = eng.last_launch_shape()
+    kernel_name = {1: "selfplay_kernel<WPS=1>", 2: "selfplay_kernel<WPS=2>", 3: "selfplay_kernel_quads",
+                   4: "selfplay_kernel_lanes"}.get(shape, "?") + f" <<<{sgrid}, {sthreads}>>>"
     last_ms = kernel_ms[-1]
     avg_ms = float(np.mean(kernel_ms))
 
@@ -163,7 +166,7 @@ def main():
         gbs = algorithmic_bytes(c) / (last_ms * 1e-3) / 1e9
         mfma = {"bound": "mfma", "achieved": tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "selfplay_kernel_quads (fused select/expand + Connect4Net f32 MFMA + backprop)",
+                "kernel": kernel_name + " (fused select/expand + Connect4Net f32 MFMA + backprop)",
                 "kernel_ms_avg": avg_ms, "flop_per_leaf_eval": FLOP_PER_EVAL}
         hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                "traffic": None, "algorithmic_bytes_per_explore": algorithmic_bytes(c) / max(1, c["explores"]),

@@ -224,6 +224,12 @@ int syn_replay_deduplicate(syn_engine* h, const uint64_t* my_bb, const uint64_t*
  * the engine stream: kernel_ms = device time of the dominant kernel launch(es), n_launches = how many. */
 int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches);
 
+/* Launch shape the last syn_selfplay_run / syn_mcts_search used (the engine picks it from the number of concurrent games,
+ * DESIGN.md §6.1): *shape = 1 row-per-tree kernel with the weights in registers (16 trees per workgroup), 2 = the same
+ * with two workgroups per CU, 3 = quad-async row kernel (several 16-tree quads per workgroup), 4 = lane-per-tree kernel
+ * (one tree per lane); grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
+int syn_last_launch_shape(const syn_engine* h, int* shape, int* grid, int* threads);
+
 /* Device-side RNG / math primitives exposed for parity tests against the oracle (no reference counterpart):
  * out[i] = i-th u32 of StdRng::seed_from_u64(seed) as generated on the GPU. */
 int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out);

@@ -35,6 +35,7 @@ struct syn_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int slots = 0;
+    int last_shape = 0, last_grid = 0, last_threads = 0;
     int pool_slots = 0;  // tree slabs actually allocated (slots rounded up to the largest workgroup + slack)
     int max_explores = 0;
     uint32_t cap = 0;
@@ -177,11 +178,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // <= 32 -> two such workgroups per CU (hybrid register/LDS weights); more -> the quad-async kernel (NQ quads of 16
     // trees per workgroup sharing one LDS weight image). SYN_QUADS=0..4 overrides (0 = never use the quad kernel).
     // Lane-per-tree kernel (lane_kernel.cuh): one tree per lane, NW waves per workgroup, one workgroup per CU.
-    // SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it; by default it takes over once every CU can be given at
-    // least 512 trees.
+    // SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it (0 = never); by default it takes over once every CU can
+    // be given at least 512 trees (8 waves) and uses 12 waves from 768 trees per CU (16 waves spill: measured slower).
     {
         int nw = 0;
-        if (want_slots >= h->num_cus * 512) nw = want_slots >= h->num_cus * 1024 ? 16 : 8;
+        if (want_slots >= h->num_cus * 512) nw = want_slots >= h->num_cus * 768 ? 12 : 8;
         if (const char* ev = std::getenv("SYN_LANES")) nw = std::atoi(ev);
         if (nw == 4 || nw == 8 || nw == 12 || nw == 16) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
@@ -210,6 +211,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             else if (nw == 12) { if (fast) SYN_LAUNCH_L(12, true) else SYN_LAUNCH_L(12, false) }
             else { if (fast) SYN_LAUNCH_L(16, true) else SYN_LAUNCH_L(16, false) }
 #undef SYN_LAUNCH_L
+            h->last_shape = 4; h->last_grid = lgrid; h->last_threads = 64 * nw;
             if (out_grid) *out_grid = -lgrid;  // negative: lane kernel (profile layout differs)
             if (out_nt) *out_nt = 64 * nw;
             return hipGetLastError();
@@ -236,6 +238,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         else if (nq == 3) { if (fast) SYN_LAUNCH_Q(3, true) else SYN_LAUNCH_Q(3, false) }
         else { if (fast) SYN_LAUNCH_Q(4, true) else SYN_LAUNCH_Q(4, false) }
 #undef SYN_LAUNCH_Q
+        h->last_shape = 3; h->last_grid = qgrid; h->last_threads = 256 * nq;
         if (out_grid) *out_grid = qgrid;
         if (out_nt) *out_nt = 256 * nq;
         return hipGetLastError();
@@ -246,6 +249,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (fast) SYN_LAUNCH(2, true) else SYN_LAUNCH(2, false)
     }
 #undef SYN_LAUNCH
+    h->last_shape = grid <= h->num_cus ? 1 : 2; h->last_grid = grid; h->last_threads = 256;
     if (out_grid) *out_grid = grid;
     if (out_nt) *out_nt = 256;
     return hipGetLastError();
@@ -919,6 +923,14 @@ int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (kernel_ms) *kernel_ms = h->last_kernel_ms;
     if (n_launches) *n_launches = h->last_launches;
+    return SYN_OK;
+}
+
+int syn_last_launch_shape(const syn_engine* h, int* shape, int* grid, int* threads) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (shape) *shape = h->last_shape;
+    if (grid) *grid = h->last_grid;
+    if (threads) *threads = h->last_threads;
     return SYN_OK;
 }
 

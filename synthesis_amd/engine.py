@@ -17,7 +17,7 @@ NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/p
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate",
 ]
@@ -104,6 +104,7 @@ def load_library():
     lib.syn_selfplay_run.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int] + \
                                     [C.c_void_p] * 8
     lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.syn_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.syn_debug_stdrng_u32.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
@@ -268,6 +269,12 @@ class Engine:
             r["counters"] = {name: int(getattr(ctr, name)) for name, _ in CCounters._fields_}
         r["kernel_ms"] = self.last_kernel_ms()
         return r
+
+    def last_launch_shape(self):
+        """(shape, workgroups, threads per workgroup) of the last search / self-play launch; shape 4 = lane-per-tree."""
+        s, g, t = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.syn_last_launch_shape(self._h, C.byref(s), C.byref(g), C.byref(t)))
+        return s.value, g.value, t.value
 
     def last_kernel_ms(self):
         ms = C.c_float()

@@ -391,7 +391,58 @@ def test_quad_async_kernel_matches_oracle(blob, oracle, monkeypatch, quads):
     eng.close()
 
 
-def test_selfplay_full_size_properties(blob, oracle):
+@pytest.mark.parametrize("waves", [4, 8, 12, 16])
+def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
+    """The high-concurrency launch shape (lane_kernel.cuh: one tree per lane, own record layout, path-buffer backprop,
+    free-running waves) is normally chosen from 131,072 concurrent games; force it on a small engine (partial last
+    wave, partial last workgroup) and hold it to the same bit-exact bar as the row-per-tree kernels: searches incl.
+    late-game solver positions, every config family, whole self-play games with refill and all value targets."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    monkeypatch.setenv("SYN_LANES", str(waves))
+    eng = sa.Engine(concurrent_games=1100, max_explores=800)
+    eng.load_weights(blob)
+    my, op = random_positions(oracle, 300, seed=31, max_moves=60)
+    got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
+    assert eng.last_launch_shape()[0] == 4 and eng.last_launch_shape()[2] == 64 * waves
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, f"lanes={waves} search")
+    for kw in (dict(exploration=0, c=1.4), dict(fpu=1), dict(solve=0), dict(correct_values_on_solve=0),
+               dict(select_solved_nodes=0), dict(auto_extend=0), dict(noise=1, noise_weight=0.25)):
+        ocfg = parity_mcts_config(**kw)
+        scfg = sa.MCTSConfig(exploration=sa.Exploration(ocfg.exploration), c=ocfg.c, solve=bool(ocfg.solve),
+                             correct_values_on_solve=bool(ocfg.correct_values_on_solve),
+                             select_solved_nodes=bool(ocfg.select_solved_nodes), auto_extend=bool(ocfg.auto_extend),
+                             fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value,
+                             root_policy_noise=sa.PolicyNoise(ocfg.noise), noise_weight=ocfg.noise_weight)
+        got = eng.mcts_search(scfg, my[:120], op[:120], 90, action_selection=0)
+        ref = oracle.c4_mcts_search(ocfg, blob, my[:120], op[:120], 90, action_selection=0, nn_mode=oracle.ACC_FMA)
+        assert_search_equal(got, ref, f"lanes={waves} variant {kw}")
+    got = eng.selfplay(sa.parity_rollout_config(50), base_seed=77, n_games=2500, counters=True)
+    assert eng.last_launch_shape()[0] == 4
+    ref = oracle.c4_selfplay(parity_rollout_config(50), blob, 77, 2500, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"lanes={waves} self-play")
+    for k in ("explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals",
+              "backprop_levels", "solver_children", "solved_hits", "max_depth"):
+        assert got["counters"][k] == ref["counters"][k], (waves, k)
+    assert got["counters"]["games"] == 2500 and got["counters"]["moves"] == int(got["plies"].sum())
+    for sv, ov in ((dict(value_target=sa.ValueTarget.Z), dict(value_target=0)),
+                   (dict(value_target=sa.ValueTarget.QZaverage, value_target_p=0.3), dict(value_target=2, vt_p=0.3)),
+                   (dict(value_target=sa.ValueTarget.QtoZ, value_target_from=0.1, value_target_to=0.9),
+                    dict(value_target=3, vt_from=0.1, vt_to=0.9)),
+                   (dict(stop_games_when_solved=True, action=sa.ActionSelection.Q, random_actions_until=3),
+                    dict(stop_games_when_solved=1, action=0, random_actions_until=3))):
+        got = eng.selfplay(sa.parity_rollout_config(40, **sv), base_seed=9, n_games=64)
+        ref = oracle.c4_selfplay(parity_rollout_config(40, **ov), blob, 9, 64, threads=8, nn_mode=oracle.ACC_FMA)
+        assert_selfplay_equal(got, ref, f"lanes={waves} {sv}")
+    got = eng.selfplay(sa.parity_rollout_config(800), base_seed=5, n_games=6)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 5, 6, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"lanes={waves} 800 explores")
+    eng.close()
+
+
+def test_selfplay_full_size_properties(blob, oracle, monkeypatch):
     """BASELINE full size: 4096 concurrent games x 800 explores. Too big for the oracle, so size-independent
     properties: replaying the recorded actions with the oracle's Connect4 reproduces every recorded position and ends
     exactly at the recorded ply; visit distributions sum to 1 and are zero on illegal columns; value targets are
@@ -432,3 +483,12 @@ def test_selfplay_full_size_properties(blob, oracle):
     r3 = big.selfplay(cfg, base_seed=2024, n_games=4096)
     assert_selfplay_equal(r3, r, "16384-slot engine")
     big.close()
+    # ... and on the lane-per-tree kernel (different record layout, different backprop): bit-identical again
+    monkeypatch.setenv("SYN_LANES", "12")
+    lanes = sa.Engine(concurrent_games=4096, max_explores=800)
+    lanes.load_weights(blob)
+    r4 = lanes.selfplay(cfg, base_seed=2024, n_games=4096, counters=True)
+    assert lanes.last_launch_shape()[0] == 4
+    assert_selfplay_equal(r4, r, "lane-per-tree kernel")
+    assert r4["counters"] == r["counters"]
+    lanes.close()
