@@ -28,11 +28,11 @@ out, tag = sys.argv[1], sys.argv[2]
 def rows(path):
     return list(csv.DictReader(open(path)))
 def timed(rs):  # the un-instrumented (COUNT = false) launches of the headline kernel (timed steps + warm-up)
-    return [r for r in rs if "selfplay_kernel_quads<0, false" in r["Kernel_Name"]]
+    return [r for r in rs if "selfplay_kernel_lanes<0, false" in r["Kernel_Name"]]
 f = timed(rows(f"{out}/{tag}_pmc_fetch.csv")); w = timed(rows(f"{out}/{tag}_pmc_write.csv"))
 fetch_kb = sum(float(r["Counter_Value"]) for r in f) / max(1, len(f))
 write_kb = sum(float(r["Counter_Value"]) for r in w) / max(1, len(w))
-ks = [r for r in rows(f"{out}/{tag}_kernel_stats.csv") if "selfplay_kernel_quads<0, false" in r["Name"]]
+ks = [r for r in rows(f"{out}/{tag}_kernel_stats.csv") if "selfplay_kernel_lanes<0, false" in r["Name"]]
 summary = {
     "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096",
     "kernel": ks[0]["Name"] if ks else None,
