@@ -44,7 +44,7 @@ struct syn_engine {
     float* d_wimg = nullptr;
     bool has_weights = false;
     int* d_job_next = nullptr;
-    uint2* d_path = nullptr;   // lane kernel's per-wave descent logs
+    uint4* d_path = nullptr;   // lane kernel's per-wave descent logs
     size_t path_bytes = 0;
     unsigned long long* d_counters = nullptr;
     // self-play output buffers (device), grown on demand
@@ -187,7 +187,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (nw == 4 || nw == 8 || nw == 12 || nw == 16) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
-            const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint2);
+            const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint4);
             if (need_path > h->path_bytes) {
                 if (h->d_path) (void)hipFree(h->d_path);
                 h->d_path = nullptr;
@@ -198,6 +198,10 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             }
             EngineParams PL = P;
             PL.path = h->d_path;
+            PL.lane_thresh = 48;
+            if (const char* ev = std::getenv("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
+            if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
+            PL.lane_thresh &= ~15;  // whole tiles
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \
@@ -541,6 +545,7 @@ static int common_params(syn_engine* h, EngineParams& P, int explores) {
     P.job_next = h->d_job_next;
     P.error = h->d_job_next + 8;  // same 64-byte block, zeroed before every launch
     P.path = nullptr;
+    P.lane_thresh = 48;
     P.counters = h->d_counters;
     return SYN_OK;
 }
@@ -671,16 +676,18 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (pgrid < 0) {  // lane kernel: per wave [A, B, C, move, rounds, tiles, active lanes, evals]
             int nwv = -pgrid * (pnt / 64);
-            std::vector<unsigned long long> hp((size_t)nwv * 8);
+            std::vector<unsigned long long> hp((size_t)nwv * 10);
             HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
             HIP_TRY(h, hipFree(d_prof));
-            double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int w = 0; w < nwv; w++)
-                for (int j = 0; j < 8; j++) s[j] += (double)hp[(size_t)w * 8 + j];
-            fprintf(stderr, "[syn profile lanes] grid=%d nt=%d waves=%d rounds/wave=%.0f | ticks per round (100 MHz): A=%.1f B=%.1f C=%.1f "
-                            "move=%.1f total=%.1f | tiles/round=%.3f active lanes/round=%.2f evals/round=%.2f evals/tile=%.2f\n",
-                    -pgrid, pnt, nwv, s[4] / nwv, s[0] / s[4], s[1] / s[4], s[2] / s[4], s[3] / s[4],
-                    (s[0] + s[1] + s[2] + s[3]) / s[4], s[5] / s[4], s[6] / s[4], s[7] / s[4], s[7] / s[5]);
+                for (int j = 0; j < 10; j++) s[j] += (double)hp[(size_t)w * 10 + j];
+            fprintf(stderr, "[syn profile lanes] grid=%d nt=%d waves=%d rounds/wave=%.0f | cycles per round: A=%.0f B=%.0f C: children=%.0f "
+                            "solver walk=%.0f sweep=%.0f move=%.0f total=%.0f | per round: tiles=%.3f explores finished=%.2f evals=%.2f "
+                            "(%.2f per tile) | cycles per finished explore=%.0f\n",
+                    -pgrid, pnt, nwv, s[4] / nwv, s[0] / s[4], s[1] / s[4], s[6] / s[4], s[7] / s[4], s[2] / s[4], s[3] / s[4],
+                    (s[0] + s[1] + s[2] + s[3] + s[6] + s[7]) / s[4], s[5] / s[4], s[8] / s[4], s[9] / s[4], s[9] / s[5],
+                    (s[0] + s[1] + s[2] + s[3] + s[6] + s[7]) / s[8]);
             d_prof = nullptr;
         }
     }

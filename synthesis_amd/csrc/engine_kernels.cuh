@@ -44,7 +44,8 @@ struct EngineParams {
     unsigned long long* counters;  // DevCounters (may be null)
     unsigned long long* prof;      // PROF builds: per-wave cycle sums [A, wait1, B, wait2, C, iterations]
     int* error;                    // set to 1 by a quad whose bounded spin gave up (quad-async kernel)
-    uint2* path;                   // lane kernel: per-wave descent log [wave][level 0..63][lane 0..63]
+    int lane_thresh;               // lane kernel: a round ends once this many lanes of a wave stand on a leaf
+    uint4* path;                   // lane kernel: per-wave descent log [wave][level 0..63][lane 0..63]
     // self-play
     unsigned long long base_seed;  // game g uses StdRng::seed_from_u64(base_seed + first_game + g)
     unsigned long long first_game;

@@ -58,13 +58,25 @@ struct LaneTree {
     uint32_t rng_index;
 };
 
-struct LaneLeaf {             // phase A -> phase C
-    int depth;                // level of the node the backprop starts from (root = 0)
+// Descent state of a lane. It persists across rounds: a round ends as soon as `thresh` lanes of the wave stand on a
+// leaf (or nobody is descending any more), the lanes that are still on their way down simply continue in the next
+// round. So a wave never idles 63 lanes while its deepest tree finishes, and the network runs on (nearly) full tiles.
+struct LaneWalk {
+    bool descending;
+    bool pending;             // stands on an expanded leaf whose network call did not fit this round's full tiles
+    uint32_t pend_fc, pend_lmask;
+    uint32_t node, wcur;      // current node and its packed word
+    float pN, pq;             // its N and stored q
+    uint64_t my, op;          // its position
+    int level;
+};
+
+struct LaneLeaf {             // phase A -> phase C (valid for lanes with at_leaf)
+    bool at_leaf;             // this lane finished its descent in this round
     uint32_t fc;              // first child of the node that needs its children created (valid if needs_eval)
     uint32_t legal_mask;
     bool needs_eval, solved;
     float p0, p1, p2;
-    uint64_t leaf_my, leaf_op;
 };
 
 SYN_DEV float4 ln_sel(const unsigned char* slab, uint32_t i) {
@@ -105,22 +117,32 @@ SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
 // ---------------------------------------------------------------------------------------------- phase A
 // pl = this lane's column of the wave's path buffer: level L lives at pl[L * 64]
 template <bool COUNT, bool FAST>
-SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X, bool active, uint2* pl, uint32_t cap,
-                                uint32_t* ctr) {
+SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
+                                uint32_t cap, int thresh, uint32_t* ctr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
-    uint32_t node = 0;
-    int level = 0;
-    uint64_t my = T.root_my, op = T.root_op;
-    X.needs_eval = false;
+    const bool pending = active && Wk.pending;
+    X.at_leaf = false;
+    X.needs_eval = pending;
     X.solved = false;
     X.p0 = X.p1 = X.p2 = 0.0f;
-    X.fc = 0;
-    X.legal_mask = 0;
-    uint32_t wcur = 0;  // packed word of the current node (the root has action 0 and no solution while it is searched)
-    float pN = 0.0f, pq = 0.0f;
-    if (active) {
+    X.fc = Wk.pend_fc;
+    X.legal_mask = Wk.pend_lmask;
+    uint32_t node = Wk.node, wcur = Wk.wcur;
+    float pN = Wk.pN, pq = Wk.pq;
+    uint64_t my = Wk.my, op = Wk.op;
+    int level = Wk.level;
+    bool desc = active && Wk.descending;
+    if (active && !desc && !pending) {
+        // explore() starts at the root (mcts.rs:310-312)
         if (COUNT) ctr[CTR_EXPLORES]++;
+        node = 0;
+        level = 0;
+        my = T.root_my;
+        op = T.root_op;
+        wcur = 0;  // the root has action 0 and no solution while it is searched
+        pN = 0.0f;
+        pq = 0.0f;
         if (T.next_node == 0) {
             T.next_node = 1;  // MCTS::with_capacity pushes the root (mcts.rs:125); its record is written by backprop
         } else {
@@ -131,59 +153,66 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X
                 pq = -((a.z - a.x) / pN);
             }
         }
-        pl[0] = make_uint2(0u, f32_bits(pN));
+        pl[0] = make_uint4(0u, f32_bits(pN), wcur, 0u);
+        desc = true;
     }
 
-    // ---- descent (mcts.rs:310-341): every lane walks its own tree; the wave iterates until its deepest lane is done
-    bool hit_solved = false;
-    bool go = active;
-    while (go) {
-        if (pw_some(wcur)) { hit_solved = true; break; }
-        const uint32_t nc = pw_nc(wcur);
-        if (nc == 0) break;
-        const uint32_t fc = pw_fc(wcur);
-        const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -pq;  // parent.q() = -(stored q)
-        const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
-        // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces)
-        float best_v = 0.0f, bN = 0.0f, bq = 0.0f;
-        uint32_t best_i = 0, bw = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 9; i++) {
-            // indices past the last child re-read the last child (valid address, no predicate in front of the loads,
-            // so the nine loads of a level are in flight together)
-            const float4 s = ln_sel(slab, fc + (i < nc ? i : nc - 1u));
-            const uint32_t w = f32_bits(s.w);
-            const uint32_t k = pw_kind(w);
-            // outcome.reversed().value(): child Win -> -1, Draw -> 0, Lose -> +1 (game.rs:29-43)
-            const float q_solved = cfg.select_solved() ? (k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
-            float q = pw_nc(w) == 0u ? q_fpu : s.y;
-            q = pw_some(w) ? q_solved : q;
-            float u;
-            if (cfg.puct()) u = cfg.cc() * s.z * visits / (1.0f + s.x);
-            else u = visits / sqrtf(s.x);
-            const float v = q + u;
-            const bool take = i == 0u || (i < nc && v > best_v);
-            best_v = take ? v : best_v;
-            best_i = take ? i : best_i;
-            bw = take ? w : bw;
-            bN = take ? s.x : bN;
-            bq = take ? s.y : bq;
+    // ---- descent (mcts.rs:310-341): every lane walks its own tree, one level per iteration
+    // A round ends when `thresh` lanes (a whole number of 16-position tiles) stand on a leaf that needs the network, or
+    // when nobody is descending any more.
+    bool hit_solved = false, at_leaf = pending;
+    for (;;) {
+        if (desc) {
+            if (pw_some(wcur)) { hit_solved = true; desc = false; at_leaf = true; }
+            else if (pw_nc(wcur) == 0u) { desc = false; at_leaf = true; }
         }
-        if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
-        const int a = (int)pw_action(bw);
-        const int ha = c4::col_height(my | op, a);
-        const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
-        my = nmy;
-        op = nop;
-        node = fc + best_i;
-        wcur = bw;
-        pN = bN;
-        pq = bq;
-        level++;
-        pl[level * 64] = make_uint2(node, f32_bits(pN));
+        if (__ballot(desc) == 0ull || __popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
+        if (desc) {
+            const uint32_t nc = pw_nc(wcur);
+            const uint32_t fc = pw_fc(wcur);
+            const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -pq;  // parent.q() = -(stored q)
+            const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
+            // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces)
+            float best_v = 0.0f, bN = 0.0f, bq = 0.0f;
+            uint32_t best_i = 0, bw = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) {
+                // indices past the last child re-read the last child (valid address, no predicate in front of the
+                // loads, so the nine loads of a level are in flight together)
+                const float4 s = ln_sel(slab, fc + (i < nc ? i : nc - 1u));
+                const uint32_t w = f32_bits(s.w);
+                const uint32_t k = pw_kind(w);
+                // outcome.reversed().value(): child Win -> -1, Draw -> 0, Lose -> +1 (game.rs:29-43)
+                const float q_solved = cfg.select_solved() ? (k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
+                float q = pw_nc(w) == 0u ? q_fpu : s.y;
+                q = pw_some(w) ? q_solved : q;
+                float u;
+                if (cfg.puct()) u = cfg.cc() * s.z * visits / (1.0f + s.x);
+                else u = visits / sqrtf(s.x);
+                const float v = q + u;
+                const bool take = i == 0u || (i < nc && v > best_v);
+                best_v = take ? v : best_v;
+                best_i = take ? i : best_i;
+                bw = take ? w : bw;
+                bN = take ? s.x : bN;
+                bq = take ? s.y : bq;
+            }
+            if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
+            const int a = (int)pw_action(bw);
+            const int ha = c4::col_height(my | op, a);
+            const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
+            my = nmy;
+            op = nop;
+            node = fc + best_i;
+            wcur = bw;
+            pN = bN;
+            pq = bq;
+            level++;
+            pl[level * 64] = make_uint4(node, f32_bits(pN), wcur, f32_bits(pq));
+        }
     }
 
-    if (active) {
+    if (at_leaf && !pending) {
         if (hit_solved) {
             const uint32_t k = pw_kind(wcur);
             X.p0 = k == 0u ? 1.0f : 0.0f;
@@ -205,6 +234,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X
                 T.next_node = first + n_new;
                 wcur = (wcur & ~(PW_FC_MASK | (0xFu << PW_NC_SHIFT))) | first | (n_new << PW_NC_SHIFT);
                 st_sel_w(slab, node, wcur);
+                pl[level * 64].z = wcur;  // the solver walk reads fc / nc of the path's nodes from the log
                 if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
                 if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
 
@@ -221,7 +251,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X
                     my = nmy;
                     op = nop;
                     level++;
-                    pl[level * 64] = make_uint2(node, f32_bits(0.0f));
+                    pl[level * 64] = make_uint4(node, f32_bits(0.0f), wcur, 0u);
                     if (aw || afull) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
                         X.p0 = aw ? 1.0f : 0.0f;
                         X.p1 = aw ? 0.0f : 1.0f;
@@ -238,15 +268,22 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneLeaf& X
             }
         }
     }
-    X.depth = level;
-    X.leaf_my = my;
-    X.leaf_op = op;
+    X.at_leaf = at_leaf;
+    Wk.descending = desc;
+    Wk.node = node;
+    Wk.wcur = wcur;
+    Wk.pN = pN;
+    Wk.pq = pq;
+    Wk.my = my;
+    Wk.op = op;
+    Wk.level = level;
 }
 
 // ---------------------------------------------------------------------------------------------- phase C
 // The rest of visit() for the node expanded in phase A (mcts.rs:389-423): creates its children (terminal ones already
 // solved) with the legal-move softmax of the nine raw logits as priors. Returns any_solved.
-SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, const float (&lg)[9], float equal_noise_weight) {
+SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
+                                  const float (&lg)[9], float equal_noise_weight) {
     const uint32_t lmask = X.legal_mask;
     float mx = -__builtin_inff();
 #pragma unroll
@@ -261,7 +298,7 @@ SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, const 
     }
     const uint32_t nc = (uint32_t)__popc(lmask);
     const float noise = 1.0f / (float)nc;
-    const uint64_t my = X.leaf_my, occ = X.leaf_my | X.leaf_op;
+    const uint64_t my = leaf_my, occ = leaf_my | leaf_op;
     uint32_t idx = 0;
     bool any_solved = false;
 #pragma unroll
@@ -291,16 +328,19 @@ SYN_DEV int wave_max_i32(int v) {
     return v;
 }
 
-// backprop (mcts.rs:429-488) replayed from the path buffer.
-//   phase 1 (per lane, rare): the MCTS-Solver walk, level by level while the subtree below stays proven.
+// backprop (mcts.rs:429-488) replayed from the path buffer (entries {node, N, packed word, q|turns} as of the descent).
+//   phase 1 (per lane): the MCTS-Solver walk, level by level while the subtree below stays proven. Everything a level
+//            needs is addressed by its path entry, so its aux record, its children's records and the NEXT level's path
+//            entry are fetched together: one memory round trip per level.
 //   phase 2 (whole wave, four levels per step): every remaining level just adds the leaf's outcome distribution
 //            (win/lose swapped once per level climbed) and one visit, so the levels are independent: the four path rows
-//            and then the four aux records are fetched together — two memory round trips per four levels.
-// `leaf_solved`: the backprop starts at a node that already carries a solution (explore() hit a solved node, or an
+//            and then the four aux records are fetched together — two round trips per four levels.
+// `leaf_solved`: the walk starts at a node that already carries a solution (explore() hit a solved node, or an
 // auto-extended terminal child); its q slot holds the turn count and must stay that way even with the solver off.
 template <bool COUNT, bool FAST>
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
-                           bool leaf_solved, bool active, const uint2* pl, uint32_t cap, uint32_t* ctr) {
+                           bool leaf_solved, bool active, const uint4* pl, uint32_t cap, uint32_t* ctr,
+                           unsigned long long* t_mid = nullptr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     if (COUNT && active) {
@@ -310,68 +350,75 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
     int L = active ? depth : -1;
     bool keep_turns = leaf_solved;  // only ever true for the first level handled
     // ---- phase 1
-    while (cfg.solve() && solved && L >= 0) {
-        const uint2 pe = pl[L * 64];
-        const uint32_t node = pe.x;
-        float N = bits_f32(pe.y);
-        const float4 a = ln_aux(slab, cap, node);
-        // a node that was never backpropagated into has no aux record yet
-        float W0 = N == 0.0f ? 0.0f : a.x, W1 = N == 0.0f ? 0.0f : a.y, W2 = N == 0.0f ? 0.0f : a.z;
-        const float4 s = ln_sel(slab, node);
-        uint32_t w = f32_bits(s.w);
-        const uint32_t nc = pw_nc(w), fc = pw_fc(w);
-        bool all_solved = true;
-        uint32_t key = outcome_key(pw_some(w), pw_kind(w), f32_bits(s.y));
-        if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+    if (cfg.solve() && solved && L >= 0) {
+        uint4 pe = pl[L * 64];
+        for (;;) {
+            const uint32_t node = pe.x;
+            float N = bits_f32(pe.y);
+            uint32_t w = pe.z;
+            const uint32_t nc = pw_nc(w), fc = pw_fc(w);
+            // one batch: the node's sums, its children (indices past the last child re-read the last one), next entry
+            const float4 a = ln_aux(slab, cap, node);
+            float4 cs[9];
 #pragma unroll
-        for (uint32_t i = 0; i < 9; i++) {
-            if (i < nc) {
-                const float4 cs = ln_sel(slab, fc + i);
-                const uint32_t cw = f32_bits(cs.w);
-                all_solved = all_solved && pw_some(cw);
-                // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
-                const uint32_t ck = pw_kind(cw);
-                const uint32_t rk = pw_some(cw) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, f32_bits(cs.y) + 1u) : 0u;
-                key = rk > key ? rk : key;
+            for (uint32_t i = 0; i < 9; i++) cs[i] = ln_sel(slab, nc == 0u ? node : fc + (i < nc ? i : nc - 1u));
+            const uint4 pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
+            // a node that was never backpropagated into has no aux record yet
+            float W0 = N == 0.0f ? 0.0f : a.x, W1 = N == 0.0f ? 0.0f : a.y, W2 = N == 0.0f ? 0.0f : a.z;
+            bool all_solved = true;
+            uint32_t key = outcome_key(pw_some(w), pw_kind(w), pe.w);
+            if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) {
+                if (i < nc) {
+                    const uint32_t cw = f32_bits(cs[i].w);
+                    all_solved = all_solved && pw_some(cw);
+                    // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
+                    const uint32_t ck = pw_kind(cw);
+                    const uint32_t rk = pw_some(cw) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, f32_bits(cs[i].y) + 1u) : 0u;
+                    key = rk > key ? rk : key;
+                }
             }
+            bool bsome;
+            uint32_t bkind, bturns;
+            outcome_from_key(key, bsome, bkind, bturns);
+            if (bsome && bkind == 2u) {
+                if (cfg.correct_values()) {
+                    d0 = -W0;
+                    d1 = -W1;
+                    d2 = -W2;
+                    d2 += N + 1.0f;
+                }
+            } else if (bsome && all_solved) {
+                if (cfg.correct_values()) {
+                    d0 = -W0;
+                    d1 = -W1;
+                    d2 = -W2;
+                    if (bkind == 1u) d1 += N + 1.0f;
+                    else d0 += N + 1.0f;
+                }
+            } else {
+                break;  // this level and everything above belongs to phase 2
+            }
+            w = (w & ~(PW_SOME_BIT | (3u << PW_KIND_SHIFT))) | PW_SOME_BIT | (bkind << PW_KIND_SHIFT);
+            st_sel_w(slab, node, w);
+            if (L == 0) T.root_solved = true;
+            W0 += d0;
+            W1 += d1;
+            W2 += d2;
+            N += 1.0f;
+            st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
+            *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, bits_f32(bturns));
+            const float t = d0;
+            d0 = d2;
+            d2 = t;
+            keep_turns = false;
+            L--;
+            if (L < 0) break;
+            pe = pe_next;
         }
-        bool bsome;
-        uint32_t bkind, bturns;
-        outcome_from_key(key, bsome, bkind, bturns);
-        if (bsome && bkind == 2u) {
-            if (cfg.correct_values()) {
-                d0 = -W0;
-                d1 = -W1;
-                d2 = -W2;
-                d2 += N + 1.0f;
-            }
-        } else if (bsome && all_solved) {
-            if (cfg.correct_values()) {
-                d0 = -W0;
-                d1 = -W1;
-                d2 = -W2;
-                if (bkind == 1u) d1 += N + 1.0f;
-                else d0 += N + 1.0f;
-            }
-        } else {
-            solved = false;
-            break;  // this level and everything above belongs to phase 2
-        }
-        w = (w & ~(PW_SOME_BIT | (3u << PW_KIND_SHIFT))) | PW_SOME_BIT | (bkind << PW_KIND_SHIFT);
-        st_sel_w(slab, node, w);
-        if (L == 0) T.root_solved = true;
-        W0 += d0;
-        W1 += d1;
-        W2 += d2;
-        N += 1.0f;
-        st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
-        *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, bits_f32(bturns));
-        const float t = d0;
-        d0 = d2;
-        d2 = t;
-        keep_turns = false;
-        L--;
     }
+    if (t_mid) *t_mid = (unsigned long long)__builtin_readcyclecounter();
     // ---- phase 2: levels L..0 of this lane; (d0,d1,d2) is the delta for level L
     for (int base = wave_max_i32(L); base >= 0; base -= 4) {
         uint2 pe[4];
@@ -379,7 +426,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
-            pe[j] = pl[(Lj < 0 ? 0 : Lj) * 64];
+            pe[j] = *reinterpret_cast<const uint2*>(pl + (Lj < 0 ? 0 : Lj) * 64);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -691,7 +738,8 @@ __device__ __attribute__((noinline)) LaneTree lane_search_finish_call(const Engi
 template <int NW>
 struct LaneLds {
     static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
-    static constexpr size_t BYTES = OUT_OFF + (size_t)NW * 1024;       // + 1 KB result patch per wave
+    static constexpr size_t IDX_OFF = OUT_OFF + (size_t)NW * 1024;     // + 1 KB result patch per wave
+    static constexpr size_t BYTES = IDX_OFF + (size_t)NW * 64;         // + 64 B compaction index per wave
 };
 
 SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
@@ -721,14 +769,21 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     LaneTree T;
     const size_t slot = (size_t)blockIdx.x * NT + (size_t)tid;
     T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
-    // this lane's column of its wave's path buffer ([level 0..63][lane 0..63] entries of 8 bytes)
-    uint2* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * 4096 + (size_t)lane;
+    // this lane's column of its wave's path buffer ([level 0..63][lane 0..63] entries of 16 bytes)
+    uint4* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * 4096 + (size_t)lane;
     const uint32_t cap = P.cap;
     lane_start_job<MODE>(P, T);
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
 
     const int n_explores = P.roll.num_explores;
-    unsigned long long pA = 0, pB = 0, pC = 0, pM = 0, pT = 0, pTiles = 0, pRounds = 0, pLanes = 0, pEvals = 0;
+    const int thresh = P.lane_thresh;
+    unsigned char* const idxw = smem_raw + LaneLds<NW>::IDX_OFF + wave * 64;  // compaction: rank -> lane
+    LaneWalk Wk;
+    Wk.descending = false;
+    Wk.pending = false;
+    Wk.pend_fc = 0; Wk.pend_lmask = 0;
+    Wk.node = 0; Wk.wcur = 0; Wk.pN = 0.0f; Wk.pq = 0.0f; Wk.my = 0; Wk.op = 0; Wk.level = 0;
+    unsigned long long pA = 0, pB = 0, pC = 0, pC1 = 0, pC2 = 0, pM = 0, pT = 0, pTiles = 0, pRounds = 0, pLanes = 0, pEvals = 0;
 #define SYN_STAMP() (PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
 #define SYN_LAP(acc) if (PROF) { unsigned long long n_ = SYN_STAMP(); acc += n_ - pT; pT = n_; }
     for (;;) {
@@ -736,24 +791,38 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, X, active, pl, cap, ctr);
+        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, cap, thresh, ctr);
         SYN_LAP(pA)
-        const bool need = active && X.needs_eval;
+        // ---- phase B: the lanes that need the network, compacted into tiles of 16 positions. While other lanes are still
+        // descending only whole tiles are evaluated: requests beyond `thresh` stay pending and go first next round.
+        bool need = X.at_leaf && X.needs_eval;
+        const unsigned long long want_mask = __ballot(need);
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(want_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want_mask, 0u));
+        const int quota = __ballot(Wk.descending) != 0ull ? thresh : 64;
+        Wk.pending = need && rank >= quota;
+        if (Wk.pending) { Wk.pend_fc = X.fc; Wk.pend_lmask = X.legal_mask; }
+        need = need && rank < quota;
+        const bool fin = X.at_leaf && !Wk.pending;  // this lane's explore gets its network call / backprop in this round
         if (COUNT && need) ctr[CTR_POLICY_EVALS]++;
-
-        // ---- phase B: this wave's (up to) four 16-position tiles
         const unsigned long long need_mask = __ballot(need);
+        const int n_need = __popcll(need_mask);
+        idxw[lane] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (need) idxw[rank] = (unsigned char)lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint64_t hi, lo;
-        feature_boards(X.leaf_my, X.leaf_op, hi, lo);
+        feature_boards(Wk.my, Wk.op, hi, lo);
         float lg[9];
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
 #pragma unroll
         for (int c = 0; c < 9; c++) lg[c] = 0.0f;
 #pragma unroll 1
-        for (int j = 0; j < 4; j++) {
-            if (((need_mask >> (16 * j)) & 0xFFFFull) == 0ull) continue;  // wave-uniform
+        for (int j = 0; j * 16 < n_need; j++) {
             if (PROF) pTiles++;
-            const int src = 16 * j + (lane & 15);
+            const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
             const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
             f32x4 o = mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             const int q = lane >> 4;
@@ -766,10 +835,11 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (q == j) {
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(outw + (lane & 15) * 16);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(outw + (lane & 15) * 16 + 4);
-                const f32x4 r2 = *reinterpret_cast<const f32x4*>(outw + (lane & 15) * 16 + 8);
+            if (need && (rank >> 4) == j) {
+                const float* mine = outw + (rank & 15) * 16;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(mine);
+                const f32x4 r1 = *reinterpret_cast<const f32x4*>(mine + 4);
+                const f32x4 r2 = *reinterpret_cast<const f32x4*>(mine + 8);
                 lg[0] = r0[0]; lg[1] = r0[1]; lg[2] = r0[2]; lg[3] = r0[3];
                 lg[4] = r1[0]; lg[5] = r1[1]; lg[6] = r1[2]; lg[7] = r1[3];
                 lg[8] = r2[0]; v0 = r2[1]; v1 = r2[2]; v2 = r2[3];
@@ -780,23 +850,28 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         }
 
         SYN_LAP(pB)
-        if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(active)); pEvals += (unsigned long long)__popcll(need_mask); }
+        if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(fin)); pEvals += (unsigned long long)n_need; }
 
         // ---- phase C
         float d0 = X.p0, d1 = X.p1, d2 = X.p2;
         bool solved = X.solved;
         if (need) {
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
-            solved = lane_create_children(T.slab, X, lg,
-                                          (P.mcts.noise == 1 && T.iter == 0 && X.depth == 0) ? P.mcts.noise_weight : -1.0f);
+            solved = lane_create_children(T.slab, X, Wk.my, Wk.op, lg,
+                                          (P.mcts.noise == 1 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise_weight : -1.0f);
             d0 = v0;
             d1 = v1;
             d2 = v2;
         }
-        lane_backprop<COUNT, FAST>(P.mcts, T, X.depth, d0, d1, d2, solved, X.solved && !need, active, pl, cap, ctr);
+        SYN_LAP(pC1)
+        unsigned long long tmid = 0;
+        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, d0, d1, d2, solved, X.solved && !need, fin, pl, cap, ctr,
+                                   PROF ? &tmid : nullptr);
+        if (PROF) { pC2 += tmid - pT; pT = tmid; }
         SYN_LAP(pC)
-        if (active) {
+        if (fin) {
             T.iter += 1;
+            // explore_n (mcts.rs:139-147): the root visit, then up to n explores unless the root is solved
             if (T.iter > n_explores || T.root_solved) {
                 // a private copy of the arguments goes to the callee and the slab pointer is re-derived afterwards, so
                 // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
@@ -812,8 +887,8 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 #undef SYN_LAP
     if (PROF) {
         if (P.prof && lane == 0) {
-            unsigned long long* o = P.prof + ((size_t)blockIdx.x * NW + wave) * 8;
-            o[0] = pA; o[1] = pB; o[2] = pC; o[3] = pM; o[4] = pRounds; o[5] = pTiles; o[6] = pLanes; o[7] = pEvals;
+            unsigned long long* o = P.prof + ((size_t)blockIdx.x * NW + wave) * 10;
+            o[0] = pA; o[1] = pB; o[2] = pC; o[3] = pM; o[4] = pRounds; o[5] = pTiles; o[6] = pC1; o[7] = pC2; o[8] = pLanes; o[9] = pEvals;
         }
     }
 
