@@ -184,7 +184,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         int nw = 0;
         if (want_slots >= h->num_cus * 512) nw = want_slots >= h->num_cus * 768 ? 12 : 8;
         if (const char* ev = std::getenv("SYN_LANES")) nw = std::atoi(ev);
-        if (nw == 4 || nw == 8 || nw == 12 || nw == 16) {
+        if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
             const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint4);

@@ -25,26 +25,39 @@ namespace syn {
 
 // Node records of this launch shape (private to it: the pool's contents never outlive a launch). A tree slab of `cap`
 // nodes is two arrays of 16-byte records:
-//   sel[node] = { N, q | turns, P, packed }      everything select_best_child needs about a child: ONE 16-byte load
-//       q       = -((W_win - W_lose) / N), rewritten by every backprop (the value exploit_value would recompute,
-//                 mcts.rs:343-359); once the node is solved the slot holds the solution's turn count instead (a solved
-//                 child is scored from its outcome kind alone)
-//       packed  = first_child[0:19] | num_children[20:23] | action[24:27] | solved[28] | kind[29:30]
+//   sel[node] = { N, q, P, packed }              everything select_best_child needs about a child: ONE 16-byte load
+//       q       = exploit_value as the parent will see it (mcts.rs:343-359): -((W_win - W_lose) / N), rewritten by every
+//                 backprop (the float the reference recomputes at selection time); the constant of its outcome once the
+//                 node is solved; the FPU constant while it is unvisited (Fpu::Const; Fpu::ParentQ is patched in by the
+//                 descent). With the reference's config family the descent uses it as is — no decoding per child.
+//       packed  = first_child[0:15] | num_children[16:19] | action[20:23] | solution[24:25] (0 none, 1 Lose, 2 Draw,
+//                 3 Win) | turns[26:31]
 //   aux[node] = { W_lose, W_draw, W_win, - }     touched only by backprop (never read while N == 0: no initialisation)
 // Children of a node are contiguous, so a level of the descent is nine 16-byte loads from one 144-byte span (two cache
 // lines) — half the requests and lines of the 32-byte records, which is what the per-CU vector-memory pipeline (the
 // bottleneck of this shape) charges for. There are no parent links: the descent logs (node, N) per level into
 // a per-wave path buffer [level][lane] (coalesced 512-byte rows) and backprop replays it from the leaf's level down to
 // 0, all lanes of a wave on the same level, so backprop has no dependent pointer chase at all.
-constexpr uint32_t PW_FC_MASK = 0xFFFFFu, PW_NC_SHIFT = 20, PW_ACT_SHIFT = 24, PW_SOME_BIT = 1u << 28, PW_KIND_SHIFT = 29;
-SYN_DEV uint32_t pw_make(uint32_t fc, uint32_t nc, uint32_t action, bool some, uint32_t kind) {
-    return fc | (nc << PW_NC_SHIFT) | (action << PW_ACT_SHIFT) | (some ? PW_SOME_BIT : 0u) | (kind << PW_KIND_SHIFT);
+constexpr uint32_t PW_FC_MASK = 0xFFFFu, PW_NC_SHIFT = 16, PW_ACT_SHIFT = 20, PW_SOL_SHIFT = 24, PW_TURNS_SHIFT = 26;
+constexpr uint32_t LANE_MAX_CAP = 1u << 16;  // first_child has 16 bits: trees of up to 65,536 nodes (7,280 explores)
+SYN_DEV uint32_t pw_make(uint32_t fc, uint32_t nc, uint32_t action, bool some, uint32_t kind, uint32_t turns = 0) {
+    return fc | (nc << PW_NC_SHIFT) | (action << PW_ACT_SHIFT) | ((some ? kind + 1u : 0u) << PW_SOL_SHIFT) |
+           (turns << PW_TURNS_SHIFT);
 }
 SYN_DEV uint32_t pw_fc(uint32_t w) { return w & PW_FC_MASK; }
 SYN_DEV uint32_t pw_nc(uint32_t w) { return (w >> PW_NC_SHIFT) & 0xFu; }
 SYN_DEV uint32_t pw_action(uint32_t w) { return (w >> PW_ACT_SHIFT) & 0xFu; }
-SYN_DEV bool pw_some(uint32_t w) { return (w & PW_SOME_BIT) != 0u; }
-SYN_DEV uint32_t pw_kind(uint32_t w) { return (w >> PW_KIND_SHIFT) & 3u; }
+SYN_DEV bool pw_some(uint32_t w) { return ((w >> PW_SOL_SHIFT) & 3u) != 0u; }
+SYN_DEV uint32_t pw_kind(uint32_t w) { return ((w >> PW_SOL_SHIFT) & 3u) - 1u; }  // 0 Lose, 1 Draw, 2 Win (if pw_some)
+SYN_DEV uint32_t pw_turns(uint32_t w) { return w >> PW_TURNS_SHIFT; }
+SYN_DEV uint32_t pw_with_solution(uint32_t w, uint32_t kind, uint32_t turns) {
+    return (w & ((1u << PW_SOL_SHIFT) - 1u)) | ((kind + 1u) << PW_SOL_SHIFT) | (turns << PW_TURNS_SHIFT);
+}
+// exploit_value of a solved child (mcts.rs:343-350): outcome.reversed().value() — child Win -> -1, Draw -> 0,
+// Lose -> +1 (game.rs:29-43) — or -inf when solved nodes are not to be selected
+SYN_DEV float pw_q_solved(uint32_t kind, bool select_solved) {
+    return select_solved ? (kind == 2u ? -1.0f : (kind == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
+}
 
 struct LaneTree {
     unsigned char* slab;      // this lane's records: sel[cap] then aux[cap]
@@ -82,8 +95,8 @@ struct LaneLeaf {             // phase A -> phase C (valid for lanes with at_lea
 SYN_DEV float4 ln_sel(const unsigned char* slab, uint32_t i) {
     return *reinterpret_cast<const float4*>(slab + (size_t)i * 16u);
 }
-SYN_DEV void st_sel(unsigned char* slab, uint32_t i, float N, uint32_t y, float P, uint32_t w) {
-    *reinterpret_cast<float4*>(slab + (size_t)i * 16u) = make_float4(N, bits_f32(y), P, bits_f32(w));
+SYN_DEV void st_sel(unsigned char* slab, uint32_t i, float N, float y, float P, uint32_t w) {
+    *reinterpret_cast<float4*>(slab + (size_t)i * 16u) = make_float4(N, y, P, bits_f32(w));
 }
 SYN_DEV void st_sel_w(unsigned char* slab, uint32_t i, uint32_t w) {
     *reinterpret_cast<uint32_t*>(slab + (size_t)i * 16u + 12u) = w;
@@ -121,6 +134,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
                                 uint32_t cap, int thresh, uint32_t* ctr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
+    const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
     const bool pending = active && Wk.pending;
     X.at_leaf = false;
     X.needs_eval = pending;
@@ -181,11 +195,8 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
                 // loads, so the nine loads of a level are in flight together)
                 const float4 s = ln_sel(slab, fc + (i < nc ? i : nc - 1u));
                 const uint32_t w = f32_bits(s.w);
-                const uint32_t k = pw_kind(w);
-                // outcome.reversed().value(): child Win -> -1, Draw -> 0, Lose -> +1 (game.rs:29-43)
-                const float q_solved = cfg.select_solved() ? (k == 2u ? -1.0f : (k == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
-                float q = pw_nc(w) == 0u ? q_fpu : s.y;
-                q = pw_some(w) ? q_solved : q;
+                // exploit_value: the record's q slot, except Fpu::ParentQ for an unvisited child
+                const float q = (!cfg.fpu_const() && pw_nc(w) == 0u && !pw_some(w)) ? q_fpu : s.y;
                 float u;
                 if (cfg.puct()) u = cfg.cc() * s.z * visits / (1.0f + s.x);
                 else u = visits / sqrtf(s.x);
@@ -246,7 +257,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
                     const bool aw = c4::won(nop);
                     const bool afull = (occ | abit) == c4::FULL;
                     wcur = pw_make(0, 0, (uint32_t)a, aw || afull, aw ? 0u : 1u);
-                    st_sel(slab, first, 0.0f, 0u, 1.0f, wcur);
+                    st_sel(slab, first, 0.0f, (aw || afull) ? pw_q_solved(aw ? 0u : 1u, cfg.select_solved()) : y_unvisited, 1.0f, wcur);
                     node = first;
                     my = nmy;
                     op = nop;
@@ -283,7 +294,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
 // The rest of visit() for the node expanded in phase A (mcts.rs:389-423): creates its children (terminal ones already
 // solved) with the legal-move softmax of the nine raw logits as priors. Returns any_solved.
 SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
-                                  const float (&lg)[9], float equal_noise_weight) {
+                                  const float (&lg)[9], float equal_noise_weight, float y_unvisited, bool select_solved) {
     const uint32_t lmask = X.legal_mask;
     float mx = -__builtin_inff();
 #pragma unroll
@@ -311,7 +322,8 @@ SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, uint64
             const bool w = c4::won(my | bit);  // child.op_bb = the mover's stones (connect4.rs:224-229)
             const bool over = w || (occ | bit) == c4::FULL;
             // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost
-            st_sel(slab, X.fc + idx, 0.0f, 0u, p, pw_make(0, 0, (uint32_t)c, over, w ? 0u : 1u));
+            st_sel(slab, X.fc + idx, 0.0f, over ? pw_q_solved(w ? 0u : 1u, select_solved) : y_unvisited, p,
+                   pw_make(0, 0, (uint32_t)c, over, w ? 0u : 1u));
             any_solved = any_solved || over;
             idx++;
         }
@@ -336,7 +348,7 @@ SYN_DEV int wave_max_i32(int v) {
 //            (win/lose swapped once per level climbed) and one visit, so the levels are independent: the four path rows
 //            and then the four aux records are fetched together — two round trips per four levels.
 // `leaf_solved`: the walk starts at a node that already carries a solution (explore() hit a solved node, or an
-// auto-extended terminal child); its q slot holds the turn count and must stay that way even with the solver off.
+// auto-extended terminal child); its q slot holds the outcome's constant and must stay that way even with the solver off.
 template <bool COUNT, bool FAST>
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
                            bool leaf_solved, bool active, const uint4* pl, uint32_t cap, uint32_t* ctr,
@@ -348,7 +360,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
         if ((uint32_t)(depth + 1) > ctr[CTR_MAX_DEPTH]) ctr[CTR_MAX_DEPTH] = (uint32_t)(depth + 1);
     }
     int L = active ? depth : -1;
-    bool keep_turns = leaf_solved;  // only ever true for the first level handled
+    bool keep_q = leaf_solved;  // only ever true for the first level handled
     // ---- phase 1
     if (cfg.solve() && solved && L >= 0) {
         uint4 pe = pl[L * 64];
@@ -366,7 +378,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
             // a node that was never backpropagated into has no aux record yet
             float W0 = N == 0.0f ? 0.0f : a.x, W1 = N == 0.0f ? 0.0f : a.y, W2 = N == 0.0f ? 0.0f : a.z;
             bool all_solved = true;
-            uint32_t key = outcome_key(pw_some(w), pw_kind(w), pe.w);
+            uint32_t key = outcome_key(pw_some(w), pw_kind(w), pw_turns(w));
             if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
 #pragma unroll
             for (uint32_t i = 0; i < 9; i++) {
@@ -375,7 +387,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                     all_solved = all_solved && pw_some(cw);
                     // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
                     const uint32_t ck = pw_kind(cw);
-                    const uint32_t rk = pw_some(cw) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, f32_bits(cs[i].y) + 1u) : 0u;
+                    const uint32_t rk = pw_some(cw) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, pw_turns(cw) + 1u) : 0u;
                     key = rk > key ? rk : key;
                 }
             }
@@ -400,7 +412,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
             } else {
                 break;  // this level and everything above belongs to phase 2
             }
-            w = (w & ~(PW_SOME_BIT | (3u << PW_KIND_SHIFT))) | PW_SOME_BIT | (bkind << PW_KIND_SHIFT);
+            w = pw_with_solution(w, bkind, bturns);
             st_sel_w(slab, node, w);
             if (L == 0) T.root_solved = true;
             W0 += d0;
@@ -408,11 +420,11 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
             W2 += d2;
             N += 1.0f;
             st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
-            *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, bits_f32(bturns));
+            *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, pw_q_solved(bkind, cfg.select_solved()));
             const float t = d0;
             d0 = d2;
             d2 = t;
-            keep_turns = false;
+            keep_q = false;
             L--;
             if (L < 0) break;
             pe = pe_next;
@@ -447,7 +459,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 N += 1.0f;
                 st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
                 const float q = -((W2 - W0) / N);
-                if (keep_turns && Lj == L) *reinterpret_cast<float*>(slab + (size_t)node * 16u) = N;
+                if (keep_q && Lj == L) *reinterpret_cast<float*>(slab + (size_t)node * 16u) = N;
                 else *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, q);
             }
         }
@@ -526,7 +538,7 @@ SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_se
             float k0, k1;
             if (pw_some(cw)) {
                 const uint32_t kind = pw_kind(cw);
-                const float t = (float)f32_bits(cs.y);
+                const float t = (float)pw_turns(cw);
                 if (kind == 2u) { k0 = 0.0f; k1 = t; }
                 else if (kind == 1u) { k0 = 2.0f; k1 = -t; }
                 else { k0 = 3.0f; k1 = -t; }
@@ -707,7 +719,7 @@ SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
         const bool some = ch && pw_some(cw);
         out->child_sol[c][0] = some ? 1 : 0;
         out->child_sol[c][1] = some ? (int)pw_kind(cw) : 0;
-        out->child_sol[c][2] = some ? (int)f32_bits(cs.y) : 0;
+        out->child_sol[c][2] = some ? (int)pw_turns(cw) : 0;
         out->target_pi[c] = pi[c] / wtotal;
     }
     const float4 ra = ln_aux(T.slab, P.cap, 0);
@@ -716,7 +728,7 @@ SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
     const bool some = pw_some(R.root_w);
     out->root_sol[0] = some ? 1 : 0;
     out->root_sol[1] = some ? (int)pw_kind(R.root_w) : 0;
-    out->root_sol[2] = some ? (int)f32_bits(ln_sel(T.slab, 0).y) : 0;
+    out->root_sol[2] = some ? (int)pw_turns(R.root_w) : 0;
     out->num_nodes = T.next_node;
     out->best_action = best;
     out->target_q[0] = q0; out->target_q[1] = q1; out->target_q[2] = q2;
@@ -857,8 +869,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         bool solved = X.solved;
         if (need) {
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
+            const CfgView<FAST> cv{P.mcts};
             solved = lane_create_children(T.slab, X, Wk.my, Wk.op, lg,
-                                          (P.mcts.noise == 1 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise_weight : -1.0f);
+                                          (P.mcts.noise == 1 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise_weight : -1.0f,
+                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, cv.select_solved());
             d0 = v0;
             d1 = v1;
             d2 = v2;
