@@ -1,0 +1,108 @@
+// C++ caller of the drop-in boundary, standing in for the reference's Rust host (SURVEY.md §8b "Callers"): exercises
+// include/synthesis_amd.hpp the way study-connect4 would — Policy::eval through the adaptor, run_n_games into a
+// ReplayBuffer, deduplicate, one learner step — and prints everything as "key v v v ..." lines (floats as hex bit
+// patterns) for tests/test_cpp_host.py to compare with the oracle. No GPU: prints "error <code> <message>", exits 3.
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+#include "synthesis_amd.hpp"
+
+using namespace synthesis;
+
+static void put(const char* key, const float* v, size_t n) {
+    std::printf("%s", key);
+    for (size_t i = 0; i < n; i++) {
+        uint32_t u;
+        std::memcpy(&u, &v[i], 4);
+        std::printf(" %08x", u);
+    }
+    std::printf("\n");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: host_harness <blob.f32>\n"); return 2; }
+    std::ifstream f(argv[1], std::ios::binary);
+    std::vector<float> blob(30492);
+    f.read(reinterpret_cast<char*>(blob.data()), (std::streamsize)(blob.size() * 4));
+    if (!f) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
+    try {
+        Engine engine(256, 64);
+        engine.load_weights(blob);
+
+        // Policy::eval on a scripted opening, position by position (batch of one), then as one batch
+        HipPolicy policy(engine);
+        Connect4 game;
+        std::vector<Connect4> line{game};
+        for (int col : {4, 4, 3, 5, 2, 4, 0, 8, 8}) {
+            if (game.step(col)) break;
+            line.push_back(game);
+        }
+        for (size_t i = 0; i < line.size(); i++) {
+            auto out = policy.eval(line[i]);
+            std::printf("pos %zu %llu %llu %d\n", i, (unsigned long long)line[i].my_bb(), (unsigned long long)line[i].op_bb(),
+                        (int)line[i].player());
+            put("logits", out.first.data(), 9);
+            put("value", out.second.data(), 3);
+            put("features", line[i].features().data(), 63);
+        }
+        std::vector<std::array<float, 9>> bl;
+        std::vector<std::array<float, 3>> bv;
+        policy.eval_batch(line, bl, bv);
+        for (size_t i = 0; i < line.size(); i++) put("batch_logits", bl[i].data(), 9);
+
+        // run_n_games -> ReplayBuffer
+        RolloutConfig cfg;
+        cfg.num_explores = 64;
+        syn_counters ctr{};
+        ReplayBuffer buffer = run_n_games(engine, cfg, 12, 5, 0, &ctr);
+        std::printf("buffer %zu %zu %zu %llu\n", buffer.total_games_played(), buffer.curr_games(), buffer.curr_steps(),
+                    (unsigned long long)ctr.policy_evals);
+        for (size_t i = 0; i < buffer.curr_steps(); i++) {
+            std::printf("step %llu %llu\n", (unsigned long long)buffer.games[i].my_bb(), (unsigned long long)buffer.games[i].op_bb());
+            put("pi", buffer.pis[i].data(), 9);
+            put("v", buffer.vs[i].data(), 3);
+        }
+        ReplayBuffer more = run_n_games(engine, cfg, 4, 5, 12);
+        buffer.extend(more);
+        buffer.keep_last_n_games(10);
+        std::printf("kept %zu %zu %zu\n", buffer.total_games_played(), buffer.curr_games(), buffer.curr_steps());
+        FlatBatch flat = buffer.deduplicate(engine);
+        std::printf("dedup %zu\n", flat.vs.size());
+
+        // a search of the empty board
+        auto res = mcts_search(engine, MCTSConfig(), {Connect4()}, 64);
+        put("child_N", res[0].child_N, 9);
+        std::printf("best %d nodes %u\n", res[0].best_action, res[0].num_nodes);
+
+        // one learner step on the first 32 unique states, then self-play continues on the trained network
+        Learner learner(engine, blob, 1e-6f, 1.0f, 1.0f);
+        std::vector<Connect4> bg(flat.games.begin(), flat.games.begin() + 32);
+        std::vector<std::array<float, 9>> bp(flat.pis.begin(), flat.pis.begin() + 32);
+        std::vector<std::array<float, 3>> bvv(flat.vs.begin(), flat.vs.begin() + 32);
+        auto losses = learner.step(bg, bp, bvv, 1e-3f);
+        put("losses", losses.data(), 2);
+        learner.publish();
+        auto out2 = policy.eval(Connect4());
+        put("logits_after_step", out2.first.data(), 9);
+
+        // error behaviour: the reference panics; here a typed exception with the ABI's status code
+        try {
+            engine.load_weights(std::vector<float>(7));
+            std::printf("no_error\n");
+        } catch (const Error& e) {
+            std::printf("caught %d\n", e.code);
+        }
+        try {
+            Connect4 g;
+            for (int i = 0; i < 8; i++) g.step(0);
+            std::printf("no_error\n");
+        } catch (const Error& e) {
+            std::printf("caught %d\n", e.code);
+        }
+    } catch (const Error& e) {
+        std::printf("error %d %s\n", e.code, e.what());
+        return 3;
+    }
+    return 0;
+}
