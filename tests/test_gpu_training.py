@@ -136,3 +136,41 @@ def test_replay_deduplicate_matches_oracle(engine, oracle, blob):
     assert empty["num"].size == 0
     one = engine.replay_deduplicate(my[:1], op[:1], pi[:1], v[:1])
     assert one["num"].tolist() == [1] and np.array_equal(one["pis"][0], pi[0])
+
+
+def test_data_parallel_learner_two_ranks(oracle, blob, gold, tmp_path):
+    """BASELINE configs[4] end to end on one box: two processes (torch.distributed.run, gloo, both on GPU 0) each train on
+    half of every batch through DataParallelLearner; both ranks end with identical weights, equal to the oracle applying
+    Adam to the mean of the two shard gradients, and within float rounding of the single-process full-batch steps."""
+    import subprocess
+    import sys
+
+    from tests.oracle_lib import default_train_hyper
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "tests", "dp_learner_worker.py"), str(tmp_path)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for k in ("weights", "m", "v", "losses"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert int(r0["step"]) == 4
+    hp = default_train_hyper()
+    w, m, v, step = blob.copy(), np.zeros_like(blob), np.zeros_like(blob), 0
+    B = gold["my_bb"].shape[1]; h = B // 2
+    for s in range(4):
+        gs, ls = [], []
+        for r in range(2):
+            sl = slice(r * h, (r + 1) * h)
+            X = oracle.c4_features(gold["my_bb"][s, sl], gold["op_bb"][s, sl])
+            g, l = oracle.train_gradients(w, hp, X, gold["target_pi"][s, sl], gold["target_v"][s, sl])
+            gs.append(g); ls.append(l)
+        w, m, v, step = oracle.train_adam(w, hp, (gs[0] + gs[1]) * np.float32(0.5), float(gold["lrs"][s]), m, v, step)
+        assert np.array_equal(r0["losses"][s], (ls[0] + ls[1]) / np.float32(2)), s
+    assert np.array_equal(r0["weights"], w) and np.array_equal(r0["m"], m) and np.array_equal(r0["v"], v)
+    # against the single-process run on the full batches (torch float64 goldens after 4 steps are not stored: use the oracle)
+    X = np.stack([oracle.c4_features(gold["my_bb"][s], gold["op_bb"][s]) for s in range(4)])
+    wf, _, _, _, _ = oracle.train_steps(blob, hp, X, gold["target_pi"][:4], gold["target_v"][:4], gold["lrs"][:4])
+    assert np.abs(r0["weights"] - wf).max() < 1e-5
