@@ -70,6 +70,28 @@ def measured_traffic(args):
     return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (the GPU boxes give
+    a container 16 CPUs of quota on a 256-thread host; timing 256 threads there measures the throttle, not the code)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(blob, explores, sample_games, threads):
     from tests import oracle_lib
 
@@ -101,7 +123,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
                                                            "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
-    ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 4 games per host thread")
+    ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 64 games per worker thread")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = two per CPU the cgroup quota / affinity mask allows")
     args = ap.parse_args()
 
     import torch  # device sync + (N > 1) the RCCL barrier / max-reduce; the engine itself does not use torch
@@ -205,9 +228,12 @@ def main():
                                                "games": 16384, "plies_per_game": float(r2["plies"].mean())}
             e2.close()
         if world == 1 and not args.no_cpu_baseline:
-            threads = os.cpu_count() or 1
-            sample = args.cpu_sample_games or 4 * threads
+            budget, quota = host_cpu_budget()
+            # two worker threads per usable CPU (measured best on the 16-CPU-quota boxes: 16 -> 103, 32 -> 130 games/s)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 2 * budget)
+            sample = args.cpu_sample_games or 64 * threads  # ~15-20 s of wall time
             out["cpu_baseline"] = cpu_baseline(blob, args.explores, sample, threads)
+            out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
         print(json.dumps(out), flush=True)
 
     eng.close()

@@ -314,11 +314,14 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
         net.blob = blob;
         net.mode = nn_mode;
         PolicyWithCache<Connect4Net> cached((size_t)Connect4::MAX_TURNS * (size_t)(count > 0 ? count : 1), &net);
+        // counters live on the worker's own stack while it runs: neighbouring elements of `ctrs` share cache lines, and
+        // hundreds of threads incrementing them would time false sharing instead of the search
+        MCTSCounters local;
         for (int g = start; g < start + count; g++) {
             ChaChaRng rng = ChaChaRng::seed_from_u64(base_seed + first_game + (uint64_t)g);
             GameRecord rec;
-            if (use_cache) run_game(cfg, cached, rng, rec, &ctrs[w]);
-            else run_game(cfg, net, rng, rec, &ctrs[w]);
+            if (use_cache) run_game(cfg, cached, rng, rec, &local);
+            else run_game(cfg, net, rng, rec, &local);
             if (plies) plies[g] = rec.plies;
             if (final_kind) final_kind[g] = rec.final_kind;
             for (int k = 0; k < rec.plies; k++) {
@@ -330,6 +333,7 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
                 if (root_nodes) root_nodes[p] = rec.root_nodes[k];
             }
         }
+        ctrs[w] = local;
         hits[w] = cached.hits;
         misses[w] = cached.misses;
     };
