@@ -444,7 +444,12 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
             const bool ok = Lj >= 0 && Lj <= L;
-            a[j] = ln_aux(slab, cap, ok ? pe[j].x : 0u);  // (idle lanes re-read their root's record: a valid address)
+            // a node that was never backpropagated into (N == 0: the fresh leaf of most explores) has no aux record to
+            // read, and idle lanes have no node: both fetch their own path entry instead — a valid address that is hot in
+            // L2 — so neither costs an HBM sector
+            const unsigned char* src = (ok && pe[j].y != 0u) ? slab + (size_t)(cap + pe[j].x) * 16u
+                                                             : reinterpret_cast<const unsigned char*>(pl + (Lj < 0 ? 0 : Lj) * 64);
+            a[j] = *reinterpret_cast<const float4*>(src);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
