@@ -179,10 +179,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // trees per workgroup sharing one LDS weight image). SYN_QUADS=0..4 overrides (0 = never use the quad kernel).
     // Lane-per-tree kernel (lane_kernel.cuh): one tree per lane, NW waves per workgroup, one workgroup per CU.
     // SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it (0 = never); by default it takes over once every CU can
-    // be given at least 512 trees (8 waves) and uses 12 waves from 768 trees per CU (16 waves spill: measured slower).
+    // be given 256 trees (4 waves; measured 41.9k games/s at 65,536 concurrent games against 31.8k for the queued
+    // row-per-tree workgroups), 8 waves up to 512 trees per CU, 12 beyond (16 waves spill: measured slower).
     {
         int nw = 0;
-        if (want_slots >= h->num_cus * 512) nw = want_slots >= h->num_cus * 768 ? 12 : 8;
+        if (want_slots >= h->num_cus * 256) nw = want_slots > h->num_cus * 512 ? 12 : (want_slots > h->num_cus * 256 ? 8 : 4);
         if (const char* ev = std::getenv("SYN_LANES")) nw = std::atoi(ev);
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);

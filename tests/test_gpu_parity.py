@@ -394,7 +394,7 @@ def test_quad_async_kernel_matches_oracle(blob, oracle, monkeypatch, quads):
 @pytest.mark.parametrize("waves", [4, 8, 12, 16])
 def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
     """The high-concurrency launch shape (lane_kernel.cuh: one tree per lane, own record layout, path-buffer backprop,
-    free-running waves) is normally chosen from 131,072 concurrent games; force it on a small engine (partial last
+    free-running waves) is normally chosen from 65,536 concurrent games; force it on a small engine (partial last
     wave, partial last workgroup) and hold it to the same bit-exact bar as the row-per-tree kernels: searches incl.
     late-game solver positions, every config family, whole self-play games with refill and all value targets."""
     import synthesis_amd as sa
