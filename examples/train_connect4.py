@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""The reference's learning loop (synthesis/src/alpha_zero.rs:16-118, configured like study-connect4/src/main.rs:11-52)
+with every heavy step on the MI355X: self-play (fused MCTS + network kernel), replay de-duplication (sort + segmented
+reduce) and the optimiser steps (HIP forward/backward/Adam), the trained weights going back to the self-play network on
+the device. Host code only moves indices: the replay buffer lives in numpy arrays, batches are drawn by a seeded
+permutation (BatchRandSampler, data.rs:6-64, drop_last = true).
+
+    python examples/train_connect4.py --iterations 3 --games-per-train 4096 --explores 200
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_connect4.py ...
+        (one rank per GPU: every rank plays its share of the games; the optimiser step is data-parallel with a gradient
+         all-reduce over RCCL, synthesis_amd/learner.py)
+
+Differences from the reference, all forced by determinism on a GPU: Fpu::Const(1.0) instead of Fpu::Func(N(1, 0.1))
+(main.rs:43-47), one StdRng stream per game, torch's randperm replaced by numpy's seeded permutation.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def lr_at(schedule, i_iter):
+    """alpha_zero.rs:62-69: the last (iteration, lr) entry whose iteration is <= i_iter + 1"""
+    lr = schedule[0][1]
+    for it, v in schedule:
+        if it <= i_iter + 1:
+            lr = v
+    return lr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iterations", type=int, default=3)            # num_iterations (main.rs:16: 200)
+    ap.add_argument("--games-per-train", type=int, default=4096)    # main.rs:27: 1000
+    ap.add_argument("--games-to-keep", type=int, default=20000)     # main.rs:26
+    ap.add_argument("--explores", type=int, default=200)            # main.rs:30: 1600
+    ap.add_argument("--epochs", type=int, default=2)                # main.rs:21: 20
+    ap.add_argument("--batch-size", type=int, default=32)           # main.rs:22
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--concurrent", type=int, default=65536)
+    ap.add_argument("--out", default="")
+    args = ap.parse_args()
+
+    import torch  # noqa: F401  (before the engine: one HIP runtime per process)
+
+    import synthesis_amd as sa
+    from bench import make_weights
+    from synthesis_amd import dist_util
+    from synthesis_amd.learner import DataParallelLearner
+
+    rank, local_rank, world = dist_util.rank_info()
+    dist = dist_util.init_process_group("nccl", local_rank) if world > 1 else None
+    lr_schedule = [(1, 1e-3), (20, 5e-4), (40, 1e-4), (60, 5e-5), (80, 1e-5)]  # main.rs:18
+    cfg = sa.parity_rollout_config(args.explores)
+
+    eng = sa.Engine(concurrent_games=min(args.concurrent, max(16, args.games_per_train // world)), max_explores=args.explores,
+                    device=local_rank)
+    blob = make_weights(args.seed + 20211003)  # P::new(&vs): fixed-seed init, identical on every rank
+    eng.load_weights(blob)
+    learner = DataParallelLearner(eng, blob, dist=dist, device=local_rank, weight_decay=1e-6, policy_weight=1.0,
+                                  value_weight=1.0)
+    # replay buffer: positions as bitboards + targets + the game each step came from
+    R = dict(my=np.zeros(0, np.uint64), op=np.zeros(0, np.uint64), pi=np.zeros((0, 9), np.float32),
+             v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
+    games_played = 0
+    log = []
+    for it in range(args.iterations):
+        t0 = time.perf_counter()
+        # ---- gather_experience (alpha_zero.rs:120-179): this rank's share of the new games, seeds never reused
+        first, count = dist_util.step_game_range(it, rank, world, args.games_per_train // world)
+        sp = eng.selfplay(cfg, base_seed=args.seed, n_games=count, first_game=first)
+        t_play = time.perf_counter() - t0
+        n = sp["plies"]
+        mask = np.arange(63)[None, :] < n[:, None]
+        gid = (games_played + first - it * args.games_per_train + np.arange(count))[:, None].repeat(63, 1)[mask]
+        R = dict(my=np.concatenate([R["my"], sp["states_bb"][..., 0][mask]]), op=np.concatenate([R["op"], sp["states_bb"][..., 1][mask]]),
+                 pi=np.concatenate([R["pi"], sp["pis"][mask]]), v=np.concatenate([R["v"], sp["vs"][mask]]),
+                 gid=np.concatenate([R["gid"], gid]))
+        games_played += args.games_per_train
+        keep = R["gid"] >= games_played - args.games_to_keep  # keep_last_n_games
+        R = {k: a[keep] for k, a in R.items()}
+        # ---- deduplicate on the GPU (data.rs:196-235)
+        t1 = time.perf_counter()
+        D = eng.replay_deduplicate(R["my"], R["op"], R["pi"], R["v"])
+        t_dedup = time.perf_counter() - t1
+        n_unique = D["num"].size
+        lr = lr_at(lr_schedule, it)
+        # ---- epochs of optimiser steps (alpha_zero.rs:72-94)
+        t2 = time.perf_counter()
+        epoch_losses = []
+        steps = 0
+        if world == 1:
+            eng.train_set_data(D["my_bb"], D["op_bb"], D["pis"], D["vs"])  # one upload per iteration
+        for ep in range(args.epochs):
+            perm = np.random.default_rng([args.seed, it, ep, rank]).permutation(n_unique)
+            n_steps = n_unique // args.batch_size  # drop_last = true
+            if world == 1:
+                # one call per epoch: batches are gathered on the device, no host round trip between the steps
+                sl = eng.train_epoch(perm[: n_steps * args.batch_size], args.batch_size, lr)
+                el = sl.astype(np.float64).sum(axis=0)
+            else:
+                el = np.zeros(2, np.float64)
+                for b in range(0, n_steps * args.batch_size, args.batch_size):
+                    idx = perm[b:b + args.batch_size]
+                    el += learner.step(D["my_bb"][idx], D["op_bb"][idx], D["pis"][idx], D["vs"][idx], lr)
+            steps += n_steps
+            epoch_losses.append((el * args.batch_size / n_unique).tolist())
+        t_train = time.perf_counter() - t2
+        learner.publish()  # model_{i+1}: the next iteration's self-play runs on the trained network
+        rec = dict(iteration=it + 1, lr=lr, games=int(count * world), steps_in_buffer=int(R["my"].size), unique=int(n_unique),
+                   plies_per_game=float(n.mean()), draws=float((sp["final_kind"] == 1).mean()), optimiser_steps=steps,
+                   epoch_losses=epoch_losses, seconds=dict(selfplay=round(t_play, 3), dedup=round(t_dedup, 3), train=round(t_train, 3)),
+                   selfplay_games_per_s=count * world / t_play, train_steps_per_s=steps / max(t_train, 1e-9))
+        log.append(rec)
+        if rank == 0:
+            print(json.dumps(rec), flush=True)
+    if rank == 0 and args.out:
+        json.dump(log, open(args.out, "w"), indent=1)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -213,6 +213,15 @@ int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long l
 /* Replaces: vs.save(model_{i+1}.ot) + the workers' vs.load (alpha_zero.rs:97,194): the trained parameters become the
  * engine's policy for syn_policy_eval_batch / syn_mcts_search / syn_selfplay_run. */
 int syn_trainer_publish_weights(syn_engine* h);
+/* Epochs without the host in the loop. syn_train_set_data uploads the de-duplicated buffer once per iteration (the
+ * tensors `states / target_pis / target_vs` of alpha_zero.rs:52-58, positions as bitboards); syn_train_epoch then runs
+ * n_steps optimiser steps in one call: step s trains on the states perm[s*batch .. (s+1)*batch) — the BatchRandSampler's
+ * index_select (data.rs:41-62; the caller draws the permutation and applies drop_last) — and step_losses[s][0..1]
+ * receives its (pi_loss, v_loss). Bit-identical to n_steps calls of syn_train_step on the gathered batches. */
+int syn_train_set_data(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
+                       const float* target_v, size_t n);
+int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batch, float lr, float* step_losses);
+
 /* Replaces: ReplayBuffer::deduplicate (data.rs:196-235): identical states are merged, their targets summed in buffer
  * order and divided by the count. Outputs are sized for n entries; *out_count = number of unique states, emitted in
  * ascending (my_bb, op_bb) order (the reference's order is HashMap iteration order, i.e. unspecified). */

@@ -44,6 +44,8 @@ struct syn_engine {
     float* d_wimg = nullptr;
     bool has_weights = false;
     int* d_job_next = nullptr;
+    void* d_train_data = nullptr;  // syn_train_set_data: [my u64 n][op u64 n][pi 9 f32 n][v 3 f32 n]
+    size_t train_data_cap = 0, train_data_n = 0;
     uint4* d_path = nullptr;   // lane kernel's per-wave descent logs
     size_t path_bytes = 0;
     unsigned long long* d_counters = nullptr;
@@ -343,6 +345,7 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_wimg);
     hipFree(h->d_job_next);
     hipFree(h->d_path);
+    hipFree(h->d_train_data);
     hipFree(h->d_counters);
     hipFree(h->d_plies);
     hipFree(h->d_states);
@@ -754,12 +757,13 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
 }
 
 static int launch_grads(syn_engine* h, const unsigned long long* d_my, const unsigned long long* d_op,
-                        const float* d_tpi, const float* d_tv, int batch, float* d_grads) {
+                        const float* d_tpi, const float* d_tv, int batch, float* d_grads, float* d_losses = nullptr,
+                        const int* d_idx = nullptr) {
     auto k = train_grad_kernel;
     const size_t lds = (size_t)TrainGeom::LDS_FLOATS * 4;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k, dim3(1), dim3(1024), lds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
-                       d_grads, h->d_tloss);
+                       d_grads, d_losses ? d_losses : h->d_tloss, d_idx);
     HIP_TRY(h, hipGetLastError());
     return SYN_OK;
 }
@@ -826,6 +830,65 @@ int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, 
     rc = launch_adam(h, h->d_tgrad, lr, 1.0f);
     if (rc != SYN_OK) return rc;
     if (losses) HIP_TRY(h, hipMemcpyAsync(losses, h->d_tloss, 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+// ---- epochs without the host in the loop: the de-duplicated buffer is uploaded once per iteration, an epoch is one call
+int syn_train_set_data(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
+                       const float* target_v, size_t n) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (n < 1 || n > 0x7FFFFFFFu || !my_bb || !op_bb || !target_pi || !target_v)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_train_set_data");
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (n > h->train_data_cap) {
+        (void)hipFree(h->d_train_data);
+        h->d_train_data = nullptr;
+        h->train_data_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_train_data, n * 64));
+        h->train_data_cap = n;
+    }
+    unsigned char* base = static_cast<unsigned char*>(h->d_train_data);
+    HIP_TRY(h, hipMemcpyAsync(base, my_bb, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(base + n * 8, op_bb, n * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(base + n * 16, target_pi, n * 36, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(base + n * 52, target_v, n * 12, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->train_data_n = n;
+    return SYN_OK;
+}
+
+int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batch, float lr, float* step_losses) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (h->train_data_n == 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "call syn_train_set_data first");
+    if (batch < 1 || (n_steps > 0 && !perm) || n_steps * (size_t)batch > 0x7FFFFFFFu)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_train_epoch");
+    if (n_steps == 0) return SYN_OK;
+    for (size_t i = 0; i < n_steps * (size_t)batch; i++)
+        if (perm[i] < 0 || (size_t)perm[i] >= h->train_data_n)
+            return fail(h, SYN_ERR_INVALID_ARGUMENT, "perm[%zu] = %d is outside the %zu uploaded states", i, perm[i],
+                        h->train_data_n);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t n = h->train_data_n, ni = n_steps * (size_t)batch;
+    int rc = ensure_scratch(h, ni * 4 + n_steps * 8 + 256);
+    if (rc != SYN_OK) return rc;
+    int* d_perm = static_cast<int*>(h->d_scratch);
+    float* d_losses = reinterpret_cast<float*>(d_perm + ((ni + 63) & ~(size_t)63));
+    HIP_TRY(h, hipMemcpyAsync(d_perm, perm, ni * 4, hipMemcpyHostToDevice, h->stream));
+    const unsigned char* base = static_cast<const unsigned char*>(h->d_train_data);
+    const unsigned long long* d_my = reinterpret_cast<const unsigned long long*>(base);
+    const unsigned long long* d_op = reinterpret_cast<const unsigned long long*>(base + n * 8);
+    const float* d_tpi = reinterpret_cast<const float*>(base + n * 16);
+    const float* d_tv = reinterpret_cast<const float*>(base + n * 52);
+    for (size_t s = 0; s < n_steps; s++) {  // steps are dependent (weights of step s feed step s+1): queued, never synced
+        rc = launch_grads(h, d_my, d_op, d_tpi, d_tv, batch, h->d_tgrad, d_losses + 2 * s, d_perm + s * (size_t)batch);
+        if (rc != SYN_OK) return rc;
+        rc = launch_adam(h, h->d_tgrad, lr, 1.0f);
+        if (rc != SYN_OK) return rc;
+    }
+    if (step_losses) HIP_TRY(h, hipMemcpyAsync(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SYN_OK;
 }

@@ -6,7 +6,7 @@
 //
 // The reference trains with batch_size 32 on a 30,492-parameter MLP: one optimiser step is ~3 MFLOP — far too small for
 // anything but latency to matter. train_grad_kernel therefore runs the whole forward + backward of a minibatch in ONE
-// workgroup with every activation and activation-gradient resident in LDS (99 KB), one thread per output element and
+// workgroup with every activation and activation-gradient resident in LDS (99 KB) plus the current layer's weights (49 KB, staged per layer), one thread per output element and
 // fixed-order fma chains (bit-identical to oracle/train.hpp); gradients go to a caller-provided device buffer so that a
 // data-parallel run can all-reduce them (RCCL, 122 KB) before adam_kernel applies the update.
 #pragma once
@@ -38,7 +38,9 @@ struct TrainGeom {
         return off;
     }
     static constexpr int KL_OFF = A_FLOATS + CHUNK * (129 + 97 + 65 + 49 + 13);  // per-sample KL terms [CHUNK][2]
-    static constexpr int LDS_FLOATS = KL_OFF + 2 * CHUNK;
+    static constexpr int WL_OFF = (KL_OFF + 2 * CHUNK + 3) & ~3;   // the current layer's weights, staged per layer (16-B aligned)
+    static constexpr int WL_FLOATS = 128 * 96;                    // largest layer
+    static constexpr int LDS_FLOATS = WL_OFF + WL_FLOATS;
 };
 
 struct DevTrainHyper {
@@ -52,7 +54,8 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
                                                           const unsigned long long* __restrict__ op_bb,
                                                           const float* __restrict__ tpi, const float* __restrict__ tv,
                                                           int B, DevTrainHyper hp, float* __restrict__ grads,
-                                                          float* __restrict__ losses) {
+                                                          float* __restrict__ losses,
+                                                          const int* __restrict__ idx = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using G = TrainGeom;
     const int tid = threadIdx.x;
@@ -66,7 +69,8 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
             int b = i / 63, f = i - b * 63;
             float x = 0.0f;
             if (b < nb) {
-                uint64_t my = my_bb[c0 + b], op = op_bb[c0 + b];
+                const size_t s = idx ? (size_t)idx[c0 + b] : (size_t)(c0 + b);  // BatchRandSampler's index_select
+                uint64_t my = my_bb[s], op = op_bb[s];
                 x = c4::feature(my, op, c4::next_free_cells(my | op), f);
             }
             lds[G::a_off(0) + b * G::stride(0) + f] = x;
@@ -76,7 +80,14 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
 #pragma unroll
         for (int l = 0; l < G::NL; l++) {
             const int K = G::D[l], O = G::D[l + 1];
-            const float* W = w + G::w_off(l);
+            // stage the layer's weights in LDS: one coalesced pass instead of K dependent global loads per output
+            {
+                const float4* src = reinterpret_cast<const float4*>(w + G::w_off(l));
+                float4* dst = reinterpret_cast<float4*>(lds + G::WL_OFF);
+                for (int i = tid; i < K * O / 4; i += 1024) dst[i] = src[i];
+            }
+            __syncthreads();
+            const float* W = lds + G::WL_OFF;
             const float* bias = w + G::b_off(l);
             const float* Ain = lds + G::a_off(l);
             float* Aout = lds + G::a_off(l + 1);
@@ -99,7 +110,8 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
             float kl = 0.0f;
             if (b < nb) {
                 const float* x = lds + G::a_off(5) + b * G::stride(5) + off;
-                const float* t = head == 0 ? tpi + (size_t)(c0 + b) * 9 : tv + (size_t)(c0 + b) * 3;
+                const size_t si = idx ? (size_t)idx[c0 + b] : (size_t)(c0 + b);
+                const float* t = head == 0 ? tpi + si * 9 : tv + si * 3;
                 const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
                 float mx = x[0];
                 for (int j = 1; j < n; j++) mx = x[j] > mx ? x[j] : mx;
@@ -130,10 +142,16 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
 #pragma unroll
         for (int l = G::NL - 1; l >= 1; l--) {
             const int K = G::D[l], O = G::D[l + 1];
-            const float* W = w + G::w_off(l);
+            const float* W = lds + G::WL_OFF;
             const float* dZ = lds + G::d_off(l + 1);
             const float* A = lds + G::a_off(l);
             float* dA = lds + G::d_off(l);
+            __syncthreads();
+            {
+                const float4* src = reinterpret_cast<const float4*>(w + G::w_off(l));
+                float4* dst = reinterpret_cast<float4*>(lds + G::WL_OFF);
+                for (int i = tid; i < K * O / 4; i += 1024) dst[i] = src[i];
+            }
             __syncthreads();
             for (int i = tid; i < K * G::CHUNK; i += 1024) {
                 int k = i >> 5, b = i & 31;

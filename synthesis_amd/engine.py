@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
-    "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate",
+    "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
 
 
@@ -118,6 +118,8 @@ def load_library():
     lib.syn_trainer_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong),
                                           C.c_void_p]
     lib.syn_trainer_publish_weights.argtypes = [C.c_void_p]
+    lib.syn_train_set_data.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.syn_train_epoch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_void_p]
     lib.syn_replay_deduplicate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_size_t)]
@@ -314,6 +316,22 @@ class Engine:
         step = C.c_longlong()
         self._check(self._lib.syn_trainer_get_state(self._h, _p(blob), _p(m), _p(v), C.byref(step), _p(g)))
         return dict(weights=blob, m=m, v=v, step=int(step.value), grads=g)
+
+    def train_set_data(self, my_bb, op_bb, target_pi, target_v):
+        """Uploads the de-duplicated buffer once; train_epoch then indexes it on the device."""
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        tpi = np.ascontiguousarray(target_pi, dtype=np.float32).reshape(my.size, 9)
+        tv = np.ascontiguousarray(target_v, dtype=np.float32).reshape(my.size, 3)
+        self._check(self._lib.syn_train_set_data(self._h, _p(my), _p(op), _p(tpi), _p(tv), int(my.size)))
+
+    def train_epoch(self, perm, batch_size, lr):
+        """len(perm) // batch_size optimiser steps in one call (drop_last = true); returns the per-step losses [steps][2]."""
+        perm = np.ascontiguousarray(perm, dtype=np.int32).ravel()
+        steps = perm.size // int(batch_size)
+        losses = np.zeros((steps, 2), np.float32)
+        self._check(self._lib.syn_train_epoch(self._h, _p(perm), steps, int(batch_size), float(lr), _p(losses)))
+        return losses
 
     def trainer_publish_weights(self):
         self._check(self._lib.syn_trainer_publish_weights(self._h))

@@ -69,6 +69,35 @@ def test_train_ragged_batches_and_hyper(engine, oracle, blob, gold):
         assert np.array_equal(st["weights"], wo), B
 
 
+def test_device_resident_epoch_equals_step_by_step(engine, oracle, blob, gold):
+    """syn_train_set_data + syn_train_epoch (one call per epoch, batches gathered on the device by the sampler's
+    permutation) give the bits of the same steps issued one by one — and of the oracle."""
+    from tests.oracle_lib import default_train_hyper
+
+    my = gold["my_bb"].reshape(-1); op = gold["op_bb"].reshape(-1)
+    tpi = gold["target_pi"].reshape(-1, 9); tv = gold["target_v"].reshape(-1, 3)
+    n, B = my.size, 32
+    perm = np.random.default_rng(11).permutation(n).astype(np.int32)
+    steps = n // B
+    engine.trainer_init(blob)
+    engine.train_set_data(my, op, tpi, tv)
+    losses = engine.train_epoch(perm, B, 1e-3)
+    st = engine.trainer_state()
+    assert losses.shape == (steps, 2) and st["step"] == steps
+    engine.trainer_init(blob)
+    ref_losses = np.stack([engine.train_step(my[perm[s * B:(s + 1) * B]], op[perm[s * B:(s + 1) * B]],
+                                             tpi[perm[s * B:(s + 1) * B]], tv[perm[s * B:(s + 1) * B]], 1e-3) for s in range(steps)])
+    st2 = engine.trainer_state()
+    assert np.array_equal(losses, ref_losses)
+    assert np.array_equal(st["weights"], st2["weights"]) and np.array_equal(st["m"], st2["m"]) and np.array_equal(st["v"], st2["v"])
+    X = oracle.c4_features(my, op)
+    idx = perm[: steps * B].reshape(steps, B)
+    wo, mo, vo, _, lo = oracle.train_steps(blob, default_train_hyper(), X[idx], tpi[idx], tv[idx], [1e-3] * steps)
+    assert np.array_equal(st["weights"], wo) and np.array_equal(losses, lo)
+    with pytest.raises(Exception):
+        engine.train_epoch(np.array([n] * B, np.int32), B, 1e-3)  # index outside the uploaded buffer
+
+
 def test_data_parallel_gradient_path(engine, oracle, blob, gold):
     """configs[4] plumbing on one GPU: two 'ranks' compute gradients of their half-batches into caller-owned device
     buffers, the sum is applied with grad_scale = 1/2 — equals (to f32 rounding) one step on the combined batch, and is
