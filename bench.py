@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
                                                            "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 64 games per worker thread")
@@ -227,6 +228,23 @@ def main():
             out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
                                                "games": 16384, "plies_per_game": float(r2["plies"].mean())}
             e2.close()
+        if world == 1 and not args.no_policy_cache:
+            # the reference's run_n_games wraps the policy in PolicyWithCache (alpha_zero.rs:197-198), and so does the CPU
+            # baseline below; the headline above evaluates every leaf with the network, this is the same workload with the
+            # device-side cache (2^28 entries, 17 GB) — one step of 1,048,576 games at 131,072 concurrent games
+            eng.close()
+            e3 = sa.Engine(concurrent_games=131072, max_explores=args.explores, device=local_rank, policy_cache_log2=28)
+            e3.load_weights(blob)
+            e3.selfplay(cfg, base_seed=2, n_games=131072, outputs=False)
+            t1 = time.perf_counter()
+            r3 = e3.selfplay(cfg, base_seed=2, n_games=1048576, first_game=131072, outputs=False)
+            dt = time.perf_counter() - t1
+            hits, misses = e3.last_cache_stats()
+            out["with_policy_cache"] = {"games_per_s": 1048576 / dt, "kernel_ms": r3["kernel_ms"], "games": 1048576,
+                                        "concurrent_games": 131072, "table_entries_log2": 28,
+                                        "hit_rate": hits / max(1, hits + misses),
+                                        "network_evals_per_s": misses / dt, "policy_eval_calls_per_s": (hits + misses) / dt}
+            e3.close()
         if world == 1 and not args.no_cpu_baseline:
             budget, quota = host_cpu_budget()
             # two worker threads per usable CPU (measured best on the 16-CPU-quota boxes: 16 -> 103, 32 -> 130 games/s)
@@ -236,7 +254,10 @@ def main():
             out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
         print(json.dumps(out), flush=True)
 
-    eng.close()
+    try:
+        eng.close()
+    except Exception:
+        pass
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

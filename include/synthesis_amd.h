@@ -84,7 +84,9 @@ typedef struct syn_rollout_config {
 typedef struct syn_engine_config {
     int32_t concurrent_games;   /* trees resident on the GPU at once (BASELINE: 4096); rounded up to a multiple of 16 */
     int32_t max_explores;       /* node-pool slab per tree = 1 + 9*(max_explores+1) nodes */
-    int32_t reserved0;
+    int32_t policy_cache_log2;  /* PolicyWithCache (policies/cache.rs:19-32) on the device: 0 = off, else a table of
+                                 * 2^policy_cache_log2 entries of 64 bytes (10..30) shared by all games of the engine;
+                                 * semantics-neutral (the network is deterministic), used by the lane-per-tree kernel */
     int32_t reserved1;
 } syn_engine_config;
 
@@ -232,6 +234,10 @@ int syn_replay_deduplicate(syn_engine* h, const uint64_t* my_bb, const uint64_t*
 /* Timing of the last syn_selfplay_run / syn_mcts_search / *_device call on this handle, measured with HIP events on
  * the engine stream: kernel_ms = device time of the dominant kernel launch(es), n_launches = how many. */
 int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches);
+
+/* PolicyWithCache statistics of the last syn_selfplay_run / syn_mcts_search: Policy::eval calls answered from the table and
+ * calls that ran the network (both 0 when the cache is off or the row-per-tree kernels ran). */
+int syn_last_cache_stats(const syn_engine* h, uint64_t* hits, uint64_t* misses);
 
 /* Launch shape the last syn_selfplay_run / syn_mcts_search used (the engine picks it from the number of concurrent games,
  * DESIGN.md §6.1): *shape = 1 row-per-tree kernel with the weights in registers (16 trees per workgroup), 2 = the same

@@ -179,10 +179,12 @@ struct Policy {  // policies/traits.rs:4-6
 // One engine handle = one GPU + one stream + a device node pool (the reference's "one policy per worker thread").
 class Engine {
 public:
-    Engine(int concurrent_games, int max_explores, int device = 0) {
+    // policy_cache_log2 > 0: PolicyWithCache (policies/cache.rs) on the device, a table of 2^n 64-byte entries
+    Engine(int concurrent_games, int max_explores, int device = 0, int policy_cache_log2 = 0) {
         syn_engine_config cfg{};
         cfg.concurrent_games = concurrent_games;
         cfg.max_explores = max_explores;
+        cfg.policy_cache_log2 = policy_cache_log2;
         const int rc = syn_engine_create(&cfg, device, &h_);
         if (rc != SYN_OK) throw Error(rc, syn_last_error(nullptr));
     }

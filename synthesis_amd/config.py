@@ -60,7 +60,7 @@ class CRolloutConfig(C.Structure):        # struct syn_rollout_config
 
 
 class CEngineConfig(C.Structure):         # struct syn_engine_config
-    _fields_ = [("concurrent_games", C.c_int32), ("max_explores", C.c_int32), ("reserved0", C.c_int32),
+    _fields_ = [("concurrent_games", C.c_int32), ("max_explores", C.c_int32), ("policy_cache_log2", C.c_int32),
                 ("reserved1", C.c_int32)]
 
 

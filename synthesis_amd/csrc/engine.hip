@@ -44,6 +44,10 @@ struct syn_engine {
     float* d_wimg = nullptr;
     bool has_weights = false;
     int* d_job_next = nullptr;
+    uint4* d_cache = nullptr;      // PolicyWithCache table (policy_cache_log2 > 0)
+    int cache_log2 = 0;
+    unsigned long long* d_cache_stats = nullptr;
+    unsigned long long last_cache_hits = 0, last_cache_misses = 0;
     void* d_train_data = nullptr;  // syn_train_set_data: [my u64 n][op u64 n][pi 9 f32 n][v 3 f32 n]
     size_t train_data_cap = 0, train_data_n = 0;
     uint4* d_path = nullptr;   // lane kernel's per-wave descent logs
@@ -291,6 +295,8 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     *out = nullptr;
     if (cfg->concurrent_games < 1 || cfg->max_explores < 1)
         return fail(nullptr, SYN_ERR_INVALID_ARGUMENT, "concurrent_games and max_explores must be >= 1");
+    if (cfg->policy_cache_log2 != 0 && (cfg->policy_cache_log2 < 10 || cfg->policy_cache_log2 > 30))
+        return fail(nullptr, SYN_ERR_INVALID_ARGUMENT, "policy_cache_log2 must be 0 (off) or 10..30");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, SYN_ERR_NO_DEVICE, "no HIP device visible (the engine has no CPU fallback)");
@@ -330,6 +336,13 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     size_t nodes = (size_t)h->pool_slots * h->cap;
     if ((e = hipMalloc(&h->d_stat, nodes * 32)) != hipSuccess) return bail("hipMalloc(node pool)", e);
     h->d_edge = reinterpret_cast<uint4*>(h->d_stat);  // same records, edge half = odd 16-byte elements
+    if (cfg->policy_cache_log2 != 0) {
+        h->cache_log2 = cfg->policy_cache_log2;
+        const size_t bytes = (size_t)64 << h->cache_log2;
+        if ((e = hipMalloc(&h->d_cache, bytes)) != hipSuccess) return bail("hipMalloc(policy cache)", e);
+        if ((e = hipMemset(h->d_cache, 0, bytes)) != hipSuccess) return bail("hipMemset(policy cache)", e);  // empty: an all-zero entry never verifies
+    }
+    if ((e = hipMalloc(&h->d_cache_stats, 16)) != hipSuccess) return bail("hipMalloc(cache stats)", e);
     if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
     if ((e = hipMalloc(&h->d_job_next, 64)) != hipSuccess) return bail("hipMalloc(job)", e);
     if ((e = hipMalloc(&h->d_counters, sizeof(DevCounters))) != hipSuccess) return bail("hipMalloc(counters)", e);
@@ -346,6 +359,8 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_job_next);
     hipFree(h->d_path);
     hipFree(h->d_train_data);
+    hipFree(h->d_cache);
+    hipFree(h->d_cache_stats);
     hipFree(h->d_counters);
     hipFree(h->d_plies);
     hipFree(h->d_states);
@@ -550,6 +565,9 @@ static int common_params(syn_engine* h, EngineParams& P, int explores) {
     P.error = h->d_job_next + 8;  // same 64-byte block, zeroed before every launch
     P.path = nullptr;
     P.lane_thresh = 48;
+    P.cache = h->d_cache;
+    P.cache_shift = (uint32_t)(64 - h->cache_log2);
+    P.cache_stats = h->d_cache_stats;
     P.counters = h->d_counters;
     return SYN_OK;
 }
@@ -581,6 +599,7 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
     HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_cache_stats, 0, 16, h->stream));
     P.roll.num_explores = explores;
     P.n_jobs = n;
     P.in_my = d_my;
@@ -592,8 +611,12 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(results, d_res, nb * sizeof(DevSearchResult), hipMemcpyDeviceToHost, h->stream));
     int kerr = 0;
+    unsigned long long cstats[2] = {0, 0};
     HIP_TRY(h, hipMemcpyAsync(&kerr, h->d_job_next + 8, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(cstats, h->d_cache_stats, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->last_cache_hits = cstats[0];
+    h->last_cache_misses = cstats[1];
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
@@ -661,6 +684,7 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     P.root_nodes = h->d_root_nodes;
     P.final_kind = h->d_final;
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_cache_stats, 0, 16, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), h->stream));
     // SYN_PROFILE=1: diagnostic build of the kernel with s_memtime stamps around each phase (never timed/benched)
     const bool prof = !counters && std::getenv("SYN_PROFILE") != nullptr;
@@ -723,8 +747,12 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (counters)
         HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
     int kerr = 0;
+    unsigned long long cstats[2] = {0, 0};
     HIP_TRY(h, hipMemcpyAsync(&kerr, h->d_job_next + 8, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(cstats, h->d_cache_stats, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->last_cache_hits = cstats[0];
+    h->last_cache_misses = cstats[1];
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
@@ -994,6 +1022,13 @@ int syn_last_timing(const syn_engine* h, float* kernel_ms, int* n_launches) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (kernel_ms) *kernel_ms = h->last_kernel_ms;
     if (n_launches) *n_launches = h->last_launches;
+    return SYN_OK;
+}
+
+int syn_last_cache_stats(const syn_engine* h, uint64_t* hits, uint64_t* misses) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (hits) *hits = h->last_cache_hits;
+    if (misses) *misses = h->last_cache_misses;
     return SYN_OK;
 }
 

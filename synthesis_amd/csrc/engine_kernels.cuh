@@ -45,6 +45,9 @@ struct EngineParams {
     unsigned long long* prof;      // PROF builds: per-wave cycle sums [A, wait1, B, wait2, C, iterations]
     int* error;                    // set to 1 by a quad whose bounded spin gave up (quad-async kernel)
     int lane_thresh;               // lane kernel: a round ends once this many lanes of a wave stand on a leaf
+    uint4* cache;                  // lane kernel: PolicyWithCache table (4 x 16 B per entry), null = off
+    uint32_t cache_shift;          // 64 - log2(entries)
+    unsigned long long* cache_stats;  // [hits, misses]
     uint4* path;                   // lane kernel: per-wave descent log [wave][level 0..63][lane 0..63]
     // self-play
     unsigned long long base_seed;  // game g uses StdRng::seed_from_u64(base_seed + first_game + g)

@@ -86,6 +86,7 @@ struct LaneWalk {
 
 struct LaneLeaf {             // phase A -> phase C (valid for lanes with at_leaf)
     bool at_leaf;             // this lane finished its descent in this round
+    bool was_pending;         // ... in an earlier round (its position already missed the policy cache)
     uint32_t fc;              // first child of the node that needs its children created (valid if needs_eval)
     uint32_t legal_mask;
     bool needs_eval, solved;
@@ -137,6 +138,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
     const bool pending = active && Wk.pending;
     X.at_leaf = false;
+    X.was_pending = pending;
     X.needs_eval = pending;
     X.solved = false;
     X.p0 = X.p1 = X.p2 = 0.0f;
@@ -751,6 +753,58 @@ __device__ __attribute__((noinline)) LaneTree lane_search_finish_call(const Engi
     return t;
 }
 
+// ---------------------------------------------------------------------------------------------- PolicyWithCache
+// policies/cache.rs:19-32 on the device: memoises Policy::eval by position in one direct-mapped table shared by every game
+// of the engine (the reference keeps one HashMap per worker thread). Entry = 64 bytes = one HBM sector:
+//   { 12 output words (9 logits, 3 outcome probabilities) | my_bb ^ f | op_bb ^ rotl(f, 32) },  f = 64-bit fold of the outputs
+// Lanes of different CUs overwrite slots without any lock; an entry torn by concurrent writers (or never written: all
+// zero) fails the fold check and is simply a miss, so a hit always returns exactly what the network computed for that
+// position — the cache cannot change a result (the reference's argument for a deterministic net).
+SYN_DEV uint64_t cache_mix(uint64_t h, uint64_t w) {
+    h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+SYN_DEV uint64_t cache_slot(uint64_t my, uint64_t op, uint32_t shift) {
+    return cache_mix(cache_mix(0x243F6A8885A308D3ull, my), op) >> shift;
+}
+SYN_DEV uint64_t cache_fold(const float (&lg)[9], float v0, float v1, float v2) {
+    uint64_t h = 0x13198A2E03707344ull;
+    h = cache_mix(h, (uint64_t)f32_bits(lg[0]) | ((uint64_t)f32_bits(lg[1]) << 32));
+    h = cache_mix(h, (uint64_t)f32_bits(lg[2]) | ((uint64_t)f32_bits(lg[3]) << 32));
+    h = cache_mix(h, (uint64_t)f32_bits(lg[4]) | ((uint64_t)f32_bits(lg[5]) << 32));
+    h = cache_mix(h, (uint64_t)f32_bits(lg[6]) | ((uint64_t)f32_bits(lg[7]) << 32));
+    h = cache_mix(h, (uint64_t)f32_bits(lg[8]) | ((uint64_t)f32_bits(v0) << 32));
+    h = cache_mix(h, (uint64_t)f32_bits(v1) | ((uint64_t)f32_bits(v2) << 32));
+    return h;
+}
+SYN_DEV bool cache_lookup(const uint4* table, uint32_t shift, uint64_t my, uint64_t op, float (&lg)[9], float& v0, float& v1,
+                          float& v2) {
+    const uint4* e = table + cache_slot(my, op, shift) * 4;
+    const uint4 a = e[0], b = e[1], c = e[2], d = e[3];
+    float t[9] = {bits_f32(a.x), bits_f32(a.y), bits_f32(a.z), bits_f32(a.w), bits_f32(b.x), bits_f32(b.y), bits_f32(b.z),
+                  bits_f32(b.w), bits_f32(c.x)};
+    const float u0 = bits_f32(c.y), u1 = bits_f32(c.z), u2 = bits_f32(c.w);
+    const uint64_t f = cache_fold(t, u0, u1, u2);
+    const uint64_t k0 = (uint64_t)d.x | ((uint64_t)d.y << 32), k1 = (uint64_t)d.z | ((uint64_t)d.w << 32);
+    const bool hit = (k0 ^ f) == my && (k1 ^ ((f << 32) | (f >> 32))) == op;
+    if (hit) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) lg[i] = t[i];
+        v0 = u0; v1 = u1; v2 = u2;
+    }
+    return hit;
+}
+SYN_DEV void cache_insert(uint4* table, uint32_t shift, uint64_t my, uint64_t op, const float (&lg)[9], float v0, float v1,
+                          float v2) {
+    uint4* e = table + cache_slot(my, op, shift) * 4;
+    const uint64_t f = cache_fold(lg, v0, v1, v2);
+    const uint64_t k0 = my ^ f, k1 = op ^ ((f << 32) | (f >> 32));
+    e[0] = make_uint4(f32_bits(lg[0]), f32_bits(lg[1]), f32_bits(lg[2]), f32_bits(lg[3]));
+    e[1] = make_uint4(f32_bits(lg[4]), f32_bits(lg[5]), f32_bits(lg[6]), f32_bits(lg[7]));
+    e[2] = make_uint4(f32_bits(lg[8]), f32_bits(v0), f32_bits(v1), f32_bits(v2));
+    e[3] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), (uint32_t)k1, (uint32_t)(k1 >> 32));
+}
+
 // ---------------------------------------------------------------------------------------------- the kernel
 template <int NW>
 struct LaneLds {
@@ -795,6 +849,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     const int n_explores = P.roll.num_explores;
     const int thresh = P.lane_thresh;
     unsigned char* const idxw = smem_raw + LaneLds<NW>::IDX_OFF + wave * 64;  // compaction: rank -> lane
+    unsigned long long cache_hits = 0, cache_misses = 0;
     LaneWalk Wk;
     Wk.descending = false;
     Wk.pending = false;
@@ -812,15 +867,29 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         SYN_LAP(pA)
         // ---- phase B: the lanes that need the network, compacted into tiles of 16 positions. While other lanes are still
         // descending only whole tiles are evaluated: requests beyond `thresh` stay pending and go first next round.
-        bool need = X.at_leaf && X.needs_eval;
+        const bool want_nn = X.at_leaf && X.needs_eval;  // this lane's expanded leaf needs Policy::eval
+        float lg[9];
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; c++) lg[c] = 0.0f;
+        // PolicyWithCache: a position that some game already evaluated skips the network (and its tile slot)
+        bool hit = false;
+        if (P.cache != nullptr && want_nn && !X.was_pending) {
+            hit = cache_lookup(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
+        }
+        bool need = want_nn && !hit;
         const unsigned long long want_mask = __ballot(need);
+        if (P.cache != nullptr) {  // wave-uniform tallies (scalar registers), flushed once at the end of the kernel
+            cache_hits += (unsigned long long)__popcll(__ballot(hit));
+            cache_misses += (unsigned long long)__popcll(__ballot(want_nn && !hit && !X.was_pending));
+        }
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(want_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want_mask, 0u));
         const int quota = __ballot(Wk.descending) != 0ull ? thresh : 64;
         Wk.pending = need && rank >= quota;
         if (Wk.pending) { Wk.pend_fc = X.fc; Wk.pend_lmask = X.legal_mask; }
         need = need && rank < quota;
         const bool fin = X.at_leaf && !Wk.pending;  // this lane's explore gets its network call / backprop in this round
-        if (COUNT && need) ctr[CTR_POLICY_EVALS]++;
+        if (COUNT && (need || hit)) ctr[CTR_POLICY_EVALS]++;
         const unsigned long long need_mask = __ballot(need);
         const int n_need = __popcll(need_mask);
         idxw[lane] = 0;
@@ -832,10 +901,6 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint64_t hi, lo;
         feature_boards(Wk.my, Wk.op, hi, lo);
-        float lg[9];
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 9; c++) lg[c] = 0.0f;
 #pragma unroll 1
         for (int j = 0; j * 16 < n_need; j++) {
             if (PROF) pTiles++;
@@ -869,10 +934,12 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         SYN_LAP(pB)
         if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(fin)); pEvals += (unsigned long long)n_need; }
 
+        if (P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
+
         // ---- phase C
         float d0 = X.p0, d1 = X.p1, d2 = X.p2;
         bool solved = X.solved;
-        if (need) {
+        if (need || hit) {
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
             solved = lane_create_children(T.slab, X, Wk.my, Wk.op, lg,
@@ -884,7 +951,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         }
         SYN_LAP(pC1)
         unsigned long long tmid = 0;
-        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, d0, d1, d2, solved, X.solved && !need, fin, pl, cap, ctr,
+        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, d0, d1, d2, solved, X.solved && !(need || hit), fin, pl, cap, ctr,
                                    PROF ? &tmid : nullptr);
         if (PROF) { pC2 += tmid - pT; pT = tmid; }
         SYN_LAP(pC)
@@ -911,6 +978,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         }
     }
 
+    if (P.cache != nullptr && lane == 0 && (cache_hits | cache_misses) != 0ull) {
+        atomicAdd(P.cache_stats + 0, cache_hits);
+        atomicAdd(P.cache_stats + 1, cache_misses);
+    }
     if (COUNT) {
         if (P.counters) {
 #pragma unroll

@@ -17,7 +17,7 @@ NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/p
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -105,6 +105,7 @@ def load_library():
                                     [C.c_void_p] * 8
     lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.syn_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.syn_last_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.syn_debug_stdrng_u32.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
@@ -144,10 +145,10 @@ def shard_games(n_games, rank, world_size):
 class Engine:
     """One handle = one GPU + one stream (the reference's one policy per worker thread, alpha_zero.rs:192-198)."""
 
-    def __init__(self, concurrent_games=4096, max_explores=800, device=0):
+    def __init__(self, concurrent_games=4096, max_explores=800, device=0, policy_cache_log2=0):
         self._lib = load_library()
         self._h = C.c_void_p()
-        cfg = CEngineConfig(int(concurrent_games), int(max_explores), 0, 0)
+        cfg = CEngineConfig(int(concurrent_games), int(max_explores), int(policy_cache_log2), 0)
         rc = self._lib.syn_engine_create(C.byref(cfg), int(device), C.byref(self._h))
         if rc != 0:
             msg = self._lib.syn_last_error(None)
@@ -271,6 +272,12 @@ class Engine:
             r["counters"] = {name: int(getattr(ctr, name)) for name, _ in CCounters._fields_}
         r["kernel_ms"] = self.last_kernel_ms()
         return r
+
+    def last_cache_stats(self):
+        """(hits, misses) of the device PolicyWithCache during the last search / self-play call."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.syn_last_cache_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def last_launch_shape(self):
         """(shape, workgroups, threads per workgroup) of the last search / self-play launch; shape 4 = lane-per-tree."""

@@ -442,6 +442,41 @@ def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
     eng.close()
 
 
+@pytest.mark.parametrize("log2", [10, 22])
+def test_policy_cache_is_semantics_neutral(blob, oracle, monkeypatch, log2):
+    """PolicyWithCache on the device (policies/cache.rs:19-32; lane-per-tree kernel): searches and whole self-play games
+    are bit-identical to the oracle whether a position's evaluation came from the table or from the network — also with
+    a 1,024-entry table where almost every slot is fought over by concurrent games (torn / overwritten entries must
+    read as misses) — and the big table does hit."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    monkeypatch.setenv("SYN_LANES", "8")
+    eng = sa.Engine(concurrent_games=1100, max_explores=800, policy_cache_log2=log2)
+    eng.load_weights(blob)
+    my, op = random_positions(oracle, 300, seed=31, max_moves=60)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
+    for rep in range(2):  # the second pass finds the first pass's entries
+        got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
+        assert_search_equal(got, ref, f"cache 2^{log2} search pass {rep}")
+    hits, misses = eng.last_cache_stats()
+    assert hits + misses > 0 and (log2 == 10 or hits > misses)
+    ref = oracle.c4_selfplay(parity_rollout_config(50), blob, 77, 2500, threads=8, nn_mode=oracle.ACC_FMA)
+    got = eng.selfplay(sa.parity_rollout_config(50), base_seed=77, n_games=2500, counters=True)
+    assert eng.last_launch_shape()[0] == 4
+    assert_selfplay_equal(got, ref, f"cache 2^{log2} self-play")
+    hits, misses = eng.last_cache_stats()
+    assert hits + misses == got["counters"]["policy_evals"] == ref["counters"]["policy_evals"]
+    if log2 == 22:
+        assert hits > 0.3 * (hits + misses)  # openings and re-searched subtrees repeat
+    got = eng.selfplay(sa.parity_rollout_config(800), base_seed=5, n_games=6)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 5, 6, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"cache 2^{log2} 800 explores")
+    eng.close()
+    with pytest.raises(sa.SynthesisAmdError):
+        sa.Engine(concurrent_games=64, max_explores=64, policy_cache_log2=5)
+
+
 def test_selfplay_full_size_properties(blob, oracle, monkeypatch):
     """BASELINE full size: 4096 concurrent games x 800 explores. Too big for the oracle, so size-independent
     properties: replaying the recorded actions with the oracle's Connect4 reproduces every recorded position and ends

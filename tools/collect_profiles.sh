@@ -9,7 +9,7 @@ R=$PWD
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT $R/gpurun_out/prof_trace $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
 export TMPDIR=/tmp
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096"
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache"
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $BENCH > $OUT/bench_under_trace.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $BENCH > $OUT/bench_under_fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $BENCH > $OUT/bench_under_write.log 2>&1
@@ -34,7 +34,7 @@ fetch_kb = sum(float(r["Counter_Value"]) for r in f) / max(1, len(f))
 write_kb = sum(float(r["Counter_Value"]) for r in w) / max(1, len(w))
 ks = [r for r in rows(f"{out}/{tag}_kernel_stats.csv") if "selfplay_kernel_lanes<0, false" in r["Name"]]
 summary = {
-    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096",
+    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache",
     "kernel": ks[0]["Name"] if ks else None,
     "kernel_calls": int(ks[0]["Calls"]) if ks else None,
     "kernel_avg_ms": float(ks[0]["AverageNs"]) / 1e6 if ks else None,

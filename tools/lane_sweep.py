@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Developer tool: throughput of the lane-per-tree kernel. Args: conc:nw[:games] ... (nw = waves per workgroup, 0 = row kernels)"""
+"""Developer tool: throughput of the lane-per-tree kernel. Args: conc:nw[:games[:policy_cache_log2]] ... (nw = waves per
+workgroup, 0 = the engine's own choice)"""
 import os, sys, time
 import numpy as np
 import torch  # noqa
@@ -13,13 +14,16 @@ cfg = sa.parity_rollout_config(800)
 for c in combos:
     conc, nw = c[0], c[1]
     n = c[2] if len(c) > 2 else 2 * conc
+    clog = c[3] if len(c) > 3 else 0
     if nw: os.environ["SYN_LANES"] = str(nw)
     else: os.environ.pop("SYN_LANES", None)
-    eng = sa.Engine(concurrent_games=conc, max_explores=800)
+    eng = sa.Engine(concurrent_games=conc, max_explores=800, policy_cache_log2=clog)
     eng.load_weights(blob)
     eng.selfplay(cfg, 0, 256, outputs=False)
     t0 = time.perf_counter()
     r = eng.selfplay(cfg, 0, n, first_game=conc, outputs=False)
     dt = time.perf_counter() - t0
-    print(f"concurrent={conc} lanes_nw={nw}: {n} games in {dt:.3f} s = {n / dt:.0f} games/s  (mean plies {r['plies'].mean():.2f})", flush=True)
+    hits, misses = eng.last_cache_stats()
+    extra = f"  policy cache 2^{clog}: {hits / max(1, hits + misses):.3f} hit rate" if clog else ""
+    print(f"concurrent={conc} lanes_nw={nw}: {n} games in {dt:.3f} s = {n / dt:.0f} games/s  (mean plies {r['plies'].mean():.2f}){extra}", flush=True)
     eng.close()
