@@ -790,9 +790,24 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
     auto k = train_grad_kernel;
     const size_t lds = (size_t)TrainGeom::LDS_FLOATS * 4;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // SYN_TRAIN_PROFILE=1: diagnostic stamps of the kernel's phases (first chunk), printed to stderr
+    static const bool prof = std::getenv("SYN_TRAIN_PROFILE") != nullptr;
+    unsigned long long* d_prof = nullptr;
+    if (prof) {
+        HIP_TRY(h, hipMalloc(&d_prof, 4096));
+        HIP_TRY(h, hipMemsetAsync(d_prof, 0, 4096, h->stream));
+    }
     hipLaunchKernelGGL(k, dim3(1), dim3(1024), lds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
-                       d_grads, d_losses ? d_losses : h->d_tloss, d_idx);
+                       d_grads, d_losses ? d_losses : h->d_tloss, d_idx, d_prof);
     HIP_TRY(h, hipGetLastError());
+    if (prof) {
+        unsigned long long t[8] = {0};
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipMemcpy(t, d_prof, sizeof(t), hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipFree(d_prof));
+        fprintf(stderr, "[syn train profile] cycles: features %llu forward %llu heads %llu backward %llu param-grads %llu\n",
+                t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4]);
+    }
     return SYN_OK;
 }
 
@@ -900,18 +915,30 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
                         h->train_data_n);
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = h->train_data_n, ni = n_steps * (size_t)batch;
-    int rc = ensure_scratch(h, ni * 4 + n_steps * 8 + 256);
+    // scratch: [perm ni x 4][losses n_steps x 8][step-ordered batches: my, op (8 B each), pi (36 B), v (12 B) per sample]
+    const size_t perm_bytes = (ni * 4 + 255) & ~(size_t)255, loss_bytes = (n_steps * 8 + 255) & ~(size_t)255;
+    int rc = ensure_scratch(h, perm_bytes + loss_bytes + ni * 64 + 256);
     if (rc != SYN_OK) return rc;
-    int* d_perm = static_cast<int*>(h->d_scratch);
-    float* d_losses = reinterpret_cast<float*>(d_perm + ((ni + 63) & ~(size_t)63));
+    unsigned char* sc = static_cast<unsigned char*>(h->d_scratch);
+    int* d_perm = reinterpret_cast<int*>(sc);
+    float* d_losses = reinterpret_cast<float*>(sc + perm_bytes);
+    unsigned long long* g_my = reinterpret_cast<unsigned long long*>(sc + perm_bytes + loss_bytes);
+    unsigned long long* g_op = g_my + ni;
+    float* g_tpi = reinterpret_cast<float*>(g_op + ni);
+    float* g_tv = g_tpi + ni * 9;
     HIP_TRY(h, hipMemcpyAsync(d_perm, perm, ni * 4, hipMemcpyHostToDevice, h->stream));
     const unsigned char* base = static_cast<const unsigned char*>(h->d_train_data);
-    const unsigned long long* d_my = reinterpret_cast<const unsigned long long*>(base);
-    const unsigned long long* d_op = reinterpret_cast<const unsigned long long*>(base + n * 8);
-    const float* d_tpi = reinterpret_cast<const float*>(base + n * 16);
-    const float* d_tv = reinterpret_cast<const float*>(base + n * 52);
+    // one gather for the whole epoch (the sampler's index_select), so a step reads its batch from consecutive addresses
+    // instead of chasing perm -> sample inside the latency-bound step kernel
+    hipLaunchKernelGGL(train_gather_kernel, dim3((unsigned)((ni * 16 + 255) / 256)), dim3(256), 0, h->stream, d_perm, (int)ni,
+                       reinterpret_cast<const unsigned long long*>(base),
+                       reinterpret_cast<const unsigned long long*>(base + n * 8),
+                       reinterpret_cast<const float*>(base + n * 16), reinterpret_cast<const float*>(base + n * 52), g_my,
+                       g_op, g_tpi, g_tv);
+    HIP_TRY(h, hipGetLastError());
     for (size_t s = 0; s < n_steps; s++) {  // steps are dependent (weights of step s feed step s+1): queued, never synced
-        rc = launch_grads(h, d_my, d_op, d_tpi, d_tv, batch, h->d_tgrad, d_losses + 2 * s, d_perm + s * (size_t)batch);
+        const size_t o = s * (size_t)batch;
+        rc = launch_grads(h, g_my + o, g_op + o, g_tpi + o * 9, g_tv + o * 3, batch, h->d_tgrad, d_losses + 2 * s);
         if (rc != SYN_OK) return rc;
         rc = launch_adam(h, h->d_tgrad, lr, 1.0f);
         if (rc != SYN_OK) return rc;

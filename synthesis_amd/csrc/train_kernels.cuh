@@ -6,7 +6,8 @@
 //
 // The reference trains with batch_size 32 on a 30,492-parameter MLP: one optimiser step is ~3 MFLOP — far too small for
 // anything but latency to matter. train_grad_kernel therefore runs the whole forward + backward of a minibatch in ONE
-// workgroup with every activation and activation-gradient resident in LDS (99 KB) plus the current layer's weights (49 KB, staged per layer), one thread per output element and
+// workgroup with every activation and activation-gradient resident in LDS (104 KB) plus the current layer's weights (49 KB,
+// staged per layer), register-tiled threads (4 outputs x 2 samples forward/backward, 4 x 4 parameters for dW) and
 // fixed-order fma chains (bit-identical to oracle/train.hpp); gradients go to a caller-provided device buffer so that a
 // data-parallel run can all-reduce them (RCCL, 122 KB) before adam_kernel applies the update.
 #pragma once
@@ -19,7 +20,10 @@ struct TrainGeom {
     static constexpr int D[NL + 1] = {63, 128, 96, 64, 48, 12};
     static constexpr int NUM_PARAMS = 30492;
     static constexpr int CHUNK = 32;  // samples resident in LDS at a time (the reference's batch_size)
-    __host__ __device__ static constexpr int stride(int l) { return D[l] | 1; }  // odd row stride: conflict-free columns
+    // activation rows: width rounded up to a multiple of 4 (16-byte vector reads along k) plus 4 floats of skew, which
+    // spreads the rows of the 16 sample tiles of a wave over all LDS banks
+    __host__ __device__ static constexpr int kp(int l) { return (D[l] + 3) & ~3; }     // padded width of layer l's input
+    __host__ __device__ static constexpr int stride(int l) { return kp(l) + 4; }
     __host__ __device__ static constexpr int w_off(int l) {
         int off = 0;
         for (int i = 0; i < l; i++) off += D[i] * D[i + 1] + D[i + 1];
@@ -31,21 +35,192 @@ struct TrainGeom {
         for (int i = 0; i < l; i++) off += CHUNK * stride(i);
         return off;
     }
-    static constexpr int A_FLOATS = CHUNK * (65 + 129 + 97 + 65 + 49 + 13);
+    static constexpr int A_FLOATS = CHUNK * (68 + 132 + 100 + 68 + 52 + 16);
     __host__ __device__ static constexpr int d_off(int l) {  // activation gradients dZ[l], l = 1..5
         int off = A_FLOATS;
         for (int i = 1; i < l; i++) off += CHUNK * stride(i);
         return off;
     }
-    static constexpr int KL_OFF = A_FLOATS + CHUNK * (129 + 97 + 65 + 49 + 13);  // per-sample KL terms [CHUNK][2]
-    static constexpr int WL_OFF = (KL_OFF + 2 * CHUNK + 3) & ~3;   // the current layer's weights, staged per layer (16-B aligned)
+    static constexpr int KL_OFF = A_FLOATS + CHUNK * (132 + 100 + 68 + 52 + 16);  // per-sample KL terms [CHUNK][2]
+    static constexpr int WL_OFF = (KL_OFF + 2 * CHUNK + 3) & ~3;   // the current layer's weights [O][kp], staged per layer
     static constexpr int WL_FLOATS = 128 * 96;                    // largest layer
-    static constexpr int LDS_FLOATS = WL_OFF + WL_FLOATS;
+    static constexpr int LDS_FLOATS = WL_OFF + WL_FLOATS;         // 38,464 floats = 153,856 B
 };
 
 struct DevTrainHyper {
     float weight_decay, policy_weight, value_weight, beta1, beta2, eps;
 };
+
+typedef float tf4 __attribute__((ext_vector_type(4)));
+
+// Where layer L's weights sit inside the staging buffer: layers 0 and 1 use it alone, layers 2, 3 and 4 (24 + 12 + 2 KB)
+// share it, so they are staged once for the forward pass and are still there for the backward pass.
+__host__ __device__ constexpr int train_wl_off(int L) {
+    return TrainGeom::WL_OFF + (L == 3 ? 96 * 64 : (L == 4 ? 96 * 64 + 64 * 48 : 0));
+}
+
+// Copies layer L's weights [O][K] (global, row-major) into LDS rows of kp floats (zero padded).
+template <int L>
+SYN_DEV void train_stage_weights(const float* __restrict__ w, float* __restrict__ lds, int tid) {
+    using G = TrainGeom;
+    constexpr int K = G::D[L], O = G::D[L + 1], KP = G::kp(L);
+    const float* src = w + G::w_off(L);
+    float* dst = lds + train_wl_off(L);
+    // all loads are issued before the first store (a load -> store loop would expose one global round trip per iteration)
+    if (K == KP) {
+        constexpr int N = K * O / 4, IT = (N + 1023) / 1024;
+        tf4 r[IT];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * 1024;
+            r[it] = i < N ? reinterpret_cast<const tf4*>(src)[i] : tf4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * 1024;
+            if (i < N) reinterpret_cast<tf4*>(dst)[i] = r[it];
+        }
+    } else {
+        constexpr int N = KP * O, IT = (N + 1023) / 1024;
+        float r[IT];
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * 1024, o = i / KP, kk = i - o * KP;
+            r[it] = (i < N && kk < K) ? src[o * K + kk] : 0.0f;
+        }
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * 1024;
+            if (i < N) dst[i] = r[it];
+        }
+    }
+}
+
+// Forward layer L for the 32 samples of the chunk: thread tile = 4 outputs x 2 samples, each output an independent
+// chain  fma(x[K-1], w[K-1], ... fma(x[0], w[0], bias))  in ascending k (oracle/train.hpp).
+template <int L>
+SYN_DEV void train_forward_layer(const float* __restrict__ w, float* __restrict__ lds, int tid) {
+    using G = TrainGeom;
+    constexpr int K = G::D[L], O = G::D[L + 1], KP = G::kp(L), SA = G::stride(L), SO = G::stride(L + 1);
+    constexpr int K4 = K & ~3;
+    if (tid < O * 4) {
+        const int o0 = (tid >> 4) * 4, b0 = (tid & 15) * 2;
+        const float* W = lds + train_wl_off(L) + o0 * KP;
+        const float* A = lds + G::a_off(L) + b0 * SA;
+        const float* bias = w + G::b_off(L) + o0;
+        float acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i][0] = acc[i][1] = bias[i];
+#pragma unroll 2
+        for (int k = 0; k < K4; k += 4) {
+            tf4 wv[4], av[2];
+#pragma unroll
+            for (int i = 0; i < 4; i++) wv[i] = *reinterpret_cast<const tf4*>(W + i * KP + k);
+#pragma unroll
+            for (int j = 0; j < 2; j++) av[j] = *reinterpret_cast<const tf4*>(A + j * SA + k);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) acc[i][j] = __builtin_fmaf(av[j][kk], wv[i][kk], acc[i][j]);
+        }
+#pragma unroll
+        for (int k = K4; k < K; k++)  // tail of the 63-wide first layer (no padded term: -0 + 0 would not be an identity)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_fmaf(A[j * SA + k], W[i * KP + k], acc[i][j]);
+        float* Aout = lds + G::a_off(L + 1) + b0 * SO + o0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            tf4 r;
+#pragma unroll
+            for (int i = 0; i < 4; i++) r[i] = (L < G::NL - 1) ? (acc[i][j] > 0.0f ? acc[i][j] : 0.0f) : acc[i][j];
+            *reinterpret_cast<tf4*>(Aout + j * SO) = r;
+        }
+    }
+}
+
+// dA of layer L's INPUT (L = 4..1): dA[b][k] = relu'(A[b][k]) * chain over o ascending of fma(dZ[b][o], W[o][k], .)
+template <int L>
+SYN_DEV void train_backward_act(float* __restrict__ lds, int tid) {
+    using G = TrainGeom;
+    constexpr int K = G::D[L], O = G::D[L + 1], KP = G::kp(L), SA = G::stride(L), SZ = G::stride(L + 1);
+    if (tid < K * 4) {  // K / 4 column tiles x 16 sample tiles
+        const int k0 = (tid >> 4) * 4, b0 = (tid & 15) * 2;
+        const float* W = lds + train_wl_off(L) + k0;
+        const float* dZ = lds + G::d_off(L + 1) + b0 * SZ;
+        tf4 a[2];
+        a[0] = a[1] = tf4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int o = 0; o < O; o += 4) {
+            tf4 dz[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) dz[j] = *reinterpret_cast<const tf4*>(dZ + j * SZ + o);
+#pragma unroll
+            for (int oo = 0; oo < 4; oo++) {
+                const tf4 wv = *reinterpret_cast<const tf4*>(W + (o + oo) * KP);
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) a[j][kk] = __builtin_fmaf(dz[j][oo], wv[kk], a[j][kk]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const tf4 act = *reinterpret_cast<const tf4*>(lds + G::a_off(L) + (b0 + j) * SA + k0);
+            tf4 r;
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) r[kk] = act[kk] > 0.0f ? a[j][kk] : 0.0f;
+            *reinterpret_cast<tf4*>(lds + G::d_off(L) + (b0 + j) * SA + k0) = r;
+        }
+    }
+}
+
+// dW / db of layer L: thread tile = 4 outputs x 4 inputs, chains over the samples in ascending order, continued across
+// chunks through the gradient buffer.
+// T0 = first thread of the range that works on this layer (several layers run side by side on disjoint thread ranges).
+template <int L, int T0>
+SYN_DEV void train_param_grads(const float* __restrict__ lds, float* __restrict__ grads, int nb, bool first_chunk, int tid_) {
+    using G = TrainGeom;
+    constexpr int K = G::D[L], O = G::D[L + 1], KP = G::kp(L), SA = G::stride(L), SZ = G::stride(L + 1);
+    constexpr int KT = KP / 4;
+    static_assert(T0 + (O / 4) * KT <= 1024, "thread range");
+    const int tid = tid_ - T0;
+    if (tid >= 0 && tid < (O / 4) * KT) {
+        const int o0 = (tid / KT) * 4, k0 = (tid % KT) * 4;
+        const float* dZ = lds + G::d_off(L + 1) + o0;
+        const float* A = lds + G::a_off(L) + k0;
+        float* gW = grads + G::w_off(L);
+        float* gb = grads + G::b_off(L);
+        float g[4][4], db[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            db[i] = (first_chunk || k0 != 0) ? 0.0f : gb[o0 + i];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) g[i][kk] = (first_chunk || k0 + kk >= K) ? 0.0f : gW[(o0 + i) * K + k0 + kk];
+        }
+#pragma unroll 4
+        for (int b = 0; b < nb; b++) {
+            const tf4 dz = *reinterpret_cast<const tf4*>(dZ + b * SZ);
+            const tf4 av = *reinterpret_cast<const tf4*>(A + b * SA);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) g[i][kk] = __builtin_fmaf(dz[i], av[kk], g[i][kk]);
+                db[i] += dz[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                if (k0 + kk < K) gW[(o0 + i) * K + k0 + kk] = g[i][kk];
+            if (k0 == 0) gb[o0 + i] = db[i];
+        }
+    }
+}
 
 // grads[NUM_PARAMS] (device) receives d(loss)/d(param) of the minibatch; losses[0..1] = pi_loss, v_loss.
 // Positions are given as bitboards; features are generated in the kernel (connect4.rs:235-258).
@@ -55,53 +230,64 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
                                                           const float* __restrict__ tpi, const float* __restrict__ tv,
                                                           int B, DevTrainHyper hp, float* __restrict__ grads,
                                                           float* __restrict__ losses,
-                                                          const int* __restrict__ idx = nullptr) {
+                                                          const int* __restrict__ idx = nullptr,
+                                                          unsigned long long* __restrict__ prof = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using G = TrainGeom;
     const int tid = threadIdx.x;
+    int pslot = 0;
+#define SYN_TSTAMP() do { if (prof && tid == 0) prof[pslot++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+    SYN_TSTAMP();
     const float bm = 1.0f / (float)B;
     float pi_acc = 0.0f, v_acc = 0.0f;  // thread 0 only
 
     for (int c0 = 0; c0 < B; c0 += G::CHUNK) {
         const int nb = B - c0 < G::CHUNK ? B - c0 : G::CHUNK;
-        // ---- features -> A[0]
-        for (int i = tid; i < G::CHUNK * 63; i += 1024) {
-            int b = i / 63, f = i - b * 63;
-            float x = 0.0f;
-            if (b < nb) {
-                const size_t s = idx ? (size_t)idx[c0 + b] : (size_t)(c0 + b);  // BatchRandSampler's index_select
-                uint64_t my = my_bb[s], op = op_bb[s];
-                x = c4::feature(my, op, c4::next_free_cells(my | op), f);
+        // ---- layer 0's weights, the features and the targets are all global-latency bound: issue them together
+        train_stage_weights<0>(w, lds, tid);
+        float tgt[9];  // this (sample, head) thread's target row, consumed after the forward pass
+#pragma unroll
+        for (int j = 0; j < 9; j++) tgt[j] = 0.0f;
+        if (tid < 2 * G::CHUNK && (tid >> 1) < nb) {
+            const int b = tid >> 1;
+            const size_t si = idx ? (size_t)idx[c0 + b] : (size_t)(c0 + b);
+            if ((tid & 1) == 0) {
+#pragma unroll
+                for (int j = 0; j < 9; j++) tgt[j] = tpi[si * 9 + j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 3; j++) tgt[j] = tv[si * 3 + j];
             }
-            lds[G::a_off(0) + b * G::stride(0) + f] = x;
+        }
+        // ---- features -> A[0] (columns 63.. of the padded rows are zero); 2 elements per thread, boards loaded first
+        {
+            uint64_t bmy[2], bop[2];
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int b = (tid + it * 1024) >> 6;
+                const size_t s = b < nb ? (idx ? (size_t)idx[c0 + b] : (size_t)(c0 + b)) : 0;  // BatchRandSampler's index_select
+                bmy[it] = b < nb ? my_bb[s] : 0ull;
+                bop[it] = b < nb ? op_bb[s] : 0ull;
+            }
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int i = tid + it * 1024, b = i >> 6, f = i & 63;
+                float x = 0.0f;
+                if (b < nb && f < 63) x = c4::feature(bmy[it], bop[it], c4::next_free_cells(bmy[it] | bop[it]), f);
+                lds[G::a_off(0) + b * G::stride(0) + f] = x;
+            }
         }
         __syncthreads();
-        // ---- forward
-#pragma unroll
-        for (int l = 0; l < G::NL; l++) {
-            const int K = G::D[l], O = G::D[l + 1];
-            // stage the layer's weights in LDS: one coalesced pass instead of K dependent global loads per output
-            {
-                const float4* src = reinterpret_cast<const float4*>(w + G::w_off(l));
-                float4* dst = reinterpret_cast<float4*>(lds + G::WL_OFF);
-                for (int i = tid; i < K * O / 4; i += 1024) dst[i] = src[i];
-            }
-            __syncthreads();
-            const float* W = lds + G::WL_OFF;
-            const float* bias = w + G::b_off(l);
-            const float* Ain = lds + G::a_off(l);
-            float* Aout = lds + G::a_off(l + 1);
-            for (int i = tid; i < O * G::CHUNK; i += 1024) {
-                int o = i >> 5, b = i & 31;
-                float acc = bias[o];
-                const float* wr = W + o * K;
-                const float* ar = Ain + b * G::stride(l);
-                for (int k = 0; k < K; k++) acc = __builtin_fmaf(ar[k], wr[k], acc);
-                if (l < G::NL - 1) acc = acc > 0.0f ? acc : 0.0f;
-                Aout[b * G::stride(l + 1) + o] = acc;
-            }
-            __syncthreads();
-        }
+        SYN_TSTAMP();  // features
+        // ---- forward: stage the weights (one coalesced pass), then 4x2 register tiles
+        train_forward_layer<0>(w, lds, tid); __syncthreads();
+        train_stage_weights<1>(w, lds, tid); __syncthreads(); train_forward_layer<1>(w, lds, tid); __syncthreads();
+        train_stage_weights<2>(w, lds, tid); train_stage_weights<3>(w, lds, tid); train_stage_weights<4>(w, lds, tid);
+        __syncthreads();
+        train_forward_layer<2>(w, lds, tid); __syncthreads();
+        train_forward_layer<3>(w, lds, tid); __syncthreads();
+        train_forward_layer<4>(w, lds, tid); __syncthreads();
+        SYN_TSTAMP();  // forward
         // ---- heads: log_softmax + kl_div and their gradient; one thread per (sample, head)
         if (tid < 2 * G::CHUNK) {
             const int b = tid >> 1, head = tid & 1;
@@ -110,24 +296,36 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
             float kl = 0.0f;
             if (b < nb) {
                 const float* x = lds + G::a_off(5) + b * G::stride(5) + off;
-                const size_t si = idx ? (size_t)idx[c0 + b] : (size_t)(c0 + b);
-                const float* t = head == 0 ? tpi + si * 9 : tv + si * 3;
                 const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
-                float mx = x[0];
-                for (int j = 1; j < n; j++) mx = x[j] > mx ? x[j] : mx;
+                // fixed trip count 9 with predicates (the value head has 3 entries): tgt[] stays in registers
+                float xv[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) xv[j] = j < n ? x[j] : 0.0f;
+                float mx = xv[0];
+#pragma unroll
+                for (int j = 1; j < 9; j++) mx = (j < n && xv[j] > mx) ? xv[j] : mx;
                 float se = 0.0f;
-                for (int j = 0; j < n; j++) se += det_expf(x[j] - mx);
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    if (j < n) se += det_expf(xv[j] - mx);
                 const float lse = mx + det_logf(se);
                 float tsum = 0.0f;
-                for (int j = 0; j < n; j++) {
-                    float logp = x[j] - lse;
-                    if (t[j] > 0.0f) kl += t[j] * (det_logf(t[j]) - logp);
-                    tsum += t[j];
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    if (j < n) {
+                        const float logp = xv[j] - lse;
+                        if (tgt[j] > 0.0f) kl += tgt[j] * (det_logf(tgt[j]) - logp);
+                        tsum += tgt[j];
+                    }
                 }
                 const float s = weight * bm;
-                for (int j = 0; j < n; j++) dz[j] = s * (det_expf(x[j] - lse) * tsum - t[j]);
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    if (j < n) dz[j] = s * (det_expf(xv[j] - lse) * tsum - tgt[j]);
             } else {
-                for (int j = 0; j < n; j++) dz[j] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    if (j < n) dz[j] = 0.0f;
             }
             lds[G::KL_OFF + b * 2 + head] = kl;  // summed in sample order by thread 0 below
         }
@@ -138,57 +336,28 @@ __global__ __launch_bounds__(1024) void train_grad_kernel(const float* __restric
                 v_acc += lds[G::KL_OFF + b * 2 + 1];
             }
         }
-        // ---- backward: activation gradients for layers 4..1 (needs the OLD weights of every layer)
-#pragma unroll
-        for (int l = G::NL - 1; l >= 1; l--) {
-            const int K = G::D[l], O = G::D[l + 1];
-            const float* W = lds + G::WL_OFF;
-            const float* dZ = lds + G::d_off(l + 1);
-            const float* A = lds + G::a_off(l);
-            float* dA = lds + G::d_off(l);
-            __syncthreads();
-            {
-                const float4* src = reinterpret_cast<const float4*>(w + G::w_off(l));
-                float4* dst = reinterpret_cast<float4*>(lds + G::WL_OFF);
-                for (int i = tid; i < K * O / 4; i += 1024) dst[i] = src[i];
-            }
-            __syncthreads();
-            for (int i = tid; i < K * G::CHUNK; i += 1024) {
-                int k = i >> 5, b = i & 31;
-                float a = 0.0f;
-                const float* dz = dZ + b * G::stride(l + 1);
-                for (int o = 0; o < O; o++) a = __builtin_fmaf(dz[o], W[o * K + k], a);
-                dA[b * G::stride(l) + k] = A[b * G::stride(l) + k] > 0.0f ? a : 0.0f;
-            }
-        }
+        SYN_TSTAMP();  // heads
+        // ---- backward: activation gradients for layers 4..1 (layers 4, 3, 2 are still staged)
+        train_backward_act<4>(lds, tid); __syncthreads();
+        train_backward_act<3>(lds, tid); __syncthreads();
+        train_backward_act<2>(lds, tid); __syncthreads();
+        train_stage_weights<1>(w, lds, tid); __syncthreads(); train_backward_act<1>(lds, tid); __syncthreads();
+        SYN_TSTAMP();  // backward
+        // ---- parameter gradients (no barrier between the layers: they only read LDS)
+        // pass 1: layers 1 (768 threads), 3 (192) and 4 (36) side by side; pass 2: layers 0 (512) and 2 (384)
+        train_param_grads<1, 0>(lds, grads, nb, c0 == 0, tid);
+        train_param_grads<3, 768>(lds, grads, nb, c0 == 0, tid);
+        train_param_grads<4, 960>(lds, grads, nb, c0 == 0, tid);
+        train_param_grads<0, 0>(lds, grads, nb, c0 == 0, tid);
+        train_param_grads<2, 512>(lds, grads, nb, c0 == 0, tid);
         __syncthreads();
-        // ---- parameter gradients: one thread per parameter, chain over the samples continues across chunks
-#pragma unroll
-        for (int l = 0; l < G::NL; l++) {
-            const int K = G::D[l], O = G::D[l + 1];
-            const float* dZ = lds + G::d_off(l + 1);
-            const float* A = lds + G::a_off(l);
-            float* gW = grads + G::w_off(l);
-            float* gb = grads + G::b_off(l);
-            for (int i = tid; i < O * K; i += 1024) {
-                int o = i / K, k = i - o * K;
-                float a = c0 == 0 ? 0.0f : gW[i];
-                for (int b = 0; b < nb; b++)
-                    a = __builtin_fmaf(dZ[b * G::stride(l + 1) + o], A[b * G::stride(l) + k], a);
-                gW[i] = a;
-            }
-            for (int o = tid; o < O; o += 1024) {
-                float a = c0 == 0 ? 0.0f : gb[o];
-                for (int b = 0; b < nb; b++) a += dZ[b * G::stride(l + 1) + o];
-                gb[o] = a;
-            }
-        }
-        __syncthreads();
+        SYN_TSTAMP();  // parameter gradients
     }
     if (tid == 0) {
         losses[0] = bm * pi_acc;
         losses[1] = bm * v_acc;
     }
+#undef SYN_TSTAMP
 }
 
 // torch::optim::Adam (amsgrad off) on device gradients; scalars prepared on the host in double like libtorch does.
@@ -250,6 +419,20 @@ __global__ void dedup_reduce_kernel(const unsigned* __restrict__ order, const un
         out_op[row] = op_bb[i];
         out_num[row] = s1 - s0;
     }
+}
+// BatchRandSampler's index_select for a whole epoch at once: sample i of the step-ordered arrays = buffer entry perm[i]
+__global__ void train_gather_kernel(const int* __restrict__ perm, int n, const unsigned long long* __restrict__ my,
+                                    const unsigned long long* __restrict__ op, const float* __restrict__ tpi,
+                                    const float* __restrict__ tv, unsigned long long* __restrict__ g_my,
+                                    unsigned long long* __restrict__ g_op, float* __restrict__ g_tpi,
+                                    float* __restrict__ g_tv) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, j = threadIdx.x & 15;
+    if (i >= n) return;
+    const size_t s = (size_t)perm[i];
+    if (j < 9) g_tpi[(size_t)i * 9 + j] = tpi[s * 9 + j];
+    else if (j < 12) g_tv[(size_t)i * 3 + (j - 9)] = tv[s * 3 + (j - 9)];
+    else if (j == 12) g_my[i] = my[s];
+    else if (j == 13) g_op[i] = op[s];
 }
 __global__ void iota_kernel(unsigned* p, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
