@@ -51,7 +51,8 @@ class CCounters(C.Structure):  # struct syn_counters
 
 
 def library_path():
-    return os.path.join(_HERE, "libsynthesis_amd.so")
+    """The in-tree build; SYNTHESIS_AMD_LIB points developer tools at another build of the same ABI (A/B timing)."""
+    return os.environ.get("SYNTHESIS_AMD_LIB") or os.path.join(_HERE, "libsynthesis_amd.so")
 
 
 _lib = None
