@@ -527,3 +527,17 @@ def test_selfplay_full_size_properties(blob, oracle, monkeypatch):
     assert_selfplay_equal(r4, r, "lane-per-tree kernel")
     assert r4["counters"] == r["counters"]
     lanes.close()
+
+
+def test_every_launch_shape_plays_the_same_games():
+    """Results depend only on (config, seed, game index): five configuration families (Uct without auto-extend, ParentQ +
+    Equal noise, solver off + stop_games_when_solved + ActionSelection::Q, deep trees + QtoZ targets, parity), 3,000 games
+    each, on the row-per-tree kernel, the lane-per-tree kernel and the lane kernel with the policy cache — every output
+    array and every counter identical (tools/stress_cross_kernel.py)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_cross_kernel.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert p.returncode == 0 and "ALL IDENTICAL" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
