@@ -245,6 +245,40 @@ void orc_ttt_root_priors(uint64_t seed, float* priors9, int* n_children) {
 // ---------------------------------------------------------------- Connect4 MCTS search on given roots
 // For each root i: builds MCTS::with_capacity(explores+1, cfg, policy, root) and runs explore_n(explores).
 // Outputs per root: child_* arrays are indexed by ACTION (column), zero where the column is not a child.
+}  // extern "C"
+template <class P>
+static void c4_search_collect(MCTS<Connect4, P>& mcts, int i, int action_selection, float* child_N, float* child_W,
+                              float* child_P, int* child_sol, float* root_stat, int* root_sol, unsigned* num_nodes,
+                              int* best_action, float* target_pi, float* target_q) {
+    const auto& r = mcts.nodes[mcts.root];
+    for (int a = 0; a < 9; a++) {
+        child_N[i * 9 + a] = 0;
+        child_P[i * 9 + a] = 0;
+        for (int j = 0; j < 3; j++) child_W[(i * 9 + a) * 3 + j] = 0;
+        for (int j = 0; j < 3; j++) child_sol[(i * 9 + a) * 3 + j] = 0;
+    }
+    for (uint32_t c = r.first_child; c < r.last_child(); c++) {
+        const auto& ch = mcts.nodes[c];
+        int a = ch.action;
+        child_N[i * 9 + a] = ch.num_visits;
+        child_P[i * 9 + a] = ch.action_prob;
+        for (int j = 0; j < 3; j++) child_W[(i * 9 + a) * 3 + j] = ch.outcome_probs[j];
+        child_sol[(i * 9 + a) * 3 + 0] = ch.solution.some;
+        child_sol[(i * 9 + a) * 3 + 1] = ch.solution.o.kind;
+        child_sol[(i * 9 + a) * 3 + 2] = (int)ch.solution.o.turns;
+    }
+    root_stat[i * 4 + 0] = r.num_visits;
+    for (int j = 0; j < 3; j++) root_stat[i * 4 + 1 + j] = r.outcome_probs[j];
+    root_sol[i * 3 + 0] = r.solution.some;
+    root_sol[i * 3 + 1] = r.solution.o.kind;
+    root_sol[i * 3 + 2] = (int)r.solution.o.turns;
+    num_nodes[i] = (unsigned)mcts.nodes.size();
+    best_action[i] = mcts.best_action(action_selection);
+    mcts.target_policy(target_pi + i * 9);
+    mcts.target_q(target_q + i * 3);
+}
+extern "C" {
+
 void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn_mode, const uint64_t* my_bb,
                         const uint64_t* op_bb, int n, int explores, int action_selection, float* child_N,
                         float* child_W, float* child_P, int* child_sol, float* root_stat, int* root_sol,
@@ -257,32 +291,26 @@ void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn
         Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
         MCTS<Connect4, Connect4Net> mcts((size_t)explores + 1, cfg, &net, root);
         mcts.explore_n((size_t)explores);
-        const auto& r = mcts.nodes[mcts.root];
-        for (int a = 0; a < 9; a++) {
-            child_N[i * 9 + a] = 0;
-            child_P[i * 9 + a] = 0;
-            for (int j = 0; j < 3; j++) child_W[(i * 9 + a) * 3 + j] = 0;
-            for (int j = 0; j < 3; j++) child_sol[(i * 9 + a) * 3 + j] = 0;
-        }
-        for (uint32_t c = r.first_child; c < r.last_child(); c++) {
-            const auto& ch = mcts.nodes[c];
-            int a = ch.action;
-            child_N[i * 9 + a] = ch.num_visits;
-            child_P[i * 9 + a] = ch.action_prob;
-            for (int j = 0; j < 3; j++) child_W[(i * 9 + a) * 3 + j] = ch.outcome_probs[j];
-            child_sol[(i * 9 + a) * 3 + 0] = ch.solution.some;
-            child_sol[(i * 9 + a) * 3 + 1] = ch.solution.o.kind;
-            child_sol[(i * 9 + a) * 3 + 2] = (int)ch.solution.o.turns;
-        }
-        root_stat[i * 4 + 0] = r.num_visits;
-        for (int j = 0; j < 3; j++) root_stat[i * 4 + 1 + j] = r.outcome_probs[j];
-        root_sol[i * 3 + 0] = r.solution.some;
-        root_sol[i * 3 + 1] = r.solution.o.kind;
-        root_sol[i * 3 + 2] = (int)r.solution.o.turns;
-        num_nodes[i] = (unsigned)mcts.nodes.size();
-        best_action[i] = mcts.best_action(action_selection);
-        mcts.target_policy(target_pi + i * 9);
-        mcts.target_q(target_q + i * 3);
+        c4_search_collect(mcts, i, action_selection, child_N, child_W, child_P, child_sol, root_stat, root_sol, num_nodes,
+                          best_action, target_pi, target_q);
+    }
+}
+
+// VanillaMCTS of the evaluator (evaluator.rs:187-227): the same MCTS over RolloutPolicy (rollout.rs:8-31); root i draws
+// its playouts from its own StdRng::seed_from_u64(seed + i), consumed in explore order.
+void orc_c4_mcts_search_rollout(const orc_mcts_config* cfg_in, uint64_t seed, const uint64_t* my_bb, const uint64_t* op_bb,
+                                int n, int explores, int action_selection, float* child_N, float* child_W,
+                                float* child_P, int* child_sol, float* root_stat, int* root_sol, unsigned* num_nodes,
+                                int* best_action, float* target_pi, float* target_q) {
+    MCTSConfig cfg = to_cfg(*cfg_in);
+    for (int i = 0; i < n; i++) {
+        ChaChaRng rng = ChaChaRng::seed_from_u64(seed + (uint64_t)i);
+        RolloutPolicy<Connect4> policy{&rng};
+        Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
+        MCTS<Connect4, RolloutPolicy<Connect4>> mcts((size_t)explores + 1, cfg, &policy, root);
+        mcts.explore_n((size_t)explores);
+        c4_search_collect(mcts, i, action_selection, child_N, child_W, child_P, child_sol, root_stat, root_sol, num_nodes,
+                          best_action, target_pi, target_q);
     }
 }
 

@@ -266,6 +266,35 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     return hipGetLastError();
 }
 
+// VanillaMCTS search: always the lane-per-tree kernel (8 waves per workgroup), RolloutPolicy instead of the network
+static hipError_t launch_rollout_search(syn_engine* h, const EngineParams& P, int jobs) {
+    if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
+    const int nw = 8;
+    int want_slots = h->slots < jobs ? h->slots : jobs;
+    int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
+    if (lgrid < 1) lgrid = 1;
+    const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint4);
+    if (need_path > h->path_bytes) {
+        if (h->d_path) (void)hipFree(h->d_path);
+        h->d_path = nullptr;
+        h->path_bytes = 0;
+        hipError_t pe = hipMalloc(&h->d_path, need_path);
+        if (pe != hipSuccess) return pe;
+        h->path_bytes = need_path;
+    }
+    EngineParams PL = P;
+    PL.path = h->d_path;
+    PL.lane_thresh = 64;
+    PL.cache = nullptr;
+    auto k = selfplay_kernel_lanes<MODE_SEARCH, false, false, 8, false, 1>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LaneLds<8>::BYTES);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * nw), LaneLds<8>::BYTES, h->stream, PL);
+    h->last_shape = 4; h->last_grid = lgrid; h->last_threads = 64 * nw;
+    return hipGetLastError();
+}
+
 extern "C" {
 
 void syn_default_rollout_config(syn_rollout_config* cfg) {
@@ -551,8 +580,8 @@ static bool valid_root(uint64_t my, uint64_t op) {
     return any_free;
 }
 
-static int common_params(syn_engine* h, EngineParams& P, int explores) {
-    if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+static int common_params(syn_engine* h, EngineParams& P, int explores, bool need_weights = true) {
+    if (need_weights && !h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
     if (explores < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "explores must be >= 0");
     if (explores > h->max_explores)
         return fail(h, SYN_ERR_CAPACITY, "explores %d exceeds the engine's max_explores %d", explores, h->max_explores);
@@ -572,15 +601,15 @@ static int common_params(syn_engine* h, EngineParams& P, int explores) {
     return SYN_OK;
 }
 
-int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
-                    int explores, int action_selection, syn_search_result* results) {
+static int mcts_search_impl(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
+                            int explores, int action_selection, syn_search_result* results, bool rollout, uint64_t seed) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (n < 0 || (n > 0 && (!my_bb || !op_bb || !results)))
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_mcts_search");
     if (action_selection != SYN_ACTION_Q && action_selection != SYN_ACTION_NUM_VISITS)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection %d", action_selection);
     EngineParams P;
-    int rc = common_params(h, P, explores);
+    int rc = common_params(h, P, explores, /*need_weights=*/!rollout);
     if (rc != SYN_OK) return rc;
     rc = convert_mcts(h, cfg, P.mcts);
     if (rc != SYN_OK) return rc;
@@ -607,7 +636,10 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
     P.results = d_res;
     P.action_selection = action_selection;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    HIP_TRY(h, (launch_engine<MODE_SEARCH, false>(h, P, n)));
+    P.base_seed = seed;
+    P.first_game = 0;
+    if (rollout) HIP_TRY(h, launch_rollout_search(h, P, n));
+    else HIP_TRY(h, (launch_engine<MODE_SEARCH, false>(h, P, n)));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(results, d_res, nb * sizeof(DevSearchResult), hipMemcpyDeviceToHost, h->stream));
     int kerr = 0;
@@ -621,6 +653,16 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
     return SYN_OK;
+}
+
+int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
+                    int explores, int action_selection, syn_search_result* results) {
+    return mcts_search_impl(h, cfg, my_bb, op_bb, n, explores, action_selection, results, false, 0);
+}
+
+int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t seed, const uint64_t* my_bb,
+                            const uint64_t* op_bb, int n, int explores, int action_selection, syn_search_result* results) {
+    return mcts_search_impl(h, cfg, my_bb, op_bb, n, explores, action_selection, results, true, seed);
 }
 
 static int ensure_outputs(syn_engine* h, int n_games) {

@@ -805,6 +805,46 @@ SYN_DEV void cache_insert(uint4* table, uint32_t shift, uint64_t my, uint64_t op
     e[3] = make_uint4((uint32_t)k0, (uint32_t)(k0 >> 32), (uint32_t)k1, (uint32_t)(k1 >> 32));
 }
 
+// ---------------------------------------------------------------------------------------------- RolloutPolicy
+// policies/rollout.rs:8-31: uniformly random legal moves until the game ends; logits all zero, value = one-hot outcome for
+// the player to move at the leaf. Random numbers: Rng::gen_range(0..n as u8) on the tree's own StdRng stream, word
+// `rng_index` onwards (every rollout of a tree continues where the previous one stopped).
+SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, uint32_t& rng_index, float& v0, float& v1,
+                          float& v2) {
+    StdRng rng;
+    rng.seed_from_u64(seed);
+    rng.index = rng_index;
+    bool leaf_player_moves = true;  // `my` is the side to move; the leaf itself is never terminal
+    for (;;) {
+        const uint64_t occ = my | op;
+        uint32_t lmask = 0;
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+            if (c4::col_height(occ, c) < c4::HEIGHT) lmask |= 1u << c;
+        const uint32_t n = (uint32_t)__popc(lmask);
+        const uint32_t pick = rng.gen_range_u8(n);
+        uint32_t m = lmask;
+        for (uint32_t i = 0; i < pick; i++) m &= m - 1u;  // iter_actions().nth(pick)
+        const int col = __ffs((int)m) - 1;
+        const uint64_t bit = 1ull << (c4::col_height(occ, col) + 7 * col);
+        const uint64_t mover = my | bit;
+        if (c4::won(mover)) {  // reward(leaf player): +1 if it made the four, -1 otherwise
+            v0 = leaf_player_moves ? 0.0f : 1.0f;
+            v1 = 0.0f;
+            v2 = leaf_player_moves ? 1.0f : 0.0f;
+            break;
+        }
+        if ((occ | bit) == c4::FULL) {
+            v0 = 0.0f; v1 = 1.0f; v2 = 0.0f;
+            break;
+        }
+        my = op;
+        op = mover;
+        leaf_player_moves = !leaf_player_moves;
+    }
+    rng_index = rng.index;
+}
+
 // ---------------------------------------------------------------------------------------------- the kernel
 template <int NW>
 struct LaneLds {
@@ -819,7 +859,8 @@ SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-template <int MODE, bool COUNT, bool FAST, int NW, bool PROF = false>
+// POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (VanillaMCTS of the evaluator; searches only)
+template <int MODE, bool COUNT, bool FAST, int NW, bool PROF = false, int POLICY = 0>
 __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 64 * NW;
@@ -874,12 +915,16 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         for (int c = 0; c < 9; c++) lg[c] = 0.0f;
         // PolicyWithCache: a position that some game already evaluated skips the network (and its tile slot)
         bool hit = false;
-        if (P.cache != nullptr && want_nn && !X.was_pending) {
+        if (POLICY == 1) {
+            // RolloutPolicy: the "evaluation" is a random playout on this lane (no tiles, nothing deferred)
+            if (want_nn) lane_rollout(Wk.my, Wk.op, P.base_seed + (unsigned long long)T.job, T.rng_index, v0, v1, v2);
+            hit = want_nn;
+        } else if (P.cache != nullptr && want_nn && !X.was_pending) {
             hit = cache_lookup(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
         }
         bool need = want_nn && !hit;
         const unsigned long long want_mask = __ballot(need);
-        if (P.cache != nullptr) {  // wave-uniform tallies (scalar registers), flushed once at the end of the kernel
+        if (POLICY == 0 && P.cache != nullptr) {  // wave-uniform tallies (scalar registers), flushed once at the end of the kernel
             cache_hits += (unsigned long long)__popcll(__ballot(hit));
             cache_misses += (unsigned long long)__popcll(__ballot(want_nn && !hit && !X.was_pending));
         }

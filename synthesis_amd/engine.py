@@ -17,7 +17,7 @@ NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/p
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_mcts_search", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -102,6 +102,8 @@ def load_library():
                                                                       C.c_void_p, C.c_int]
     lib.syn_mcts_search.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]
+    lib.syn_mcts_search_rollout.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int,
+                                            C.c_int, C.c_int, C.c_void_p]
     lib.syn_selfplay_run.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int] + \
                                     [C.c_void_p] * 8
     lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -236,14 +238,20 @@ class Engine:
         return y
 
     # ---- MCTS::with_capacity + explore_n on n roots (mcts.rs:123-147)
-    def mcts_search(self, cfg: MCTSConfig, my_bb, op_bb, explores, action_selection=1):
+    def mcts_search(self, cfg: MCTSConfig, my_bb, op_bb, explores, action_selection=1, rollout_seed=None):
+        """rollout_seed=None: the network is the leaf policy. Otherwise VanillaMCTS (evaluator.rs:187-227): RolloutPolicy
+        leaf evaluations, root i on StdRng::seed_from_u64(rollout_seed + i)."""
         my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
         op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
         n = int(my.size)
         res = (CSearchResult * max(n, 1))()
         c = cfg.to_c()
-        self._check(self._lib.syn_mcts_search(self._h, C.byref(c), _p(my), _p(op), n, int(explores),
-                                              int(action_selection), C.cast(res, C.c_void_p)))
+        if rollout_seed is None:
+            self._check(self._lib.syn_mcts_search(self._h, C.byref(c), _p(my), _p(op), n, int(explores),
+                                                  int(action_selection), C.cast(res, C.c_void_p)))
+        else:
+            self._check(self._lib.syn_mcts_search_rollout(self._h, C.byref(c), int(rollout_seed), _p(my), _p(op), n,
+                                                          int(explores), int(action_selection), C.cast(res, C.c_void_p)))
         raw = np.frombuffer(res, dtype=np.uint8).reshape(max(n, 1), C.sizeof(CSearchResult))[:n]
         dt = np.dtype([("child_N", np.float32, (9,)), ("child_W", np.float32, (9, 3)), ("child_P", np.float32, (9,)),
                        ("child_sol", np.int32, (9, 3)), ("root_N", np.float32), ("root_W", np.float32, (3,)),

@@ -222,6 +222,21 @@ class Oracle:
                                     _p(r["target_pi"]), _p(r["target_q"]))
         return r
 
+    def c4_mcts_search_rollout(self, cfg, seed, my_bb, op_bb, explores, action_selection=1):
+        """VanillaMCTS: MCTS over RolloutPolicy; root i plays its rollouts from StdRng::seed_from_u64(seed + i)."""
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
+        n = int(my.size)
+        r = dict(child_N=np.zeros((n, 9), np.float32), child_W=np.zeros((n, 9, 3), np.float32),
+                 child_P=np.zeros((n, 9), np.float32), child_sol=np.zeros((n, 9, 3), np.int32),
+                 root_stat=np.zeros((n, 4), np.float32), root_sol=np.zeros((n, 3), np.int32),
+                 num_nodes=np.zeros(n, np.uint32), best_action=np.zeros(n, np.int32),
+                 target_pi=np.zeros((n, 9), np.float32), target_q=np.zeros((n, 3), np.float32))
+        self.lib.orc_c4_mcts_search_rollout(C.byref(cfg), C.c_uint64(seed), _p(my), _p(op), n, explores, action_selection,
+                                            _p(r["child_N"]), _p(r["child_W"]), _p(r["child_P"]), _p(r["child_sol"]),
+                                            _p(r["root_stat"]), _p(r["root_sol"]), _p(r["num_nodes"]), _p(r["best_action"]),
+                                            _p(r["target_pi"]), _p(r["target_q"]))
+        return r
+
     # ---- training step / dedup (SURVEY §8f #1)
     def train_gradients(self, blob, hp, X, tpi, tv):
         blob = np.ascontiguousarray(blob, np.float32)

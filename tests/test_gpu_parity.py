@@ -529,6 +529,34 @@ def test_selfplay_full_size_properties(blob, oracle, monkeypatch):
     lanes.close()
 
 
+def test_vanilla_mcts_with_rollout_policy_matches_oracle(oracle):
+    """VanillaMCTS of the evaluator (evaluator.rs:187-227): the search with RolloutPolicy (rollout.rs:8-31) leaf
+    evaluations — random playouts on the tree's own StdRng stream, uniform priors — as the reference configures it
+    (Uct, no auto-extend, fpu = inf, study-connect4/src/main.rs:74-82) and with the AlphaZero-style config; no network
+    weights are loaded. Visit counts, sums, solutions and targets bit-identical to the oracle."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config
+
+    eng = sa.Engine(concurrent_games=600, max_explores=800)
+    my, op = random_positions(oracle, 500, seed=71, max_moves=50)
+    my[0] = 0; op[0] = 0
+    for kw, explores in ((dict(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf")), 400),
+                         (dict(exploration=0, c=0.7, fpu_value=0.5), 150), (dict(), 300)):
+        ocfg = parity_mcts_config(**kw)
+        scfg = sa.MCTSConfig(exploration=sa.Exploration(ocfg.exploration), c=ocfg.c, solve=bool(ocfg.solve),
+                             correct_values_on_solve=bool(ocfg.correct_values_on_solve),
+                             select_solved_nodes=bool(ocfg.select_solved_nodes), auto_extend=bool(ocfg.auto_extend),
+                             fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value)
+        for sel in (0, 1):
+            got = eng.mcts_search(scfg, my, op, explores, action_selection=sel, rollout_seed=1234)
+            ref = oracle.c4_mcts_search_rollout(ocfg, 1234, my, op, explores, action_selection=sel)
+            assert_search_equal(got, ref, f"rollout {kw} sel {sel}")
+    assert eng.last_launch_shape()[0] == 4
+    with pytest.raises(sa.SynthesisAmdError):
+        eng.mcts_search(sa.parity_mcts_config(), my[:4], op[:4], 50)  # the network path still needs weights
+    eng.close()
+
+
 def test_every_launch_shape_plays_the_same_games():
     """Results depend only on (config, seed, game index): five configuration families (Uct without auto-extend, ParentQ +
     Equal noise, solver off + stop_games_when_solved + ActionSelection::Q, deep trees + QtoZ targets, parity), 3,000 games
