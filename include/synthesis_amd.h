@@ -157,8 +157,8 @@ typedef struct syn_search_result {
 int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
                     int explores, int action_selection, syn_search_result* results);
 
-/* Replaces: the VanillaMCTS players of the evaluator (evaluator.rs:187-227): the same search with RolloutPolicy
- * (policies/rollout.rs:8-31) as the leaf evaluation — uniformly random playouts, zero logits, one-hot outcome. Root i
+/* Replaces: MCTS<G, RolloutPolicy> (the pairing of the reference's MCTS tests, mcts.rs:691-868): the same search with
+ * RolloutPolicy (policies/rollout.rs:8-31) as the leaf evaluation — uniformly random playouts, zero logits, one-hot outcome. Root i
  * draws its playouts from its own StdRng::seed_from_u64(seed + i), in explore order. No network weights are needed. */
 int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t seed, const uint64_t* my_bb,
                             const uint64_t* op_bb, int n, int explores, int action_selection, syn_search_result* results);

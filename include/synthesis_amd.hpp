@@ -12,7 +12,7 @@
 //   synthesis::ReplayBuffer                          synthesis/src/data.rs:107-235 (new_game, add, extend,
 //                                                    keep_last_n_games, deduplicate, the counters)
 //   synthesis::run_n_games                           synthesis/src/alpha_zero.rs:181-209
-//   synthesis::vanilla_mcts_search                   MCTS over RolloutPolicy (policies/rollout.rs:8-31, evaluator.rs:187-227)
+//   synthesis::vanilla_mcts_search                   MCTS over RolloutPolicy (policies/rollout.rs:8-31; mcts.rs:691-868)
 //   synthesis::Learner                               the optimiser half of alpha_zero.rs:28-36,72-94
 // Errors: the reference panics (unwrap / assert!) on this path; here every failed C-ABI call throws synthesis::Error
 // carrying the status code and syn_last_error's text. Nothing is computed on the host: without the library or without
@@ -346,7 +346,7 @@ inline std::vector<syn_search_result> mcts_search(Engine& e, const MCTSConfig& c
     return out;
 }
 
-// VanillaMCTS of the evaluator (evaluator.rs:187-227): the same search with RolloutPolicy (policies/rollout.rs:8-31) leaf
+// MCTS over RolloutPolicy (policies/rollout.rs:8-31), the pairing of the reference's MCTS tests: leaf
 // evaluations; root i plays its random playouts from StdRng::seed_from_u64(seed + i). Needs no network weights.
 inline std::vector<syn_search_result> vanilla_mcts_search(Engine& e, const MCTSConfig& cfg, uint64_t seed,
                                                           const std::vector<Connect4>& roots, int explores,

@@ -296,7 +296,8 @@ void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn
     }
 }
 
-// VanillaMCTS of the evaluator (evaluator.rs:187-227): the same MCTS over RolloutPolicy (rollout.rs:8-31); root i draws
+// MCTS<Connect4, RolloutPolicy> — the pairing the reference's own MCTS tests use (mcts.rs:691-868, there with
+// TicTacToe); RolloutPolicy = rollout.rs:8-31. (The evaluator's rollout players use the separate FrozenMCTS tree.) root i draws
 // its playouts from its own StdRng::seed_from_u64(seed + i), consumed in explore order.
 void orc_c4_mcts_search_rollout(const orc_mcts_config* cfg_in, uint64_t seed, const uint64_t* my_bb, const uint64_t* op_bb,
                                 int n, int explores, int action_selection, float* child_N, float* child_W,

@@ -266,7 +266,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     return hipGetLastError();
 }
 
-// VanillaMCTS search: always the lane-per-tree kernel (8 waves per workgroup), RolloutPolicy instead of the network
+// MCTS over RolloutPolicy: always the lane-per-tree kernel (8 waves per workgroup), RolloutPolicy instead of the network
 static hipError_t launch_rollout_search(syn_engine* h, const EngineParams& P, int jobs) {
     if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
     const int nw = 8;

@@ -859,7 +859,7 @@ SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (VanillaMCTS of the evaluator; searches only)
+// POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (policies/rollout.rs; searches only)
 template <int MODE, bool COUNT, bool FAST, int NW, bool PROF = false, int POLICY = 0>
 __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];

@@ -239,7 +239,7 @@ class Engine:
 
     # ---- MCTS::with_capacity + explore_n on n roots (mcts.rs:123-147)
     def mcts_search(self, cfg: MCTSConfig, my_bb, op_bb, explores, action_selection=1, rollout_seed=None):
-        """rollout_seed=None: the network is the leaf policy. Otherwise VanillaMCTS (evaluator.rs:187-227): RolloutPolicy
+        """rollout_seed=None: the network is the leaf policy. Otherwise MCTS over RolloutPolicy (policies/rollout.rs:8-31, the pairing of the reference's MCTS tests, mcts.rs:691-868): playout
         leaf evaluations, root i on StdRng::seed_from_u64(rollout_seed + i)."""
         my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
         op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()

@@ -223,7 +223,7 @@ class Oracle:
         return r
 
     def c4_mcts_search_rollout(self, cfg, seed, my_bb, op_bb, explores, action_selection=1):
-        """VanillaMCTS: MCTS over RolloutPolicy; root i plays its rollouts from StdRng::seed_from_u64(seed + i)."""
+        """MCTS over RolloutPolicy (rollout.rs:8-31); root i plays its rollouts from StdRng::seed_from_u64(seed + i)."""
         my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
         n = int(my.size)
         r = dict(child_N=np.zeros((n, 9), np.float32), child_W=np.zeros((n, 9, 3), np.float32),

@@ -530,7 +530,7 @@ def test_selfplay_full_size_properties(blob, oracle, monkeypatch):
 
 
 def test_vanilla_mcts_with_rollout_policy_matches_oracle(oracle):
-    """VanillaMCTS of the evaluator (evaluator.rs:187-227): the search with RolloutPolicy (rollout.rs:8-31) leaf
+    """MCTS over RolloutPolicy (rollout.rs:8-31; the pairing of the reference's MCTS tests, mcts.rs:691-868): leaf
     evaluations — random playouts on the tree's own StdRng stream, uniform priors — as the reference configures it
     (Uct, no auto-extend, fpu = inf, study-connect4/src/main.rs:74-82) and with the AlphaZero-style config; no network
     weights are loaded. Visit counts, sums, solutions and targets bit-identical to the oracle."""
