@@ -44,6 +44,10 @@ def main():
     ap.add_argument("--batch-size", type=int, default=32)           # main.rs:22
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--concurrent", type=int, default=65536)
+    ap.add_argument("--eval-games", type=int, default=0, help="after every iteration: this many games as each colour against "
+                                                              "rollout MCTS players (evaluator.rs:52-77), rank 0 only")
+    ap.add_argument("--eval-explores", type=int, default=0, help="explores of the network player in evaluation (0 = --explores)")
+    ap.add_argument("--eval-opponents", default="200,800", help="explores of the rollout MCTS opponents")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -70,6 +74,7 @@ def main():
              v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
     games_played = 0
     log = []
+    eval_eng = None
     for it in range(args.iterations):
         t0 = time.perf_counter()
         # ---- gather_experience (alpha_zero.rs:120-179): this rank's share of the new games, seeds never reused
@@ -113,10 +118,29 @@ def main():
             epoch_losses.append((el * args.batch_size / n_unique).tolist())
         t_train = time.perf_counter() - t2
         learner.publish()  # model_{i+1}: the next iteration's self-play runs on the trained network
+        evaluation = {}
+        if args.eval_games > 0 and rank == 0:
+            # evaluator.rs:52-77: the new model against every rollout baseline, as first and as second player
+            from synthesis_amd import match
+
+            opponents = [int(x) for x in args.eval_opponents.split(",") if x]
+            my_explores = args.eval_explores or args.explores
+            if eval_eng is None:  # its own engine: the opponents search deeper than self-play does
+                eval_eng = sa.Engine(concurrent_games=max(16, args.eval_games), max_explores=max(opponents + [my_explores]),
+                                     device=local_rank)
+            eval_eng.load_weights(eng.trainer_state()["weights"])
+            me = match.Player(f"model_{it + 1}", my_explores, cfg.mcts_cfg, cfg.action)
+            for ox in opponents:
+                opp = match.rollout_player(ox)
+                r1, _ = match.play_match(eval_eng, me, opp, args.eval_games, seed=1000 * it)
+                r2, _ = match.play_match(eval_eng, opp, me, args.eval_games, seed=1000 * it + 500)
+                w, d, l, s, elo = match.score(np.concatenate([r1, -r2]))
+                evaluation[opp.name] = dict(wins=w, draws=d, losses=l, score=round(s, 4), elo_diff=round(elo, 1))
         rec = dict(iteration=it + 1, lr=lr, games=int(count * world), steps_in_buffer=int(R["my"].size), unique=int(n_unique),
                    plies_per_game=float(n.mean()), draws=float((sp["final_kind"] == 1).mean()), optimiser_steps=steps,
                    epoch_losses=epoch_losses, seconds=dict(selfplay=round(t_play, 3), dedup=round(t_dedup, 3), train=round(t_train, 3)),
-                   selfplay_games_per_s=count * world / t_play, train_steps_per_s=steps / max(t_train, 1e-9))
+                   selfplay_games_per_s=count * world / t_play, train_steps_per_s=steps / max(t_train, 1e-9),
+                   evaluation=evaluation)
         log.append(rec)
         if rank == 0:
             print(json.dumps(rec), flush=True)

@@ -1,0 +1,96 @@
+"""Matches between two MCTS players with every search on the GPU — the compute of the reference's evaluation
+(synthesis/src/evaluator.rs:129-227: `MCTS::exploit` per move = `with_capacity` + `explore_n` + `best_action`).
+
+All games of a match advance in lockstep on the host: per ply, the positions where player A is to move go through one
+batched `Engine.mcts_search` call and player B's through another, each root on its own device-resident tree. A player is
+(MCTSConfig, explores, action selection, leaf policy): the engine's network, or `RolloutPolicy` playouts
+(`rollout_seed`). The rollout opponent here is MCTS over RolloutPolicy; the reference's evaluator uses its separate
+`FrozenMCTS` tree for that role (not built), so ratings are comparable in kind, not in number.
+
+Host code only applies the chosen moves (numpy bitboards, connect4.rs:221-233) — no search, no network."""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .config import ActionSelection, Exploration, Fpu, MCTSConfig
+
+_U = np.uint64
+_COLS0TO5 = _U(sum(0x7F << (7 * c) for c in range(6)))
+_ROW0 = _U(sum(1 << (7 * c) for c in range(9)))
+_ROWS = lambda lo, hi: _U(sum(int(_ROW0) << i for i in range(lo, hi + 1)))  # noqa: E731
+_D1, _D2, _H, _V = _COLS0TO5 & _ROWS(3, 6), _COLS0TO5 & _ROWS(0, 3), _COLS0TO5, _ROWS(0, 3)
+FULL = _U((1 << 63) - 1)
+
+
+def won(bb):
+    """four in a row on a bitboard (bit = row + 7 * col), vectorised; connect4.rs:77-83"""
+    bb = np.asarray(bb, dtype=np.uint64)
+    s = lambda k: bb >> _U(k)  # noqa: E731
+    d1 = bb & s(6) & s(12) & s(18) & _D1
+    d2 = bb & s(8) & s(16) & s(24) & _D2
+    h = bb & s(7) & s(14) & s(21) & _H
+    v = bb & s(1) & s(2) & s(3) & _V
+    return (d1 | d2 | h | v) != 0
+
+
+def step(my, op, col):
+    """Game::step for arrays of positions: returns (my', op', over, mover_won)"""
+    my = np.asarray(my, np.uint64); op = np.asarray(op, np.uint64); col = np.asarray(col, np.int64)
+    occ = my | op
+    colbits = (occ >> (_U(7) * col.astype(np.uint64))) & _U(0x7F)
+    height = np.zeros(col.shape, np.uint64)
+    for r in range(7):
+        height += (colbits >> _U(r)) & _U(1)
+    bit = _U(1) << (height + _U(7) * col.astype(np.uint64))
+    mover = my | bit
+    w = won(mover)
+    over = w | ((occ | bit) == FULL)
+    return op.copy(), mover, over, w
+
+
+@dataclass
+class Player:
+    name: str
+    explores: int
+    mcts_cfg: MCTSConfig = field(default_factory=MCTSConfig)
+    action: ActionSelection = ActionSelection.NumVisits
+    rollout: bool = False          # False: the engine's network is the leaf policy; True: RolloutPolicy playouts
+
+
+def rollout_player(explores, name=None):
+    """rollout_mcts_cfg of study-connect4/src/main.rs:74-82: Uct{c: 2}, no auto-extend, fpu = inf, ActionSelection::NumVisits"""
+    return Player(name or f"RolloutMCTS{explores}", explores,
+                  MCTSConfig(exploration=Exploration.Uct, c=2.0, auto_extend=False, fpu=Fpu.Const, fpu_value=float("inf")),
+                  ActionSelection.NumVisits, rollout=True)
+
+
+def play_match(engine, first: Player, second: Player, n_games, seed=0):
+    """n_games from the empty board, `first` moving first. Returns rewards for `first` per game: +1 win, 0 draw, -1 loss
+    (game.reward(first_player), evaluator.rs:160) and the number of plies."""
+    my = np.zeros(n_games, np.uint64); op = np.zeros(n_games, np.uint64)
+    alive = np.ones(n_games, bool)
+    reward = np.zeros(n_games, np.float32)
+    plies = np.zeros(n_games, np.int32)
+    for ply in range(63):
+        idx = np.nonzero(alive)[0]
+        if idx.size == 0:
+            break
+        p = first if ply % 2 == 0 else second
+        kw = dict(rollout_seed=int(seed) + ply * n_games) if p.rollout else {}
+        res = engine.mcts_search(p.mcts_cfg, my[idx], op[idx], p.explores, action_selection=int(p.action), **kw)
+        nmy, nop, over, w = step(my[idx], op[idx], res["best_action"])
+        my[idx], op[idx] = nmy, nop
+        plies[idx] += 1
+        mover_is_first = ply % 2 == 0
+        reward[idx[over & w]] = 1.0 if mover_is_first else -1.0
+        alive[idx[over]] = False
+    return reward, plies
+
+
+def score(rewards):
+    """(wins, draws, losses, score in [0, 1], Elo difference implied by the score)"""
+    r = np.asarray(rewards)
+    w, d, l = int((r > 0).sum()), int((r == 0).sum()), int((r < 0).sum())
+    s = (w + 0.5 * d) / max(1, r.size)
+    s_c = min(max(s, 1e-3), 1 - 1e-3)
+    return w, d, l, s, float(-400.0 * np.log10(1.0 / s_c - 1.0))

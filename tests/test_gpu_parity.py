@@ -557,6 +557,43 @@ def test_vanilla_mcts_with_rollout_policy_matches_oracle(oracle):
     eng.close()
 
 
+def test_match_play_reproduces_the_oracle_move_by_move(oracle, blob):
+    """synthesis_amd.match (the evaluator's per-move `MCTS::exploit`, evaluator.rs:129-161, batched over games): a match
+    network-MCTS vs rollout-MCTS replayed with the oracle — every move of every game is the oracle's best_action for that
+    position, and the rewards follow the oracle's rules."""
+    import synthesis_amd as sa
+    from synthesis_amd import match
+    from tests.oracle_lib import parity_mcts_config
+
+    eng = sa.Engine(concurrent_games=256, max_explores=200)
+    eng.load_weights(blob)
+    me = match.Player("net", 120)
+    opp = match.rollout_player(150)
+    n, seed = 48, 17
+    # replay the lockstep on the host with the oracle choosing every move
+    my = np.zeros(n, np.uint64); op = np.zeros(n, np.uint64); alive = np.ones(n, bool); ref_reward = np.zeros(n, np.float32)
+    ocfg_net = parity_mcts_config()
+    ocfg_roll = parity_mcts_config(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf"))
+    for ply in range(63):
+        idx = np.nonzero(alive)[0]
+        if idx.size == 0:
+            break
+        if ply % 2 == 0:
+            a = oracle.c4_mcts_search(ocfg_net, blob, my[idx], op[idx], 120, nn_mode=oracle.ACC_FMA)["best_action"]
+        else:
+            a = oracle.c4_mcts_search_rollout(ocfg_roll, seed + ply * n, my[idx], op[idx], 150)["best_action"]
+        nmy, nop, over, w = match.step(my[idx], op[idx], a)
+        my[idx], op[idx] = nmy, nop
+        ref_reward[idx[over & w]] = 1.0 if ply % 2 == 0 else -1.0
+        alive[idx[over]] = False
+    got, plies = match.play_match(eng, me, opp, n, seed=seed)
+    assert np.array_equal(got, ref_reward)
+    assert plies.min() >= 7 and plies.max() <= 63
+    w, d, l, s, elo = match.score(got)
+    assert w + d + l == n and 0.0 <= s <= 1.0
+    eng.close()
+
+
 def test_every_launch_shape_plays_the_same_games():
     """Results depend only on (config, seed, game index): five configuration families (Uct without auto-extend, ParentQ +
     Equal noise, solver off + stop_games_when_solved + ActionSelection::Q, deep trees + QtoZ targets, parity), 3,000 games
