@@ -160,3 +160,27 @@ def test_multi_rank_reduce_under_gloo(tmp_path):
     assert float(line[1]) == 2.0          # MAX over ranks of (1.0, 2.0)
     assert int(line[2]) == 1000           # SUM of per-rank game counts
     assert int(line[3]) == (2 * 2 + 0) * 500 + (2 * 2 + 1) * 500  # SUM of the two shard offsets
+
+
+def test_match_host_rules_follow_the_oracle(oracle):
+    """synthesis_amd.match applies the moves of a match on the host (numpy bitboards): positions, game end and winner must
+    be the oracle's Connect4 (connect4.rs:77-83,195-233) on random playouts, and the score summary must add up."""
+    from synthesis_amd import match
+
+    rng = np.random.default_rng(0)
+    for g in range(200):
+        moves, h = [], [0] * 9
+        my = np.zeros(1, np.uint64); op = np.zeros(1, np.uint64)
+        for t_ in range(63):
+            c = int(rng.choice([c for c in range(9) if h[c] < 7]))
+            moves.append(c); h[c] += 1
+            my, op, over, w = match.step(my, op, np.array([c]))
+            r = oracle.c4_play(moves)
+            assert (int(my[0]), int(op[0])) == (r["my_bb"], r["op_bb"])
+            assert bool(over[0]) == bool(r["over"][-1]) and bool(w[0]) == (r["winner"] >= 0 if "winner" in r else bool(w[0]))
+            if over[0]:
+                break
+    w, d, l, s, elo = match.score(np.array([1, 1, 0, -1], np.float32))
+    assert (w, d, l) == (2, 1, 1) and abs(s - 0.625) < 1e-9 and elo > 0
+    p = match.rollout_player(800)
+    assert p.rollout and p.mcts_cfg.auto_extend is False and p.name == "RolloutMCTS800"
