@@ -209,6 +209,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             if (const char* ev = std::getenv("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
             if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
             PL.lane_thresh &= ~15;  // whole tiles
+            {
+                int stagger = 0;
+                if (const char* ev = std::getenv("SYN_LANE_STAGGER")) stagger = std::atoi(ev);
+                PL.lane_thresh |= (stagger & 0xFF) << 8;
+            }
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \
@@ -748,7 +753,7 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
             int nwv = -pgrid * (pnt / 64);
             std::vector<unsigned long long> hp((size_t)nwv * 10);
             HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
-            HIP_TRY(h, hipFree(d_prof));
+            unsigned long long* d_prof_keep = d_prof;
             double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int w = 0; w < nwv; w++)
                 for (int j = 0; j < 10; j++) s[j] += (double)hp[(size_t)w * 10 + j];
@@ -758,6 +763,20 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
                     -pgrid, pnt, nwv, s[4] / nwv, s[0] / s[4], s[1] / s[4], s[6] / s[4], s[7] / s[4], s[2] / s[4], s[3] / s[4],
                     (s[0] + s[1] + s[2] + s[3] + s[6] + s[7]) / s[4], s[5] / s[4], s[8] / s[4], s[9] / s[4], s[9] / s[5],
                     (s[0] + s[1] + s[2] + s[3] + s[6] + s[7]) / s[8]);
+            {
+                std::vector<unsigned long long> tlv(4 * 16 * 3);
+                (void)hipMemcpy(tlv.data(), d_prof_keep + 40000, tlv.size() * 8, hipMemcpyDeviceToHost);
+                unsigned long long t0 = ~0ull;
+                for (auto v : tlv) if (v && v < t0) t0 = v;
+                for (int w = 0; w < pnt / 256; w++) {
+                    fprintf(stderr, "[timeline wave %d of SIMD 0] (B start, B end, round end) kilo-cycles:", w * 4);
+                    for (int r = 0; r < 8; r++)
+                        fprintf(stderr, " (%.0f %.0f %.0f)", (tlv[(w * 16 + r) * 3] - t0) / 1e3, (tlv[(w * 16 + r) * 3 + 1] - t0) / 1e3,
+                                (tlv[(w * 16 + r) * 3 + 2] - t0) / 1e3);
+                    fprintf(stderr, "\n");
+                }
+                (void)hipFree(d_prof_keep);
+            }
             d_prof = nullptr;
         }
     }

@@ -23,49 +23,71 @@
 
 namespace syn {
 
-// Node records of this launch shape (private to it: the pool's contents never outlive a launch). A tree slab of `cap`
-// nodes is two arrays of 16-byte records:
-//   sel[node] = { N, q, P, packed }              everything select_best_child needs about a child: ONE 16-byte load
-//       q       = exploit_value as the parent will see it (mcts.rs:343-359): -((W_win - W_lose) / N), rewritten by every
-//                 backprop (the float the reference recomputes at selection time); the constant of its outcome once the
-//                 node is solved; the FPU constant while it is unvisited (Fpu::Const; Fpu::ParentQ is patched in by the
-//                 descent). With the reference's config family the descent uses it as is — no decoding per child.
-//       packed  = first_child[0:15] | num_children[16:19] | action[20:23] | solution[24:25] (0 none, 1 Lose, 2 Draw,
-//                 3 Win) | turns[26:31]
-//   aux[node] = { W_lose, W_draw, W_win, - }     touched only by backprop (never read while N == 0: no initialisation)
-// Children of a node are contiguous, so a level of the descent is nine 16-byte loads from one 144-byte span (two cache
-// lines) — half the requests and lines of the 32-byte records, which is what the per-CU vector-memory pipeline (the
-// bottleneck of this shape) charges for. There are no parent links: the descent logs (node, N) per level into
-// a per-wave path buffer [level][lane] (coalesced 512-byte rows) and backprop replays it from the leaf's level down to
-// 0, all lanes of a wave on the same level, so backprop has no dependent pointer chase at all.
-constexpr uint32_t PW_FC_MASK = 0xFFFFu, PW_NC_SHIFT = 16, PW_ACT_SHIFT = 20, PW_SOL_SHIFT = 24, PW_TURNS_SHIFT = 26;
-constexpr uint32_t LANE_MAX_CAP = 1u << 16;  // first_child has 16 bits: trees of up to 65,536 nodes (7,280 explores)
-SYN_DEV uint32_t pw_make(uint32_t fc, uint32_t nc, uint32_t action, bool some, uint32_t kind, uint32_t turns = 0) {
-    return fc | (nc << PW_NC_SHIFT) | (action << PW_ACT_SHIFT) | ((some ? kind + 1u : 0u) << PW_SOL_SHIFT) |
-           (turns << PW_TURNS_SHIFT);
+// Node storage of this launch shape (private to it: the pool's contents never outlive a launch): 128-byte BLOCKS, each
+// exactly one aligned cache line — the unit the memory system charges for (tools/ubench/gather_blocks.hip: 49 G random
+// lines/s whether a visit needs 16 or 128 bytes of the line; a 144-byte children block costs two). A block belongs to one
+// expanded node (its owner) and holds everything a visit of that node touches:
+//   bytes   0..11   W_lose, W_draw, W_win of the owner         (read-modify-written by backprop)
+//   bytes  12..15   spare
+//   bytes 16..123   nine 12-byte child records { q | turns, P, N[0:14] solved[15] | block[16:29] kind[30:31] }
+//       q      = exploit value as select_best_child will see it (mcts.rs:343-359): -((W_win - W_lose) / N) rewritten by
+//                every backprop; the FPU constant while unvisited (Fpu::ParentQ is patched in by the descent); once the
+//                child is solved the slot holds the solution's turn count and the value comes from `kind`
+//       block  = the child's own block (0 = not expanded); N counts visits (<= 32,767)
+// So one level of the descent is ONE line (seven 16-byte loads of the record area), and one level of backprop is one line
+// read (the owner's sums, skipped for a fresh node) plus two dirtied lines (own header, own record in the parent's block).
+// Children are the legal columns of the owner's position in ascending order, so their count and their actions are derived
+// from the board the descent carries anyway. A node is named by its record (parent block * 16 + slot); the root has no
+// record (its N is the pass counter). There are no parent links: the descent logs {record, N, block|count|solution,
+// q|turns} per level into a per-wave path buffer [level][lane] (coalesced 1 KB rows) and backprop replays it.
+constexpr uint32_t LANE_MAX_CAP = 1u << 16;   // blocks per tree = cap / 4 must fit the 14-bit block field
+constexpr uint32_t REC_ROOT = 0xFFFFFFFFu;
+
+SYN_DEV uint32_t nf_make(uint32_t n, bool solved, uint32_t blk, uint32_t kind) {
+    return n | ((solved ? 1u : 0u) << 15) | (blk << 16) | (kind << 30);
 }
-SYN_DEV uint32_t pw_fc(uint32_t w) { return w & PW_FC_MASK; }
-SYN_DEV uint32_t pw_nc(uint32_t w) { return (w >> PW_NC_SHIFT) & 0xFu; }
-SYN_DEV uint32_t pw_action(uint32_t w) { return (w >> PW_ACT_SHIFT) & 0xFu; }
-SYN_DEV bool pw_some(uint32_t w) { return ((w >> PW_SOL_SHIFT) & 3u) != 0u; }
-SYN_DEV uint32_t pw_kind(uint32_t w) { return ((w >> PW_SOL_SHIFT) & 3u) - 1u; }  // 0 Lose, 1 Draw, 2 Win (if pw_some)
-SYN_DEV uint32_t pw_turns(uint32_t w) { return w >> PW_TURNS_SHIFT; }
-SYN_DEV uint32_t pw_with_solution(uint32_t w, uint32_t kind, uint32_t turns) {
-    return (w & ((1u << PW_SOL_SHIFT) - 1u)) | ((kind + 1u) << PW_SOL_SHIFT) | (turns << PW_TURNS_SHIFT);
+SYN_DEV float nf_N(uint32_t nf) { return (float)(nf & 0x7FFFu); }
+SYN_DEV bool nf_solved(uint32_t nf) { return ((nf >> 15) & 1u) != 0u; }
+SYN_DEV uint32_t nf_blk(uint32_t nf) { return (nf >> 16) & 0x3FFFu; }
+SYN_DEV uint32_t nf_kind(uint32_t nf) { return nf >> 30; }
+// path entry .z: block[0:13] | num_children[14:17] | solved[18] | kind[19:20]
+SYN_DEV uint32_t pm_make(uint32_t blk, uint32_t nc, bool solved, uint32_t kind) {
+    return blk | (nc << 14) | ((solved ? 1u : 0u) << 18) | (kind << 19);
 }
+SYN_DEV uint32_t pm_blk(uint32_t m) { return m & 0x3FFFu; }
+SYN_DEV uint32_t pm_nc(uint32_t m) { return (m >> 14) & 0xFu; }
+SYN_DEV bool pm_solved(uint32_t m) { return ((m >> 18) & 1u) != 0u; }
+SYN_DEV uint32_t pm_kind(uint32_t m) { return (m >> 19) & 3u; }
 // exploit_value of a solved child (mcts.rs:343-350): outcome.reversed().value() — child Win -> -1, Draw -> 0,
 // Lose -> +1 (game.rs:29-43) — or -inf when solved nodes are not to be selected
 SYN_DEV float pw_q_solved(uint32_t kind, bool select_solved) {
     return select_solved ? (kind == 2u ? -1.0f : (kind == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
 }
+SYN_DEV unsigned char* blk_ptr(unsigned char* slab, uint32_t b) { return slab + (size_t)b * 128u; }
+SYN_DEV unsigned char* rec_ptr(unsigned char* slab, uint32_t rec) {
+    return slab + (size_t)(rec >> 4) * 128u + 16u + (rec & 15u) * 12u;
+}
+SYN_DEV uint32_t legal_mask_of(uint64_t occ) {
+    uint32_t lm = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+        if (c4::col_height(occ, c) < c4::HEIGHT) lm |= 1u << c;
+    return lm;
+}
+typedef uint32_t lu3 __attribute__((ext_vector_type(3)));
+SYN_DEV void st_rec(unsigned char* slab, uint32_t rec, uint32_t qt, float P, uint32_t nf) {
+    *reinterpret_cast<lu3*>(rec_ptr(slab, rec)) = lu3{qt, f32_bits(P), nf};
+}
+SYN_DEV lu3 ld_rec(unsigned char* slab, uint32_t rec) { return *reinterpret_cast<const lu3*>(rec_ptr(slab, rec)); }
 
 struct LaneTree {
-    unsigned char* slab;      // this lane's records: sel[cap] then aux[cap]
+    unsigned char* slab;      // this lane's blocks
     uint64_t root_my, root_op;
-    uint32_t next_node;       // nodes.len()
-    uint32_t root_fc, root_nc;
+    uint32_t next_block;      // 0 = fresh tree; block ids start at 1, the root's block is always 1
+    uint32_t num_nodes;       // nodes.len() of the reference tree (the root + every child record created)
     int iter;                 // passes done on this tree (root visit = 1) == root.num_visits
     bool root_solved;
+    uint32_t root_sol;        // kind | turns << 2 of the root's solution
     int job;                  // game / root index, -1 = idle
     int turn;
     uint32_t rng_index;
@@ -77,9 +99,12 @@ struct LaneTree {
 struct LaneWalk {
     bool descending;
     bool pending;             // stands on an expanded leaf whose network call did not fit this round's full tiles
-    uint32_t pend_fc, pend_lmask;
-    uint32_t node, wcur;      // current node and its packed word
-    float pN, pq;             // its N and stored q
+    uint32_t pend_lmask;
+    uint32_t rec, blk;        // current node: its record and its own block (0 = none)
+    bool solved;
+    uint32_t kind;
+    uint32_t qt;              // its q slot (q bits, or turns when solved)
+    float pN;                 // its N
     uint64_t my, op;          // its position
     int level;
 };
@@ -87,27 +112,10 @@ struct LaneWalk {
 struct LaneLeaf {             // phase A -> phase C (valid for lanes with at_leaf)
     bool at_leaf;             // this lane finished its descent in this round
     bool was_pending;         // ... in an earlier round (its position already missed the policy cache)
-    uint32_t fc;              // first child of the node that needs its children created (valid if needs_eval)
-    uint32_t legal_mask;
+    uint32_t legal_mask;      // legal columns of the node whose children are to be created (valid if needs_eval)
     bool needs_eval, solved;
     float p0, p1, p2;
 };
-
-SYN_DEV float4 ln_sel(const unsigned char* slab, uint32_t i) {
-    return *reinterpret_cast<const float4*>(slab + (size_t)i * 16u);
-}
-SYN_DEV void st_sel(unsigned char* slab, uint32_t i, float N, float y, float P, uint32_t w) {
-    *reinterpret_cast<float4*>(slab + (size_t)i * 16u) = make_float4(N, y, P, bits_f32(w));
-}
-SYN_DEV void st_sel_w(unsigned char* slab, uint32_t i, uint32_t w) {
-    *reinterpret_cast<uint32_t*>(slab + (size_t)i * 16u + 12u) = w;
-}
-SYN_DEV float4 ln_aux(const unsigned char* slab, uint32_t cap, uint32_t i) {
-    return *reinterpret_cast<const float4*>(slab + (size_t)(cap + i) * 16u);
-}
-SYN_DEV void st_aux(unsigned char* slab, uint32_t cap, uint32_t i, float4 v) {
-    *reinterpret_cast<float4*>(slab + (size_t)(cap + i) * 16u) = v;
-}
 
 template <int MODE>
 SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
@@ -115,11 +123,11 @@ SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
     T.job = j < P.n_jobs ? j : -1;
     T.turn = 0;
     T.rng_index = 0;
-    T.next_node = 0;
-    T.root_fc = 0;
-    T.root_nc = 0;
+    T.next_block = 0;
+    T.num_nodes = 0;
     T.iter = 0;
     T.root_solved = false;
+    T.root_sol = 0;
     T.root_my = 0;
     T.root_op = 0;
     if (MODE == MODE_SEARCH && T.job >= 0) {
@@ -128,11 +136,21 @@ SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
     }
 }
 
+SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
+    uint32_t b = T.next_block;
+    T.next_block = b + 1u;
+    if (b >= bcap) {  // cannot happen for explores <= max_explores (engine.hip sizes the slab); never write outside it
+        *error = 2;
+        b = bcap - 1u;
+    }
+    return b;
+}
+
 // ---------------------------------------------------------------------------------------------- phase A
 // pl = this lane's column of the wave's path buffer: level L lives at pl[L * 64]
 template <bool COUNT, bool FAST>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
-                                uint32_t cap, int thresh, uint32_t* ctr) {
+                                uint32_t bcap, int thresh, uint32_t* ctr, int* error) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
@@ -142,113 +160,129 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     X.needs_eval = pending;
     X.solved = false;
     X.p0 = X.p1 = X.p2 = 0.0f;
-    X.fc = Wk.pend_fc;
     X.legal_mask = Wk.pend_lmask;
-    uint32_t node = Wk.node, wcur = Wk.wcur;
-    float pN = Wk.pN, pq = Wk.pq;
+    uint32_t rec = Wk.rec, blk = Wk.blk, kind = Wk.kind, qt = Wk.qt;
+    bool nsolved = Wk.solved;
+    float pN = Wk.pN;
     uint64_t my = Wk.my, op = Wk.op;
     int level = Wk.level;
     bool desc = active && Wk.descending;
     if (active && !desc && !pending) {
         // explore() starts at the root (mcts.rs:310-312)
         if (COUNT) ctr[CTR_EXPLORES]++;
-        node = 0;
+        rec = REC_ROOT;
         level = 0;
         my = T.root_my;
         op = T.root_op;
-        wcur = 0;  // the root has action 0 and no solution while it is searched
-        pN = 0.0f;
-        pq = 0.0f;
-        if (T.next_node == 0) {
-            T.next_node = 1;  // MCTS::with_capacity pushes the root (mcts.rs:125); its record is written by backprop
+        nsolved = false;
+        kind = 0;
+        qt = 0;
+        if (T.next_block == 0) {
+            T.next_block = 1;  // MCTS::with_capacity pushes the root (mcts.rs:125): not expanded yet, no block
+            T.num_nodes = 1;
+            blk = 0;
+            pN = 0.0f;
         } else {
-            wcur = pw_make(T.root_fc, T.root_nc, 0, false, 0);
+            blk = 1;           // the root's block
             pN = (float)T.iter;
             if (!cfg.fpu_const()) {  // Fpu::ParentQ at the first level needs the root's q
-                const float4 a = ln_aux(slab, cap, 0);
-                pq = -((a.z - a.x) / pN);
+                const float4 a = *reinterpret_cast<const float4*>(blk_ptr(slab, 1));
+                qt = f32_bits(-((a.z - a.x) / pN));
             }
         }
-        pl[0] = make_uint4(0u, f32_bits(pN), wcur, 0u);
+        pl[0] = make_uint4(REC_ROOT, f32_bits(pN), pm_make(blk, (uint32_t)__popc(legal_mask_of(my | op)), false, 0), 0u);
         desc = true;
     }
 
-    // ---- descent (mcts.rs:310-341): every lane walks its own tree, one level per iteration
+    // ---- descent (mcts.rs:310-341): every lane walks its own tree, one level (= one cache line) per iteration.
     // A round ends when `thresh` lanes (a whole number of 16-position tiles) stand on a leaf that needs the network, or
     // when nobody is descending any more.
     bool hit_solved = false, at_leaf = pending;
     for (;;) {
         if (desc) {
-            if (pw_some(wcur)) { hit_solved = true; desc = false; at_leaf = true; }
-            else if (pw_nc(wcur) == 0u) { desc = false; at_leaf = true; }
+            if (nsolved) { hit_solved = true; desc = false; at_leaf = true; }
+            else if (blk == 0u) { desc = false; at_leaf = true; }
         }
         if (__ballot(desc) == 0ull || __popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
         if (desc) {
-            const uint32_t nc = pw_nc(wcur);
-            const uint32_t fc = pw_fc(wcur);
-            const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -pq;  // parent.q() = -(stored q)
+            const uint32_t lm = legal_mask_of(my | op);
+            const uint32_t nc = (uint32_t)__popc(lm);
+            const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, blk));
+            uint32_t d[28];
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+                const uint4 t = line[1 + j];
+                d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
+            }
+            const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(qt);  // parent.q() = -(stored q)
             const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
             // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces)
-            float best_v = 0.0f, bN = 0.0f, bq = 0.0f;
-            uint32_t best_i = 0, bw = 0;
+            float best_v = 0.0f;
+            uint32_t best_i = 0, b_qt = 0, b_nf = 0, b_act = 0;
+            uint32_t m = lm;
 #pragma unroll
             for (uint32_t i = 0; i < 9; i++) {
-                // indices past the last child re-read the last child (valid address, no predicate in front of the
-                // loads, so the nine loads of a level are in flight together)
-                const float4 s = ln_sel(slab, fc + (i < nc ? i : nc - 1u));
-                const uint32_t w = f32_bits(s.w);
-                // exploit_value: the record's q slot, except Fpu::ParentQ for an unvisited child
-                const float q = (!cfg.fpu_const() && pw_nc(w) == 0u && !pw_some(w)) ? q_fpu : s.y;
+                const uint32_t act = (uint32_t)(__ffs((int)m) - 1);  // child i = the i-th legal column
+                m &= m - 1u;
+                const uint32_t cq = d[3 * i], nf = d[3 * i + 2];
+                const float cP = bits_f32(d[3 * i + 1]);
+                const float cN = nf_N(nf);
+                // exploit_value: solved -> its outcome; unvisited under Fpu::ParentQ -> parent's q; else the q slot
+                float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? q_fpu : bits_f32(cq);
+                q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
                 float u;
-                if (cfg.puct()) u = cfg.cc() * s.z * visits / (1.0f + s.x);
-                else u = visits / sqrtf(s.x);
+                if (cfg.puct()) u = cfg.cc() * cP * visits / (1.0f + cN);
+                else u = visits / sqrtf(cN);
                 const float v = q + u;
                 const bool take = i == 0u || (i < nc && v > best_v);
                 best_v = take ? v : best_v;
                 best_i = take ? i : best_i;
-                bw = take ? w : bw;
-                bN = take ? s.x : bN;
-                bq = take ? s.y : bq;
+                b_qt = take ? cq : b_qt;
+                b_nf = take ? nf : b_nf;
+                b_act = take ? act : b_act;
             }
             if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
-            const int a = (int)pw_action(bw);
+            const int a = (int)b_act;
             const int ha = c4::col_height(my | op, a);
             const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
             my = nmy;
             op = nop;
-            node = fc + best_i;
-            wcur = bw;
-            pN = bN;
-            pq = bq;
+            rec = blk * 16u + best_i;
+            blk = nf_blk(b_nf);
+            nsolved = nf_solved(b_nf);
+            kind = nf_kind(b_nf);
+            qt = b_qt;
+            pN = nf_N(b_nf);
             level++;
-            pl[level * 64] = make_uint4(node, f32_bits(pN), wcur, f32_bits(pq));
+            pl[level * 64] = make_uint4(rec, f32_bits(pN), pm_make(blk, (uint32_t)__popc(legal_mask_of(my | op)), nsolved, kind), qt);
         }
     }
 
     if (at_leaf && !pending) {
         if (hit_solved) {
-            const uint32_t k = pw_kind(wcur);
-            X.p0 = k == 0u ? 1.0f : 0.0f;
-            X.p1 = k == 1u ? 1.0f : 0.0f;
-            X.p2 = k == 2u ? 1.0f : 0.0f;
+            X.p0 = kind == 0u ? 1.0f : 0.0f;
+            X.p1 = kind == 1u ? 1.0f : 0.0f;
+            X.p2 = kind == 2u ? 1.0f : 0.0f;
             X.solved = true;
             if (COUNT) ctr[CTR_SOLVED_HITS]++;
+            if (blk == 0u) {
+                // first visit of a terminal node: it gets a block for its outcome sums
+                blk = lane_alloc_block(T, bcap, error);
+                *reinterpret_cast<unsigned short*>(rec_ptr(slab, rec) + 10) = (unsigned short)(blk | (kind << 14));
+                pl[level * 64].z = pm_make(blk, 0u, true, kind);
+            }
         } else {
-            // visit() (mcts.rs:374-406): allocate the children; their records are written in phase C together with
-            // their priors. Only an auto-extended single child is written here (prior 1.0, no policy call).
+            // visit() (mcts.rs:374-406): give the node its block; the children's records are written in phase C together
+            // with their priors. Only an auto-extended single child is written here (prior 1.0, no policy call).
             for (;;) {
                 const uint64_t occ = my | op;
-                uint32_t lmask = 0;
-#pragma unroll
-                for (int c = 0; c < 9; c++)
-                    if (c4::col_height(occ, c) < c4::HEIGHT) lmask |= 1u << c;
+                const uint32_t lmask = legal_mask_of(occ);
                 const uint32_t n_new = (uint32_t)__popc(lmask);
-                const uint32_t first = T.next_node;
-                T.next_node = first + n_new;
-                wcur = (wcur & ~(PW_FC_MASK | (0xFu << PW_NC_SHIFT))) | first | (n_new << PW_NC_SHIFT);
-                st_sel_w(slab, node, wcur);
-                pl[level * 64].z = wcur;  // the solver walk reads fc / nc of the path's nodes from the log
-                if (node == 0) { T.root_fc = first; T.root_nc = n_new; }
+                const uint32_t nb = lane_alloc_block(T, bcap, error);
+                T.num_nodes += n_new;
+                if (rec != REC_ROOT) *reinterpret_cast<unsigned short*>(rec_ptr(slab, rec) + 10) = (unsigned short)nb;
+                blk = nb;
+                pl[level * 64].z = pm_make(nb, n_new, false, 0u);
                 if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
 
                 if (cfg.auto_extend() && n_new == 1u) {
@@ -257,25 +291,32 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
                     const uint64_t abit = 1ull << (ha + 7 * a);
                     const uint64_t nmy = op, nop = my | abit;
                     const bool aw = c4::won(nop);
-                    const bool afull = (occ | abit) == c4::FULL;
-                    wcur = pw_make(0, 0, (uint32_t)a, aw || afull, aw ? 0u : 1u);
-                    st_sel(slab, first, 0.0f, (aw || afull) ? pw_q_solved(aw ? 0u : 1u, cfg.select_solved()) : y_unvisited, 1.0f, wcur);
-                    node = first;
+                    const bool over = aw || (occ | abit) == c4::FULL;
+                    // the only child: slot 0 of the new block (the block's own sums are written by backprop)
+                    rec = nb * 16u;
+                    kind = aw ? 0u : 1u;
+                    nsolved = over;
+                    qt = over ? 0u : f32_bits(y_unvisited);
+                    st_rec(slab, rec, qt, 1.0f, nf_make(0u, over, 0u, over ? kind : 0u));
+                    blk = 0;
                     my = nmy;
                     op = nop;
+                    pN = 0.0f;
                     level++;
-                    pl[level * 64] = make_uint4(node, f32_bits(0.0f), wcur, 0u);
-                    if (aw || afull) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
+                    pl[level * 64] = make_uint4(rec, f32_bits(0.0f), pm_make(0u, (uint32_t)__popc(legal_mask_of(my | op)), over, over ? kind : 0u), qt);
+                    if (over) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
                         X.p0 = aw ? 1.0f : 0.0f;
                         X.p1 = aw ? 0.0f : 1.0f;
                         X.p2 = 0.0f;
                         X.solved = true;
+                        blk = lane_alloc_block(T, bcap, error);
+                        *reinterpret_cast<unsigned short*>(rec_ptr(slab, rec) + 10) = (unsigned short)(blk | (kind << 14));
+                        pl[level * 64].z = pm_make(blk, 0u, true, kind);
                         break;
                     }
                     continue;
                 }
                 X.needs_eval = true;
-                X.fc = first;
                 X.legal_mask = lmask;
                 break;
             }
@@ -283,20 +324,22 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     }
     X.at_leaf = at_leaf;
     Wk.descending = desc;
-    Wk.node = node;
-    Wk.wcur = wcur;
+    Wk.rec = rec;
+    Wk.blk = blk;
+    Wk.solved = nsolved;
+    Wk.kind = kind;
+    Wk.qt = qt;
     Wk.pN = pN;
-    Wk.pq = pq;
     Wk.my = my;
     Wk.op = op;
     Wk.level = level;
 }
 
 // ---------------------------------------------------------------------------------------------- phase C
-// The rest of visit() for the node expanded in phase A (mcts.rs:389-423): creates its children (terminal ones already
-// solved) with the legal-move softmax of the nine raw logits as priors. Returns any_solved.
-SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
-                                  const float (&lg)[9], float equal_noise_weight, float y_unvisited, bool select_solved) {
+// The rest of visit() for the node expanded in phase A (mcts.rs:389-423): writes its block — zero sums and one record per
+// legal column (terminal children already solved), priors = legal-move softmax of the nine raw logits. Returns any_solved.
+SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
+                                  const float (&lg)[9], float equal_noise_weight, float y_unvisited) {
     const uint32_t lmask = X.legal_mask;
     float mx = -__builtin_inff();
 #pragma unroll
@@ -312,6 +355,7 @@ SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, uint64
     const uint32_t nc = (uint32_t)__popc(lmask);
     const float noise = 1.0f / (float)nc;
     const uint64_t my = leaf_my, occ = leaf_my | leaf_op;
+    *reinterpret_cast<float4*>(blk_ptr(slab, blk)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t idx = 0;
     bool any_solved = false;
 #pragma unroll
@@ -323,9 +367,8 @@ SYN_DEV bool lane_create_children(unsigned char* slab, const LaneLeaf& X, uint64
             const uint64_t bit = 1ull << (h + 7 * c);
             const bool w = c4::won(my | bit);  // child.op_bb = the mover's stones (connect4.rs:224-229)
             const bool over = w || (occ | bit) == c4::FULL;
-            // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost
-            st_sel(slab, X.fc + idx, 0.0f, over ? pw_q_solved(w ? 0u : 1u, select_solved) : y_unvisited, p,
-                   pw_make(0, 0, (uint32_t)c, over, w ? 0u : 1u));
+            // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost; turns 0
+            st_rec(slab, blk * 16u + idx, over ? 0u : f32_bits(y_unvisited), p, nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u));
             any_solved = any_solved || over;
             idx++;
         }
@@ -342,19 +385,16 @@ SYN_DEV int wave_max_i32(int v) {
     return v;
 }
 
-// backprop (mcts.rs:429-488) replayed from the path buffer (entries {node, N, packed word, q|turns} as of the descent).
-//   phase 1 (per lane): the MCTS-Solver walk, level by level while the subtree below stays proven. Everything a level
-//            needs is addressed by its path entry, so its aux record, its children's records and the NEXT level's path
-//            entry are fetched together: one memory round trip per level.
+// backprop (mcts.rs:429-488) replayed from the path buffer.
+//   phase 1 (per lane): the MCTS-Solver walk, level by level while the subtree below stays proven. A level needs ONE
+//            line — the node's block holds its sums and its children's solutions — fetched together with the next
+//            level's path entry: one memory round trip per level.
 //   phase 2 (whole wave, four levels per step): every remaining level just adds the leaf's outcome distribution
 //            (win/lose swapped once per level climbed) and one visit, so the levels are independent: the four path rows
-//            and then the four aux records are fetched together — two round trips per four levels.
-// `leaf_solved`: the walk starts at a node that already carries a solution (explore() hit a solved node, or an
-// auto-extended terminal child); its q slot holds the outcome's constant and must stay that way even with the solver off.
+//            and then the four block headers are fetched together — two round trips per four levels.
 template <bool COUNT, bool FAST>
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
-                           bool leaf_solved, bool active, const uint4* pl, uint32_t cap, uint32_t* ctr,
-                           unsigned long long* t_mid = nullptr) {
+                           bool active, const uint4* pl, uint32_t* ctr, unsigned long long* t_mid = nullptr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     if (COUNT && active) {
@@ -362,34 +402,37 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
         if ((uint32_t)(depth + 1) > ctr[CTR_MAX_DEPTH]) ctr[CTR_MAX_DEPTH] = (uint32_t)(depth + 1);
     }
     int L = active ? depth : -1;
-    bool keep_q = leaf_solved;  // only ever true for the first level handled
     // ---- phase 1
     if (cfg.solve() && solved && L >= 0) {
         uint4 pe = pl[L * 64];
         for (;;) {
-            const uint32_t node = pe.x;
+            const uint32_t rec = pe.x, meta = pe.z;
             float N = bits_f32(pe.y);
-            uint32_t w = pe.z;
-            const uint32_t nc = pw_nc(w), fc = pw_fc(w);
-            // one batch: the node's sums, its children (indices past the last child re-read the last one), next entry
-            const float4 a = ln_aux(slab, cap, node);
-            float4 cs[9];
+            const uint32_t blk = pm_blk(meta), nc = pm_nc(meta);
+            // one line: the node's sums and its children's records; plus the next level's path entry
+            const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, blk));
+            const uint4 hdr = line[0];
+            uint32_t d[28];
 #pragma unroll
-            for (uint32_t i = 0; i < 9; i++) cs[i] = ln_sel(slab, nc == 0u ? node : fc + (i < nc ? i : nc - 1u));
+            for (int j = 0; j < 7; j++) {
+                const uint4 t = line[1 + j];
+                d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
+            }
             const uint4 pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
-            // a node that was never backpropagated into has no aux record yet
-            float W0 = N == 0.0f ? 0.0f : a.x, W1 = N == 0.0f ? 0.0f : a.y, W2 = N == 0.0f ? 0.0f : a.z;
+            // a node that was never backpropagated into has nothing in its header yet
+            float W0 = N == 0.0f ? 0.0f : bits_f32(hdr.x), W1 = N == 0.0f ? 0.0f : bits_f32(hdr.y),
+                  W2 = N == 0.0f ? 0.0f : bits_f32(hdr.z);
             bool all_solved = true;
-            uint32_t key = outcome_key(pw_some(w), pw_kind(w), pw_turns(w));
+            uint32_t key = outcome_key(pm_solved(meta), pm_kind(meta), pe.w);
             if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
 #pragma unroll
             for (uint32_t i = 0; i < 9; i++) {
                 if (i < nc) {
-                    const uint32_t cw = f32_bits(cs[i].w);
-                    all_solved = all_solved && pw_some(cw);
+                    const uint32_t nf = d[3 * i + 2];
+                    all_solved = all_solved && nf_solved(nf);
                     // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
-                    const uint32_t ck = pw_kind(cw);
-                    const uint32_t rk = pw_some(cw) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, pw_turns(cw) + 1u) : 0u;
+                    const uint32_t ck = nf_kind(nf);
+                    const uint32_t rk = nf_solved(nf) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
                     key = rk > key ? rk : key;
                 }
             }
@@ -414,19 +457,23 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
             } else {
                 break;  // this level and everything above belongs to phase 2
             }
-            w = pw_with_solution(w, bkind, bturns);
-            st_sel_w(slab, node, w);
-            if (L == 0) T.root_solved = true;
             W0 += d0;
             W1 += d1;
             W2 += d2;
             N += 1.0f;
-            st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
-            *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, pw_q_solved(bkind, cfg.select_solved()));
+            *reinterpret_cast<float4*>(blk_ptr(slab, blk)) = make_float4(W0, W1, W2, 0.0f);
+            if (rec != REC_ROOT) {
+                // the node is (still) solved: its q slot carries the turn count, its record the outcome
+                unsigned char* r = rec_ptr(slab, rec);
+                *reinterpret_cast<uint32_t*>(r) = bturns;
+                *reinterpret_cast<uint32_t*>(r + 8) = nf_make((uint32_t)N, true, blk, bkind);
+            } else {
+                T.root_solved = true;
+                T.root_sol = bkind | (bturns << 2);
+            }
             const float t = d0;
             d0 = d2;
             d2 = t;
-            keep_q = false;
             L--;
             if (L < 0) break;
             pe = pe_next;
@@ -435,21 +482,21 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
     if (t_mid) *t_mid = (unsigned long long)__builtin_readcyclecounter();
     // ---- phase 2: levels L..0 of this lane; (d0,d1,d2) is the delta for level L
     for (int base = wave_max_i32(L); base >= 0; base -= 4) {
-        uint2 pe[4];
+        uint4 pe[4];
         float4 a[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
-            pe[j] = *reinterpret_cast<const uint2*>(pl + (Lj < 0 ? 0 : Lj) * 64);
+            pe[j] = pl[(Lj < 0 ? 0 : Lj) * 64];
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
             const bool ok = Lj >= 0 && Lj <= L;
-            // a node that was never backpropagated into (N == 0: the fresh leaf of most explores) has no aux record to
-            // read, and idle lanes have no node: both fetch their own path entry instead — a valid address that is hot in
-            // L2 — so neither costs an HBM sector
-            const unsigned char* src = (ok && pe[j].y != 0u) ? slab + (size_t)(cap + pe[j].x) * 16u
+            // a node that was never backpropagated into (N == 0: the fresh leaf of most explores) has no sums to read,
+            // and idle lanes have no node: both fetch their own path entry instead — a valid address that is hot in
+            // L2 — so neither costs an HBM line
+            const unsigned char* src = (ok && pe[j].y != 0u) ? blk_ptr(slab, pm_blk(pe[j].z))
                                                              : reinterpret_cast<const unsigned char*>(pl + (Lj < 0 ? 0 : Lj) * 64);
             a[j] = *reinterpret_cast<const float4*>(src);
         }
@@ -457,17 +504,20 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
             if (Lj >= 0 && Lj <= L) {
-                const uint32_t node = pe[j].x;
+                const uint32_t rec = pe[j].x, meta = pe[j].z;
                 float N = bits_f32(pe[j].y);
                 const bool flip = ((L - Lj) & 1) != 0;  // delta[0] <-> delta[2] once per level climbed
                 const float W0 = (N == 0.0f ? 0.0f : a[j].x) + (flip ? d2 : d0);
                 const float W1 = (N == 0.0f ? 0.0f : a[j].y) + d1;
                 const float W2 = (N == 0.0f ? 0.0f : a[j].z) + (flip ? d0 : d2);
                 N += 1.0f;
-                st_aux(slab, cap, node, make_float4(W0, W1, W2, 0.0f));
-                const float q = -((W2 - W0) / N);
-                if (keep_q && Lj == L) *reinterpret_cast<float*>(slab + (size_t)node * 16u) = N;
-                else *reinterpret_cast<float2*>(slab + (size_t)node * 16u) = make_float2(N, q);
+                *reinterpret_cast<float4*>(blk_ptr(slab, pm_blk(meta))) = make_float4(W0, W1, W2, 0.0f);
+                if (rec != REC_ROOT) {
+                    unsigned char* r = rec_ptr(slab, rec);
+                    // a solved node (explore() hit it, or the solver is off) keeps its turn count in the q slot
+                    if (!pm_solved(meta)) *reinterpret_cast<float*>(r) = -((W2 - W0) / N);
+                    *reinterpret_cast<unsigned short*>(r + 8) = (unsigned short)((uint32_t)N | (pm_solved(meta) ? 0x8000u : 0u));
+                }
             }
         }
     }
@@ -475,40 +525,31 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
 
 // ---------------------------------------------------------------------------------------------- end of a search
 struct LaneRoot {
-    uint32_t fc, nc, root_w, lmask;
+    uint32_t nc, lmask;
     float rootN;
 };
 SYN_DEV LaneRoot lane_root(const LaneTree& T) {
     LaneRoot R;
-    const float4 s = ln_sel(T.slab, 0);
-    R.root_w = f32_bits(s.w);
-    R.fc = pw_fc(R.root_w);
-    R.nc = pw_nc(R.root_w);
-    R.rootN = s.x;
-    const uint64_t occ = T.root_my | T.root_op;
-    uint32_t lm = 0;
-#pragma unroll
-    for (int c = 0; c < 9; c++)
-        if (c4::col_height(occ, c) < c4::HEIGHT) lm |= 1u << c;
-    R.lmask = R.nc == 0u ? 0u : lm;  // the children of the root are its legal columns in ascending order
+    R.rootN = (float)T.iter;
+    R.lmask = T.next_block > 1u ? legal_mask_of(T.root_my | T.root_op) : 0u;  // the root's children: its legal columns
+    R.nc = (uint32_t)__popc(R.lmask);
     return R;
 }
 
 // MCTS::target_policy numerators (mcts.rs:174-211) per column (0 for non-children) and their sum in child order
 SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&wts)[9]) {
     const bool first_visit = R.rootN == 1.0f;
-    const bool root_win = pw_some(R.root_w) && pw_kind(R.root_w) == 2u;
+    const bool root_win = T.root_solved && (T.root_sol & 3u) == 2u;
     float total = 0.0f;
     uint32_t idx = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         wts[c] = 0.0f;
         if ((R.lmask >> c) & 1u) {
-            const float4 cs = ln_sel(T.slab, R.fc + idx);
-            const uint32_t cw = f32_bits(cs.w);
+            const uint32_t nf = ld_rec(T.slab, 16u + idx)[2];
             float v;
-            if (first_visit) v = root_win ? ((pw_some(cw) && pw_kind(cw) == 0u) ? 1.0f : 0.0f) : 1.0f;
-            else v = cs.x;
+            if (first_visit) v = root_win ? ((nf_solved(nf) && nf_kind(nf) == 0u) ? 1.0f : 0.0f) : 1.0f;
+            else v = nf_N(nf);
             wts[c] = v;
             total += v;
             idx++;
@@ -517,56 +558,57 @@ SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&
     return total;
 }
 
-SYN_DEV void lane_target_q(const LaneTree& T, const LaneRoot& R, uint32_t cap, float& q0, float& q1, float& q2) {
-    if (pw_some(R.root_w)) {
-        const uint32_t k = pw_kind(R.root_w);
+SYN_DEV void lane_target_q(const LaneTree& T, const LaneRoot& R, float& q0, float& q1, float& q2) {
+    if (T.root_solved) {
+        const uint32_t k = T.root_sol & 3u;
         q0 = k == 0u ? 1.0f : 0.0f;
         q1 = k == 1u ? 1.0f : 0.0f;
         q2 = k == 2u ? 1.0f : 0.0f;
     } else {
-        const float4 a = ln_aux(T.slab, cap, 0);
+        const float4 a = *reinterpret_cast<const float4*>(blk_ptr(T.slab, 1));
         q0 = a.x / R.rootN;
         q1 = a.y / R.rootN;
         q2 = a.z / R.rootN;
     }
 }
 
-// MCTS::best_action (mcts.rs:273-294); also returns the packed word of the chosen child
-SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_selection, uint32_t& best_w) {
+// MCTS::best_action (mcts.rs:273-294); also returns the record word (N | solved | block | kind) of the chosen child
+SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_selection, uint32_t& best_nf) {
     int best = -1;
     float b0 = 0.0f, b1 = 0.0f;
-    best_w = 0;
+    best_nf = 0;
     uint32_t idx = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         if ((R.lmask >> c) & 1u) {
-            const float4 cs = ln_sel(T.slab, R.fc + idx);
-            const uint32_t cw = f32_bits(cs.w);
+            const lu3 r = ld_rec(T.slab, 16u + idx);
+            const uint32_t nf = r[2];
             float k0, k1;
-            if (pw_some(cw)) {
-                const uint32_t kind = pw_kind(cw);
-                const float t = (float)pw_turns(cw);
+            if (nf_solved(nf)) {
+                const uint32_t kind = nf_kind(nf);
+                const float t = (float)r[0];
                 if (kind == 2u) { k0 = 0.0f; k1 = t; }
                 else if (kind == 1u) { k0 = 2.0f; k1 = -t; }
                 else { k0 = 3.0f; k1 = -t; }
             } else {
                 k0 = 1.0f;
                 // -child.q(): the stored q, except for a never-visited child where the reference divides 0 by 0
-                const float nq = cs.x == 0.0f ? -((0.0f - 0.0f) / cs.x) : cs.y;
-                k1 = action_selection == 0 ? nq : cs.x;
+                const float cN = nf_N(nf);
+                const float nq = cN == 0.0f ? -((0.0f - 0.0f) / cN) : bits_f32(r[0]);
+                k1 = action_selection == 0 ? nq : cN;
             }
             const bool gt = best < 0 || (k0 > b0) || (k0 == b0 && k1 > b1);
-            if (gt) { best = c; b0 = k0; b1 = k1; best_w = cw; }
+            if (gt) { best = c; b0 = k0; b1 = k1; best_nf = nf; }
             idx++;
         }
     }
     return best;
 }
 
-SYN_DEV uint32_t lane_child_w(const LaneTree& T, const LaneRoot& R, int action, bool& is_child) {
+SYN_DEV uint32_t lane_child_nf(const LaneTree& T, const LaneRoot& R, int action, bool& is_child) {
     is_child = ((R.lmask >> action) & 1u) != 0u;
     const uint32_t idx = (uint32_t)__popc(R.lmask & ((1u << action) - 1u));
-    return is_child ? f32_bits(ln_sel(T.slab, R.fc + idx).w) : 0u;
+    return is_child ? ld_rec(T.slab, 16u + idx)[2] : 0u;
 }
 
 // run_game's per-move tail (alpha_zero.rs:243-264) + game end (fill_state_info / store_rewards, 296-338)
@@ -587,11 +629,11 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
 #pragma unroll
     for (int c = 0; c < 9; c++) pi[c] = pi[c] / wtotal;
     float q0, q1, q2;
-    lane_target_q(T, R, P.cap, q0, q1, q2);
+    lane_target_q(T, R, q0, q1, q2);
     const size_t pos = (size_t)T.job * 63 + (size_t)T.turn;
     P.states_bb[pos * 2 + 0] = T.root_my;
     P.states_bb[pos * 2 + 1] = T.root_op;
-    P.root_nodes[pos] = T.next_node;
+    P.root_nodes[pos] = T.num_nodes;
 #pragma unroll
     for (int c = 0; c < 9; c++) P.pis[pos * 9 + c] = pi[c];
     P.vs[pos * 3 + 0] = q0;
@@ -599,8 +641,8 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     P.vs[pos * 3 + 2] = q2;
 
     // sample_action (alpha_zero.rs:270-294)
-    uint32_t best_w;
-    const int best = lane_best_action(T, R, rc.action, best_w);
+    uint32_t best_nf;
+    const int best = lane_best_action(T, R, rc.action, best_nf);
     int action;
     if (want_random) {
         const uint32_t n = (uint32_t)__popc(R.lmask);
@@ -617,7 +659,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
         uint32_t m = R.lmask;
         for (uint32_t i = 0; i < r; i++) m &= m - 1u;
         action = __ffs((int)m) - 1;
-    } else if (maybe_sample && (!pw_some(best_w) || !rc.stop_when_solved)) {
+    } else if (maybe_sample && (!nf_solved(best_nf) || !rc.stop_when_solved)) {
         float total = pi[0];
         const float chosen_unit = bits_f32((rnd >> 9) | 0x3F800000u) - 1.0f;
         float cum[8];
@@ -638,9 +680,9 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     P.actions[pos] = (unsigned char)action;
 
     bool a_child;
-    const uint32_t a_w = lane_child_w(T, R, action, a_child);
-    bool sol_some = a_child && pw_some(a_w);
-    uint32_t sol_kind = pw_kind(a_w);
+    const uint32_t a_nf = lane_child_nf(T, R, action, a_child);
+    bool sol_some = a_child && nf_solved(a_nf);
+    uint32_t sol_kind = nf_kind(a_nf);
 
     const uint64_t occ = T.root_my | T.root_op;
     const int h = c4::col_height(occ, action);
@@ -660,9 +702,11 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     if (!sol_some) {
         T.root_my = nmy;
         T.root_op = nop;
-        T.next_node = 0;
+        T.next_block = 0;
+        T.num_nodes = 0;
         T.iter = 0;
         T.root_solved = false;
+        T.root_sol = 0;
         return;
     }
 
@@ -702,41 +746,39 @@ SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
     float pi[9];
     const float wtotal = lane_policy_weights(T, R, pi);
     float q0, q1, q2;
-    lane_target_q(T, R, P.cap, q0, q1, q2);
-    uint32_t bw;
-    const int best = lane_best_action(T, R, P.action_selection, bw);
+    lane_target_q(T, R, q0, q1, q2);
+    uint32_t bnf;
+    const int best = lane_best_action(T, R, P.action_selection, bnf);
     DevSearchResult* out = P.results + T.job;
     uint32_t idx = 0;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const bool ch = ((R.lmask >> c) & 1u) != 0u;
-        float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+        lu3 r = lu3{0u, 0u, 0u};
         float4 ca = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ch) {
-            cs = ln_sel(T.slab, R.fc + idx);
-            if (cs.x != 0.0f) ca = ln_aux(T.slab, P.cap, R.fc + idx);
+            r = ld_rec(T.slab, 16u + idx);
+            if (nf_N(r[2]) != 0.0f) ca = *reinterpret_cast<const float4*>(blk_ptr(T.slab, nf_blk(r[2])));
             idx++;
         }
-        const uint32_t cw = f32_bits(cs.w);
-        out->child_N[c] = cs.x;
+        out->child_N[c] = nf_N(r[2]);
         out->child_W[c][0] = ca.x;
         out->child_W[c][1] = ca.y;
         out->child_W[c][2] = ca.z;
-        out->child_P[c] = ch ? cs.z : 0.0f;
-        const bool some = ch && pw_some(cw);
+        out->child_P[c] = ch ? bits_f32(r[1]) : 0.0f;
+        const bool some = ch && nf_solved(r[2]);
         out->child_sol[c][0] = some ? 1 : 0;
-        out->child_sol[c][1] = some ? (int)pw_kind(cw) : 0;
-        out->child_sol[c][2] = some ? (int)pw_turns(cw) : 0;
+        out->child_sol[c][1] = some ? (int)nf_kind(r[2]) : 0;
+        out->child_sol[c][2] = some ? (int)r[0] : 0;
         out->target_pi[c] = pi[c] / wtotal;
     }
-    const float4 ra = ln_aux(T.slab, P.cap, 0);
+    const float4 ra = *reinterpret_cast<const float4*>(blk_ptr(T.slab, 1));
     out->root_N = R.rootN;
     out->root_W[0] = ra.x; out->root_W[1] = ra.y; out->root_W[2] = ra.z;
-    const bool some = pw_some(R.root_w);
-    out->root_sol[0] = some ? 1 : 0;
-    out->root_sol[1] = some ? (int)pw_kind(R.root_w) : 0;
-    out->root_sol[2] = some ? (int)pw_turns(R.root_w) : 0;
-    out->num_nodes = T.next_node;
+    out->root_sol[0] = T.root_solved ? 1 : 0;
+    out->root_sol[1] = T.root_solved ? (int)(T.root_sol & 3u) : 0;
+    out->root_sol[2] = T.root_solved ? (int)(T.root_sol >> 2) : 0;
+    out->num_nodes = T.num_nodes;
     out->best_action = best;
     out->target_q[0] = q0; out->target_q[1] = q1; out->target_q[2] = q2;
     lane_start_job<MODE_SEARCH>(P, T);
@@ -850,7 +892,8 @@ template <int NW>
 struct LaneLds {
     static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
     static constexpr size_t IDX_OFF = OUT_OFF + (size_t)NW * 1024;     // + 1 KB result patch per wave
-    static constexpr size_t BYTES = IDX_OFF + (size_t)NW * 64;         // + 64 B compaction index per wave
+    static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;        // + 64 B compaction index per wave
+    static constexpr size_t BYTES = FT_OFF + 64;                       // + the four feature shift tables (16 B each)
 };
 
 SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
@@ -872,7 +915,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     float* outw = reinterpret_cast<float*>(smem_raw + LaneLds<NW>::OUT_OFF) + wave * 256;
 
     stage_weight_image(wimg, P.wimg, tid, NT);
-    const FeatureTable FT = make_feature_table(lane >> 4);
+    if (tid < 4) {
+        const FeatureTable f = make_feature_table(tid);
+        *reinterpret_cast<uint4*>(smem_raw + LaneLds<NW>::FT_OFF + tid * 16) = make_uint4(f.t[0], f.t[1], f.t[2], f.t[3]);
+    }
 
     uint32_t ctr[COUNT ? CTR_COUNT : 1];
 #pragma unroll
@@ -883,19 +929,27 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
     // this lane's column of its wave's path buffer ([level 0..63][lane 0..63] entries of 16 bytes)
     uint4* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * 4096 + (size_t)lane;
-    const uint32_t cap = P.cap;
+    const uint32_t bcap = P.cap / 4u;  // 128-byte blocks in this lane's slab
     lane_start_job<MODE>(P, T);
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
 
     const int n_explores = P.roll.num_explores;
-    const int thresh = P.lane_thresh;
+    const int thresh = P.lane_thresh & 0xFF;
+    // Waves that share a SIMD (wave, wave + 4, wave + 8, ...) start one after the other: identical waves that start
+    // together stay in lock-step for ever — all chasing pointers while the matrix pipe idles, then all queueing for it —
+    // whereas an initial offset persists (nothing synchronises them), so one wave's matrix phase overlaps its
+    // neighbours' tree phases.
+    {
+        const int stagger = (P.lane_thresh >> 8) & 0xFF;  // units of 8,128 cycles (s_sleep 127)
+        for (int i = 0; i < stagger * (wave >> 2); i++) __builtin_amdgcn_s_sleep(127);
+    }
     unsigned char* const idxw = smem_raw + LaneLds<NW>::IDX_OFF + wave * 64;  // compaction: rank -> lane
     unsigned long long cache_hits = 0, cache_misses = 0;
     LaneWalk Wk;
     Wk.descending = false;
     Wk.pending = false;
-    Wk.pend_fc = 0; Wk.pend_lmask = 0;
-    Wk.node = 0; Wk.wcur = 0; Wk.pN = 0.0f; Wk.pq = 0.0f; Wk.my = 0; Wk.op = 0; Wk.level = 0;
+    Wk.pend_lmask = 0;
+    Wk.rec = REC_ROOT; Wk.blk = 0; Wk.solved = false; Wk.kind = 0; Wk.qt = 0; Wk.pN = 0.0f; Wk.my = 0; Wk.op = 0; Wk.level = 0;
     unsigned long long pA = 0, pB = 0, pC = 0, pC1 = 0, pC2 = 0, pM = 0, pT = 0, pTiles = 0, pRounds = 0, pLanes = 0, pEvals = 0;
 #define SYN_STAMP() (PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
 #define SYN_LAP(acc) if (PROF) { unsigned long long n_ = SYN_STAMP(); acc += n_ - pT; pT = n_; }
@@ -904,13 +958,16 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, cap, thresh, ctr);
+        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error);
         SYN_LAP(pA)
+        // PROF: timeline of the three waves of SIMD 0 of workgroup 0 (rounds 2000..2015): [A end = B start, B end, C end]
+        const bool tl = PROF && P.prof && blockIdx.x == 0 && (wave & 3) == 0 && pRounds >= 2000 && pRounds < 2016;
+        if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 0] = SYN_STAMP();
         // ---- phase B: the lanes that need the network, compacted into tiles of 16 positions. While other lanes are still
         // descending only whole tiles are evaluated: requests beyond `thresh` stay pending and go first next round.
         const bool want_nn = X.at_leaf && X.needs_eval;  // this lane's expanded leaf needs Policy::eval
         float lg[9];
-        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        float v0 = X.p0, v1 = X.p1, v2 = X.p2;  // outcome distribution to back up: a solved leaf's, else the network's
 #pragma unroll
         for (int c = 0; c < 9; c++) lg[c] = 0.0f;
         // PolicyWithCache: a position that some game already evaluated skips the network (and its tile slot)
@@ -931,7 +988,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(want_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want_mask, 0u));
         const int quota = __ballot(Wk.descending) != 0ull ? thresh : 64;
         Wk.pending = need && rank >= quota;
-        if (Wk.pending) { Wk.pend_fc = X.fc; Wk.pend_lmask = X.legal_mask; }
+        if (Wk.pending) Wk.pend_lmask = X.legal_mask;
         need = need && rank < quota;
         const bool fin = X.at_leaf && !Wk.pending;  // this lane's explore gets its network call / backprop in this round
         if (COUNT && (need || hit)) ctr[CTR_POLICY_EVALS]++;
@@ -944,11 +1001,16 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint64_t hi, lo;
-        feature_boards(Wk.my, Wk.op, hi, lo);
 #pragma unroll 1
         for (int j = 0; j * 16 < n_need; j++) {
             if (PROF) pTiles++;
+            // everything a tile needs is re-derived here instead of living in registers across the whole matrix phase:
+            // the two derived boards (10 VALU) and the lane's feature shift table (one 16-byte LDS read)
+            uint64_t hi, lo;
+            feature_boards(Wk.my, Wk.op, hi, lo);
+            const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + LaneLds<NW>::FT_OFF + (lane >> 4) * 16);
+            FeatureTable FT;
+            FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
             const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
             const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
             f32x4 o = mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
@@ -976,28 +1038,24 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
+        if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 1] = SYN_STAMP();
         SYN_LAP(pB)
         if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(fin)); pEvals += (unsigned long long)n_need; }
 
         if (P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
 
         // ---- phase C
-        float d0 = X.p0, d1 = X.p1, d2 = X.p2;
         bool solved = X.solved;
         if (need || hit) {
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
-            solved = lane_create_children(T.slab, X, Wk.my, Wk.op, lg,
+            solved = lane_create_children(T.slab, Wk.blk, X, Wk.my, Wk.op, lg,
                                           (P.mcts.noise == 1 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise_weight : -1.0f,
-                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, cv.select_solved());
-            d0 = v0;
-            d1 = v1;
-            d2 = v2;
+                                          cv.fpu_const() ? cv.fpu_value() : 0.0f);
         }
         SYN_LAP(pC1)
         unsigned long long tmid = 0;
-        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, d0, d1, d2, solved, X.solved && !(need || hit), fin, pl, cap, ctr,
-                                   PROF ? &tmid : nullptr);
+        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, PROF ? &tmid : nullptr);
         if (PROF) { pC2 += tmid - pT; pT = tmid; }
         SYN_LAP(pC)
         if (fin) {
@@ -1012,6 +1070,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
             }
         }
+        if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 1 - 2000)) * 3 + 2] = SYN_STAMP();
         SYN_LAP(pM)
     }
 #undef SYN_STAMP

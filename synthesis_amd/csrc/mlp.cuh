@@ -104,7 +104,11 @@ SYN_DEV void mlp_layer(const float* __restrict__ wimg, const float* __restrict__
     for (int s4 = 0; s4 < S4; s4++) {
         f32x4 a[NOB];
 #pragma unroll
+#ifdef SYN_EXPERIMENT_NO_LDS_WEIGHTS
+        for (int ob = 0; ob < NOB; ob++) a[ob] = f32x4{0.001f * (float)s4, 0.002f, 0.003f * (float)ob, 0.004f};  // timing experiment only
+#else
         for (int ob = 0; ob < NOB; ob++) a[ob] = *reinterpret_cast<const f32x4*>(wl + (s4 * NOB + ob) * 256);
+#endif
         f32x4 b = bop(s4);
 #pragma unroll
         for (int r = 0; r < 4; r++)

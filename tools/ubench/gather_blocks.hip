@@ -38,6 +38,17 @@
         : "v"(p)                                                                                                    \
         : "memory")
 
+#define LOAD7(POL)                                                                                                   \
+    asm volatile(                                                                                                   \
+        "global_load_dwordx4 %0, %7, off offset:16" POL "\n global_load_dwordx4 %1, %7, off offset:32" POL "\n"    \
+        "global_load_dwordx4 %2, %7, off offset:48" POL "\n global_load_dwordx4 %3, %7, off offset:64" POL "\n"   \
+        "global_load_dwordx4 %4, %7, off offset:80" POL "\n global_load_dwordx4 %5, %7, off offset:96" POL "\n"   \
+        "global_load_dwordx4 %6, %7, off offset:112" POL "\n"                                                      \
+        "s_waitcnt vmcnt(0)"                                                                                        \
+        : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6])                  \
+        : "v"(p)                                                                                                    \
+        : "memory")
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int VARIANT>
@@ -48,7 +59,7 @@ __global__ __launch_bounds__(512) void walk(const unsigned char* pool, uint32_t 
     uint32_t idx = (state >> 8) % nblocks_per_lane;
     uint32_t acc = 0;
     for (int s = 0; s < steps; s++) {
-        const unsigned char* p = slab + (size_t)idx * 288;
+        const unsigned char* p = VARIANT == 8 ? slab + (size_t)idx * 128 : slab + (size_t)idx * 288;
         u32x4 r[18];
         for (int i = 0; i < 18; i++) r[i] = u32x4{0, 0, 0, 0};
         if (VARIANT == 0) LOAD18("");
@@ -58,6 +69,7 @@ __global__ __launch_bounds__(512) void walk(const unsigned char* pool, uint32_t 
         else if (VARIANT == 4) LOAD9("");
         else if (VARIANT == 5) LOAD9(" sc1");
         else if (VARIANT == 6) LOAD9(" nt");
+        else if (VARIANT == 8) LOAD7("");
         else if (VARIANT == 7) {  // touch one dword per 128-byte line first, wait, then the 18 loads
             uint32_t t0, t1, t2;
             asm volatile("global_load_dword %0, %3, off\n global_load_dword %1, %3, off offset:128\n global_load_dword %2, %3, off offset:256\n s_waitcnt vmcnt(0)"
@@ -83,9 +95,9 @@ int main() {
     hipMalloc(&out, lanes * 4);
     hipMemset(pool, 1, lanes * nb * 288);
     const int steps = 2000;
-    const char* names[] = {"18 x 16B plain", "18 x 16B sc1", "18 x 16B nt", "18 x 16B sc0 sc1", "9 x 16B plain", "9 x 16B sc1", "9 x 16B nt", "touch 3 lines, wait, 18 x 16B plain"};
+    const char* names[] = {"18 x 16B plain", "18 x 16B sc1", "18 x 16B nt", "18 x 16B sc0 sc1", "9 x 16B plain", "9 x 16B sc1", "9 x 16B nt", "touch 3 lines, wait, 18 x 16B plain", "7 x 16B of a 128-B aligned block (one line)"};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int v = 0; v < 8; v++) {
+    for (int v = 0; v < 9; v++) {
         float best = 1e30f;
         for (int rep = 0; rep < 2; rep++) {
             hipEventRecord(e0);
@@ -98,6 +110,7 @@ int main() {
                 case 5: hipLaunchKernelGGL(walk<5>, dim3(grid), dim3(nt), 0, 0, pool, nb, steps, out); break;
                 case 6: hipLaunchKernelGGL(walk<6>, dim3(grid), dim3(nt), 0, 0, pool, nb, steps, out); break;
                 case 7: hipLaunchKernelGGL(walk<7>, dim3(grid), dim3(nt), 0, 0, pool, nb, steps, out); break;
+                case 8: hipLaunchKernelGGL(walk<8>, dim3(grid), dim3(nt), 0, 0, pool, nb, steps, out); break;
             }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
