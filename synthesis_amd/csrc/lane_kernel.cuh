@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
             const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
             const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
-            f32x4 o = mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+            f32x4 o = NW >= 16 ? mlp_tile16_lowreg(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             const int q = lane >> 4;
             if (q == 2) {
                 float a = o[1], b = o[2], c = o[3];

@@ -104,11 +104,7 @@ SYN_DEV void mlp_layer(const float* __restrict__ wimg, const float* __restrict__
     for (int s4 = 0; s4 < S4; s4++) {
         f32x4 a[NOB];
 #pragma unroll
-#ifdef SYN_EXPERIMENT_NO_LDS_WEIGHTS
-        for (int ob = 0; ob < NOB; ob++) a[ob] = f32x4{0.001f * (float)s4, 0.002f, 0.003f * (float)ob, 0.004f};  // timing experiment only
-#else
         for (int ob = 0; ob < NOB; ob++) a[ob] = *reinterpret_cast<const f32x4*>(wl + (s4 * NOB + ob) * 256);
-#endif
         f32x4 b = bop(s4);
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -145,6 +141,62 @@ SYN_DEV f32x4 mlp_tile16(const float* __restrict__ wimg, const float* __restrict
 
     f32x4 h3[4];
     mlp_layer<2, 4, 6>(wimg, bimg, lane, [&](int s4) { return h2[s4]; }, h3);
+    relu_inplace(h3);
+
+    f32x4 h4[3];
+    mlp_layer<3, 3, 4>(wimg, bimg, lane, [&](int s4) { return h3[s4]; }, h4);
+    relu_inplace(h4);
+
+    f32x4 out[1];
+    mlp_layer<4, 1, 3>(wimg, bimg, lane, [&](int s4) { return h4[s4]; }, out);
+    return out[0];
+}
+
+// Output blocks [OB0, OB0 + NB) of a layer with NOB blocks in total: same operands, same per-output fma chains as
+// mlp_layer, but only NB accumulators and NB weight fragments are live at a time.
+template <int LAYER, int NOB, int OB0, int NB, int S4, class BOperand>
+SYN_DEV void mlp_layer_part(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane, BOperand bop,
+                            f32x4* acc) {
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ob = 0; ob < NB; ob++)
+        acc[ob] = *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[LAYER] + ((OB0 + ob) * 4 + q) * 4);
+    const float* wl = wimg + MlpGeom::W_OFF[LAYER] + lane * 4;
+#pragma unroll
+    for (int s4 = 0; s4 < S4; s4++) {
+        f32x4 a[NB];
+#pragma unroll
+        for (int ob = 0; ob < NB; ob++) a[ob] = *reinterpret_cast<const f32x4*>(wl + (s4 * NOB + OB0 + ob) * 256);
+        f32x4 b = bop(s4);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int ob = 0; ob < NB; ob++)
+                acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob][r], b[r], acc[ob], 0, 0, 0);
+    }
+}
+
+// mlp_tile16 with a smaller register footprint (the two wide layers run in two passes over their output blocks): for the
+// 16-waves-per-workgroup launch shape, whose budget is 128 VGPRs. Bit-identical outputs.
+SYN_DEV f32x4 mlp_tile16_lowreg(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane,
+                                const FeatureTable& FT, uint64_t hi, uint64_t lo) {
+    auto feat = [&](int s4) {
+        return s4 == 0 ? feature_quad<0>(FT, hi, lo) : s4 == 1 ? feature_quad<1>(FT, hi, lo)
+             : s4 == 2 ? feature_quad<2>(FT, hi, lo) : feature_quad<3>(FT, hi, lo);
+    };
+    f32x4 h1[8];
+    mlp_layer_part<0, 8, 0, 4, 4>(wimg, bimg, lane, feat, h1);
+    mlp_layer_part<0, 8, 4, 4, 4>(wimg, bimg, lane, feat, h1 + 4);
+    relu_inplace(h1);
+
+    f32x4 h2[6];
+    mlp_layer_part<1, 6, 0, 3, 8>(wimg, bimg, lane, [&](int s4) { return h1[s4]; }, h2);
+    mlp_layer_part<1, 6, 3, 3, 8>(wimg, bimg, lane, [&](int s4) { return h1[s4]; }, h2 + 3);
+    relu_inplace(h2);
+
+    f32x4 h3[4];
+    mlp_layer_part<2, 4, 0, 2, 6>(wimg, bimg, lane, [&](int s4) { return h2[s4]; }, h3);
+    mlp_layer_part<2, 4, 2, 2, 6>(wimg, bimg, lane, [&](int s4) { return h2[s4]; }, h3 + 2);
     relu_inplace(h3);
 
     f32x4 h4[3];
