@@ -14,10 +14,11 @@
 // pointer-chasing phases on the same SIMD. The price is concurrency (a CU wants 1024 games) and divergence (a wave
 // descends until its deepest tree is done), which is why the row kernels stay for <= 16 k concurrent games.
 //
-//   phase A (per lane)   select + expand (global loads of 32-byte child records, 9 per level)
+//   phase A (per lane)   select + expand (one 128-byte block = one cache line per level)
 //   phase B (per wave)   up to four mlp_tile16 evaluations; leaf boards reach the tile layout by ds_bpermute, the 12
 //                        outputs per position return through a 1 KB per-wave LDS patch
-//   phase C (per lane)   legal softmax -> priors, backprop along parent links, move step when the search is over
+//   phase C (per lane)   legal softmax -> children records, backprop replayed from the path log, move step when the
+//                        search is over
 #pragma once
 #include "engine_kernels.cuh"
 
