@@ -151,7 +151,7 @@ SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
 // pl = this lane's column of the wave's path buffer: level L lives at pl[L * 64]
 template <bool COUNT, bool FAST>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
-                                uint32_t bcap, int thresh, uint32_t* ctr, int* error) {
+                                uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
@@ -173,8 +173,9 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
         if (COUNT) ctr[CTR_EXPLORES]++;
         rec = REC_ROOT;
         level = 0;
-        my = T.root_my;
-        op = T.root_op;
+        // the root position is parked in LDS between searches (it is only needed here and at the end of a search)
+        my = (uint64_t)pk[0] | ((uint64_t)pk[pk_stride] << 32);
+        op = (uint64_t)pk[2 * pk_stride] | ((uint64_t)pk[3 * pk_stride] << 32);
         nsolved = false;
         kind = 0;
         qt = 0;
@@ -894,7 +895,8 @@ struct LaneLds {
     static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
     static constexpr size_t IDX_OFF = OUT_OFF + (size_t)NW * 1024;     // + 1 KB result patch per wave
     static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;        // + 64 B compaction index per wave
-    static constexpr size_t BYTES = FT_OFF + 64;                       // + the four feature shift tables (16 B each)
+    static constexpr size_t PARK_OFF = FT_OFF + 64;                    // + the four feature shift tables (16 B each)
+    static constexpr size_t BYTES = PARK_OFF + (size_t)NW * 64 * 20;   // + 5 parked dwords per lane (root boards, turn|rng)
 };
 
 SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
@@ -932,6 +934,25 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     uint4* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * 4096 + (size_t)lane;
     const uint32_t bcap = P.cap / 4u;  // 128-byte blocks in this lane's slab
     lane_start_job<MODE>(P, T);
+    // Cold per-lane state lives in LDS between the ends of searches (5 dwords per lane, lane-linear): the root position and
+    // the game's turn / RNG position. That takes them out of the register budget of the hot loop.
+    uint32_t* const pk = reinterpret_cast<uint32_t*>(smem_raw + LaneLds<NW>::PARK_OFF) + tid;
+#define SYN_PARK()                                                                                           \
+    do {                                                                                                     \
+        pk[0] = (uint32_t)T.root_my; pk[NT] = (uint32_t)(T.root_my >> 32);                                   \
+        pk[2 * NT] = (uint32_t)T.root_op; pk[3 * NT] = (uint32_t)(T.root_op >> 32);                          \
+        pk[4 * NT] = (uint32_t)T.turn | (T.rng_index << 8);                                                  \
+        T.root_my = 0; T.root_op = 0; T.turn = 0;                                                            \
+        if (POLICY == 0) T.rng_index = 0;                                                                    \
+    } while (0)
+#define SYN_UNPARK()                                                                                         \
+    do {                                                                                                     \
+        T.root_my = (uint64_t)pk[0] | ((uint64_t)pk[NT] << 32);                                              \
+        T.root_op = (uint64_t)pk[2 * NT] | ((uint64_t)pk[3 * NT] << 32);                                     \
+        T.turn = (int)(pk[4 * NT] & 0xFFu);                                                                  \
+        if (POLICY == 0) T.rng_index = pk[4 * NT] >> 8;                                                      \
+    } while (0)
+    SYN_PARK();
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
 
     const int n_explores = P.roll.num_explores;
@@ -959,7 +980,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error);
+        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT);
         SYN_LAP(pA)
         // PROF: timeline of the three waves of SIMD 0 of workgroup 0 (rounds 2000..2015): [A end = B start, B end, C end]
         const bool tl = PROF && P.prof && blockIdx.x == 0 && (wave & 3) == 0 && pRounds >= 2000 && pRounds < 2016;
@@ -1066,9 +1087,11 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 // a private copy of the arguments goes to the callee and the slab pointer is re-derived afterwards, so
                 // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
                 EngineParams Pc = P;
+                SYN_UNPARK();
                 if (MODE == MODE_SELFPLAY) T = lane_move_step_call<COUNT>(Pc, T, ctr);
                 else T = lane_search_finish_call(Pc, T);
                 T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
+                SYN_PARK();
             }
         }
         if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 1 - 2000)) * 3 + 2] = SYN_STAMP();
@@ -1076,6 +1099,8 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     }
 #undef SYN_STAMP
 #undef SYN_LAP
+#undef SYN_PARK
+#undef SYN_UNPARK
     if (PROF) {
         if (P.prof && lane == 0) {
             unsigned long long* o = P.prof + ((size_t)blockIdx.x * NW + wave) * 10;
