@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
         }
         if (tid == 0) evalflag[(it + 1) & 1] = 0;
         if (PROF) { unsigned long long n = SYN_STAMP(); pB += n - pT; pT = n; }
-        __syncthreads();
+        lds_barrier();  // barrier 2: network outputs (LDS) visible; node-pool stores keep draining in the background
         if (PROF) { unsigned long long n = SYN_STAMP(); pW2 += n - pT; pT = n; }
 
         // ---- phase C

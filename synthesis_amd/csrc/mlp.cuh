@@ -20,6 +20,12 @@ namespace syn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier for waves that exchange data through LDS only: waits for this wave's LDS traffic, not for its
+// global stores (`__syncthreads()` also drains vmcnt, i.e. every node-pool store still in flight).
+SYN_DEV void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct MlpGeom {
     static constexpr int NL = 5;
     static constexpr int K[NL] = {63, 128, 96, 64, 48};      // inputs per layer
@@ -327,7 +333,7 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
         exA[mw * 64 + lane] = relu4(a0);
         exA[(mw + 4) * 64 + lane] = relu4(a1);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- L2: block mw (all waves) and block 4+mw (waves 0,1); B = exA[0..7]
     {
         const bool two = mw < 2;
@@ -344,7 +350,7 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
         exB[mw * 64 + lane] = relu4(a0);
         if (two) exB[(4 + mw) * 64 + lane] = relu4(a1);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- L3: block mw; B = exB[0..5]
     {
         f32x4 a0 = bias(2, mw);
@@ -357,7 +363,7 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
         }
         exA[mw * 64 + lane] = relu4(a0);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- L4: waves 1..3 compute block mw-1; B = exA[0..3]
     if (mw > 0) {
         f32x4 a0 = bias(3, mw - 1);
@@ -370,7 +376,7 @@ SYN_DEV f32x4 mlp_split_tile16(const MlpSplitWeights& W, const float* __restrict
         }
         exB[(mw - 1) * 64 + lane] = relu4(a0);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- L5: wave 0; B = exB[0..2]
     f32x4 out = {0.f, 0.f, 0.f, 0.f};
     if (mw == 0) {
