@@ -654,6 +654,9 @@ static int mcts_search_impl(syn_engine* h, const syn_mcts_config* cfg, const uin
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last_cache_hits = cstats[0];
     h->last_cache_misses = cstats[1];
+    if (kerr == 2)
+        return fail(h, SYN_ERR_CAPACITY, "a tree ran out of node blocks (lane-per-tree kernel: %u blocks per tree for max_explores %d)",
+                    h->cap / 4, h->max_explores);
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
@@ -814,6 +817,9 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last_cache_hits = cstats[0];
     h->last_cache_misses = cstats[1];
+    if (kerr == 2)
+        return fail(h, SYN_ERR_CAPACITY, "a tree ran out of node blocks (lane-per-tree kernel: %u blocks per tree for max_explores %d)",
+                    h->cap / 4, h->max_explores);
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
