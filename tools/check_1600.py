@@ -1,7 +1,7 @@
 """Developer tool (GPU): self-play at the reference's default 1,600 explores per move on the lane-per-tree kernel, and the
 same 4,096 games on a small engine for comparison."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch
 import synthesis_amd as sa
 from bench import make_weights
