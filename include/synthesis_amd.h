@@ -106,7 +106,7 @@ const char* syn_last_error(const syn_engine* h);
 /* Replaces: vs.load(models/model_i.ot) (alpha_zero.rs:194). blob = l_1.weight[128x63], l_1.bias[128],
  * l_2.weight[96x128], l_2.bias[96], l_3.weight[64x96], l_3.bias[64], l_4.weight[48x64], l_4.bias[48],
  * l_5.weight[12x48], l_5.bias[12] (VarStore names, study-connect4/src/policies.rs:20-24), row-major [out][in],
- * n_floats must be 30492. */
+ * n_floats must be 30492. Empties the policy cache (its entries belong to the previous network). */
 int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats);
 
 /* ---- leaf evaluation ------------------------------------------------------------------------------------------- */

@@ -426,6 +426,9 @@ int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
     build_weight_image(blob, img);
     HIP_TRY(h, hipMemcpyAsync(h->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // PolicyWithCache entries belong to the network that produced them (the reference builds a fresh cache per
+    // run_n_games, alpha_zero.rs:196-198): a new network starts with an empty table
+    if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));
     h->has_weights = true;
     return SYN_OK;
 }

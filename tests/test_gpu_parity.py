@@ -472,6 +472,12 @@ def test_policy_cache_is_semantics_neutral(blob, oracle, monkeypatch, log2):
     got = eng.selfplay(sa.parity_rollout_config(800), base_seed=5, n_games=6)
     ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 5, 6, threads=8, nn_mode=oracle.ACC_FMA)
     assert_selfplay_equal(got, ref, f"cache 2^{log2} 800 explores")
+    # a new network must not see the old network's cached evaluations
+    blob2 = (blob * np.float32(0.5)).astype(np.float32)
+    eng.load_weights(blob2)
+    got = eng.mcts_search(sa.parity_mcts_config(), my[:100], op[:100], 120)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob2, my[:100], op[:100], 120, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, f"cache 2^{log2} after new weights")
     eng.close()
     with pytest.raises(sa.SynthesisAmdError):
         sa.Engine(concurrent_games=64, max_explores=64, policy_cache_log2=5)
