@@ -209,11 +209,6 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             if (const char* ev = std::getenv("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
             if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
             PL.lane_thresh &= ~15;  // whole tiles
-            {
-                int stagger = 0;
-                if (const char* ev = std::getenv("SYN_LANE_STAGGER")) stagger = std::atoi(ev);
-                PL.lane_thresh |= (stagger & 0xFF) << 8;
-            }
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \

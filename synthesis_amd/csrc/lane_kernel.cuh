@@ -956,15 +956,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
 
     const int n_explores = P.roll.num_explores;
-    const int thresh = P.lane_thresh & 0xFF;
-    // Waves that share a SIMD (wave, wave + 4, wave + 8, ...) start one after the other: identical waves that start
-    // together stay in lock-step for ever — all chasing pointers while the matrix pipe idles, then all queueing for it —
-    // whereas an initial offset persists (nothing synchronises them), so one wave's matrix phase overlaps its
-    // neighbours' tree phases.
-    {
-        const int stagger = (P.lane_thresh >> 8) & 0xFF;  // units of 8,128 cycles (s_sleep 127)
-        for (int i = 0; i < stagger * (wave >> 2); i++) __builtin_amdgcn_s_sleep(127);
-    }
+    const int thresh = P.lane_thresh;
     unsigned char* const idxw = smem_raw + LaneLds<NW>::IDX_OFF + wave * 64;  // compaction: rank -> lane
     unsigned long long cache_hits = 0, cache_misses = 0;
     LaneWalk Wk;
