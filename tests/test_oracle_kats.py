@@ -267,3 +267,15 @@ def test_selfplay_oracle_properties(oracle, golden_dir):
         assert r["root_nodes"][g, :n].max() <= 1 + 9 * 49
     assert r["counters"]["cache_hits"] > 0 and r1["counters"]["cache_hits"] == 0
     assert r1["counters"]["policy_evals"] == r["counters"]["policy_evals"]
+
+
+def test_oracle_is_clean_under_asan_and_ubsan():
+    """The CPU restatement under AddressSanitizer + UndefinedBehaviorSanitizer (GPU sanitizers are unavailable on the
+    pool): oracle/sanitize_check.cpp drives the TicTacToe KATs, Connect4 searches with both leaf policies, multi-threaded
+    self-play with PolicyWithCache, de-duplication and training steps; any report aborts the binary."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "sanitize_check ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
