@@ -45,9 +45,9 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--concurrent", type=int, default=65536)
     ap.add_argument("--eval-games", type=int, default=0, help="after every iteration: this many games as each colour against "
-                                                              "rollout MCTS players (evaluator.rs:52-77), rank 0 only")
+                                                              "the VanillaMCTS baselines (evaluator.rs:52-77), rank 0 only")
     ap.add_argument("--eval-explores", type=int, default=0, help="explores of the network player in evaluation (0 = --explores)")
-    ap.add_argument("--eval-opponents", default="200,800", help="explores of the rollout MCTS opponents")
+    ap.add_argument("--eval-opponents", default="200,800", help="explores of the VanillaMCTS opponents")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
 
@@ -131,7 +131,7 @@ def main():
             eval_eng.load_weights(eng.trainer_state()["weights"])
             me = match.Player(f"model_{it + 1}", my_explores, cfg.mcts_cfg, cfg.action)
             for ox in opponents:
-                opp = match.rollout_player(ox)
+                opp = match.vanilla_player(ox)  # the evaluator's "VanillaMCTS<n>" baseline (FrozenMCTS over RolloutPolicy)
                 r1, _ = match.play_match(eval_eng, me, opp, args.eval_games, seed=1000 * it)
                 r2, _ = match.play_match(eval_eng, opp, me, args.eval_games, seed=1000 * it + 500)
                 w, d, l, s, elo = match.score(np.concatenate([r1, -r2]))

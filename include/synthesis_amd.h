@@ -163,6 +163,34 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
 int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t seed, const uint64_t* my_bb,
                             const uint64_t* op_bb, int n, int explores, int action_selection, syn_search_result* results);
 
+/* ---- evaluator baseline ---------------------------------------------------------------------------------------- */
+
+/* One root of the evaluator's baseline tree after the search (evaluator.rs:233-243 Node fields of the root's children,
+ * indexed by action; children of illegal actions are all-zero). */
+typedef struct syn_frozen_result {
+    float child_N[9];          /* Node::num_visits  */
+    float child_cum[9];        /* Node::cum_value   */
+    float child_P[9];          /* Node::action_prob */
+    int32_t child_sol[9][3];   /* {is_some, kind (0 Lose, 1 Draw, 2 Win), turns} of Node::solution */
+    float root_N;
+    float root_cum;
+    int32_t root_sol[3];
+    uint32_t num_nodes;        /* nodes.len() */
+    int32_t best_action;       /* FrozenMCTS::best_action (evaluator.rs:364-389) */
+} syn_frozen_result;
+
+/* Replaces: FrozenMCTS::exploit(explores, cfg, &mut RolloutPolicy { rng }, game, action_selection) (evaluator.rs:308-319
+ * with policies/rollout.rs:8-31) — the "VanillaMCTS<explores>" baseline of eval_against_rollout_mcts / mcts_vs_mcts
+ * (evaluator.rs:163-228) — for n independent roots, one device-resident tree each. Root i draws its playouts from
+ * StdRng::seed_from_u64(seeds[i]) starting at 32-bit output word rng_words[i]; on return rng_words[i] is the first word the
+ * search did not use, so a caller that replays a match move by move keeps ONE generator per match as the reference does
+ * (pass 0 for the first move, hand the value back for the next). explores[i] is per root (mcts_vs_mcts gives each side its own).
+ * cfg: Exploration::Uct and Fpu::Const only — the reference panics on anything else (SYN_ERR_UNSUPPORTED here); the
+ * baseline ignores every other field except `solve`. No network weights are needed. */
+int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* seeds, uint64_t* rng_words,
+                              const uint64_t* my_bb, const uint64_t* op_bb, const int32_t* explores, int n,
+                              int action_selection, syn_frozen_result* results);
+
 /* ---- self-play ------------------------------------------------------------------------------------------------- */
 
 /* Event counters summed over all games of a run (definitions: SURVEY.md §8d; used for algorithmic-bytes accounting) */
@@ -248,7 +276,7 @@ int syn_last_cache_stats(const syn_engine* h, uint64_t* hits, uint64_t* misses);
 /* Launch shape the last syn_selfplay_run / syn_mcts_search used (the engine picks it from the number of concurrent games,
  * DESIGN.md §6.1): *shape = 1 row-per-tree kernel with the weights in registers (16 trees per workgroup), 2 = the same
  * with two workgroups per CU, 3 = quad-async row kernel (several 16-tree quads per workgroup), 4 = lane-per-tree kernel
- * (one tree per lane); grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
+ * (one tree per lane), 5 = the evaluator baseline's lane-per-tree kernel; grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
 int syn_last_launch_shape(const syn_engine* h, int* shape, int* grid, int* threads);
 
 /* Device-side RNG / math primitives exposed for parity tests against the oracle (no reference counterpart):

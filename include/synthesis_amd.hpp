@@ -13,6 +13,8 @@
 //                                                    keep_last_n_games, deduplicate, the counters)
 //   synthesis::run_n_games                           synthesis/src/alpha_zero.rs:181-209
 //   synthesis::vanilla_mcts_search                   MCTS over RolloutPolicy (policies/rollout.rs:8-31; mcts.rs:691-868)
+//   synthesis::frozen_mcts_exploit / mcts_vs_mcts /  the evaluator's baseline and its two match loops,
+//     eval_against_rollout_mcts                      synthesis/src/evaluator.rs:163-228, 308-319 (FrozenMCTS over RolloutPolicy)
 //   synthesis::Learner                               the optimiser half of alpha_zero.rs:28-36,72-94
 // Errors: the reference panics (unwrap / assert!) on this path; here every failed C-ABI call throws synthesis::Error
 // carrying the status code and syn_last_error's text. Nothing is computed on the host: without the library or without
@@ -20,6 +22,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -358,6 +361,105 @@ inline std::vector<syn_search_result> vanilla_mcts_search(Engine& e, const MCTSC
     e.check(syn_mcts_search_rollout(e.handle(), &mc, seed, my.data(), op.data(), (int)roots.size(), explores, (int)action,
                                     out.data()));
     return out;
+}
+
+// ---- evaluator.rs: the rollout baseline ("VanillaMCTS<n>") and its match loops -------------------------------------------
+// The `StdRng::seed_from_u64(seed)` behind a match's `RolloutPolicy { rng }` (evaluator.rs:171-172, 207-208): the seed plus
+// how many 32-bit words the match has drawn so far. The generator itself lives on the device.
+struct RolloutRng {
+    uint64_t seed = 0;
+    uint64_t words = 0;
+};
+
+inline MCTSConfig rollout_mcts_cfg() {  // study-connect4/src/main.rs:74-82
+    MCTSConfig c;
+    c.exploration = Exploration::Uct;
+    c.c = 2.0f;
+    c.auto_extend = false;
+    c.fpu = Fpu::Const;
+    c.fpu_value = std::numeric_limits<float>::infinity();
+    return c;
+}
+
+// FrozenMCTS::exploit(explores, cfg, &mut RolloutPolicy { rng }, game, action_selection) (evaluator.rs:308-319) for a batch
+// of independent (game, generator) pairs; rngs[i] advances past the words search i used.
+inline std::vector<syn_frozen_result> frozen_mcts_exploit(Engine& e, const MCTSConfig& cfg, std::vector<RolloutRng>& rngs,
+                                                          const std::vector<Connect4>& roots, const std::vector<int32_t>& explores,
+                                                          ActionSelection action = ActionSelection::NumVisits) {
+    if (rngs.size() != roots.size() || explores.size() != roots.size())
+        throw Error(SYN_ERR_INVALID_ARGUMENT, "frozen_mcts_exploit: one generator and one explore count per root");
+    const syn_mcts_config mc = cfg.to_c();
+    const size_t n = roots.size();
+    std::vector<uint64_t> my(n), op(n), seeds(n), words(n);
+    for (size_t i = 0; i < n; i++) {
+        my[i] = roots[i].my_bb(); op[i] = roots[i].op_bb(); seeds[i] = rngs[i].seed; words[i] = rngs[i].words;
+    }
+    std::vector<syn_frozen_result> out(n);
+    e.check(syn_frozen_search_rollout(e.handle(), &mc, seeds.data(), words.data(), my.data(), op.data(), explores.data(), (int)n,
+                                      (int)action, out.data()));
+    for (size_t i = 0; i < n; i++) rngs[i].words = words[i];
+    return out;
+}
+
+// The two match loops of the evaluator, all matches of a batch in lockstep (one search call per ply and side).
+// `policy_explores` < 0: both sides are baselines (mcts_vs_mcts, evaluator.rs:200-228: `player` searches with p1_explores, the
+// other side with p2_explores). Otherwise eval_against_rollout_mcts (evaluator.rs:163-198): `player` is the engine's network
+// under MCTS::exploit(policy_explores, policy_cfg, .., policy_action), the other side the baseline with p2_explores.
+// Returns game.reward(first_player) per match (seed).
+namespace detail {
+inline std::vector<float> rollout_matches(Engine& e, const MCTSConfig& rollout_cfg, ActionSelection rollout_action,
+                                          Connect4::PlayerId player, int p1_explores, int p2_explores,
+                                          const std::vector<uint64_t>& seeds, int policy_explores,
+                                          const MCTSConfig& policy_cfg, ActionSelection policy_action) {
+    const size_t n = seeds.size();
+    std::vector<Connect4> games(n);
+    std::vector<RolloutRng> rngs(n);
+    for (size_t i = 0; i < n; i++) rngs[i].seed = seeds[i];
+    std::vector<float> reward(n, 0.0f);
+    std::vector<char> over(n, 0);
+    const Connect4::PlayerId first_player = Connect4().player();
+    for (;;) {
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < n; i++)
+            if (!over[i]) idx.push_back(i);
+        if (idx.empty()) break;
+        // lockstep: every live match is at the same ply, so the same side is to move in all of them
+        const bool players_turn = games[idx[0]].player() == player;
+        std::vector<Connect4> roots;
+        for (size_t i : idx) roots.push_back(games[i]);
+        std::vector<int> actions(idx.size());
+        if (players_turn && policy_explores >= 0) {
+            auto res = mcts_search(e, policy_cfg, roots, policy_explores, policy_action);
+            for (size_t k = 0; k < idx.size(); k++) actions[k] = res[k].best_action;
+        } else {
+            std::vector<RolloutRng> r;
+            for (size_t i : idx) r.push_back(rngs[i]);
+            std::vector<int32_t> ex(idx.size(), players_turn ? p1_explores : p2_explores);
+            auto res = frozen_mcts_exploit(e, rollout_cfg, r, roots, ex, rollout_action);
+            for (size_t k = 0; k < idx.size(); k++) { actions[k] = res[k].best_action; rngs[idx[k]] = r[k]; }
+        }
+        for (size_t k = 0; k < idx.size(); k++) {
+            Connect4& g = games[idx[k]];
+            if (g.step(actions[k])) { over[idx[k]] = 1; reward[idx[k]] = g.reward(first_player); }
+        }
+    }
+    return reward;
+}
+}  // namespace detail
+
+inline std::vector<float> mcts_vs_mcts(Engine& e, const MCTSConfig& rollout_cfg, ActionSelection rollout_action,
+                                       Connect4::PlayerId player, int p1_explores, int p2_explores,
+                                       const std::vector<uint64_t>& seeds) {
+    return detail::rollout_matches(e, rollout_cfg, rollout_action, player, p1_explores, p2_explores, seeds, -1, MCTSConfig(),
+                                   ActionSelection::NumVisits);
+}
+
+inline std::vector<float> eval_against_rollout_mcts(Engine& e, const MCTSConfig& policy_cfg, int policy_explores,
+                                                    ActionSelection policy_action, const MCTSConfig& rollout_cfg,
+                                                    ActionSelection rollout_action, Connect4::PlayerId player,
+                                                    int opponent_explores, const std::vector<uint64_t>& seeds) {
+    return detail::rollout_matches(e, rollout_cfg, rollout_action, player, 0, opponent_explores, seeds, policy_explores,
+                                   policy_cfg, policy_action);
 }
 
 // The optimiser half of alpha_zero.rs:28-36,72-94 (Adam::default + weight decay; kl_div losses) on the device.

@@ -11,6 +11,7 @@
 
 #include "connect4.hpp"
 #include "det_math.hpp"
+#include "frozen_mcts.hpp"
 #include "mcts.hpp"
 #include "nn.hpp"
 #include "outcome.hpp"
@@ -313,6 +314,131 @@ void orc_c4_mcts_search_rollout(const orc_mcts_config* cfg_in, uint64_t seed, co
         c4_search_collect(mcts, i, action_selection, child_N, child_W, child_P, child_sol, root_stat, root_sol, num_nodes,
                           best_action, target_pi, target_q);
     }
+}
+
+}  // extern "C"
+
+// 32-bit words a generator has handed out so far (the buffer holds 64 words = four blocks per refill)
+static uint64_t words_consumed(const ChaChaRng& r) { return r.counter == 0 ? 0 : r.counter * 16 - 64 + (uint64_t)r.index; }
+
+// FrozenMCTS over RolloutPolicy (evaluator.rs:230-534 + policies/rollout.rs:8-31) on Connect4. Root i plays out on
+// StdRng::seed_from_u64(seeds[i]) after skipping rng_words[i] output words; rng_words[i] returns the words consumed in total.
+// policy_kind 0 = Connect4Net instead (restatement check only; the reference never pairs the baseline with a network).
+// Outputs per root: child_N / child_cum / child_P [9] by action, child_sol [9][3], root {N, cum}, root_sol [3],
+// num_nodes, best_action.
+template <class M>
+static void frozen_collect(const M& mcts, int i, int action_selection, float* child_N, float* child_cum, float* child_P,
+                           int* child_sol, float* root_stat, int* root_sol, unsigned* num_nodes, int* best_action) {
+    const auto& r = mcts.nodes[mcts.root];
+    for (int a = 0; a < 9; a++) {
+        child_N[i * 9 + a] = child_cum[i * 9 + a] = child_P[i * 9 + a] = 0;
+        for (int j = 0; j < 3; j++) child_sol[(i * 9 + a) * 3 + j] = 0;
+    }
+    for (uint32_t c = r.first_child; c < r.last_child(); c++) {
+        const auto& ch = mcts.nodes[c];
+        int a = ch.action;
+        child_N[i * 9 + a] = ch.num_visits;
+        child_cum[i * 9 + a] = ch.cum_value;
+        child_P[i * 9 + a] = ch.action_prob;
+        child_sol[(i * 9 + a) * 3 + 0] = ch.solution.some;
+        child_sol[(i * 9 + a) * 3 + 1] = ch.solution.some ? ch.solution.o.kind : 0;
+        child_sol[(i * 9 + a) * 3 + 2] = ch.solution.some ? (int)ch.solution.o.turns : 0;
+    }
+    root_stat[i * 2 + 0] = r.num_visits;
+    root_stat[i * 2 + 1] = r.cum_value;
+    root_sol[i * 3 + 0] = r.solution.some;
+    root_sol[i * 3 + 1] = r.solution.some ? r.solution.o.kind : 0;
+    root_sol[i * 3 + 2] = r.solution.some ? (int)r.solution.o.turns : 0;
+    num_nodes[i] = (unsigned)mcts.nodes.size();
+    best_action[i] = mcts.best_action(action_selection);
+}
+
+extern "C" {
+
+void orc_c4_frozen_search(const orc_mcts_config* cfg_in, int policy_kind, const float* blob, int nn_mode,
+                          const uint64_t* seeds, uint64_t* rng_words, const uint64_t* my_bb, const uint64_t* op_bb, int n,
+                          const int* explores, int action_selection, float* child_N, float* child_cum, float* child_P,
+                          int* child_sol, float* root_stat, int* root_sol, unsigned* num_nodes, int* best_action) {
+    MCTSConfig cfg = to_cfg(*cfg_in);
+    for (int i = 0; i < n; i++) {
+        Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
+        if (policy_kind == 0) {
+            Connect4Net net;
+            net.blob = blob;
+            net.mode = nn_mode;
+            FrozenMCTS<Connect4, Connect4Net> mcts((size_t)explores[i] + 1, cfg, &net, root);
+            mcts.explore_n((size_t)explores[i]);
+            frozen_collect(mcts, i, action_selection, child_N, child_cum, child_P, child_sol, root_stat, root_sol, num_nodes,
+                           best_action);
+        } else {
+            ChaChaRng rng = ChaChaRng::seed_from_u64(seeds[i]);
+            for (uint64_t w = 0; w < rng_words[i]; w++) (void)rng.next_u32();
+            RolloutPolicy<Connect4> policy{&rng};
+            FrozenMCTS<Connect4, RolloutPolicy<Connect4>> mcts((size_t)explores[i] + 1, cfg, &policy, root);
+            mcts.explore_n((size_t)explores[i]);
+            frozen_collect(mcts, i, action_selection, child_N, child_cum, child_P, child_sol, root_stat, root_sol, num_nodes,
+                           best_action);
+            rng_words[i] = words_consumed(rng);
+        }
+    }
+}
+
+// evaluator.rs:200-228 mcts_vs_mcts: two rollout baselines on ONE generator. `player` (0 = the side that moves first) searches
+// with p1_explores, the other side with p2_explores. Returns game.reward(first_player); moves[] / words_after[] per ply.
+float orc_c4_mcts_vs_mcts(const orc_mcts_config* rollout_cfg, int rollout_action, int player, int p1_explores,
+                          int p2_explores, uint64_t seed, uint8_t* moves, int* n_moves, uint64_t* words_after) {
+    MCTSConfig cfg = to_cfg(*rollout_cfg);
+    ChaChaRng rng = ChaChaRng::seed_from_u64(seed);
+    RolloutPolicy<Connect4> policy{&rng};
+    Connect4 game;
+    const int first_player = game.player_id();
+    int n = 0;
+    for (;;) {
+        const int explores = game.player_id() == player ? p1_explores : p2_explores;
+        FrozenMCTS<Connect4, RolloutPolicy<Connect4>> mcts((size_t)explores + 1, cfg, &policy, game);
+        mcts.explore_n((size_t)explores);
+        const int action = mcts.best_action(rollout_action);
+        moves[n] = (uint8_t)action;
+        words_after[n] = words_consumed(rng);
+        n++;
+        if (game.step(action)) break;
+    }
+    *n_moves = n;
+    return game.reward(first_player);
+}
+
+// evaluator.rs:163-198 eval_against_rollout_mcts: the network's MCTS::exploit as `player`, the rollout baseline as the other side.
+float orc_c4_eval_against_rollout(const orc_mcts_config* policy_cfg, int policy_explores, int policy_action,
+                                  const float* blob, int nn_mode, const orc_mcts_config* rollout_cfg, int rollout_action,
+                                  int player, int opponent_explores, uint64_t seed, uint8_t* moves, int* n_moves,
+                                  uint64_t* words_after) {
+    MCTSConfig pcfg = to_cfg(*policy_cfg), rcfg = to_cfg(*rollout_cfg);
+    Connect4Net net;
+    net.blob = blob;
+    net.mode = nn_mode;
+    ChaChaRng rng = ChaChaRng::seed_from_u64(seed);
+    RolloutPolicy<Connect4> policy{&rng};
+    Connect4 game;
+    const int first_player = game.player_id();
+    int n = 0;
+    for (;;) {
+        int action;
+        if (game.player_id() == player) {
+            MCTS<Connect4, Connect4Net> mcts((size_t)policy_explores + 1, pcfg, &net, game);  // mcts.rs:110-121 exploit
+            mcts.explore_n((size_t)policy_explores);
+            action = mcts.best_action(policy_action);
+        } else {
+            FrozenMCTS<Connect4, RolloutPolicy<Connect4>> mcts((size_t)opponent_explores + 1, rcfg, &policy, game);
+            mcts.explore_n((size_t)opponent_explores);
+            action = mcts.best_action(rollout_action);
+        }
+        moves[n] = (uint8_t)action;
+        words_after[n] = words_consumed(rng);
+        n++;
+        if (game.step(action)) break;
+    }
+    *n_moves = n;
+    return game.reward(first_player);
 }
 
 // ---------------------------------------------------------------- self-play (run_n_games / gather_experience)

@@ -17,6 +17,7 @@
 #include "../../include/synthesis_amd.h"
 #include "engine_kernels.cuh"
 #include "lane_kernel.cuh"
+#include "frozen_kernel.cuh"
 #include "train_kernels.cuh"
 
 #include <hipcub/hipcub.hpp>
@@ -669,6 +670,88 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
 int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t seed, const uint64_t* my_bb,
                             const uint64_t* op_bb, int n, int explores, int action_selection, syn_search_result* results) {
     return mcts_search_impl(h, cfg, my_bb, op_bb, n, explores, action_selection, results, true, seed);
+}
+
+// evaluator.rs:308-319 FrozenMCTS::exploit over RolloutPolicy for n roots (frozen_kernel.cuh)
+int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* seeds, uint64_t* rng_words,
+                              const uint64_t* my_bb, const uint64_t* op_bb, const int32_t* explores, int n,
+                              int action_selection, syn_frozen_result* results) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!cfg || n < 0 || (n > 0 && (!seeds || !rng_words || !my_bb || !op_bb || !explores || !results)))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_frozen_search_rollout");
+    if (action_selection != SYN_ACTION_Q && action_selection != SYN_ACTION_NUM_VISITS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection %d", action_selection);
+    // the baseline panics on anything else (evaluator.rs:418-421, 429-436)
+    if (cfg->exploration != SYN_EXPLORATION_UCT)
+        return fail(h, SYN_ERR_UNSUPPORTED, "FrozenMCTS supports Exploration::Uct only (evaluator.rs:429-436)");
+    if (cfg->fpu != SYN_FPU_CONST)
+        return fail(h, SYN_ERR_UNSUPPORTED, "FrozenMCTS supports Fpu::Const only (evaluator.rs:418-421)");
+    if (n == 0) return SYN_OK;
+    const size_t nodes_per_tree = (size_t)h->cap * 2;  // 16-byte records in a 32-byte-per-node slab
+    for (int i = 0; i < n; i++) {
+        if (!valid_root(my_bb[i], op_bb[i]))
+            return fail(h, SYN_ERR_INVALID_ARGUMENT, "root %d is not a searchable Connect4 position", i);
+        if (explores[i] < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "explores[%d] must be >= 0", i);
+        const size_t worst = 1 + 9 * ((size_t)explores[i] + 1);
+        if (worst > nodes_per_tree || worst > 0x7FFFFu)
+            return fail(h, SYN_ERR_CAPACITY, "explores[%d] = %d needs up to %zu nodes; the engine (max_explores %d) holds %zu per tree",
+                        i, explores[i], worst, h->max_explores, nodes_per_tree);
+        if (rng_words[i] > 0xF0000000ull)
+            return fail(h, SYN_ERR_INVALID_ARGUMENT, "rng_words[%d] is beyond the supported stream length", i);
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t nb = (size_t)n;
+    int rc = ensure_scratch(h, nb * (8 * 4 + 4 + sizeof(FrozenResult)) + 256);
+    if (rc != SYN_OK) return rc;
+    unsigned long long* d_my = static_cast<unsigned long long*>(h->d_scratch);
+    unsigned long long* d_op = d_my + nb;
+    unsigned long long* d_seed = d_op + nb;
+    unsigned long long* d_words = d_seed + nb;
+    FrozenResult* d_res = reinterpret_cast<FrozenResult*>(d_words + nb);
+    int* d_expl = reinterpret_cast<int*>(d_res + nb);
+    int grid = (n + 255) / 256;
+    if (grid > h->pool_slots / 256) grid = h->pool_slots / 256;
+    const size_t need_path = (size_t)grid * 4 * 4096 * sizeof(uint32_t);
+    if (need_path > h->path_bytes) {
+        if (h->d_path) (void)hipFree(h->d_path);
+        h->d_path = nullptr;
+        h->path_bytes = 0;
+        HIP_TRY(h, hipMalloc(&h->d_path, need_path));
+        h->path_bytes = need_path;
+    }
+    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_seed, seeds, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_words, rng_words, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_expl, explores, nb * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    FrozenParams P;
+    P.pool = reinterpret_cast<uint4*>(h->d_stat);
+    P.nodes_per_tree = nodes_per_tree;
+    P.path = reinterpret_cast<uint32_t*>(h->d_path);
+    P.in_my = d_my; P.in_op = d_op; P.seeds = d_seed; P.rng_words = d_words; P.explores = d_expl;
+    P.n_roots = n;
+    P.c = cfg->c;
+    P.fpu_value = cfg->fpu_value;
+    P.solve = cfg->solve ? 1 : 0;
+    P.action_selection = action_selection;
+    P.results = d_res;
+    P.error = h->d_job_next + 8;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(frozen_rollout_kernel, dim3(grid), dim3(256), 0, h->stream, P);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->last_shape = 5; h->last_grid = grid; h->last_threads = 256;
+    static_assert(sizeof(FrozenResult) == sizeof(syn_frozen_result), "device and ABI result records must match");
+    int kerr = 0;
+    HIP_TRY(h, hipMemcpyAsync(results, d_res, nb * sizeof(FrozenResult), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(rng_words, d_words, nb * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&kerr, h->d_job_next + 8, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (kerr) return fail(h, SYN_ERR_CAPACITY, "a baseline tree ran out of node records");
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
+    return SYN_OK;
 }
 
 static int ensure_outputs(syn_engine* h, int n_games) {

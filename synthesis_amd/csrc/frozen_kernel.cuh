@@ -1,0 +1,257 @@
+// synthesis_amd — the evaluator's baseline opponent on the device: FrozenMCTS over RolloutPolicy, one tree per lane.
+//
+// Reference: synthesis/src/evaluator.rs:230-534 (Node, exploit / with_capacity, best_action, explore, select_best_child,
+// visit, backprop, explore_n) with policies/rollout.rs:8-31 as its policy — the only pairing the reference uses
+// (evaluator.rs:170-228: eval_against_rollout_mcts, mcts_vs_mcts). It is NOT the self-play tree of mcts.rs: one scalar
+// cum_value per node, the playout runs BEFORE the children are created, unvisited children score `fpu + prior` with no
+// exploration term, Uct only, a lost child proves Win(0), explore_n never stops early.
+//
+// Shape: the baseline needs no network, so there is nothing to batch — every lane owns one root, its tree and its
+// StdRng stream, and runs the sequential algorithm; a wave serves 64 matches, the chip 65,536 per pass. The random stream
+// of a root starts at a caller-given word of StdRng::seed_from_u64(seed) and the position after the search is returned,
+// because the reference draws all playouts of one match from ONE generator (evaluator.rs:171-172, 207-208).
+//
+// Node record (16 bytes; a node's children are contiguous, in ascending legal-column order, so the child's action and
+// position are re-derived from the parent's board during the descent instead of being stored):
+//   .x cum_value   .y num_visits   .z action_prob
+//   .w first_child[0:18] | num_children[19:22] | solution: some[23] kind[24:25] turns[26:31]   (kind 0 Lose 1 Draw 2 Win)
+// Path: the node ids of the current descent, [level][lane] per wave (the reference's parent pointers).
+#pragma once
+#include "device_common.cuh"
+
+namespace syn {
+
+struct FrozenParams {
+    uint4* pool;                 // node records
+    size_t nodes_per_tree;       // record capacity of one lane's slab
+    uint32_t* path;              // [wave][level 0..63][lane]
+    const unsigned long long* in_my;
+    const unsigned long long* in_op;
+    const unsigned long long* seeds;
+    unsigned long long* rng_words;  // in: first stream word of each root; out: first unused word
+    const int* explores;         // per root
+    int n_roots;
+    float c, fpu_value;
+    int solve, action_selection;
+    struct FrozenResult* results;
+    int* error;
+};
+
+struct FrozenResult {
+    float child_N[9], child_cum[9], child_P[9];
+    int child_sol[9][3];
+    float root_N, root_cum;
+    int root_sol[3];
+    uint32_t num_nodes;
+    int best_action;
+};
+
+namespace fz {
+constexpr uint32_t LOSE = 0, DRAW = 1, WIN = 2;
+SYN_DEV uint32_t first_child(uint32_t w) { return w & 0x7FFFFu; }
+SYN_DEV uint32_t num_children(uint32_t w) { return (w >> 19) & 15u; }
+SYN_DEV bool some(uint32_t w) { return (w >> 23) & 1u; }
+SYN_DEV uint32_t kind(uint32_t w) { return (w >> 24) & 3u; }
+SYN_DEV uint32_t turns(uint32_t w) { return w >> 26; }
+SYN_DEV uint32_t sol_bits(uint32_t k, uint32_t t) { return (1u << 23) | (k << 24) | (t << 26); }
+SYN_DEV bool unvisited(uint32_t w) { return num_children(w) == 0 && !some(w); }
+// game.rs:46-60 as one integer key: Lose(t) ascending < Draw(t) ascending < Win(t) descending
+SYN_DEV uint32_t order_key(uint32_t w) { return (kind(w) << 8) | (kind(w) == WIN ? 255u - turns(w) : turns(w)); }
+SYN_DEV float value_of_kind(uint32_t k) { return k == WIN ? 1.0f : (k == DRAW ? 0.0f : -1.0f); }  // game.rs:37-43
+SYN_DEV uint32_t legal_mask(uint64_t occ) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++)
+        if (c4::col_height(occ, c) < c4::HEIGHT) m |= 1u << c;
+    return m;
+}
+SYN_DEV int nth_set(uint32_t m, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) m &= m - 1u;
+    return __ffs((int)m) - 1;
+}
+}  // namespace fz
+
+// policies/rollout.rs:8-31 on the root's stream (same playout as lane_rollout, 64-bit stream position)
+SYN_DEV float frozen_playout(uint64_t my, uint64_t op, const StdRng& base, uint32_t& rng_index) {
+    StdRng rng = base;
+    rng.index = rng_index;
+    bool leaf_player_moves = true;
+    float value;
+    for (;;) {
+        const uint64_t occ = my | op;
+        const uint32_t lmask = fz::legal_mask(occ);
+        const uint32_t pick = rng.gen_range_u8((uint32_t)__popc(lmask));
+        const int col = fz::nth_set(lmask, pick);
+        const uint64_t bit = 1ull << (c4::col_height(occ, col) + 7 * col);
+        const uint64_t mover = my | bit;
+        if (c4::won(mover)) { value = leaf_player_moves ? 1.0f : -1.0f; break; }  // dist[2] - dist[0] of the one-hot outcome
+        if ((occ | bit) == c4::FULL) { value = 0.0f; break; }
+        my = op;
+        op = mover;
+        leaf_player_moves = !leaf_player_moves;
+    }
+    rng_index = rng.index;
+    return value;
+}
+
+__global__ __launch_bounds__(256) void frozen_rollout_kernel(FrozenParams P) {
+    const int lane = threadIdx.x & 63;
+    const size_t gwave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t glane = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint4* const pool = P.pool + glane * P.nodes_per_tree;
+    uint32_t* const path = P.path + gwave * 4096 + lane;  // level l at path[l * 64]
+    const uint32_t node_cap = (uint32_t)(P.nodes_per_tree < 0x7FFFFu ? P.nodes_per_tree : 0x7FFFFu);
+
+    for (size_t root = glane; root < (size_t)P.n_roots; root += (size_t)gridDim.x * 256) {
+        const uint64_t root_my = P.in_my[root], root_op = P.in_op[root];
+        StdRng base;
+        base.seed_from_u64(P.seeds[root]);
+        uint32_t rng_index = (uint32_t)P.rng_words[root];
+        uint32_t next_node = 1;
+        bool overflow = false;
+        pool[0] = make_uint4(0u, 0u, 0u, 0u);  // Node::unvisited(0, game, None, 0, 0.0)
+        const int total = P.explores[root] + 1;  // with_capacity's own visit of the root, then explore_n (evaluator.rs:325-338)
+
+        for (int it = 0; it < total && !overflow; it++) {
+            // ---- explore (evaluator.rs:391-406): descend to a solved or unvisited node
+            uint32_t id = 0, level = 0;
+            uint64_t my = root_my, op = root_op;
+            float value;
+            bool solved;
+            for (;;) {
+                path[level * 64] = id;
+                const uint4 nd = pool[id];
+                if (fz::some(nd.w)) { value = fz::value_of_kind(fz::kind(nd.w)); solved = true; break; }
+                if (fz::num_children(nd.w) == 0) {
+                    // ---- visit (evaluator.rs:439-483): playout first, then one child per legal column
+                    value = frozen_playout(my, op, base, rng_index);
+                    const uint64_t occ = my | op;
+                    const uint32_t lmask = fz::legal_mask(occ);
+                    const uint32_t nc = (uint32_t)__popc(lmask);
+                    if (next_node + nc > node_cap) { overflow = true; break; }
+                    // stable softmax of the (all-zero) rollout logits over the legal actions
+                    float max_logit = -INFINITY;
+                    for (uint32_t j = 0; j < nc; j++) max_logit = fmaxf(max_logit, 0.0f);
+                    float e[9], tot = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) e[j] = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 9; j++)
+                        if ((uint32_t)j < nc) { e[j] = det_expf(0.0f - max_logit); tot += e[j]; }
+                    solved = false;
+                    uint32_t m = lmask;
+#pragma unroll
+                    for (int j = 0; j < 9; j++) {
+                        if ((uint32_t)j < nc) {
+                            const int col = __ffs((int)m) - 1;
+                            m &= m - 1u;
+                            const uint64_t bit = 1ull << (c4::col_height(occ, col) + 7 * col);
+                            uint32_t w = 0;
+                            if (c4::won(my | bit)) { w = fz::sol_bits(fz::LOSE, 0); solved = true; }       // reward(child.player()) = -1
+                            else if ((occ | bit) == c4::FULL) { w = fz::sol_bits(fz::DRAW, 0); solved = true; }
+                            pool[next_node + j] = make_uint4(0u, 0u, f32_bits(e[j] / tot), w);
+                        }
+                    }
+                    pool[id] = make_uint4(nd.x, nd.y, nd.z, (nd.w & 0xFF800000u) | next_node | (nc << 19));
+                    next_node += nc;
+                    break;
+                }
+                // ---- select_best_child (evaluator.rs:408-437)
+                const uint32_t fc = fz::first_child(nd.w), nc = fz::num_children(nd.w);
+                const float visits = sqrtf(P.c * det_logf(bits_f32(nd.y)));
+                uint32_t best = 0;
+                float best_value = -INFINITY;
+                for (uint32_t j = 0; j < nc; j++) {
+                    const uint4 ch = pool[fc + j];
+                    float v;
+                    if (fz::unvisited(ch.w)) {
+                        v = P.fpu_value + bits_f32(ch.z);
+                    } else {
+                        // a solved child counts from the parent's side: outcome.reversed().value()
+                        const float q = fz::some(ch.w) ? -fz::value_of_kind(fz::kind(ch.w)) : -bits_f32(ch.x) / bits_f32(ch.y);
+                        v = q + visits / sqrtf(bits_f32(ch.y));
+                    }
+                    if (j == 0 || v > best_value) { best = j; best_value = v; }
+                }
+                const uint64_t occ = my | op;
+                const int col = fz::nth_set(fz::legal_mask(occ), best);
+                const uint64_t mover = my | (1ull << (c4::col_height(occ, col) + 7 * col));
+                my = op;
+                op = mover;
+                id = fc + best;
+                level++;
+            }
+            if (overflow) break;
+
+            // ---- backprop (evaluator.rs:485-527) along the recorded path
+            for (int l = (int)level; l >= 0; l--) {
+                const uint32_t nid = path[l * 64];
+                uint4 nd = pool[nid];
+                if (P.solve && solved && !fz::some(nd.w)) {
+                    bool all_solved = true, have_worst = false;
+                    uint32_t worst = 0;
+                    const uint32_t fc = fz::first_child(nd.w), nc = fz::num_children(nd.w);
+                    for (uint32_t j = 0; j < nc; j++) {
+                        const uint32_t cw = pool[fc + j].w;
+                        if (!fz::some(cw)) all_solved = false;  // is_unvisited() || is_unsolved()
+                        else if (!have_worst || fz::order_key(cw) < fz::order_key(worst)) { worst = cw; have_worst = true; }
+                    }
+                    const float cum = bits_f32(nd.x), nv = bits_f32(nd.y);
+                    if (have_worst && fz::kind(worst) == fz::LOSE) {
+                        nd.w = (nd.w & 0x007FFFFFu) | fz::sol_bits(fz::WIN, 0);
+                        value = -cum + (nv + 1.0f);
+                    } else if (nc != 0 && all_solved) {
+                        // worst.reversed(): Win -> Lose, Draw -> Draw, one turn later (never Lose here)
+                        const uint32_t k = fz::kind(worst) == fz::WIN ? fz::LOSE : fz::DRAW;
+                        nd.w = (nd.w & 0x007FFFFFu) | fz::sol_bits(k, fz::turns(worst) + 1u);
+                        value = k == fz::DRAW ? -cum : -cum - (nv + 1.0f);
+                    } else {
+                        solved = false;
+                    }
+                }
+                nd.x = f32_bits(bits_f32(nd.x) + value);
+                nd.y = f32_bits(bits_f32(nd.y) + 1.0f);
+                pool[nid] = nd;
+                value = -value;
+            }
+        }
+        if (overflow) *P.error = 2;
+
+        // ---- results + best_action (evaluator.rs:364-389)
+        FrozenResult& R = P.results[root];
+        const uint4 rt = pool[0];
+        const uint32_t lmask = fz::legal_mask(root_my | root_op);
+        int best_action = -1;
+        float best_value = -INFINITY;
+        uint32_t m = lmask;
+        const uint32_t fc = fz::first_child(rt.w);
+        uint32_t j = 0;
+        for (int a = 0; a < 9; a++) {
+            uint4 ch = make_uint4(0u, 0u, 0u, 0u);
+            const bool legal = (m >> a) & 1u;
+            if (legal && !overflow) ch = pool[fc + j];
+            if (legal) j++;
+            R.child_N[a] = bits_f32(ch.y);
+            R.child_cum[a] = bits_f32(ch.x);
+            R.child_P[a] = bits_f32(ch.z);
+            R.child_sol[a][0] = fz::some(ch.w) ? 1 : 0;
+            R.child_sol[a][1] = fz::some(ch.w) ? (int)fz::kind(ch.w) : 0;
+            R.child_sol[a][2] = fz::some(ch.w) ? (int)fz::turns(ch.w) : 0;
+            if (!legal || overflow || fz::unvisited(ch.w)) continue;
+            float v;
+            if (fz::some(ch.w)) v = fz::kind(ch.w) == fz::WIN ? -INFINITY : (fz::kind(ch.w) == fz::DRAW ? 1e6f : INFINITY);
+            else v = P.action_selection == 0 ? -bits_f32(ch.x) / bits_f32(ch.y) : bits_f32(ch.y);
+            if (best_action < 0 || v > best_value) { best_value = v; best_action = a; }
+        }
+        R.root_N = bits_f32(rt.y);
+        R.root_cum = bits_f32(rt.x);
+        R.root_sol[0] = fz::some(rt.w) ? 1 : 0;
+        R.root_sol[1] = fz::some(rt.w) ? (int)fz::kind(rt.w) : 0;
+        R.root_sol[2] = fz::some(rt.w) ? (int)fz::turns(rt.w) : 0;
+        R.num_nodes = next_node;
+        R.best_action = best_action;
+        P.rng_words[root] = (unsigned long long)rng_index;
+    }
+}
+
+}  // namespace syn

@@ -17,7 +17,7 @@ NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/p
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -104,6 +104,8 @@ def load_library():
                                     C.c_int, C.c_void_p]
     lib.syn_mcts_search_rollout.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p]
+    lib.syn_frozen_search_rollout.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.syn_selfplay_run.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int] + \
                                     [C.c_void_p] * 8
     lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -261,6 +263,30 @@ class Engine:
         rec = raw.copy().view(dt).reshape(n)
         out = {k: rec[k].copy() for k in dt.names}
         out["root_stat"] = np.concatenate([out.pop("root_N")[:, None], out.pop("root_W")], axis=1)
+        return out
+
+    # ---- the evaluator's baseline: FrozenMCTS::exploit over RolloutPolicy on n roots (evaluator.rs:308-319)
+    FROZEN_DTYPE = np.dtype([("child_N", np.float32, (9,)), ("child_cum", np.float32, (9,)), ("child_P", np.float32, (9,)),
+                             ("child_sol", np.int32, (9, 3)), ("root_N", np.float32), ("root_cum", np.float32),
+                             ("root_sol", np.int32, (3,)), ("num_nodes", np.uint32), ("best_action", np.int32)])
+
+    def frozen_search(self, cfg: MCTSConfig, seeds, rng_words, my_bb, op_bb, explores, action_selection=1):
+        """Root i plays out on StdRng::seed_from_u64(seeds[i]) from output word rng_words[i] on (one generator per match,
+        evaluator.rs:171-172); returns the per-root records plus "rng_words", the position to hand to the match's next search.
+        `explores` is a scalar or one value per root."""
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        n = int(my.size)
+        sd = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (n,)))
+        words = np.array(np.broadcast_to(np.asarray(rng_words, dtype=np.uint64), (n,)), dtype=np.uint64)
+        ex = np.ascontiguousarray(np.broadcast_to(np.asarray(explores, dtype=np.int32), (n,)))
+        rec = np.zeros(max(n, 1), self.FROZEN_DTYPE)
+        c = cfg.to_c()
+        self._check(self._lib.syn_frozen_search_rollout(self._h, C.byref(c), _p(sd), _p(words), _p(my), _p(op), _p(ex), n,
+                                                        int(action_selection), _p(rec)))
+        out = {k: rec[k][:n].copy() for k in self.FROZEN_DTYPE.names}
+        out["root_stat"] = np.stack([out.pop("root_N"), out.pop("root_cum")], axis=1)
+        out["rng_words"] = words
         return out
 
     # ---- run_n_games (alpha_zero.rs:181-209)

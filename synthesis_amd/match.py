@@ -3,9 +3,13 @@
 
 All games of a match advance in lockstep on the host: per ply, the positions where player A is to move go through one
 batched `Engine.mcts_search` call and player B's through another, each root on its own device-resident tree. A player is
-(MCTSConfig, explores, action selection, leaf policy): the engine's network, or `RolloutPolicy` playouts
-(`rollout_seed`). The rollout opponent here is MCTS over RolloutPolicy; the reference's evaluator uses its separate
-`FrozenMCTS` tree for that role (not built), so ratings are comparable in kind, not in number.
+(MCTSConfig, explores, action selection, kind):
+  * the engine's network under `MCTS` (evaluator.rs:129-160 eval_against_old, and the policy side of :163-198),
+  * `vanilla_player`: the evaluator's "VanillaMCTS<n>" baseline = `FrozenMCTS` over `RolloutPolicy` (evaluator.rs:163-228,
+    230-534), every game on its own StdRng::seed_from_u64(seed) that lasts the whole game, as in the reference — so
+    `play_match(first=net, second=vanilla_player(n), seeds=...)` replays eval_against_rollout_mcts move for move and two
+    vanilla players replay mcts_vs_mcts,
+  * `rollout_player`: the self-play `MCTS` tree over RolloutPolicy (the pairing of the reference's MCTS tests).
 
 Host code only applies the chosen moves (numpy bitboards, connect4.rs:221-233) — no search, no network."""
 from dataclasses import dataclass, field
@@ -55,6 +59,7 @@ class Player:
     mcts_cfg: MCTSConfig = field(default_factory=MCTSConfig)
     action: ActionSelection = ActionSelection.NumVisits
     rollout: bool = False          # False: the engine's network is the leaf policy; True: RolloutPolicy playouts
+    frozen: bool = False           # True: the evaluator's FrozenMCTS baseline over RolloutPolicy (evaluator.rs:230-534)
 
 
 def rollout_player(explores, name=None):
@@ -64,26 +69,48 @@ def rollout_player(explores, name=None):
                   ActionSelection.NumVisits, rollout=True)
 
 
-def play_match(engine, first: Player, second: Player, n_games, seed=0):
+def vanilla_player(explores, name=None):
+    """The evaluator's baseline (evaluator.rs:184-190, 212-222) under rollout_mcts_cfg / rollout_action of
+    study-connect4/src/main.rs:74-83: FrozenMCTS, Uct{c: 2}, fpu = inf, ActionSelection::NumVisits"""
+    return Player(name or f"VanillaMCTS{explores}", explores,
+                  MCTSConfig(exploration=Exploration.Uct, c=2.0, auto_extend=False, fpu=Fpu.Const, fpu_value=float("inf")),
+                  ActionSelection.NumVisits, rollout=True, frozen=True)
+
+
+def play_match(engine, first: Player, second: Player, n_games, seed=0, seeds=None, record=None):
     """n_games from the empty board, `first` moving first. Returns rewards for `first` per game: +1 win, 0 draw, -1 loss
-    (game.reward(first_player), evaluator.rs:160) and the number of plies."""
+    (game.reward(first_player), evaluator.rs:160) and the number of plies. Game g's rollout generator is
+    StdRng::seed_from_u64(seeds[g]) (default seed + g), shared by both sides and alive for the whole game when the players
+    are vanilla players (evaluator.rs:171-172, 207-208). `record`: optional dict that receives "moves" [n_games, 63]."""
     my = np.zeros(n_games, np.uint64); op = np.zeros(n_games, np.uint64)
     alive = np.ones(n_games, bool)
     reward = np.zeros(n_games, np.float32)
     plies = np.zeros(n_games, np.int32)
+    seeds = (np.uint64(seed) + np.arange(n_games, dtype=np.uint64)) if seeds is None else np.asarray(seeds, np.uint64)
+    words = np.zeros(n_games, np.uint64)
+    moves = np.full((n_games, 63), 255, np.uint8)
     for ply in range(63):
         idx = np.nonzero(alive)[0]
         if idx.size == 0:
             break
         p = first if ply % 2 == 0 else second
-        kw = dict(rollout_seed=int(seed) + ply * n_games) if p.rollout else {}
-        res = engine.mcts_search(p.mcts_cfg, my[idx], op[idx], p.explores, action_selection=int(p.action), **kw)
+        if p.frozen:
+            res = engine.frozen_search(p.mcts_cfg, seeds[idx], words[idx], my[idx], op[idx], p.explores,
+                                       action_selection=int(p.action))
+            words[idx] = res["rng_words"]
+        else:
+            kw = dict(rollout_seed=int(seed) + ply * n_games) if p.rollout else {}
+            res = engine.mcts_search(p.mcts_cfg, my[idx], op[idx], p.explores, action_selection=int(p.action), **kw)
+        moves[idx, ply] = res["best_action"]
         nmy, nop, over, w = step(my[idx], op[idx], res["best_action"])
         my[idx], op[idx] = nmy, nop
         plies[idx] += 1
         mover_is_first = ply % 2 == 0
         reward[idx[over & w]] = 1.0 if mover_is_first else -1.0
         alive[idx[over]] = False
+    if record is not None:
+        record["moves"] = moves
+        record["rng_words"] = words
     return reward, plies
 
 

@@ -75,6 +75,13 @@ int main(int argc, char** argv) {
         put("child_N", res[0].child_N, 9);
         std::printf("best %d nodes %u\n", res[0].best_action, res[0].num_nodes);
 
+        // the evaluator's baseline ladder and one network-vs-baseline pairing (before the learner changes the network)
+        auto ladder = mcts_vs_mcts(engine, rollout_mcts_cfg(), ActionSelection::NumVisits, Connect4::Red, 60, 30, {1, 2, 3, 4});
+        put("vanilla_rewards", ladder.data(), (int)ladder.size());
+        auto versus = eval_against_rollout_mcts(engine, MCTSConfig(), 48, ActionSelection::NumVisits, rollout_mcts_cfg(),
+                                                ActionSelection::NumVisits, Connect4::Black, 40, {5, 6, 7});
+        put("versus_rewards", versus.data(), (int)versus.size());
+
         // one learner step on the first 32 unique states, then self-play continues on the trained network
         Learner learner(engine, blob, 1e-6f, 1.0f, 1.0f);
         std::vector<Connect4> bg(flat.games.begin(), flat.games.begin() + 32);

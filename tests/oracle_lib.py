@@ -237,6 +237,46 @@ class Oracle:
                                             _p(r["target_pi"]), _p(r["target_q"]))
         return r
 
+    def c4_frozen_search(self, cfg, seeds, rng_words, my_bb, op_bb, explores, action_selection=1, blob=None, nn_mode=1):
+        """FrozenMCTS (evaluator.rs:230-534) over RolloutPolicy on StdRng(seeds[i]) from word rng_words[i] (blob given: over the
+        network instead). Returns the records plus "rng_words" = stream position after each search."""
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
+        n = int(my.size)
+        sd = np.ascontiguousarray(np.broadcast_to(np.asarray(seeds, dtype=np.uint64), (n,)))
+        words = np.array(np.broadcast_to(np.asarray(rng_words, dtype=np.uint64), (n,)), dtype=np.uint64)
+        ex = np.ascontiguousarray(np.broadcast_to(np.asarray(explores, dtype=np.int32), (n,)))
+        r = dict(child_N=np.zeros((n, 9), np.float32), child_cum=np.zeros((n, 9), np.float32),
+                 child_P=np.zeros((n, 9), np.float32), child_sol=np.zeros((n, 9, 3), np.int32),
+                 root_stat=np.zeros((n, 2), np.float32), root_sol=np.zeros((n, 3), np.int32),
+                 num_nodes=np.zeros(n, np.uint32), best_action=np.zeros(n, np.int32))
+        kind = 1 if blob is None else 0
+        b = np.ascontiguousarray(blob, np.float32) if blob is not None else np.zeros(1, np.float32)
+        self.lib.orc_c4_frozen_search(C.byref(cfg), kind, _p(b), nn_mode, _p(sd), _p(words), _p(my), _p(op), n, _p(ex),
+                                      action_selection, _p(r["child_N"]), _p(r["child_cum"]), _p(r["child_P"]),
+                                      _p(r["child_sol"]), _p(r["root_stat"]), _p(r["root_sol"]), _p(r["num_nodes"]),
+                                      _p(r["best_action"]))
+        r["rng_words"] = words
+        return r
+
+    def c4_mcts_vs_mcts(self, rollout_cfg, player, p1_explores, p2_explores, seed, rollout_action=1):
+        """evaluator.rs:200-228. Returns (reward for the first player, moves, stream words consumed after each ply)."""
+        moves = np.zeros(63, np.uint8); words = np.zeros(63, np.uint64); n = C.c_int(0)
+        self.lib.orc_c4_mcts_vs_mcts.restype = C.c_float
+        r = self.lib.orc_c4_mcts_vs_mcts(C.byref(rollout_cfg), rollout_action, player, p1_explores, p2_explores,
+                                         C.c_uint64(seed), _p(moves), C.byref(n), _p(words))
+        return float(r), moves[:n.value].copy(), words[:n.value].copy()
+
+    def c4_eval_against_rollout(self, policy_cfg, policy_explores, blob, rollout_cfg, player, opponent_explores, seed,
+                                policy_action=1, rollout_action=1, nn_mode=1):
+        """evaluator.rs:163-198. Returns (reward for the first player, moves, stream words consumed after each ply)."""
+        moves = np.zeros(63, np.uint8); words = np.zeros(63, np.uint64); n = C.c_int(0)
+        b = np.ascontiguousarray(blob, np.float32)
+        self.lib.orc_c4_eval_against_rollout.restype = C.c_float
+        r = self.lib.orc_c4_eval_against_rollout(C.byref(policy_cfg), policy_explores, policy_action, _p(b), nn_mode,
+                                                 C.byref(rollout_cfg), rollout_action, player, opponent_explores,
+                                                 C.c_uint64(seed), _p(moves), C.byref(n), _p(words))
+        return float(r), moves[:n.value].copy(), words[:n.value].copy()
+
     # ---- training step / dedup (SURVEY §8f #1)
     def train_gradients(self, blob, hp, X, tpi, tv):
         blob = np.ascontiguousarray(blob, np.float32)

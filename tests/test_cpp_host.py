@@ -92,6 +92,13 @@ def test_cpp_host_matches_oracle(harness, oracle, golden_dir):
     assert np.array_equal(f32s(by["child_N"][0]), s["child_N"][0])
     assert (int(by["best"][0][0]), int(by["best"][0][2])) == (int(s["best_action"][0]), int(s["num_nodes"][0]))
 
+    # evaluator.rs:200-228 / 163-198 through the C++ mirror: rewards of whole matches
+    rcfg = parity_mcts_config(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf"))
+    want = [oracle.c4_mcts_vs_mcts(rcfg, 0, 60, 30, sd)[0] for sd in (1, 2, 3, 4)]
+    assert list(f32s(by["vanilla_rewards"][0])) == want
+    want = [oracle.c4_eval_against_rollout(parity_mcts_config(), 48, blob, rcfg, 1, 40, sd, nn_mode=oracle.ACC_FMA)[0] for sd in (5, 6, 7)]
+    assert list(f32s(by["versus_rewards"][0])) == want
+
     # one learner step on the first 32 unique states, published to the self-play network
     from tests.oracle_lib import default_train_hyper
 

@@ -1,0 +1,135 @@
+"""GPU parity of the evaluator's baseline opponent: FrozenMCTS over RolloutPolicy (synthesis/src/evaluator.rs:163-534) on the
+device vs the CPU oracle (oracle/frozen_mcts.hpp). Bar: every float of every root record bit-identical, identical stream
+positions, identical moves and rewards of whole matches."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import random_positions
+
+pytestmark = pytest.mark.gpu
+
+FROZEN_KEYS = ("child_N", "child_cum", "child_P", "child_sol", "root_stat", "root_sol", "num_nodes", "best_action", "rng_words")
+
+
+@pytest.fixture(scope="module")
+def blob(golden_dir):
+    import os
+
+    return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+
+
+@pytest.fixture(scope="module")
+def engine(blob):
+    import synthesis_amd as sa
+
+    eng = sa.Engine(concurrent_games=256, max_explores=400)
+    eng.load_weights(blob)
+    yield eng
+    eng.close()
+
+
+def rollout_cfgs(**kw):
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config
+
+    dev = dict(exploration=sa.Exploration.Uct, c=2.0, auto_extend=False, fpu=sa.Fpu.Const, fpu_value=float("inf"))
+    orc = dict(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf"))
+    for k, v in kw.items():
+        dev[k] = v
+        orc[k] = int(v) if isinstance(v, bool) else v
+    return sa.MCTSConfig(**dev), parity_mcts_config(**orc)
+
+
+def assert_frozen_equal(got, ref, what):
+    for k in FROZEN_KEYS:
+        g, r = np.asarray(got[k]), np.asarray(ref[k])
+        if g.dtype == np.float32:
+            g, r = g.view(np.uint32), r.view(np.uint32)
+        bad = np.nonzero(np.any((g != r).reshape(g.shape[0], -1), axis=1))[0]
+        assert bad.size == 0, f"{what}: {k} differs at roots {bad[:8]} ({bad.size} of {g.shape[0]})"
+
+
+@pytest.mark.parametrize("variant", [dict(), dict(fpu_value=1.0, c=1.3), dict(solve=False), dict(fpu_value=0.25, c=4.0)])
+def test_frozen_search_matches_oracle(engine, oracle, variant):
+    """Random reachable positions from the empty board to the last few cells (solver-heavy), per-root explores, per-root seeds,
+    searches that start in the middle of a generator's stream."""
+    dcfg, ocfg = rollout_cfgs(**variant)
+    my, op = random_positions(oracle, 600, seed=41, max_moves=62)
+    rs = np.random.RandomState(5)
+    explores = rs.choice([0, 1, 2, 9, 50, 150, 400], size=my.size).astype(np.int32)
+    seeds = rs.randint(0, 2**62, size=my.size).astype(np.uint64)
+    words = rs.choice([0, 1, 15, 16, 17, 63, 64, 65, 1000, 123457], size=my.size).astype(np.uint64)
+    for sel in (0, 1):
+        got = engine.frozen_search(dcfg, seeds, words, my, op, explores, action_selection=sel)
+        ref = oracle.c4_frozen_search(ocfg, seeds, words, my, op, explores, action_selection=sel)
+        assert_frozen_equal(got, ref, f"{variant} selection {sel}")
+    assert engine.last_launch_shape()[0] == 5
+    assert (got["root_stat"][:, 0] == explores + 1).all()      # explore_n never stops early
+    assert (got["rng_words"] > words).all()                    # the root's own visit always plays out
+
+
+def test_frozen_search_more_roots_than_lanes(engine, oracle):
+    """5,000 roots on an engine with 1,792 tree slabs: lanes take further roots in a grid-stride loop"""
+    dcfg, ocfg = rollout_cfgs()
+    my, op = random_positions(oracle, 250, seed=43, max_moves=50)
+    my, op = np.tile(my, 20), np.tile(op, 20)
+    seeds = np.arange(my.size, dtype=np.uint64) * np.uint64(7919)
+    got = engine.frozen_search(dcfg, seeds, 0, my, op, 60)
+    ref = oracle.c4_frozen_search(ocfg, seeds, 0, my, op, 60)
+    assert_frozen_equal(got, ref, "grid-stride")
+
+
+def test_mcts_vs_mcts_replays_the_oracle(engine, oracle):
+    """evaluator.rs:200-228: VanillaMCTS a vs VanillaMCTS b, one StdRng per game shared by both sides for the whole game"""
+    from synthesis_amd import match
+
+    dcfg, ocfg = rollout_cfgs()
+    n = 40
+    for first_explores, second_explores in ((200, 100), (50, 400)):
+        rec = {}
+        reward, plies = match.play_match(engine, match.vanilla_player(first_explores), match.vanilla_player(second_explores), n,
+                                         seed=100, record=rec)
+        for g in range(n):
+            r, moves, words = oracle.c4_mcts_vs_mcts(ocfg, 0, first_explores, second_explores, 100 + g)
+            assert plies[g] == moves.size and np.array_equal(rec["moves"][g, :moves.size], moves), f"game {g}"
+            assert reward[g] == r and rec["rng_words"][g] == words[-1]
+        # the same match with the roles swapped (player = second mover, evaluator.rs:38-39)
+        r, moves, _ = oracle.c4_mcts_vs_mcts(ocfg, 1, second_explores, first_explores, 100)
+        assert np.array_equal(rec["moves"][0, :moves.size], moves) and reward[0] == r
+
+
+def test_eval_against_rollout_replays_the_oracle(engine, oracle, blob):
+    """evaluator.rs:163-198: the network's MCTS::exploit on one side, the vanilla baseline on the other, both colours"""
+    import synthesis_amd as sa
+    from synthesis_amd import match
+    from tests.oracle_lib import parity_mcts_config
+
+    dcfg, ocfg = rollout_cfgs()
+    net = match.Player("net", 100, sa.parity_mcts_config())
+    n = 24
+    for net_moves_first in (True, False):
+        rec = {}
+        a, b = (net, match.vanilla_player(150)) if net_moves_first else (match.vanilla_player(150), net)
+        reward, plies = match.play_match(engine, a, b, n, seed=7, record=rec)
+        for g in range(n):
+            r, moves, words = oracle.c4_eval_against_rollout(parity_mcts_config(), 100, blob, ocfg, 0 if net_moves_first else 1,
+                                                             150, 7 + g, nn_mode=oracle.ACC_FMA)
+            assert plies[g] == moves.size and np.array_equal(rec["moves"][g, :moves.size], moves), f"game {g}"
+            assert reward[g] == r and rec["rng_words"][g] == words[-1]
+
+
+def test_frozen_search_rejects_what_the_reference_panics_on(engine):
+    import synthesis_amd as sa
+
+    z = np.zeros(1, np.uint64)
+    dcfg, _ = rollout_cfgs()
+    with pytest.raises(sa.SynthesisAmdError, match="Uct only"):
+        engine.frozen_search(sa.MCTSConfig(exploration=sa.Exploration.PolynomialUct, fpu=sa.Fpu.Const), 0, 0, z, z, 10)
+    with pytest.raises(sa.SynthesisAmdError, match="Fpu::Const only"):
+        engine.frozen_search(sa.MCTSConfig(exploration=sa.Exploration.Uct, fpu=sa.Fpu.ParentQ), 0, 0, z, z, 10)
+    with pytest.raises(sa.SynthesisAmdError, match="needs up to"):
+        engine.frozen_search(dcfg, 0, 0, z, z, 100000)
+    with pytest.raises(sa.SynthesisAmdError, match="searchable"):
+        engine.frozen_search(dcfg, 0, 0, np.array([3], np.uint64), np.array([1], np.uint64), 10)
+    got = engine.frozen_search(dcfg, 0, 0, np.zeros(0, np.uint64), np.zeros(0, np.uint64), 10)
+    assert got["best_action"].shape == (0,)
