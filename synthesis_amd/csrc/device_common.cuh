@@ -245,6 +245,28 @@ struct StdRng {
 
     SYN_DEV uint32_t next_u32() { return word(index++); }
 
+    // all sixteen words of output block `blk` (words 16*blk .. 16*blk+15), for callers that keep a block around
+    SYN_DEV void block16(uint32_t blk, uint32_t out[16]) const {
+        const uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                                key[4], key[5], key[6], key[7], blk, 0u, 0u, 0u};
+        uint32_t x[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = s[k];
+#define SYN_QR(a, b, c, d)                          \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 16); \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 12); \
+    x[a] += x[b]; x[d] ^= x[a]; x[d] = rotl(x[d], 8);  \
+    x[c] += x[d]; x[b] ^= x[c]; x[b] = rotl(x[b], 7);
+#pragma unroll 1
+        for (int r = 0; r < 6; r++) {
+            SYN_QR(0, 4, 8, 12) SYN_QR(1, 5, 9, 13) SYN_QR(2, 6, 10, 14) SYN_QR(3, 7, 11, 15)
+            SYN_QR(0, 5, 10, 15) SYN_QR(1, 6, 11, 12) SYN_QR(2, 7, 8, 13) SYN_QR(3, 4, 9, 14)
+        }
+#undef SYN_QR
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[k] = x[k] + s[k];
+    }
+
     // Rng::gen_range(0..n) for u8 (rand 0.8.3 UniformInt<u8>::sample_single): u32 widening multiply + modulus zone
     SYN_DEV uint32_t gen_range_u8(uint32_t n) {
         uint32_t ints_to_reject = (0xFFFFFFFFu - n + 1u) % n;

@@ -709,9 +709,9 @@ int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const u
     unsigned long long* d_words = d_seed + nb;
     FrozenResult* d_res = reinterpret_cast<FrozenResult*>(d_words + nb);
     int* d_expl = reinterpret_cast<int*>(d_res + nb);
-    int grid = (n + 255) / 256;
-    if (grid > h->pool_slots / 256) grid = h->pool_slots / 256;
-    const size_t need_path = (size_t)grid * 4 * 4096 * sizeof(uint32_t);
+    int grid = (n + 63) / 64;  // one wave per workgroup
+    if (grid > h->pool_slots / 64) grid = h->pool_slots / 64;
+    const size_t need_path = (size_t)grid * 4096 * sizeof(uint32_t);
     if (need_path > h->path_bytes) {
         if (h->d_path) (void)hipFree(h->d_path);
         h->d_path = nullptr;
@@ -738,10 +738,10 @@ int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const u
     P.results = d_res;
     P.error = h->d_job_next + 8;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(frozen_rollout_kernel, dim3(grid), dim3(256), 0, h->stream, P);
+    hipLaunchKernelGGL(frozen_rollout_kernel, dim3(grid), dim3(64), 0, h->stream, P);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-    h->last_shape = 5; h->last_grid = grid; h->last_threads = 256;
+    h->last_shape = 5; h->last_grid = grid; h->last_threads = 64;
     static_assert(sizeof(FrozenResult) == sizeof(syn_frozen_result), "device and ABI result records must match");
     int kerr = 0;
     HIP_TRY(h, hipMemcpyAsync(results, d_res, nb * sizeof(FrozenResult), hipMemcpyDeviceToHost, h->stream));

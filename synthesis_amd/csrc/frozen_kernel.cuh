@@ -71,12 +71,41 @@ SYN_DEV int nth_set(uint32_t m, uint32_t n) {
 }
 }  // namespace fz
 
-// policies/rollout.rs:8-31 on the root's stream (same playout as lane_rollout, 64-bit stream position)
-SYN_DEV float frozen_playout(uint64_t my, uint64_t op, const StdRng& base, uint32_t& rng_index) {
-    StdRng rng = base;
-    rng.index = rng_index;
+// The lane's view of its root's StdRng: the key, the stream position, and the 16-word output block the position lies in,
+// parked in LDS ([word][lane], conflict-free) so that a playout of ~25 moves costs two or three ChaCha12 blocks, not 25.
+struct FrozenRng {
+    StdRng base;
+    uint32_t index;      // next output word
+    uint32_t cached;     // block number held in LDS (0xFFFFFFFF = none)
+    uint32_t* lds;       // this lane's column: word k at lds[k * 64]
+
+    SYN_DEV uint32_t next_u32() {
+        const uint32_t blk = index >> 4;
+        if (blk != cached) {
+            uint32_t out[16];
+            base.block16(blk, out);
+#pragma unroll
+            for (int k = 0; k < 16; k++) lds[k * 64] = out[k];
+            cached = blk;
+        }
+        return lds[(index++ & 15u) * 64];
+    }
+    // Rng::gen_range(0..n) for u8 (rand 0.8.3 UniformInt<u8>::sample_single), as StdRng::gen_range_u8
+    SYN_DEV uint32_t gen_range_u8(uint32_t n) {
+        const uint32_t ints_to_reject = (0xFFFFFFFFu - n + 1u) % n;
+        const uint32_t zone = 0xFFFFFFFFu - ints_to_reject;
+        for (;;) {
+            const uint32_t v = next_u32();
+            const uint64_t m = (uint64_t)v * (uint64_t)n;
+            if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+        }
+    }
+};
+
+// policies/rollout.rs:8-31 on the root's stream: uniformly random legal moves to the end; returns dist[2] - dist[0] of the
+// one-hot outcome for the player to move at the leaf
+SYN_DEV float frozen_playout(uint64_t my, uint64_t op, FrozenRng& rng) {
     bool leaf_player_moves = true;
-    float value;
     for (;;) {
         const uint64_t occ = my | op;
         const uint32_t lmask = fz::legal_mask(occ);
@@ -84,29 +113,31 @@ SYN_DEV float frozen_playout(uint64_t my, uint64_t op, const StdRng& base, uint3
         const int col = fz::nth_set(lmask, pick);
         const uint64_t bit = 1ull << (c4::col_height(occ, col) + 7 * col);
         const uint64_t mover = my | bit;
-        if (c4::won(mover)) { value = leaf_player_moves ? 1.0f : -1.0f; break; }  // dist[2] - dist[0] of the one-hot outcome
-        if ((occ | bit) == c4::FULL) { value = 0.0f; break; }
+        if (c4::won(mover)) return leaf_player_moves ? 1.0f : -1.0f;
+        if ((occ | bit) == c4::FULL) return 0.0f;
         my = op;
         op = mover;
         leaf_player_moves = !leaf_player_moves;
     }
-    rng_index = rng.index;
-    return value;
 }
 
-__global__ __launch_bounds__(256) void frozen_rollout_kernel(FrozenParams P) {
-    const int lane = threadIdx.x & 63;
-    const size_t gwave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t glane = (size_t)blockIdx.x * 256 + threadIdx.x;
+// One wave per workgroup: the waves of a small batch spread over all CUs instead of filling a quarter of them.
+__global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
+    __shared__ uint32_t rng_blocks[16 * 64];
+    const int lane = threadIdx.x;
+    const size_t gwave = blockIdx.x;
+    const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x;
     uint4* const pool = P.pool + glane * P.nodes_per_tree;
     uint32_t* const path = P.path + gwave * 4096 + lane;  // level l at path[l * 64]
     const uint32_t node_cap = (uint32_t)(P.nodes_per_tree < 0x7FFFFu ? P.nodes_per_tree : 0x7FFFFu);
 
-    for (size_t root = glane; root < (size_t)P.n_roots; root += (size_t)gridDim.x * 256) {
+    for (size_t root = glane; root < (size_t)P.n_roots; root += (size_t)gridDim.x * 64) {
         const uint64_t root_my = P.in_my[root], root_op = P.in_op[root];
-        StdRng base;
-        base.seed_from_u64(P.seeds[root]);
-        uint32_t rng_index = (uint32_t)P.rng_words[root];
+        FrozenRng rng;
+        rng.base.seed_from_u64(P.seeds[root]);
+        rng.index = (uint32_t)P.rng_words[root];
+        rng.cached = 0xFFFFFFFFu;
+        rng.lds = rng_blocks + threadIdx.x;
         uint32_t next_node = 1;
         bool overflow = false;
         pool[0] = make_uint4(0u, 0u, 0u, 0u);  // Node::unvisited(0, game, None, 0, 0.0)
@@ -124,7 +155,7 @@ __global__ __launch_bounds__(256) void frozen_rollout_kernel(FrozenParams P) {
                 if (fz::some(nd.w)) { value = fz::value_of_kind(fz::kind(nd.w)); solved = true; break; }
                 if (fz::num_children(nd.w) == 0) {
                     // ---- visit (evaluator.rs:439-483): playout first, then one child per legal column
-                    value = frozen_playout(my, op, base, rng_index);
+                    value = frozen_playout(my, op, rng);
                     const uint64_t occ = my | op;
                     const uint32_t lmask = fz::legal_mask(occ);
                     const uint32_t nc = (uint32_t)__popc(lmask);
@@ -250,7 +281,7 @@ __global__ __launch_bounds__(256) void frozen_rollout_kernel(FrozenParams P) {
         R.root_sol[2] = fz::some(rt.w) ? (int)fz::turns(rt.w) : 0;
         R.num_nodes = next_node;
         R.best_action = best_action;
-        P.rng_words[root] = (unsigned long long)rng_index;
+        P.rng_words[root] = (unsigned long long)rng.index;
     }
 }
 

@@ -69,7 +69,7 @@ def test_frozen_search_matches_oracle(engine, oracle, variant):
 
 
 def test_frozen_search_more_roots_than_lanes(engine, oracle):
-    """5,000 roots on an engine with 1,792 tree slabs: lanes take further roots in a grid-stride loop"""
+    """5,000 roots on an engine with 1,792 tree slabs (28 waves): lanes take further roots in a grid-stride loop"""
     dcfg, ocfg = rollout_cfgs()
     my, op = random_positions(oracle, 250, seed=43, max_moves=50)
     my, op = np.tile(my, 20), np.tile(op, 20)
