@@ -185,6 +185,9 @@ typedef struct syn_frozen_result {
  * StdRng::seed_from_u64(seeds[i]) starting at 32-bit output word rng_words[i]; on return rng_words[i] is the first word the
  * search did not use, so a caller that replays a match move by move keeps ONE generator per match as the reference does
  * (pass 0 for the first move, hand the value back for the next). explores[i] is per root (mcts_vs_mcts gives each side its own).
+ * The trees live in the engine's node pool, re-partitioned per call for the largest explores[i] of the batch (1 + 9 records of
+ * 16 bytes per visit), so searches far deeper than the engine's max_explores run, fewer at a time (up to 233,014 explores:
+ * the reference's largest baseline is VanillaMCTS204800); SYN_ERR_CAPACITY if not even one such tree fits.
  * cfg: Exploration::Uct and Fpu::Const only — the reference panics on anything else (SYN_ERR_UNSUPPORTED here); the
  * baseline ignores every other field except `solve`. No network weights are needed. */
 int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* seeds, uint64_t* rng_words,

@@ -687,18 +687,25 @@ int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const u
     if (cfg->fpu != SYN_FPU_CONST)
         return fail(h, SYN_ERR_UNSUPPORTED, "FrozenMCTS supports Fpu::Const only (evaluator.rs:418-421)");
     if (n == 0) return SYN_OK;
-    const size_t nodes_per_tree = (size_t)h->cap * 2;  // 16-byte records in a 32-byte-per-node slab
+    // The baseline's trees live in the engine's node pool, re-partitioned for this call: every tree gets the record capacity
+    // the largest search of the batch can need (1 + 9 nodes per visit), and the pool holds as many trees at once as fit.
+    size_t max_need = 0;
     for (int i = 0; i < n; i++) {
         if (!valid_root(my_bb[i], op_bb[i]))
             return fail(h, SYN_ERR_INVALID_ARGUMENT, "root %d is not a searchable Connect4 position", i);
         if (explores[i] < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "explores[%d] must be >= 0", i);
         const size_t worst = 1 + 9 * ((size_t)explores[i] + 1);
-        if (worst > nodes_per_tree || worst > 0x7FFFFu)
-            return fail(h, SYN_ERR_CAPACITY, "explores[%d] = %d needs up to %zu nodes; the engine (max_explores %d) holds %zu per tree",
-                        i, explores[i], worst, h->max_explores, nodes_per_tree);
-        if (rng_words[i] > 0xF0000000ull)
+        if (worst > max_need) max_need = worst;
+        if (rng_words[i] > 0xC0000000ull)
             return fail(h, SYN_ERR_INVALID_ARGUMENT, "rng_words[%d] is beyond the supported stream length", i);
     }
+    const size_t nodes_per_tree = (max_need + 7) & ~(size_t)7;
+    const size_t pool_records = (size_t)h->pool_slots * h->cap * 2;  // 16-byte records in the 32-byte-per-node pool
+    if (max_need > 0x1FFFFFu || nodes_per_tree > pool_records)
+        return fail(h, SYN_ERR_CAPACITY, "a baseline search of %zu explores needs up to %zu node records; the engine's pool holds %zu "
+                    "and a tree at most 2,097,151", (max_need - 1) / 9 - 1, max_need, pool_records);
+    size_t n_lanes = pool_records / nodes_per_tree;
+    if (n_lanes > (size_t)n) n_lanes = (size_t)n;
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t nb = (size_t)n;
     int rc = ensure_scratch(h, nb * (8 * 4 + 4 + sizeof(FrozenResult)) + 256);
@@ -709,8 +716,7 @@ int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const u
     unsigned long long* d_words = d_seed + nb;
     FrozenResult* d_res = reinterpret_cast<FrozenResult*>(d_words + nb);
     int* d_expl = reinterpret_cast<int*>(d_res + nb);
-    int grid = (n + 63) / 64;  // one wave per workgroup
-    if (grid > h->pool_slots / 64) grid = h->pool_slots / 64;
+    const int grid = (int)((n_lanes + 63) / 64);  // one wave per workgroup
     const size_t need_path = (size_t)grid * 4096 * sizeof(uint32_t);
     if (need_path > h->path_bytes) {
         if (h->d_path) (void)hipFree(h->d_path);
@@ -731,6 +737,7 @@ int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const u
     P.path = reinterpret_cast<uint32_t*>(h->d_path);
     P.in_my = d_my; P.in_op = d_op; P.seeds = d_seed; P.rng_words = d_words; P.explores = d_expl;
     P.n_roots = n;
+    P.n_lanes = (int)n_lanes;
     P.c = cfg->c;
     P.fpu_value = cfg->fpu_value;
     P.solve = cfg->solve ? 1 : 0;

@@ -14,8 +14,11 @@
 // Node record (16 bytes; a node's children are contiguous, in ascending legal-column order, so the child's action and
 // position are re-derived from the parent's board during the descent instead of being stored):
 //   .x cum_value   .y num_visits   .z action_prob
-//   .w first_child[0:18] | num_children[19:22] | solution: some[23] kind[24:25] turns[26:31]   (kind 0 Lose 1 Draw 2 Win)
-// Path: the node ids of the current descent, [level][lane] per wave (the reference's parent pointers).
+//   .w first_child[0:20] | visited[21] | solution: some[22] kind[23:24] turns[25:30]   (kind 0 Lose 1 Draw 2 Win)
+// num_children is not stored either: it is the number of free columns of the node's position. 21 bits of node index hold the
+// reference's largest baseline, VanillaMCTS204800 (1 + 9 * 204,801 = 1,843,210 nodes at most).
+// Path: node id | num_children << 21 of every level of the current descent, [level][lane] per wave (the reference's parent
+// pointers).
 #pragma once
 #include "device_common.cuh"
 
@@ -31,6 +34,7 @@ struct FrozenParams {
     unsigned long long* rng_words;  // in: first stream word of each root; out: first unused word
     const int* explores;         // per root
     int n_roots;
+    int n_lanes;                 // trees the pool holds at this record capacity (<= n_roots); roots beyond take a later turn
     float c, fpu_value;
     int solve, action_selection;
     struct FrozenResult* results;
@@ -48,13 +52,14 @@ struct FrozenResult {
 
 namespace fz {
 constexpr uint32_t LOSE = 0, DRAW = 1, WIN = 2;
-SYN_DEV uint32_t first_child(uint32_t w) { return w & 0x7FFFFu; }
-SYN_DEV uint32_t num_children(uint32_t w) { return (w >> 19) & 15u; }
-SYN_DEV bool some(uint32_t w) { return (w >> 23) & 1u; }
-SYN_DEV uint32_t kind(uint32_t w) { return (w >> 24) & 3u; }
-SYN_DEV uint32_t turns(uint32_t w) { return w >> 26; }
-SYN_DEV uint32_t sol_bits(uint32_t k, uint32_t t) { return (1u << 23) | (k << 24) | (t << 26); }
-SYN_DEV bool unvisited(uint32_t w) { return num_children(w) == 0 && !some(w); }
+constexpr uint32_t ID_MASK = 0x1FFFFFu, VISITED = 1u << 21, SOL_MASK = 0x7FC00000u;
+SYN_DEV uint32_t first_child(uint32_t w) { return w & ID_MASK; }
+SYN_DEV bool visited(uint32_t w) { return (w >> 21) & 1u; }
+SYN_DEV bool some(uint32_t w) { return (w >> 22) & 1u; }
+SYN_DEV uint32_t kind(uint32_t w) { return (w >> 23) & 3u; }
+SYN_DEV uint32_t turns(uint32_t w) { return (w >> 25) & 63u; }
+SYN_DEV uint32_t sol_bits(uint32_t k, uint32_t t) { return (1u << 22) | (k << 23) | (t << 25); }
+SYN_DEV bool unvisited(uint32_t w) { return !visited(w) && !some(w); }
 // game.rs:46-60 as one integer key: Lose(t) ascending < Draw(t) ascending < Win(t) descending
 SYN_DEV uint32_t order_key(uint32_t w) { return (kind(w) << 8) | (kind(w) == WIN ? 255u - turns(w) : turns(w)); }
 SYN_DEV float value_of_kind(uint32_t k) { return k == WIN ? 1.0f : (k == DRAW ? 0.0f : -1.0f); }  // game.rs:37-43
@@ -129,9 +134,10 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
     const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x;
     uint4* const pool = P.pool + glane * P.nodes_per_tree;
     uint32_t* const path = P.path + gwave * 4096 + lane;  // level l at path[l * 64]
-    const uint32_t node_cap = (uint32_t)(P.nodes_per_tree < 0x7FFFFu ? P.nodes_per_tree : 0x7FFFFu);
+    const uint32_t node_cap = (uint32_t)(P.nodes_per_tree < fz::ID_MASK ? P.nodes_per_tree : fz::ID_MASK);
 
-    for (size_t root = glane; root < (size_t)P.n_roots; root += (size_t)gridDim.x * 64) {
+    if (glane >= (size_t)P.n_lanes) return;
+    for (size_t root = glane; root < (size_t)P.n_roots; root += (size_t)P.n_lanes) {
         const uint64_t root_my = P.in_my[root], root_op = P.in_op[root];
         FrozenRng rng;
         rng.base.seed_from_u64(P.seeds[root]);
@@ -150,15 +156,15 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
             float value;
             bool solved;
             for (;;) {
-                path[level * 64] = id;
+                const uint64_t occ = my | op;
+                const uint32_t lmask = fz::legal_mask(occ);
+                const uint32_t nc = (uint32_t)__popc(lmask);
+                path[level * 64] = id | (nc << 21);
                 const uint4 nd = pool[id];
                 if (fz::some(nd.w)) { value = fz::value_of_kind(fz::kind(nd.w)); solved = true; break; }
-                if (fz::num_children(nd.w) == 0) {
+                if (!fz::visited(nd.w)) {
                     // ---- visit (evaluator.rs:439-483): playout first, then one child per legal column
                     value = frozen_playout(my, op, rng);
-                    const uint64_t occ = my | op;
-                    const uint32_t lmask = fz::legal_mask(occ);
-                    const uint32_t nc = (uint32_t)__popc(lmask);
                     if (next_node + nc > node_cap) { overflow = true; break; }
                     // stable softmax of the (all-zero) rollout logits over the legal actions
                     float max_logit = -INFINITY;
@@ -183,12 +189,12 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
                             pool[next_node + j] = make_uint4(0u, 0u, f32_bits(e[j] / tot), w);
                         }
                     }
-                    pool[id] = make_uint4(nd.x, nd.y, nd.z, (nd.w & 0xFF800000u) | next_node | (nc << 19));
+                    pool[id] = make_uint4(nd.x, nd.y, nd.z, (nd.w & fz::SOL_MASK) | next_node | fz::VISITED);
                     next_node += nc;
                     break;
                 }
                 // ---- select_best_child (evaluator.rs:408-437)
-                const uint32_t fc = fz::first_child(nd.w), nc = fz::num_children(nd.w);
+                const uint32_t fc = fz::first_child(nd.w);
                 const float visits = sqrtf(P.c * det_logf(bits_f32(nd.y)));
                 uint32_t best = 0;
                 float best_value = -INFINITY;
@@ -204,8 +210,7 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
                     }
                     if (j == 0 || v > best_value) { best = j; best_value = v; }
                 }
-                const uint64_t occ = my | op;
-                const int col = fz::nth_set(fz::legal_mask(occ), best);
+                const int col = fz::nth_set(lmask, best);
                 const uint64_t mover = my | (1ull << (c4::col_height(occ, col) + 7 * col));
                 my = op;
                 op = mover;
@@ -216,25 +221,27 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
 
             // ---- backprop (evaluator.rs:485-527) along the recorded path
             for (int l = (int)level; l >= 0; l--) {
-                const uint32_t nid = path[l * 64];
+                const uint32_t pe = path[l * 64];
+                const uint32_t nid = pe & fz::ID_MASK, nc = pe >> 21;
                 uint4 nd = pool[nid];
                 if (P.solve && solved && !fz::some(nd.w)) {
                     bool all_solved = true, have_worst = false;
                     uint32_t worst = 0;
-                    const uint32_t fc = fz::first_child(nd.w), nc = fz::num_children(nd.w);
-                    for (uint32_t j = 0; j < nc; j++) {
+                    const uint32_t fc = fz::first_child(nd.w);
+                    const uint32_t n_scan = fz::visited(nd.w) ? nc : 0u;
+                    for (uint32_t j = 0; j < n_scan; j++) {
                         const uint32_t cw = pool[fc + j].w;
                         if (!fz::some(cw)) all_solved = false;  // is_unvisited() || is_unsolved()
                         else if (!have_worst || fz::order_key(cw) < fz::order_key(worst)) { worst = cw; have_worst = true; }
                     }
                     const float cum = bits_f32(nd.x), nv = bits_f32(nd.y);
                     if (have_worst && fz::kind(worst) == fz::LOSE) {
-                        nd.w = (nd.w & 0x007FFFFFu) | fz::sol_bits(fz::WIN, 0);
+                        nd.w = (nd.w & ~fz::SOL_MASK) | fz::sol_bits(fz::WIN, 0);
                         value = -cum + (nv + 1.0f);
-                    } else if (nc != 0 && all_solved) {
+                    } else if (fz::visited(nd.w) && all_solved) {
                         // worst.reversed(): Win -> Lose, Draw -> Draw, one turn later (never Lose here)
                         const uint32_t k = fz::kind(worst) == fz::WIN ? fz::LOSE : fz::DRAW;
-                        nd.w = (nd.w & 0x007FFFFFu) | fz::sol_bits(k, fz::turns(worst) + 1u);
+                        nd.w = (nd.w & ~fz::SOL_MASK) | fz::sol_bits(k, fz::turns(worst) + 1u);
                         value = k == fz::DRAW ? -cum : -cum - (nv + 1.0f);
                     } else {
                         solved = false;

@@ -79,6 +79,20 @@ def test_frozen_search_more_roots_than_lanes(engine, oracle):
     assert_frozen_equal(got, ref, "grid-stride")
 
 
+def test_frozen_search_deeper_than_the_engines_self_play_trees(engine, oracle):
+    """The baseline ladder goes far beyond self-play's explores (evaluator.rs:24-41: VanillaMCTS800 ... 204800): the call
+    re-partitions the node pool, so an engine built for 400-explore self-play runs 20,000-explore baseline searches (fewer at
+    a time). Mixed with tiny searches in the same batch."""
+    dcfg, ocfg = rollout_cfgs()
+    my, op = random_positions(oracle, 40, seed=47, max_moves=30)
+    explores = np.array([20000, 3, 7000, 0] * 10, np.int32)
+    seeds = np.arange(40, dtype=np.uint64) + np.uint64(900)
+    got = engine.frozen_search(dcfg, seeds, 11, my, op, explores)
+    ref = oracle.c4_frozen_search(ocfg, seeds, 11, my, op, explores)
+    assert_frozen_equal(got, ref, "deep baseline")
+    assert got["num_nodes"].max() > 2 * (1 + 9 * 401)   # really beyond the self-play slab
+
+
 def test_mcts_vs_mcts_replays_the_oracle(engine, oracle):
     """evaluator.rs:200-228: VanillaMCTS a vs VanillaMCTS b, one StdRng per game shared by both sides for the whole game"""
     from synthesis_amd import match
@@ -128,7 +142,7 @@ def test_frozen_search_rejects_what_the_reference_panics_on(engine):
     with pytest.raises(sa.SynthesisAmdError, match="Fpu::Const only"):
         engine.frozen_search(sa.MCTSConfig(exploration=sa.Exploration.Uct, fpu=sa.Fpu.ParentQ), 0, 0, z, z, 10)
     with pytest.raises(sa.SynthesisAmdError, match="needs up to"):
-        engine.frozen_search(dcfg, 0, 0, z, z, 100000)
+        engine.frozen_search(dcfg, 0, 0, z, z, 300000)   # beyond 21 bits of node index
     with pytest.raises(sa.SynthesisAmdError, match="searchable"):
         engine.frozen_search(dcfg, 0, 0, np.array([3], np.uint64), np.array([1], np.uint64), 10)
     got = engine.frozen_search(dcfg, 0, 0, np.zeros(0, np.uint64), np.zeros(0, np.uint64), 10)
