@@ -1,7 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.
 // AddressSanitizer / UndefinedBehaviorSanitizer run of the CPU restatement (GPU sanitizers are not available on the pool;
 // SURVEY.md §5 asks for sanitizers on the CPU build): drives the same C API the tests use — the TicTacToe solver KATs,
-// Connect4 searches (network and rollout policy), multi-threaded self-play with PolicyWithCache, training steps and
+// Connect4 searches (network and rollout policy), the evaluator's baseline tree and match loops, multi-threaded self-play with PolicyWithCache, training steps and
 // de-duplication — and exits non-zero on any sanitizer report or failed sanity check.
 //   make -C oracle sanitize   (g++ -fsanitize=address,undefined, runs the binary)
 #include <cstdio>
@@ -43,6 +43,21 @@ int main() {
         orc_c4_mcts_search_rollout(&uct, 7, my.data(), op.data(), n, 300, 1, cN.data(), cW.data(), cP.data(), csol.data(),
                                    rst.data(), rsol.data(), nn.data(), best.data(), tpi.data(), tq.data());
         CHECK(best[0] >= 0 && best[0] < 9);
+        // the evaluator's baseline tree and its two match loops
+        std::vector<uint64_t> seeds(n, 5), words(n, 3);
+        std::vector<int> ex(n, 250);
+        std::vector<float> fN(n * 9), fC(n * 9), fP(n * 9), frs(n * 2);
+        std::vector<int> fsol(n * 27), frsol(n * 3);
+        orc_c4_frozen_search(&uct, 1, blob.data(), 1, seeds.data(), words.data(), my.data(), op.data(), n, ex.data(), 1, fN.data(),
+                             fC.data(), fP.data(), fsol.data(), frs.data(), frsol.data(), nn.data(), best.data());
+        CHECK(frs[0] == 251.0f && words[0] > 3 && best[0] >= 0 && best[0] < 9);
+        uint8_t moves[63];
+        uint64_t after[63];
+        int nm = 0;
+        float r = orc_c4_mcts_vs_mcts(&uct, 1, 0, 120, 60, 9, moves, &nm, after);
+        CHECK(nm >= 7 && nm <= 63 && (r == 1.0f || r == 0.0f || r == -1.0f));
+        r = orc_c4_eval_against_rollout(&mc, 60, 1, blob.data(), 1, &uct, 1, 1, 80, 4, moves, &nm, after);
+        CHECK(nm >= 7 && nm <= 63 && (r == 1.0f || r == 0.0f || r == -1.0f));
     }
     {   // self-play: 12 games on 4 threads with PolicyWithCache, all outputs
         orc_rollout_config rc{120, 1, 30, 0, 1, 0.0f, 0.0f, 0.0f, 1, mc};
