@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.md §2 runs B1/B2: the restated reference CPU path (oracle) on this box's host cores — single thread with and
-without PolicyWithCache, then thread-per-worker on all cores. Usage: python tools/cpu_baseline.py [games_single] [threads]"""
+without PolicyWithCache, then thread-per-worker on all cores. Lives under tests/ because it runs the oracle
+(test infrastructure). Usage: python tests/cpu_baseline_runs.py [games_single] [threads]"""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 """Throughput of the evaluator's baseline on the device: VanillaMCTS<a> vs VanillaMCTS<b> matches (evaluator.rs:200-228),
-all games of a batch in lockstep, and the same matches on the CPU oracle for scale.
-usage: python tools/vanilla_bench.py [games] [explores_a] [explores_b] [oracle_games]"""
+all games of a batch in lockstep. (The same matches on the CPU oracle, for scale and a move-for-move check:
+tests/vanilla_baseline_cpu.py.)  usage: python tools/vanilla_bench.py [games] [explores_a] [explores_b] [moves_out.npy]"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ from synthesis_amd import match  # noqa: E402
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 ea = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 eb = int(sys.argv[3]) if len(sys.argv) > 3 else 200
-oracle_games = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+moves_out = sys.argv[4] if len(sys.argv) > 4 else None
 
 eng = sa.Engine(concurrent_games=games, max_explores=max(ea, eb))
 a, b = match.vanilla_player(ea), match.vanilla_player(eb)
@@ -28,15 +28,5 @@ w, d, l, s, elo = match.score(reward)
 searches = int(plies.sum())
 print(f"{games} matches VanillaMCTS{ea} vs VanillaMCTS{eb}: {dt:.2f} s wall = {games / dt:.0f} matches/s, "
       f"{searches / dt:.0f} searches/s, {rec['rng_words'].sum() / dt / 1e6:.0f} M playout moves/s; first player scores {s:.3f}")
-if oracle_games > 0:
-    from tests import oracle_lib
-
-    o = oracle_lib.load()
-    cfg = oracle_lib.parity_mcts_config(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf"))
-    t = time.time()
-    same = 0
-    for g in range(oracle_games):
-        r, moves, _ = o.c4_mcts_vs_mcts(cfg, 0, ea, eb, g)
-        same += int(np.array_equal(rec["moves"][g, :moves.size], moves) and r == reward[g])
-    dto = time.time() - t
-    print(f"oracle, 1 thread: {oracle_games / dto:.1f} matches/s; {same}/{oracle_games} matches identical move for move")
+if moves_out:
+    np.save(moves_out, np.concatenate([rec["moves"][:64], reward[:64, None].astype(np.int8).view(np.uint8)], axis=1))
