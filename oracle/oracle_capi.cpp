@@ -441,6 +441,28 @@ float orc_c4_eval_against_rollout(const orc_mcts_config* policy_cfg, int policy_
     return game.reward(first_player);
 }
 
+// evaluator.rs:129-160 eval_against_old: MCTS::exploit with network p1 for the first player, p2 for the second, from the
+// empty board. Returns game.reward(first_player).
+float orc_c4_eval_against_old(const orc_mcts_config* policy_cfg, int policy_explores, int policy_action, const float* blob1,
+                              const float* blob2, int nn_mode, uint8_t* moves, int* n_moves) {
+    MCTSConfig cfg = to_cfg(*policy_cfg);
+    Connect4Net p1, p2;
+    p1.blob = blob1; p1.mode = nn_mode;
+    p2.blob = blob2; p2.mode = nn_mode;
+    Connect4 game;
+    const int first_player = game.player_id();
+    int n = 0;
+    for (;;) {
+        MCTS<Connect4, Connect4Net> mcts((size_t)policy_explores + 1, cfg, game.player_id() == first_player ? &p1 : &p2, game);
+        mcts.explore_n((size_t)policy_explores);
+        const int action = mcts.best_action(policy_action);
+        moves[n++] = (uint8_t)action;
+        if (game.step(action)) break;
+    }
+    *n_moves = n;
+    return game.reward(first_player);
+}
+
 // ---------------------------------------------------------------- self-play (run_n_games / gather_experience)
 // Plays games [first_game, first_game + n_games) with per-game RNG seed_from_u64(base_seed + game_index), split over
 // `threads` OS threads the way gather_experience splits workers (alpha_zero.rs:132-154): each thread owns its

@@ -60,21 +60,24 @@ class Player:
     action: ActionSelection = ActionSelection.NumVisits
     rollout: bool = False          # False: the engine's network is the leaf policy; True: RolloutPolicy playouts
     frozen: bool = False           # True: the evaluator's FrozenMCTS baseline over RolloutPolicy (evaluator.rs:230-534)
+    weights: object = None         # network players: this player's own weight blob (None: whatever the engine holds) — lets
+                                   # two different checkpoints meet on one engine (eval_against_old, evaluator.rs:129-160)
 
 
 def rollout_player(explores, name=None):
-    """rollout_mcts_cfg of study-connect4/src/main.rs:74-82: Uct{c: 2}, no auto-extend, fpu = inf, ActionSelection::NumVisits"""
+    """The self-play MCTS tree over RolloutPolicy under rollout_mcts_cfg of study-connect4/src/main.rs:74-82 (Uct{c: 2}, no
+    auto-extend, fpu = inf), moves by visit count"""
     return Player(name or f"RolloutMCTS{explores}", explores,
                   MCTSConfig(exploration=Exploration.Uct, c=2.0, auto_extend=False, fpu=Fpu.Const, fpu_value=float("inf")),
                   ActionSelection.NumVisits, rollout=True)
 
 
-def vanilla_player(explores, name=None):
+def vanilla_player(explores, name=None, action=ActionSelection.Q):
     """The evaluator's baseline (evaluator.rs:184-190, 212-222) under rollout_mcts_cfg / rollout_action of
-    study-connect4/src/main.rs:74-83: FrozenMCTS, Uct{c: 2}, fpu = inf, ActionSelection::NumVisits"""
+    study-connect4/src/main.rs:72-82: FrozenMCTS, Uct{c: 2}, fpu = inf, ActionSelection::Q"""
     return Player(name or f"VanillaMCTS{explores}", explores,
                   MCTSConfig(exploration=Exploration.Uct, c=2.0, auto_extend=False, fpu=Fpu.Const, fpu_value=float("inf")),
-                  ActionSelection.NumVisits, rollout=True, frozen=True)
+                  action, rollout=True, frozen=True)
 
 
 def play_match(engine, first: Player, second: Player, n_games, seed=0, seeds=None, record=None):
@@ -89,6 +92,7 @@ def play_match(engine, first: Player, second: Player, n_games, seed=0, seeds=Non
     seeds = (np.uint64(seed) + np.arange(n_games, dtype=np.uint64)) if seeds is None else np.asarray(seeds, np.uint64)
     words = np.zeros(n_games, np.uint64)
     moves = np.full((n_games, 63), 255, np.uint8)
+    loaded = None
     for ply in range(63):
         idx = np.nonzero(alive)[0]
         if idx.size == 0:
@@ -99,6 +103,9 @@ def play_match(engine, first: Player, second: Player, n_games, seed=0, seeds=Non
                                        action_selection=int(p.action))
             words[idx] = res["rng_words"]
         else:
+            if p.weights is not None and not p.rollout and loaded is not p.weights:
+                engine.load_weights(p.weights)   # 122 KB upload; also empties the policy cache
+                loaded = p.weights
             kw = dict(rollout_seed=int(seed) + ply * n_games) if p.rollout else {}
             res = engine.mcts_search(p.mcts_cfg, my[idx], op[idx], p.explores, action_selection=int(p.action), **kw)
         moves[idx, ply] = res["best_action"]
@@ -112,6 +119,69 @@ def play_match(engine, first: Player, second: Player, n_games, seed=0, seeds=Non
         record["moves"] = moves
         record["rng_words"] = words
     return reward, plies
+
+
+def pgn_records(white_name, black_name, white_rewards):
+    """add_pgn_result (synthesis/src/utils.rs:31-52) for a batch of games: the text the evaluator appends to results.pgn,
+    which its rating tool (the external bayeselo binary, utils.rs:54-72) reads."""
+    out = []
+    for r in np.asarray(white_rewards, dtype=np.float32).ravel():
+        if r == 1.0:
+            result = "1-0"
+        elif r == -1.0:
+            result = "0-1"
+        else:
+            assert r == 0.0
+            result = "1/2-1/2"
+        out.append(f'[White "{white_name}"]\n[Black "{black_name}"]\n[Result "{result}"]\n{result}\n')
+    return "".join(out)
+
+
+@dataclass
+class EvaluationConfig:
+    """config.rs:59-73 (without `logs`); defaults = eval_cfg of study-connect4/src/main.rs:52-83 except the explore counts,
+    which the caller sets to its budget (the reference: policy 1600; baselines 800, 1600, ..., 204800)."""
+    policy_num_explores: int = 800
+    policy_action: ActionSelection = ActionSelection.NumVisits
+    policy_mcts_cfg: MCTSConfig = field(default_factory=MCTSConfig)
+    num_best_policies: int = 10
+    num_games_against_rollout: int = 5
+    rollout_action: ActionSelection = ActionSelection.Q
+    rollout_num_explores: tuple = (800, 1600, 3200)
+
+
+def evaluation_round(engine, cfg: EvaluationConfig, i_iter, model_name, model_weights, best_k):
+    """One pass of the evaluator's loop body (evaluator.rs:22-99) for model `i_iter`, every search on the device and all
+    pairings of a kind batched into one lockstep match each. Returns the PGN text the reference appends to results.pgn, in its
+    order: (1) baseline i_iter % n against every other baseline, seed i_iter (mcts_vs_mcts, :24-41); (2) the model against
+    every baseline, seeds 0..num_games_against_rollout-1, as first and as second player (:63-86); (3) the model against each
+    kept older model, both colours (eval_against_old, :89-95). `best_k`: list of (name, weights). Ratings and the choice of
+    which models to keep are the external bayeselo's job in the reference (utils.rs:54-72) and stay with the caller."""
+    pgn = []
+    ladder = list(cfg.rollout_num_explores)
+    i = i_iter % len(ladder)
+    for j in range(len(ladder)):
+        if i == j:
+            continue
+        a, b = vanilla_player(ladder[i], action=cfg.rollout_action), vanilla_player(ladder[j], action=cfg.rollout_action)
+        r, _ = play_match(engine, a, b, 1, seeds=[i_iter])
+        pgn.append(pgn_records(a.name, b.name, r))
+    me = Player(model_name, cfg.policy_num_explores, cfg.policy_mcts_cfg, cfg.policy_action, weights=model_weights)
+    seeds = np.arange(cfg.num_games_against_rollout, dtype=np.uint64)
+    for ex in ladder:
+        opp = vanilla_player(ex, action=cfg.rollout_action)
+        r1, _ = play_match(engine, me, opp, seeds.size, seeds=seeds)
+        r2, _ = play_match(engine, opp, me, seeds.size, seeds=seeds)
+        for g in range(seeds.size):  # the reference interleaves the two colours per seed
+            pgn.append(pgn_records(me.name, opp.name, r1[g:g + 1]))
+            pgn.append(pgn_records(opp.name, me.name, r2[g:g + 1]))
+    for prev_name, prev_w in best_k:
+        old = Player(prev_name, cfg.policy_num_explores, cfg.policy_mcts_cfg, cfg.policy_action, weights=prev_w)
+        r, _ = play_match(engine, me, old, 1)
+        pgn.append(pgn_records(me.name, old.name, r))
+        r, _ = play_match(engine, old, me, 1)
+        pgn.append(pgn_records(old.name, me.name, r))
+    return "".join(pgn)
 
 
 def score(rewards):

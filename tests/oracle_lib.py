@@ -277,6 +277,15 @@ class Oracle:
                                                  C.c_uint64(seed), _p(moves), C.byref(n), _p(words))
         return float(r), moves[:n.value].copy(), words[:n.value].copy()
 
+    def c4_eval_against_old(self, policy_cfg, policy_explores, blob1, blob2, policy_action=1, nn_mode=1):
+        """evaluator.rs:129-160. Returns (reward for the first player, moves)."""
+        moves = np.zeros(63, np.uint8); n = C.c_int(0)
+        b1 = np.ascontiguousarray(blob1, np.float32); b2 = np.ascontiguousarray(blob2, np.float32)
+        self.lib.orc_c4_eval_against_old.restype = C.c_float
+        r = self.lib.orc_c4_eval_against_old(C.byref(policy_cfg), policy_explores, policy_action, _p(b1), _p(b2), nn_mode,
+                                             _p(moves), C.byref(n))
+        return float(r), moves[:n.value].copy()
+
     # ---- training step / dedup (SURVEY §8f #1)
     def train_gradients(self, blob, hp, X, tpi, tv):
         blob = np.ascontiguousarray(blob, np.float32)

@@ -184,3 +184,14 @@ def test_match_host_rules_follow_the_oracle(oracle):
     assert (w, d, l) == (2, 1, 1) and abs(s - 0.625) < 1e-9 and elo > 0
     p = match.rollout_player(800)
     assert p.rollout and p.mcts_cfg.auto_extend is False and p.name == "RolloutMCTS800"
+
+
+def test_pgn_records_match_the_reference_format():
+    """utils.rs:31-52: three tag lines and the result line per game"""
+    from synthesis_amd import match
+
+    assert match.pgn_records("model_3.ot", "VanillaMCTS800", [1.0, -1.0, 0.0]) == (
+        '[White "model_3.ot"]\n[Black "VanillaMCTS800"]\n[Result "1-0"]\n1-0\n'
+        '[White "model_3.ot"]\n[Black "VanillaMCTS800"]\n[Result "0-1"]\n0-1\n'
+        '[White "model_3.ot"]\n[Black "VanillaMCTS800"]\n[Result "1/2-1/2"]\n1/2-1/2\n')
+    assert match.vanilla_player(800).action == 0 and match.vanilla_player(800).name == "VanillaMCTS800"   # rollout_action: Q

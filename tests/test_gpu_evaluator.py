@@ -99,16 +99,16 @@ def test_mcts_vs_mcts_replays_the_oracle(engine, oracle):
 
     dcfg, ocfg = rollout_cfgs()
     n = 40
-    for first_explores, second_explores in ((200, 100), (50, 400)):
+    for first_explores, second_explores, sel in ((200, 100, 0), (50, 400, 1)):
         rec = {}
-        reward, plies = match.play_match(engine, match.vanilla_player(first_explores), match.vanilla_player(second_explores), n,
+        reward, plies = match.play_match(engine, match.vanilla_player(first_explores, action=sel), match.vanilla_player(second_explores, action=sel), n,
                                          seed=100, record=rec)
         for g in range(n):
-            r, moves, words = oracle.c4_mcts_vs_mcts(ocfg, 0, first_explores, second_explores, 100 + g)
+            r, moves, words = oracle.c4_mcts_vs_mcts(ocfg, 0, first_explores, second_explores, 100 + g, rollout_action=sel)
             assert plies[g] == moves.size and np.array_equal(rec["moves"][g, :moves.size], moves), f"game {g}"
             assert reward[g] == r and rec["rng_words"][g] == words[-1]
         # the same match with the roles swapped (player = second mover, evaluator.rs:38-39)
-        r, moves, _ = oracle.c4_mcts_vs_mcts(ocfg, 1, second_explores, first_explores, 100)
+        r, moves, _ = oracle.c4_mcts_vs_mcts(ocfg, 1, second_explores, first_explores, 100, rollout_action=sel)
         assert np.array_equal(rec["moves"][0, :moves.size], moves) and reward[0] == r
 
 
@@ -123,11 +123,13 @@ def test_eval_against_rollout_replays_the_oracle(engine, oracle, blob):
     n = 24
     for net_moves_first in (True, False):
         rec = {}
-        a, b = (net, match.vanilla_player(150)) if net_moves_first else (match.vanilla_player(150), net)
+        sel = 0 if net_moves_first else 1   # rollout_action: Q (the reference's choice) and NumVisits
+        van = match.vanilla_player(150, action=sel)
+        a, b = (net, van) if net_moves_first else (van, net)
         reward, plies = match.play_match(engine, a, b, n, seed=7, record=rec)
         for g in range(n):
             r, moves, words = oracle.c4_eval_against_rollout(parity_mcts_config(), 100, blob, ocfg, 0 if net_moves_first else 1,
-                                                             150, 7 + g, nn_mode=oracle.ACC_FMA)
+                                                             150, 7 + g, rollout_action=sel, nn_mode=oracle.ACC_FMA)
             assert plies[g] == moves.size and np.array_equal(rec["moves"][g, :moves.size], moves), f"game {g}"
             assert reward[g] == r and rec["rng_words"][g] == words[-1]
 
@@ -147,3 +149,36 @@ def test_frozen_search_rejects_what_the_reference_panics_on(engine):
         engine.frozen_search(dcfg, 0, 0, np.array([3], np.uint64), np.array([1], np.uint64), 10)
     got = engine.frozen_search(dcfg, 0, 0, np.zeros(0, np.uint64), np.zeros(0, np.uint64), 10)
     assert got["best_action"].shape == (0,)
+
+
+def test_evaluation_round_follows_the_reference_schedule(engine, oracle, blob):
+    """evaluator.rs:22-99 for one model: the PGN text (pairings, colours, order, results) equals the one assembled from the
+    oracle's three match loops; the older model is a second, different network on the same engine."""
+    from synthesis_amd import match
+    from tests.oracle_lib import parity_mcts_config
+    import synthesis_amd as sa
+
+    old_w = np.random.RandomState(3).normal(0, 0.2, blob.size).astype(np.float32)
+    cfg = match.EvaluationConfig(policy_num_explores=80, policy_mcts_cfg=sa.parity_mcts_config(), num_games_against_rollout=2,
+                                 rollout_num_explores=(60, 120, 240))
+    got = match.evaluation_round(engine, cfg, 4, "model_4.ot", blob, [("model_1.ot", old_w)])
+    _, ocfg = rollout_cfgs()
+    pcfg = parity_mcts_config()
+    want = []
+    i = 4 % 3
+    for j in range(3):
+        if j != i:
+            r, _, _ = oracle.c4_mcts_vs_mcts(ocfg, 0, cfg.rollout_num_explores[i], cfg.rollout_num_explores[j], 4, rollout_action=0)
+            want.append(match.pgn_records(f"VanillaMCTS{cfg.rollout_num_explores[i]}", f"VanillaMCTS{cfg.rollout_num_explores[j]}", [r]))
+    for ex in cfg.rollout_num_explores:
+        for sd in range(2):
+            r, _, _ = oracle.c4_eval_against_rollout(pcfg, 80, blob, ocfg, 0, ex, sd, rollout_action=0, nn_mode=oracle.ACC_FMA)
+            want.append(match.pgn_records("model_4.ot", f"VanillaMCTS{ex}", [r]))
+            r, _, _ = oracle.c4_eval_against_rollout(pcfg, 80, blob, ocfg, 1, ex, sd, rollout_action=0, nn_mode=oracle.ACC_FMA)
+            want.append(match.pgn_records(f"VanillaMCTS{ex}", "model_4.ot", [r]))
+    r, _ = oracle.c4_eval_against_old(pcfg, 80, blob, old_w, nn_mode=oracle.ACC_FMA)
+    want.append(match.pgn_records("model_4.ot", "model_1.ot", [r]))
+    r, _ = oracle.c4_eval_against_old(pcfg, 80, old_w, blob, nn_mode=oracle.ACC_FMA)
+    want.append(match.pgn_records("model_1.ot", "model_4.ot", [r]))
+    assert got == "".join(want)
+    engine.load_weights(blob)   # leave the shared engine as the other tests expect it
