@@ -13,8 +13,8 @@
 //                                                    keep_last_n_games, deduplicate, the counters)
 //   synthesis::run_n_games                           synthesis/src/alpha_zero.rs:181-209
 //   synthesis::vanilla_mcts_search                   MCTS over RolloutPolicy (policies/rollout.rs:8-31; mcts.rs:691-868)
-//   synthesis::frozen_mcts_exploit / mcts_vs_mcts /  the evaluator's baseline and its two match loops,
-//     eval_against_rollout_mcts                      synthesis/src/evaluator.rs:163-228, 308-319 (FrozenMCTS over RolloutPolicy)
+//   synthesis::frozen_mcts_exploit / mcts_vs_mcts /  the evaluator's baseline and its three match loops,
+//     eval_against_rollout_mcts / eval_against_old   synthesis/src/evaluator.rs:129-228, 308-319 (FrozenMCTS over RolloutPolicy)
 //   synthesis::Learner                               the optimiser half of alpha_zero.rs:28-36,72-94
 // Errors: the reference panics (unwrap / assert!) on this path; here every failed C-ABI call throws synthesis::Error
 // carrying the status code and syn_last_error's text. Nothing is computed on the host: without the library or without
@@ -446,6 +446,20 @@ inline std::vector<float> rollout_matches(Engine& e, const MCTSConfig& rollout_c
     return reward;
 }
 }  // namespace detail
+
+// evaluator.rs:129-160 eval_against_old: MCTS::exploit with network `p1` for the first player and `p2` for the second, from the
+// empty board (no randomness: one game per pairing). The two checkpoints take turns on the one engine (122 KB per switch).
+inline float eval_against_old(Engine& e, const MCTSConfig& policy_cfg, int policy_explores, ActionSelection policy_action,
+                              const std::vector<float>& p1, const std::vector<float>& p2) {
+    Connect4 game;
+    const Connect4::PlayerId first_player = game.player();
+    for (;;) {
+        e.load_weights(game.player() == first_player ? p1 : p2);
+        const int action = mcts_search(e, policy_cfg, {game}, policy_explores, policy_action)[0].best_action;
+        if (game.step(action)) break;
+    }
+    return game.reward(first_player);
+}
 
 inline std::vector<float> mcts_vs_mcts(Engine& e, const MCTSConfig& rollout_cfg, ActionSelection rollout_action,
                                        Connect4::PlayerId player, int p1_explores, int p2_explores,

@@ -82,6 +82,15 @@ int main(int argc, char** argv) {
                                                 ActionSelection::NumVisits, Connect4::Black, 40, {5, 6, 7});
         put("versus_rewards", versus.data(), (int)versus.size());
 
+        {   // eval_against_old: this network against a copy with the first layer's first 200 weights negated, both colours
+            std::vector<float> other = blob;
+            for (int i = 0; i < 200; i++) other[i] = -other[i];
+            const float r[2] = {eval_against_old(engine, MCTSConfig(), 40, ActionSelection::NumVisits, blob, other),
+                                eval_against_old(engine, MCTSConfig(), 40, ActionSelection::NumVisits, other, blob)};
+            put("old_rewards", r, 2);
+            engine.load_weights(blob);
+        }
+
         // one learner step on the first 32 unique states, then self-play continues on the trained network
         Learner learner(engine, blob, 1e-6f, 1.0f, 1.0f);
         std::vector<Connect4> bg(flat.games.begin(), flat.games.begin() + 32);

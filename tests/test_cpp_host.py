@@ -99,6 +99,11 @@ def test_cpp_host_matches_oracle(harness, oracle, golden_dir):
     want = [oracle.c4_eval_against_rollout(parity_mcts_config(), 48, blob, rcfg, 1, 40, sd, nn_mode=oracle.ACC_FMA)[0] for sd in (5, 6, 7)]
     assert list(f32s(by["versus_rewards"][0])) == want
 
+    other = blob.copy(); other[:200] = -other[:200]
+    want = [oracle.c4_eval_against_old(parity_mcts_config(), 40, blob, other, nn_mode=oracle.ACC_FMA)[0],
+            oracle.c4_eval_against_old(parity_mcts_config(), 40, other, blob, nn_mode=oracle.ACC_FMA)[0]]
+    assert list(f32s(by["old_rewards"][0])) == want
+
     # one learner step on the first 32 unique states, published to the self-play network
     from tests.oracle_lib import default_train_hyper
 
