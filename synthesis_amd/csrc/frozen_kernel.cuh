@@ -63,11 +63,12 @@ SYN_DEV bool unvisited(uint32_t w) { return !visited(w) && !some(w); }
 // game.rs:46-60 as one integer key: Lose(t) ascending < Draw(t) ascending < Win(t) descending
 SYN_DEV uint32_t order_key(uint32_t w) { return (kind(w) << 8) | (kind(w) == WIN ? 255u - turns(w) : turns(w)); }
 SYN_DEV float value_of_kind(uint32_t k) { return k == WIN ? 1.0f : (k == DRAW ? 0.0f : -1.0f); }  // game.rs:37-43
+// free columns: stones stack without holes, so a column is free exactly when its top cell (row 6) is empty
 SYN_DEV uint32_t legal_mask(uint64_t occ) {
+    const uint64_t free_cells = ~occ;
     uint32_t m = 0;
 #pragma unroll
-    for (int c = 0; c < 9; c++)
-        if (c4::col_height(occ, c) < c4::HEIGHT) m |= 1u << c;
+    for (int c = 0; c < 9; c++) m |= ((uint32_t)(free_cells >> (6 + 7 * c)) & 1u) << c;
     return m;
 }
 SYN_DEV int nth_set(uint32_t m, uint32_t n) {
@@ -166,9 +167,9 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
                     // ---- visit (evaluator.rs:439-483): playout first, then one child per legal column
                     value = frozen_playout(my, op, rng);
                     if (next_node + nc > node_cap) { overflow = true; break; }
-                    // stable softmax of the (all-zero) rollout logits over the legal actions
-                    float max_logit = -INFINITY;
-                    for (uint32_t j = 0; j < nc; j++) max_logit = fmaxf(max_logit, 0.0f);
+                    // stable softmax over the legal actions (evaluator.rs:468-477); RolloutPolicy's logits are all zero, so
+                    // their maximum is zero too — the exp / sum / divide sequence is kept as the reference performs it
+                    const float max_logit = 0.0f;
                     float e[9], tot = 0.0f;
 #pragma unroll
                     for (int j = 0; j < 9; j++) e[j] = 0.0f;
