@@ -77,24 +77,34 @@ SYN_DEV int nth_set(uint32_t m, uint32_t n) {
 }
 }  // namespace fz
 
-// The lane's view of its root's StdRng: the key, the stream position, and the 16-word output block the position lies in,
-// parked in LDS ([word][lane], conflict-free) so that a playout of ~25 moves costs two or three ChaCha12 blocks, not 25.
+// The lane's view of its root's StdRng: the key, the stream position, and a ring of four 16-word ChaCha12 output blocks in
+// LDS ([slot][word][lane], conflict-free). Blocks are generated AHEAD, at the start of a playout, for all lanes of the wave
+// together (prefetch): a block function is ~800 instructions, and generated on demand inside the playout loop it would run
+// in almost every iteration for the few lanes that happen to cross a block boundary there.
 struct FrozenRng {
     StdRng base;
     uint32_t index;      // next output word
-    uint32_t cached;     // block number held in LDS (0xFFFFFFFF = none)
-    uint32_t* lds;       // this lane's column: word k at lds[k * 64]
+    uint32_t hi;         // blocks [hi - 4, hi) that were generated since `start` are in the ring (slot = block & 3)
+    uint32_t* lds;       // this lane's column: word k of slot s at lds[(s * 16 + k) * 64]
 
+    SYN_DEV void start(uint32_t first_word) { index = first_word; hi = first_word >> 4; }
+    SYN_DEV void generate_next() {
+        uint32_t out[16];
+        base.block16(hi, out);
+        uint32_t* slot = lds + (hi & 3u) * 16u * 64u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) slot[k * 64] = out[k];
+        hi++;
+    }
+    // at a point where the wave is converged: make the next 33+ words available (three blocks from the current one)
+    SYN_DEV void prefetch() {
+        const uint32_t want = (index >> 4) + 3u;
+        while (hi < want) generate_next();
+    }
     SYN_DEV uint32_t next_u32() {
         const uint32_t blk = index >> 4;
-        if (blk != cached) {
-            uint32_t out[16];
-            base.block16(blk, out);
-#pragma unroll
-            for (int k = 0; k < 16; k++) lds[k * 64] = out[k];
-            cached = blk;
-        }
-        return lds[(index++ & 15u) * 64];
+        while (blk >= hi) generate_next();  // only a playout that outruns the prefetched window gets here
+        return lds[((blk & 3u) * 16u + (index++ & 15u)) * 64u];
     }
     // Rng::gen_range(0..n) for u8 (rand 0.8.3 UniformInt<u8>::sample_single), as StdRng::gen_range_u8
     SYN_DEV uint32_t gen_range_u8(uint32_t n) {
@@ -111,6 +121,7 @@ struct FrozenRng {
 // policies/rollout.rs:8-31 on the root's stream: uniformly random legal moves to the end; returns dist[2] - dist[0] of the
 // one-hot outcome for the player to move at the leaf
 SYN_DEV float frozen_playout(uint64_t my, uint64_t op, FrozenRng& rng) {
+    rng.prefetch();
     bool leaf_player_moves = true;
     for (;;) {
         const uint64_t occ = my | op;
@@ -129,7 +140,7 @@ SYN_DEV float frozen_playout(uint64_t my, uint64_t op, FrozenRng& rng) {
 
 // One wave per workgroup: the waves of a small batch spread over all CUs instead of filling a quarter of them.
 __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
-    __shared__ uint32_t rng_blocks[16 * 64];
+    __shared__ uint32_t rng_blocks[4 * 16 * 64];
     const int lane = threadIdx.x;
     const size_t gwave = blockIdx.x;
     const size_t glane = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -142,8 +153,7 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
         const uint64_t root_my = P.in_my[root], root_op = P.in_op[root];
         FrozenRng rng;
         rng.base.seed_from_u64(P.seeds[root]);
-        rng.index = (uint32_t)P.rng_words[root];
-        rng.cached = 0xFFFFFFFFu;
+        rng.start((uint32_t)P.rng_words[root]);
         rng.lds = rng_blocks + threadIdx.x;
         uint32_t next_node = 1;
         bool overflow = false;
@@ -152,48 +162,21 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
 
         for (int it = 0; it < total && !overflow; it++) {
             // ---- explore (evaluator.rs:391-406): descend to a solved or unvisited node
-            uint32_t id = 0, level = 0;
-            uint64_t my = root_my, op = root_op;
-            float value;
-            bool solved;
+            // The descent only FINDS the node; its visit (playout + children) runs after the loop, once for the whole wave —
+            // inside the loop the playout would be replayed for every distinct leaf depth among the 64 lanes.
+            uint32_t id = 0, level = 0, lmask, nc;
+            uint64_t my = root_my, op = root_op, occ;
+            uint4 nd;
+            float value = 0.0f;
+            bool solved = false, visit;
             for (;;) {
-                const uint64_t occ = my | op;
-                const uint32_t lmask = fz::legal_mask(occ);
-                const uint32_t nc = (uint32_t)__popc(lmask);
+                occ = my | op;
+                lmask = fz::legal_mask(occ);
+                nc = (uint32_t)__popc(lmask);
                 path[level * 64] = id | (nc << 21);
-                const uint4 nd = pool[id];
-                if (fz::some(nd.w)) { value = fz::value_of_kind(fz::kind(nd.w)); solved = true; break; }
-                if (!fz::visited(nd.w)) {
-                    // ---- visit (evaluator.rs:439-483): playout first, then one child per legal column
-                    value = frozen_playout(my, op, rng);
-                    if (next_node + nc > node_cap) { overflow = true; break; }
-                    // stable softmax over the legal actions (evaluator.rs:468-477); RolloutPolicy's logits are all zero, so
-                    // their maximum is zero too — the exp / sum / divide sequence is kept as the reference performs it
-                    const float max_logit = 0.0f;
-                    float e[9], tot = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) e[j] = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 9; j++)
-                        if ((uint32_t)j < nc) { e[j] = det_expf(0.0f - max_logit); tot += e[j]; }
-                    solved = false;
-                    uint32_t m = lmask;
-#pragma unroll
-                    for (int j = 0; j < 9; j++) {
-                        if ((uint32_t)j < nc) {
-                            const int col = __ffs((int)m) - 1;
-                            m &= m - 1u;
-                            const uint64_t bit = 1ull << (c4::col_height(occ, col) + 7 * col);
-                            uint32_t w = 0;
-                            if (c4::won(my | bit)) { w = fz::sol_bits(fz::LOSE, 0); solved = true; }       // reward(child.player()) = -1
-                            else if ((occ | bit) == c4::FULL) { w = fz::sol_bits(fz::DRAW, 0); solved = true; }
-                            pool[next_node + j] = make_uint4(0u, 0u, f32_bits(e[j] / tot), w);
-                        }
-                    }
-                    pool[id] = make_uint4(nd.x, nd.y, nd.z, (nd.w & fz::SOL_MASK) | next_node | fz::VISITED);
-                    next_node += nc;
-                    break;
-                }
+                nd = pool[id];
+                if (fz::some(nd.w)) { value = fz::value_of_kind(fz::kind(nd.w)); solved = true; visit = false; break; }
+                if (!fz::visited(nd.w)) { visit = true; break; }
                 // ---- select_best_child (evaluator.rs:408-437)
                 const uint32_t fc = fz::first_child(nd.w);
                 const float visits = sqrtf(P.c * det_logf(bits_f32(nd.y)));
@@ -217,6 +200,35 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
                 op = mover;
                 id = fc + best;
                 level++;
+            }
+            if (visit) {
+                // ---- visit (evaluator.rs:439-483): playout first, then one child per legal column
+                value = frozen_playout(my, op, rng);
+                if (next_node + nc > node_cap) { overflow = true; break; }
+                // stable softmax over the legal actions (evaluator.rs:468-477); RolloutPolicy's logits are all zero, so
+                // their maximum is zero too — the exp / sum / divide sequence is kept as the reference performs it
+                const float max_logit = 0.0f;
+                float e[9], tot = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 9; j++) e[j] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 9; j++)
+                    if ((uint32_t)j < nc) { e[j] = det_expf(0.0f - max_logit); tot += e[j]; }
+                uint32_t m = lmask;
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    if ((uint32_t)j < nc) {
+                        const int col = __ffs((int)m) - 1;
+                        m &= m - 1u;
+                        const uint64_t bit = 1ull << (c4::col_height(occ, col) + 7 * col);
+                        uint32_t w = 0;
+                        if (c4::won(my | bit)) { w = fz::sol_bits(fz::LOSE, 0); solved = true; }       // reward(child.player()) = -1
+                        else if ((occ | bit) == c4::FULL) { w = fz::sol_bits(fz::DRAW, 0); solved = true; }
+                        pool[next_node + j] = make_uint4(0u, 0u, f32_bits(e[j] / tot), w);
+                    }
+                }
+                pool[id] = make_uint4(nd.x, nd.y, nd.z, (nd.w & fz::SOL_MASK) | next_node | fz::VISITED);
+                next_node += nc;
             }
             if (overflow) break;
 
