@@ -93,6 +93,19 @@ def test_frozen_search_deeper_than_the_engines_self_play_trees(engine, oracle):
     assert got["num_nodes"].max() > 2 * (1 + 9 * 401)   # really beyond the self-play slab
 
 
+def test_frozen_search_at_the_top_of_the_reference_ladder(engine, oracle):
+    """VanillaMCTS204800 (main.rs:71), the deepest baseline the reference evaluates against: 1.8 M node records per tree (21-bit
+    ids), millions of stream words per search, on the same small engine."""
+    dcfg, ocfg = rollout_cfgs()
+    my, op = random_positions(oracle, 6, seed=53, max_moves=12)
+    explores = np.array([204800, 51200, 9, 204800, 0, 102400], np.int32)
+    seeds = np.arange(6, dtype=np.uint64) + np.uint64(31)
+    got = engine.frozen_search(dcfg, seeds, 5, my, op, explores, action_selection=0)
+    ref = oracle.c4_frozen_search(ocfg, seeds, 5, my, op, explores, action_selection=0)
+    assert_frozen_equal(got, ref, "ladder top")
+    assert got["root_stat"][0, 0] == 204801.0 and got["rng_words"].max() > 2_000_000
+
+
 def test_mcts_vs_mcts_replays_the_oracle(engine, oracle):
     """evaluator.rs:200-228: VanillaMCTS a vs VanillaMCTS b, one StdRng per game shared by both sides for the whole game"""
     from synthesis_amd import match
