@@ -437,17 +437,24 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint
     if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
     if (n == 0) return SYN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    constexpr int NT = 512;  // two waves per SIMD: one wave's LDS reads / feature math overlap the other's MFMAs
+    // Two waves per SIMD (512 threads): one wave's LDS reads / feature math overlap the other's MFMAs. Large batches (every
+    // wave gets several tiles) run three waves per SIMD, which also hides the loads and stores around the tiles.
     const size_t lds = (size_t)MlpGeom::IMG_FLOATS * 4;
-    auto k = policy_eval_kernel<NT>;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int ntiles = (n + 15) / 16;
-    int grid = (ntiles + NT / 64 - 1) / (NT / 64);
-    if (grid > h->num_cus) grid = h->num_cus;
+    const int ntiles = (n + 15) / 16;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, h->stream, h->d_wimg,
-                       reinterpret_cast<const unsigned long long*>(d_my),
-                       reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);
+#define SYN_LAUNCH_EVAL(NT)                                                                                          \
+    {                                                                                                                \
+        auto k = policy_eval_kernel<NT>;                                                                             \
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds));                                                                   \
+        int grid = (ntiles + NT / 64 - 1) / (NT / 64);                                                               \
+        if (grid > h->num_cus) grid = h->num_cus;                                                                    \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, h->stream, h->d_wimg,                                       \
+                           reinterpret_cast<const unsigned long long*>(d_my),                                        \
+                           reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                 \
+    }
+    if (ntiles >= h->num_cus * 12 * 4) SYN_LAUNCH_EVAL(768) else SYN_LAUNCH_EVAL(512)
+#undef SYN_LAUNCH_EVAL
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->last_launches = 1;

@@ -768,15 +768,17 @@ __global__ __launch_bounds__(NT) void policy_eval_kernel(const float* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     stage_weight_image(smem, g_wimg, tid, NT);
     __syncthreads();
-    const float* wimg = smem;
-    const float* bimg = smem + MlpGeom::W_FLOATS;
     const int ntiles = (n + 15) >> 4;
     const int j = lane & 15, q = lane >> 4;
     const FeatureTable FT = make_feature_table(q);
     for (int tile = blockIdx.x * (NT / 64) + wave; tile < ntiles; tile += gridDim.x * (NT / 64)) {
-        // the weight fragments do not depend on the tile: make the LDS base opaque per iteration so their ~500 reads
-        // stay next to the MFMAs that consume them instead of being hoisted out of the loop into spilled registers
-        asm volatile("" : "+v"(wimg), "+v"(bimg));
+        // the weight fragments do not depend on the tile: make their LDS OFFSET opaque per iteration so the ~120 reads stay
+        // next to the MFMAs that consume them instead of being hoisted out of the loop into spilled registers. (An opaque
+        // POINTER would also lose its address space: the reads then become flat_load and wait on vmcnt and lgkmcnt.)
+        uint32_t img_off = 0;
+        asm volatile("" : "+v"(img_off));
+        const float* wimg = smem + img_off;
+        const float* bimg = wimg + MlpGeom::W_FLOATS;
         int pos = tile * 16 + j;
         bool valid = pos < n;
         uint64_t my = valid ? my_bb[pos] : 0ull, op = valid ? op_bb[pos] : 0ull;
