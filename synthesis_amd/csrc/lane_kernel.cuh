@@ -853,11 +853,33 @@ SYN_DEV void cache_insert(uint4* table, uint32_t shift, uint64_t my, uint64_t op
 // policies/rollout.rs:8-31: uniformly random legal moves until the game ends; logits all zero, value = one-hot outcome for
 // the player to move at the leaf. Random numbers: Rng::gen_range(0..n as u8) on the tree's own StdRng stream, word
 // `rng_index` onwards (every rollout of a tree continues where the previous one stopped).
-SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, uint32_t& rng_index, float& v0, float& v1,
-                          float& v2) {
+// A ring of three 16-word ChaCha12 output blocks per lane in LDS ([slot][word][lane]); the blocks a playout is going to use
+// are generated before its loop, when the wave is converged (see frozen_kernel.cuh: generated on demand inside the loop, the
+// block function would run in almost every iteration for the few lanes crossing a block boundary there).
+struct RolloutRing {
+    uint32_t* lds;   // this lane's column: word k of slot s at lds[(s * 16 + k) * 64]
+    uint32_t hi;     // blocks [hi - 3, hi) generated for `job` are in the ring (slot = block % 3)
+    int job;
+};
+
+SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, int job, uint32_t& rng_index, RolloutRing& ring,
+                          float& v0, float& v1, float& v2) {
     StdRng rng;
     rng.seed_from_u64(seed);
-    rng.index = rng_index;
+    uint32_t index = rng_index;
+    if (ring.job != job) { ring.job = job; ring.hi = index >> 4; }  // another tree's stream: nothing of it is cached
+    auto generate_next = [&]() {
+        uint32_t out[16];
+        rng.block16(ring.hi, out);
+        uint32_t* slot = ring.lds + (ring.hi % 3u) * 16u * 64u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) slot[k * 64] = out[k];
+        ring.hi++;
+    };
+    {
+        const uint32_t want = (index >> 4) + 3u;
+        while (ring.hi < want) generate_next();
+    }
     bool leaf_player_moves = true;  // `my` is the side to move; the leaf itself is never terminal
     for (;;) {
         const uint64_t occ = my | op;
@@ -866,7 +888,16 @@ SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, uin
         for (int c = 0; c < 9; c++)
             if (c4::col_height(occ, c) < c4::HEIGHT) lmask |= 1u << c;
         const uint32_t n = (uint32_t)__popc(lmask);
-        const uint32_t pick = rng.gen_range_u8(n);
+        // Rng::gen_range(0..n as u8), rand 0.8.3 UniformInt<u8>::sample_single (as StdRng::gen_range_u8)
+        const uint32_t zone = 0xFFFFFFFFu - (0xFFFFFFFFu - n + 1u) % n;
+        uint32_t pick;
+        for (;;) {
+            const uint32_t blk = index >> 4;
+            while (blk >= ring.hi) generate_next();  // only a playout that outruns the prefetched window
+            const uint32_t v = ring.lds[((blk % 3u) * 16u + (index++ & 15u)) * 64u];
+            const uint64_t m = (uint64_t)v * (uint64_t)n;
+            if ((uint32_t)m <= zone) { pick = (uint32_t)(m >> 32); break; }
+        }
         uint32_t m = lmask;
         for (uint32_t i = 0; i < pick; i++) m &= m - 1u;  // iter_actions().nth(pick)
         const int col = __ffs((int)m) - 1;
@@ -886,7 +917,7 @@ SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, uin
         op = mover;
         leaf_player_moves = !leaf_player_moves;
     }
-    rng_index = rng.index;
+    rng_index = index;
 }
 
 // ---------------------------------------------------------------------------------------------- the kernel
@@ -917,7 +948,13 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     const int wave = tid >> 6;
     float* outw = reinterpret_cast<float*>(smem_raw + LaneLds<NW>::OUT_OFF) + wave * 256;
 
-    stage_weight_image(wimg, P.wimg, tid, NT);
+    if (POLICY == 0) stage_weight_image(wimg, P.wimg, tid, NT);
+    // RolloutPolicy needs no weights: the image's LDS holds the waves' ChaCha12 block rings instead (12 KB per wave)
+    RolloutRing ring;
+    ring.lds = reinterpret_cast<uint32_t*>(smem_raw) + (size_t)wave * (3 * 16 * 64) + lane;
+    ring.hi = 0;
+    ring.job = -1;
+    static_assert(POLICY == 0 || (size_t)NW * 3 * 16 * 64 * 4 <= (size_t)MlpGeom::IMG_FLOATS * 4, "rings must fit the image region");
     if (tid < 4) {
         const FeatureTable f = make_feature_table(tid);
         *reinterpret_cast<uint4*>(smem_raw + LaneLds<NW>::FT_OFF + tid * 16) = make_uint4(f.t[0], f.t[1], f.t[2], f.t[3]);
@@ -988,7 +1025,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         bool hit = false;
         if (POLICY == 1) {
             // RolloutPolicy: the "evaluation" is a random playout on this lane (no tiles, nothing deferred)
-            if (want_nn) lane_rollout(Wk.my, Wk.op, P.base_seed + (unsigned long long)T.job, T.rng_index, v0, v1, v2);
+            if (want_nn) lane_rollout(Wk.my, Wk.op, P.base_seed + (unsigned long long)T.job, T.job, T.rng_index, ring, v0, v1, v2);
             hit = want_nn;
         } else if (P.cache != nullptr && want_nn && !X.was_pending) {
             hit = cache_lookup(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
