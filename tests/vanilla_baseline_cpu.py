@@ -21,7 +21,7 @@ cfg = oracle_lib.parity_mcts_config(exploration=0, c=2.0, auto_extend=0, fpu_val
 t = time.time()
 same = 0
 for g in range(n):
-    r, moves, _ = o.c4_mcts_vs_mcts(cfg, 0, ea, eb, g)
+    r, moves, _ = o.c4_mcts_vs_mcts(cfg, 0, ea, eb, g, rollout_action=0)  # rollout_action: Q (main.rs:72), as vanilla_player
     if dev is not None and g < dev.shape[0]:
         same += int(np.array_equal(dev[g, :moves.size], moves) and np.int8(r) == dev[g, 63].view(np.int8))
 dt = time.time() - t
