@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
             // inside the loop the playout would be replayed for every distinct leaf depth among the 64 lanes.
             uint32_t id = 0, level = 0, lmask, nc;
             uint64_t my = root_my, op = root_op, occ;
-            uint4 nd;
+            uint4 nd = pool[0];  // below the root a node's record arrives with its parent's child scan: one round trip per level
             float value = 0.0f;
             bool solved = false, visit;
             for (;;) {
@@ -174,7 +174,6 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
                 lmask = fz::legal_mask(occ);
                 nc = (uint32_t)__popc(lmask);
                 path[level * 64] = id | (nc << 21);
-                nd = pool[id];
                 if (fz::some(nd.w)) { value = fz::value_of_kind(fz::kind(nd.w)); solved = true; visit = false; break; }
                 if (!fz::visited(nd.w)) { visit = true; break; }
                 // ---- select_best_child (evaluator.rs:408-437)
@@ -182,23 +181,33 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
                 const float visits = sqrtf(P.c * det_logf(bits_f32(nd.y)));
                 uint32_t best = 0;
                 float best_value = -INFINITY;
-                for (uint32_t j = 0; j < nc; j++) {
-                    const uint4 ch = pool[fc + j];
+                uint4 best_rec = make_uint4(0u, 0u, 0u, 0u);
+                // all nine child records in one batch of independent loads (unconditional: indices past the last child are
+                // clamped onto it), then the scan — loaded inside the scan loop they are nine dependent round trips
+                uint4 chs[9];
+#pragma unroll
+                for (int j = 0; j < 9; j++) chs[j] = pool[fc + ((uint32_t)j < nc ? (uint32_t)j : nc - 1u)];
+#pragma unroll
+                for (int j = 0; j < 9; j++) {
+                    const uint4 ch = chs[j];
                     float v;
-                    if (fz::unvisited(ch.w)) {
+                    if ((uint32_t)j >= nc) {
+                        v = -INFINITY;   // not a child: never selected (j == 0 is always one)
+                    } else if (fz::unvisited(ch.w)) {
                         v = P.fpu_value + bits_f32(ch.z);
                     } else {
                         // a solved child counts from the parent's side: outcome.reversed().value()
                         const float q = fz::some(ch.w) ? -fz::value_of_kind(fz::kind(ch.w)) : -bits_f32(ch.x) / bits_f32(ch.y);
                         v = q + visits / sqrtf(bits_f32(ch.y));
                     }
-                    if (j == 0 || v > best_value) { best = j; best_value = v; }
+                    if (j == 0 || ((uint32_t)j < nc && v > best_value)) { best = (uint32_t)j; best_value = v; best_rec = ch; }
                 }
                 const int col = fz::nth_set(lmask, best);
                 const uint64_t mover = my | (1ull << (c4::col_height(occ, col) + 7 * col));
                 my = op;
                 op = mover;
                 id = fc + best;
+                nd = best_rec;
                 level++;
             }
             if (visit) {
@@ -233,10 +242,21 @@ __global__ __launch_bounds__(64) void frozen_rollout_kernel(FrozenParams P) {
             if (overflow) break;
 
             // ---- backprop (evaluator.rs:485-527) along the recorded path
+            // Loads run ahead of the level being processed (a level never modifies its ancestors' records): the path entry two
+            // levels up and the node record one level up are requested before this level's work, so a level costs its own
+            // arithmetic and store instead of two dependent round trips. The leaf's record is still in `nd` from the descent.
+            uint32_t pe_cur = path[level * 64];
+            uint32_t pe_up = path[(level >= 1u ? level - 1u : 0u) * 64];
+            uint4 nd_cur = visit ? make_uint4(nd.x, nd.y, nd.z, (nd.w & fz::SOL_MASK) | (next_node - nc) | fz::VISITED) : nd;
             for (int l = (int)level; l >= 0; l--) {
-                const uint32_t pe = path[l * 64];
+                const uint32_t pe_up2 = path[(l >= 2 ? l - 2 : 0) * 64];
+                const uint4 nd_up = pool[l >= 1 ? (pe_up & fz::ID_MASK) : 0u];
+                const uint32_t pe = pe_cur;
                 const uint32_t nid = pe & fz::ID_MASK, nc = pe >> 21;
-                uint4 nd = pool[nid];
+                uint4 nd = nd_cur;
+                pe_cur = pe_up;
+                pe_up = pe_up2;
+                nd_cur = nd_up;
                 if (P.solve && solved && !fz::some(nd.w)) {
                     bool all_solved = true, have_worst = false;
                     uint32_t worst = 0;
