@@ -92,3 +92,27 @@ def test_network_policy_variant_uses_legal_softmax(oracle, golden_dir):
     r = oracle.c4_frozen_search(cfg(fpu_value=1.0), 0, 0, my, op, 30, blob=blob)
     assert r["child_P"][0, 4] == 0.0 and abs(r["child_P"][0].sum() - 1.0) < 1e-6 and r["child_N"][0, 4] == 0.0
     assert r["root_stat"][0, 0] == 31.0 and r["rng_words"][0] == 0
+
+
+def test_cpp_oracle_equals_the_independent_python_restatement(oracle):
+    """tests/frozen_py.py restates evaluator.rs:230-534 + rollout.rs a second time (objects and Python ints instead of flat
+    arrays and bitboard tricks). Both restatements must build bit-identical trees: opening, middle-game and solver-heavy
+    end-game positions, both action selections, solver on and off, a finite fpu, a stream that starts mid-way."""
+    from tests import frozen_py
+    from tests.test_gpu_parity import random_positions
+
+    my, op = random_positions(oracle, 14, seed=61, max_moves=61)
+    my = np.concatenate([np.zeros(1, np.uint64), my]); op = np.concatenate([np.zeros(1, np.uint64), op])
+    variants = [dict(), dict(fpu_value=0.5, c=1.2), dict(solve=0)]
+    for i in range(my.size):
+        kw = variants[i % 3]
+        explores = [30, 120, 7][i % 3]
+        by_q = i % 2 == 0
+        ref = oracle.c4_frozen_search(cfg(**kw), 900 + i, 3 * i, my[i:i + 1], op[i:i + 1], explores, action_selection=0 if by_q else 1)
+        got = frozen_py.frozen_search(oracle, my[i], op[i], 900 + i, 3 * i, explores, c=kw.get("c", 2.0),
+                                      fpu=kw.get("fpu_value", np.inf), solve=bool(kw.get("solve", 1)), by_q=by_q)
+        for k in ("child_N", "child_cum", "child_P"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k][0].view(np.uint32)), (i, k)
+        assert np.array_equal(got["child_sol"], ref["child_sol"][0]) and np.array_equal(got["root_sol"], ref["root_sol"][0]), i
+        assert np.array_equal(got["root_stat"].view(np.uint32), ref["root_stat"][0].view(np.uint32)), i
+        assert (got["num_nodes"], got["best_action"], got["rng_words"]) == (ref["num_nodes"][0], ref["best_action"][0], ref["rng_words"][0]), i
