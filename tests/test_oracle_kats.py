@@ -279,3 +279,31 @@ def test_oracle_is_clean_under_asan_and_ubsan():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "sanitize_check ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_cpp_oracle_equals_the_independent_python_restatement_of_mcts(oracle, golden_dir):
+    """tests/mcts_py.py restates mcts.rs:28-488 a second time in plain Python. Both restatements must build bit-identical trees
+    and targets on Connect4 with the network policy, across the configuration space the reference's TicTacToe KATs do not
+    reach: the self-play configuration (PolynomialUct, Fpu::Const, solver + value correction + auto-extend), Uct, Fpu::ParentQ,
+    equalising root noise, and each solver switch off; opening, middle-game and end-game positions (incl. forced single moves)."""
+    import os
+
+    from tests import mcts_py
+    from tests.oracle_lib import parity_mcts_config
+    from tests.test_gpu_parity import random_positions
+
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    my, op = random_positions(oracle, 17, seed=71, max_moves=62)
+    my = np.concatenate([np.zeros(1, np.uint64), my]); op = np.concatenate([np.zeros(1, np.uint64), op])
+    variants = [dict(), dict(exploration=0, c=2.0), dict(fpu=1), dict(noise=1, noise_weight=0.25), dict(auto_extend=0),
+                dict(correct_values_on_solve=0), dict(select_solved_nodes=0), dict(solve=0), dict(exploration=0, c=1.5, fpu=1)]
+    for i in range(my.size):
+        cfg = parity_mcts_config(**variants[i % len(variants)])
+        explores = [40, 150, 9, 80][i % 4]
+        sel = i % 2
+        ref = oracle.c4_mcts_search(cfg, blob, my[i:i + 1], op[i:i + 1], explores, action_selection=sel, nn_mode=oracle.ACC_FMA)
+        got = mcts_py.mcts_search(oracle, blob, cfg, my[i], op[i], explores, by_q=(sel == 0), nn_mode=oracle.ACC_FMA)
+        for k in ("child_N", "child_W", "child_P", "root_stat", "target_pi", "target_q"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k][0].view(np.uint32)), (i, variants[i % len(variants)], k)
+        assert np.array_equal(got["child_sol"], ref["child_sol"][0]) and np.array_equal(got["root_sol"], ref["root_sol"][0]), i
+        assert (got["num_nodes"], got["best_action"]) == (ref["num_nodes"][0], ref["best_action"][0]), i
