@@ -307,3 +307,30 @@ def test_cpp_oracle_equals_the_independent_python_restatement_of_mcts(oracle, go
             assert np.array_equal(got[k].view(np.uint32), ref[k][0].view(np.uint32)), (i, variants[i % len(variants)], k)
         assert np.array_equal(got["child_sol"], ref["child_sol"][0]) and np.array_equal(got["root_sol"], ref["root_sol"][0]), i
         assert (got["num_nodes"], got["best_action"]) == (ref["num_nodes"][0], ref["best_action"][0]), i
+
+
+def test_cpp_oracle_selfplay_equals_the_independent_python_restatement(oracle, golden_dir):
+    """tests/selfplay_py.py restates run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) in
+    plain Python on top of tests/mcts_py.py. Whole games — positions, visit distributions, value targets, sampled actions,
+    tree sizes, final outcome — must equal the C++ oracle's, for every ValueTarget, stop_games_when_solved, ActionSelection::Q
+    with a short sampling horizon, and a longer random opening under Uct without auto-extend."""
+    import os
+
+    from tests import selfplay_py
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    variants = [dict(), dict(value_target=0), dict(value_target=2, vt_p=0.3), dict(value_target=3, vt_from=0.1, vt_to=0.9),
+                dict(stop_games_when_solved=1), dict(action=0, sample_actions_until=4),
+                dict(random_actions_until=3, mcts=parity_mcts_config(exploration=0, c=2.0, auto_extend=0))]
+    for i, kw in enumerate(variants):
+        for seed in (100 + i, 7000 + 13 * i):
+            cfg = parity_rollout_config(30, **kw)
+            ref = oracle.c4_selfplay(cfg, blob, seed, 1, nn_mode=oracle.ACC_FMA)
+            got = selfplay_py.run_game(oracle, blob, cfg, seed, nn_mode=oracle.ACC_FMA)
+            n = int(ref["plies"][0])
+            assert got["plies"] == n and list(ref["actions"][0, :n]) == got["actions"], (i, seed)
+            assert np.array_equal(ref["pis"][0, :n].view(np.uint32), got["pis"].view(np.uint32)), (i, seed)
+            assert np.array_equal(ref["vs"][0, :n].view(np.uint32), got["vs"].view(np.uint32)), (i, seed)
+            assert list(ref["root_nodes"][0, :n]) == got["tree_sizes"] and int(ref["final_kind"][0]) == got["final_kind"], (i, seed)
+            assert all((int(ref["states_bb"][0, k, 0]), int(ref["states_bb"][0, k, 1])) == got["states"][k] for k in range(n))
