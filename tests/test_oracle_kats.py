@@ -334,3 +334,29 @@ def test_cpp_oracle_selfplay_equals_the_independent_python_restatement(oracle, g
             assert np.array_equal(ref["vs"][0, :n].view(np.uint32), got["vs"].view(np.uint32)), (i, seed)
             assert list(ref["root_nodes"][0, :n]) == got["tree_sizes"] and int(ref["final_kind"][0]) == got["final_kind"], (i, seed)
             assert all((int(ref["states_bb"][0, k, 0]), int(ref["states_bb"][0, k, 1])) == got["states"][k] for k in range(n))
+
+
+def test_oracle_dedup_equals_a_dictionary_restatement(oracle):
+    """ReplayBuffer::deduplicate (data.rs:196-235) restated with a Python dict: sums of pi and v per distinct position in
+    buffer order (f32, sequential), divided by the count. The oracle's output order is ascending (my_bb, op_bb); the reference's
+    is HashMap iteration order (unspecified), so the comparison is per position."""
+    rs = np.random.RandomState(8)
+    base_my = rs.randint(0, 2**40, 300).astype(np.uint64); base_op = rs.randint(0, 2**40, 300).astype(np.uint64)
+    pick = rs.randint(0, 300, 2000)
+    my, op = base_my[pick], base_op[pick]
+    pis = rs.rand(2000, 9).astype(np.float32); vs = rs.rand(2000, 3).astype(np.float32)
+    got = oracle.dedup(my, op, pis, vs)
+    stats = {}
+    for i in range(2000):
+        s = stats.setdefault((int(my[i]), int(op[i])), [np.zeros(9, np.float32), np.zeros(3, np.float32), 0])
+        s[0] = (s[0] + pis[i]).astype(np.float32)
+        s[1] = (s[1] + vs[i]).astype(np.float32)
+        s[2] += 1
+    assert got["num"].size == len(stats)
+    keys = list(zip(got["my_bb"].tolist(), got["op_bb"].tolist()))
+    assert keys == sorted(keys) and set(keys) == set(stats)
+    for k, key in enumerate(keys):
+        sp, sv, n = stats[key]
+        assert got["num"][k] == n
+        assert np.array_equal(got["pis"][k].view(np.uint32), (sp / np.float32(n)).astype(np.float32).view(np.uint32))
+        assert np.array_equal(got["vs"][k].view(np.uint32), (sv / np.float32(n)).astype(np.float32).view(np.uint32))
