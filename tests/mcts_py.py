@@ -45,8 +45,10 @@ def opt_gt(a, b):
 
 
 class MctsPy:
-    def __init__(self, oracle, blob, cfg, game, nn_mode):
+    def __init__(self, oracle, blob, cfg, game, nn_mode, policy_fn=None):
         self.o, self.blob, self.cfg, self.nn_mode = oracle, blob, cfg, nn_mode
+        if policy_fn is not None:          # e.g. RolloutPolicy (tests/frozen_py.rollout_eval on a Stream)
+            self.policy = policy_fn
         self.root = Node(None, game, None, 0, 0.0)
         self.count = 1
         leaf, dist, any_solved = self.visit(self.root)
@@ -197,9 +199,9 @@ class MctsPy:
         return np.array([F(self.root.w[i] / self.root.n) for i in range(3)], F)
 
 
-def mcts_search(oracle, blob, cfg_struct, my_bb, op_bb, explores, by_q=False, nn_mode=1):
+def mcts_search(oracle, blob, cfg_struct, my_bb, op_bb, explores, by_q=False, nn_mode=1, policy_fn=None):
     cfg = {k: getattr(cfg_struct, k) for k, _ in cfg_struct._fields_}
-    t = MctsPy(oracle, blob, cfg, Game(int(my_bb), int(op_bb)), nn_mode)
+    t = MctsPy(oracle, blob, cfg, Game(int(my_bb), int(op_bb)), nn_mode, policy_fn)
     t.explore_n(explores)
     out = dict(child_N=np.zeros(9, F), child_W=np.zeros((9, 3), F), child_P=np.zeros(9, F), child_sol=np.zeros((9, 3), np.int32),
                root_stat=np.array([t.root.n] + t.root.w, F), num_nodes=t.count, best_action=t.best_action(by_q),

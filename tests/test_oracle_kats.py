@@ -360,3 +360,24 @@ def test_oracle_dedup_equals_a_dictionary_restatement(oracle):
         assert got["num"][k] == n
         assert np.array_equal(got["pis"][k].view(np.uint32), (sp / np.float32(n)).astype(np.float32).view(np.uint32))
         assert np.array_equal(got["vs"][k].view(np.uint32), (sv / np.float32(n)).astype(np.float32).view(np.uint32))
+
+
+def test_cpp_oracle_rollout_search_equals_the_python_restatement(oracle):
+    """MCTS over RolloutPolicy on Connect4 (the pairing of the reference's own MCTS tests, there on TicTacToe): the two
+    independent Python pieces — tests/mcts_py.py's tree and tests/frozen_py.py's playout on the raw StdRng words — against the
+    C++ oracle, under the rollout configuration (Uct, fpu = inf, no auto-extend) and the self-play configuration."""
+    from tests import frozen_py, mcts_py
+    from tests.oracle_lib import parity_mcts_config
+    from tests.test_gpu_parity import random_positions
+
+    my, op = random_positions(oracle, 10, seed=83, max_moves=58)
+    for i in range(my.size):
+        cfg = parity_mcts_config(exploration=0, c=2.0, auto_extend=0, fpu_value=float("inf")) if i % 2 == 0 else parity_mcts_config()
+        ref = oracle.c4_mcts_search_rollout(cfg, 40 + i, my[i:i + 1], op[i:i + 1], 120)
+        rng = frozen_py.Stream(oracle, 40 + i, 0)
+        got = mcts_py.mcts_search(oracle, None, cfg, my[i], op[i], 120, by_q=False,
+                                  policy_fn=lambda game: frozen_py.rollout_eval(game, rng))
+        for k in ("child_N", "child_W", "child_P", "root_stat", "target_pi", "target_q"):
+            assert np.array_equal(got[k].view(np.uint32), ref[k][0].view(np.uint32)), (i, k)
+        assert np.array_equal(got["child_sol"], ref["child_sol"][0]) and got["num_nodes"] == ref["num_nodes"][0], i
+        assert got["best_action"] == ref["best_action"][0], i
