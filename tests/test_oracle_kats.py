@@ -381,3 +381,70 @@ def test_cpp_oracle_rollout_search_equals_the_python_restatement(oracle):
             assert np.array_equal(got[k].view(np.uint32), ref[k][0].view(np.uint32)), (i, k)
         assert np.array_equal(got["child_sol"], ref["child_sol"][0]) and got["num_nodes"] == ref["num_nodes"][0], i
         assert got["best_action"] == ref["best_action"][0], i
+
+
+class _TicTacToe:
+    """the reference's test game (mcts.rs:539-690) for tests/mcts_py.py: cells row-major, X moves first"""
+    LINES = [(0, 1, 2), (3, 4, 5), (6, 7, 8), (0, 3, 6), (1, 4, 7), (2, 5, 8), (0, 4, 8), (2, 4, 6)]
+
+    def __init__(self, board=(None,) * 9, player=0, turn=0):
+        self.board, self.player, self.turn = board, player, turn
+
+    def won(self, p):
+        return any(all(self.board[i] == p for i in line) for line in self.LINES)
+
+    def over(self):
+        return self.won(self.player) or self.won(1 - self.player) or self.turn == 9
+
+    def actions(self):
+        return [i for i in range(9) if self.board[i] is None]
+
+    def step(self, i):
+        b = list(self.board)
+        assert b[i] is None
+        b[i] = self.player
+        g = _TicTacToe(tuple(b), 1 - self.player, self.turn + 1)
+        return g, g.over()
+
+    def reward(self, p):
+        return 1.0 if self.won(p) else (-1.0 if self.won(1 - p) else 0.0)
+
+    def reward_for_mover_to_be(self):
+        return np.float32(self.reward(self.player))
+
+
+def test_node_count_kats_with_the_python_restatement(oracle):
+    """The reference's three solver tests also assert `nodes.len()` (311 / 1533; mcts.rs:732, 778, 831). The C++ oracle
+    reproduces every other assertion of those tests but counts 244 / 69 / 1467 nodes. The independent Python restatement
+    (tests/mcts_py.py + a playout on the raw StdRng words) arrives at exactly the oracle's counts, roots and best actions — two
+    implementations written separately from the same source text agree with each other and not with the literals, which depend
+    on the rand crate's stream at the time the tests were written (Cargo.lock is not in the repository)."""
+    from tests import frozen_py, mcts_py
+    from tests.oracle_lib import parity_mcts_config
+
+    cfg_struct = parity_mcts_config(exploration=1, c=2.0, fpu_value=float("inf"))
+    cfg = {k: getattr(cfg_struct, k) for k, _ in cfg_struct._fields_}
+    openings = {0: [0, 2], 1: [0, 2, 6], 2: [0, 4]}
+    for which, moves in openings.items():
+        ref = oracle.ttt_kat(which, 0, 12)
+        game = _TicTacToe()
+        for m in moves:
+            game, _ = game.step(m)
+        rng = frozen_py.Stream(oracle, 0, 0)
+
+        def rollout(g, rng=rng):
+            player, over = g.player, g.over()
+            while not over:
+                acts = g.actions()
+                g, over = g.step(acts[rng.gen_range_u8(len(acts))])
+            r = g.reward(player)
+            z = np.float32(0)
+            o = np.float32(1)
+            return [z] * 9, ([z, o, z] if r == 0 else ([o, z, z] if r < 0 else [z, z, o]))
+
+        t = mcts_py.MctsPy(oracle, None, cfg, game, 1, policy_fn=rollout)
+        t.explore_n(100000)
+        kinds = {"L": "Lose", "D": "Draw", "W": "Win"}
+        assert t.count == ref["nodes_len"], (which, t.count, ref["nodes_len"])
+        assert (kinds[t.root.solution[0]], t.root.solution[1]) == ref["root"]
+        assert t.best_action(True) == ref["best_action_q"]
