@@ -2,7 +2,12 @@
 """bench.py — self-play throughput of the MI355X engine on BASELINE.json's metric.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 runs one process per GPU either way:
+      * under a launcher (python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...):
+        RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment;
+      * started bare (python bench.py --gpus N): this process starts the N ranks itself as child processes BEFORE it
+        touches the GPU (it never initialises HIP and never re-execs), forwards rank 0's JSON line and exits with the
+        worst child status. A rank whose GPU is not visible fails loudly (SYN_ERR_NO_DEVICE) and takes the job down.
 
 Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7 Connect4, 800 explores per move,
            deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
@@ -110,6 +115,37 @@ def cpu_baseline(blob, explores, sample_games, threads):
     }
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RANK = LOCAL_RANK = 0..N-1) as
+    children of this process, which has not touched the GPU and will not. Returns the worst exit status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    worst = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                print(f"bench.py: rank {r} exited with status {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                for o in sorted(pending):  # exactly the PIDs started above
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +162,14 @@ def main():
                                                            "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 64 games per worker thread")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = two per CPU the cgroup quota / affinity mask allows")
+    ap.add_argument("--check-launch", action="store_true",
+                    help="start the ranks, rendezvous, barrier and reduce exactly as a bench run does, print the rank "
+                         "layout and stop before any GPU work (launch-plumbing test; prints no bench line)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch  # device sync + (N > 1) the RCCL barrier / max-reduce; the engine itself does not use torch
                   # (import it BEFORE the engine library so the process holds one HIP runtime: torch's)
@@ -135,8 +178,20 @@ def main():
     from synthesis_amd import dist_util
 
     rank, local_rank, world = dist_util.rank_info()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.check_launch:
+        dist = dist_util.init_process_group("gloo") if world > 1 else None
+        dist_util.barrier(dist)
+        _, (ranks, lsum) = dist_util.reduce_scalars(dist, "cpu", 0.0, [1, local_rank])
+        if rank == 0:
+            print(json.dumps({"check_launch": True, "n_gpus": world, "ranks_joined": ranks, "local_rank_sum": lsum}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if args.dist_backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; "
+                         f"--dist-backend gloo shares GPU 0 for a dry run)")
     dist = dist_util.init_process_group(args.dist_backend, local_rank) if world > 1 else None
     reduce_device = f"cuda:{local_rank}"
     if args.dist_backend != "nccl":

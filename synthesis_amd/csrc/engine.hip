@@ -30,6 +30,14 @@ static_assert(sizeof(syn_counters) == sizeof(unsigned long long) * CTR_COUNT, "c
 
 static thread_local std::string g_create_error;
 
+// Developer knobs (launch-shape overrides, in-kernel phase stamps) are read from the environment ONLY when SYN_DEBUG=1 is
+// set as well: a stray variable must never change the launch shape of a production call.
+static const char* debug_env(const char* name) {
+    const char* on = std::getenv("SYN_DEBUG");
+    if (!on || on[0] != '1') return nullptr;
+    return std::getenv(name);
+}
+
 struct syn_engine {
     int device = 0;
     int num_cus = 256;
@@ -183,15 +191,15 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     }
     // Kernel choice by trees per CU: <= 16 -> one 16-tree workgroup per CU, weights in registers (latency-optimal);
     // <= 32 -> two such workgroups per CU (hybrid register/LDS weights); more -> the quad-async kernel (NQ quads of 16
-    // trees per workgroup sharing one LDS weight image). SYN_QUADS=0..4 overrides (0 = never use the quad kernel).
+    // trees per workgroup sharing one LDS weight image). SYN_DEBUG=1 SYN_QUADS=0..4 overrides (0 = never use the quad kernel).
     // Lane-per-tree kernel (lane_kernel.cuh): one tree per lane, NW waves per workgroup, one workgroup per CU.
-    // SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it (0 = never); by default it takes over once every CU can
+    // SYN_DEBUG=1 SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it (0 = never); by default it takes over once every CU can
     // be given 256 trees (4 waves; measured 41.9k games/s at 65,536 concurrent games against 31.8k for the queued
     // row-per-tree workgroups), 8 waves up to 512 trees per CU, 12 beyond (16 waves spill: measured slower).
     {
         int nw = 0;
         if (want_slots >= h->num_cus * 256) nw = want_slots > h->num_cus * 512 ? 12 : (want_slots > h->num_cus * 256 ? 8 : 4);
-        if (const char* ev = std::getenv("SYN_LANES")) nw = std::atoi(ev);
+        if (const char* ev = debug_env("SYN_LANES")) nw = std::atoi(ev);
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
@@ -207,7 +215,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             EngineParams PL = P;
             PL.path = h->d_path;
             PL.lane_thresh = 48;
-            if (const char* ev = std::getenv("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
+            if (const char* ev = debug_env("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
             if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
             PL.lane_thresh &= ~15;  // whole tiles
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
@@ -233,7 +241,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     {
         int per_cu = (grid + h->num_cus - 1) / h->num_cus;
         nq = per_cu <= 2 ? 0 : (per_cu >= 4 ? 4 : 3);
-        if (const char* ev = std::getenv("SYN_QUADS")) nq = std::atoi(ev);
+        if (const char* ev = debug_env("SYN_QUADS")) nq = std::atoi(ev);
         if (nq < 0 || nq == 1 || nq > 4) nq = 0;
     }
     if (nq >= 2) {
@@ -832,7 +840,7 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     HIP_TRY(h, hipMemsetAsync(h->d_cache_stats, 0, 16, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), h->stream));
     // SYN_PROFILE=1: diagnostic build of the kernel with s_memtime stamps around each phase (never timed/benched)
-    const bool prof = !counters && std::getenv("SYN_PROFILE") != nullptr;
+    const bool prof = !counters && debug_env("SYN_PROFILE") != nullptr;
     int pgrid = 0, pnt = 0;
     unsigned long long* d_prof = nullptr;
     if (prof) {
@@ -953,7 +961,7 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
     const size_t lds = (size_t)TrainGeom::LDS_FLOATS * 4;
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // SYN_TRAIN_PROFILE=1: diagnostic stamps of the kernel's phases (first chunk), printed to stderr
-    static const bool prof = std::getenv("SYN_TRAIN_PROFILE") != nullptr;
+    static const bool prof = debug_env("SYN_TRAIN_PROFILE") != nullptr;
     unsigned long long* d_prof = nullptr;
     if (prof) {
         HIP_TRY(h, hipMalloc(&d_prof, 4096));

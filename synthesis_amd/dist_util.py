@@ -42,3 +42,8 @@ def reduce_scalars(dist, device, elapsed, counts):
     c = torch.tensor(list(counts), dtype=torch.int64, device=device)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), [int(x) for x in c.tolist()]
+
+
+def barrier(dist):
+    if dist is not None:
+        dist.barrier()

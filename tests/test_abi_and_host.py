@@ -2,6 +2,7 @@
 without a GPU), struct layouts agree between the header, the ctypes mirrors and the device structs, host-side config
 mirrors carry the reference's values, and the N>1 sharding / reduce plumbing works under gloo with world_size 2."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -160,6 +161,37 @@ def test_multi_rank_reduce_under_gloo(tmp_path):
     assert float(line[1]) == 2.0          # MAX over ranks of (1.0, 2.0)
     assert int(line[2]) == 1000           # SUM of per-rank game counts
     assert int(line[3]) == (2 * 2 + 0) * 500 + (2 * 2 + 1) * 500  # SUM of the two shard offsets
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher (how the driver runs it) must start two ranks itself: the parent never
+    touches the GPU, the ranks rendezvous over 127.0.0.1 and rank 0 reports world size 2 (launch plumbing only, no GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--check-launch"],
+                                  env=env, stderr=subprocess.DEVNULL, timeout=300).decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line == {"check_launch": True, "n_gpus": 2, "ranks_joined": 2, "local_rank_sum": 1}
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    """--gpus N with WORLD_SIZE != N (a launcher started a different number of ranks) is an error, never a silent 1-GPU run"""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--check-launch"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_multi_rank_fails_loudly_without_gpus():
+    """No GPU here: every rank of `bench.py --gpus 2` must refuse to run (there is no CPU fallback) and the launcher must
+    exit non-zero without printing a bench line."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the run would succeed")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b'"metric"' not in r.stdout
 
 
 def test_match_host_rules_follow_the_oracle(oracle):

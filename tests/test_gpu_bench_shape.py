@@ -1,0 +1,114 @@
+"""GPU tests of the headline launch shape AT ITS OWN SIZE and of the multi-rank / multi-engine plumbing.
+
+* bench shape: 196,608 concurrent games (768 per CU), the engine's own launch selection (no developer knob), at least one
+  full wave of games plus refill, replay outputs on — sampled games equal the oracle game for game and every game's length
+  equals the 4,096-slot engine's (row-per-tree kernel), i.e. the 45 GB pool (14-bit block ids, > 4 GB offsets) computes
+  the same games as the small engines the other parity tests use (alpha_zero.rs:120-169: the fan-out over workers).
+* two engines on one device driven from two host threads (one handle per host thread: SURVEY §8b threading row).
+* `python bench.py --gpus 2 --dist-backend gloo` started bare: two ranks (both on GPU 0), one JSON line with n_gpus 2.
+"""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def blob(golden_dir):
+    return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+
+
+def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch):
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+    from tests.test_gpu_parity import assert_selfplay_equal
+
+    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE"):
+        monkeypatch.delenv(k, raising=False)
+    conc, n_games, seed = 196608, 196608 + 12288, 20260
+    cfg = sa.parity_rollout_config(800)
+    big = sa.Engine(concurrent_games=conc, max_explores=800, device=0)
+    big.load_weights(blob)
+    got = big.selfplay(cfg, base_seed=seed, n_games=n_games)   # counters off: the very kernel instantiation bench.py times
+    shape, grid, threads = big.last_launch_shape()
+    assert (shape, grid, threads) == (4, 256, 768), "the bench's launch shape: lane-per-tree, 256 workgroups x 12 waves"
+    big.close()
+    assert got["plies"].min() >= 7 and got["plies"].max() <= 63
+
+    # (1) game for game against the oracle: blocks of games from the first wave, the last slots of the pool (highest
+    # slab offsets: > 40 GB into the pool) and the refill tail
+    for first in (0, 65536 + 5, conc - 8, conc, n_games - 8):
+        ref = oracle.c4_selfplay(parity_rollout_config(800), blob, seed, 8, first_game=first, threads=8, nn_mode=oracle.ACC_FMA)
+        sub = {k: got[k][first:first + 8] for k in ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind")}
+        assert_selfplay_equal(sub, ref, f"bench shape, games {first}..{first + 7}")
+
+    # (2) every game against the 4,096-slot engine (row-per-tree kernel, another node layout): same lengths, same last
+    # positions and same final results
+    small = sa.Engine(concurrent_games=4096, max_explores=800, device=0)
+    small.load_weights(blob)
+    ref = small.selfplay(cfg, base_seed=seed, n_games=n_games)
+    assert small.last_launch_shape()[0] in (1, 2)
+    small.close()
+    assert np.array_equal(got["plies"], ref["plies"])
+    assert np.array_equal(got["final_kind"], ref["final_kind"])
+    last = got["plies"] - 1
+    idx = np.arange(n_games)
+    assert np.array_equal(got["states_bb"][idx, last], ref["states_bb"][idx, last])
+    assert np.array_equal(got["actions"][idx, last], ref["actions"][idx, last])
+    assert np.array_equal(got["root_nodes"][idx, last], ref["root_nodes"][idx, last])
+
+
+def test_two_engines_on_one_device_from_two_threads(blob, oracle):
+    """One handle per host thread: two engines on cuda:0, each driven by its own thread at the same time
+    (ctypes releases the GIL during the call), play disjoint game ranges; both equal the oracle's games."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+    from tests.test_gpu_parity import assert_selfplay_equal
+
+    cfg = sa.parity_rollout_config(200)
+    out, errs = {}, []
+
+    def worker(r):
+        try:
+            eng = sa.Engine(concurrent_games=512, max_explores=200, device=0)
+            eng.load_weights(blob)
+            first, count = sa.shard_games(1500, r, 2)
+            out[r] = (first, count, eng.selfplay(cfg, base_seed=3, n_games=count, first_game=first))
+            eng.close()
+        except Exception as e:  # surfaced below
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert out[0][0] == 0 and out[1][0] == out[0][1] and out[0][1] + out[1][1] == 1500
+    for r in range(2):
+        first, count, got = out[r]
+        ref = oracle.c4_selfplay(parity_rollout_config(200), blob, 3, count, first_game=first, threads=8, nn_mode=oracle.ACC_FMA)
+        assert_selfplay_equal(got, ref, f"thread {r}")
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the bench starts both ranks itself; with --dist-backend gloo both share
+    GPU 0 (dry run of the N > 1 path on a 1-GPU box). One JSON line, n_gpus 2, both ranks' games counted."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.check_output(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1", "--warmup", "0",
+         "--concurrent", "16384", "--games-per-step", "16384", "--explores", "100", "--no-4096", "--no-policy-cache",
+         "--no-cpu-baseline"], env=env, stderr=subprocess.DEVNULL, timeout=900).decode()
+    lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 1
+    assert line["config"]["games_per_step_per_gpu"] == 16384
+    assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 16384) < 1.0   # value = games of BOTH ranks / time
+    assert 7 <= line["plies_per_game"] <= 63

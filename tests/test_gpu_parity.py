@@ -374,6 +374,7 @@ def test_quad_async_kernel_matches_oracle(blob, oracle, monkeypatch, quads):
     import synthesis_amd as sa
     from tests.oracle_lib import parity_mcts_config, parity_rollout_config
 
+    monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
     monkeypatch.setenv("SYN_QUADS", str(quads))
     eng = sa.Engine(concurrent_games=208, max_explores=800)  # 13 quads: partial last workgroup for every NQ
     eng.load_weights(blob)
@@ -400,6 +401,7 @@ def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
     import synthesis_amd as sa
     from tests.oracle_lib import parity_mcts_config, parity_rollout_config
 
+    monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
     monkeypatch.setenv("SYN_LANES", str(waves))
     eng = sa.Engine(concurrent_games=1100, max_explores=800)
     eng.load_weights(blob)
@@ -451,6 +453,7 @@ def test_policy_cache_is_semantics_neutral(blob, oracle, monkeypatch, log2):
     import synthesis_amd as sa
     from tests.oracle_lib import parity_mcts_config, parity_rollout_config
 
+    monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
     monkeypatch.setenv("SYN_LANES", "8")
     eng = sa.Engine(concurrent_games=1100, max_explores=800, policy_cache_log2=log2)
     eng.load_weights(blob)
@@ -525,6 +528,7 @@ def test_selfplay_full_size_properties(blob, oracle, monkeypatch):
     assert_selfplay_equal(r3, r, "16384-slot engine")
     big.close()
     # ... and on the lane-per-tree kernel (different record layout, different backprop): bit-identical again
+    monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
     monkeypatch.setenv("SYN_LANES", "12")
     lanes = sa.Engine(concurrent_games=4096, max_explores=800)
     lanes.load_weights(blob)

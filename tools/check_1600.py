@@ -1,5 +1,7 @@
 """Developer tool (GPU): self-play at the reference's default 1,600 explores per move on the lane-per-tree kernel, and the
 same 4,096 games on a small engine for comparison."""
+import os
+os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np, torch

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: throughput of the lane-per-tree kernel. Args: conc:nw[:games[:policy_cache_log2]] ... (nw = waves per
 workgroup, 0 = the engine's own choice)"""
+import os
+os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, time
 import numpy as np
 import torch  # noqa

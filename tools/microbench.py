@@ -3,6 +3,8 @@
 stand-alone Connect4Net MFMA throughput, concurrency sweep."""
 import argparse
 import os
+os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
+import os
 import sys
 import time
 

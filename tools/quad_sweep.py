@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: throughput of the fused kernels for (concurrency, SYN_QUADS) combinations."""
+import os
+os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, time
 import numpy as np
 import torch  # noqa

@@ -2,6 +2,8 @@
 """Developer tool (GPU): every launch shape must give the same games for the same (config, seed) — results depend only
 on the game index. Plays 3,000 games per configuration family on the row-per-tree kernels and on the lane-per-tree kernel
 (8 and 12 waves, with and without the policy cache) and compares every output array."""
+import os
+os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,7 @@
 """Developer tool (GPU): three training steps with SYN_TRAIN_PROFILE=1 set print the per-phase cycle stamps of the
 training kernel. Usage: SYN_TRAIN_PROFILE=1 python tools/train_profile.py"""
+import os
+os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import synthesis_amd as sa
