@@ -11,8 +11,8 @@
 
 Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7 Connect4, 800 explores per move,
            deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
-           SoA MCTS node pool) at 196,608 concurrent games per GPU (768 per CU: the lane-per-tree kernel); configs[1]'s
-           4096 concurrent games is measured in the same run and reported under "at_4096_concurrent_games".
+           SoA MCTS node pool) at 262,144 concurrent games per GPU (1,024 per CU: the 16-wave lane-per-tree kernel);
+           configs[1]'s 4096 concurrent games is measured in the same run and reported under "at_4096_concurrent_games".
 Step     : one pass of the hot path over one batch = GAMES_PER_STEP self-play games per GPU played to completion by
            ONE launch of the fused kernel (finished games hand their tree slot to the next game index, so the slots stay busy).
 Scaling  : weak — every rank plays its own GAMES_PER_STEP games per step (games share nothing; no collective on the
@@ -61,18 +61,33 @@ def algorithmic_bytes(c):
             + 8 * c["expansions"] + 40 * c["backprop_levels"] + 4 * c["solver_children"])
 
 
-def measured_traffic(args):
-    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json,
-    produced by tools/collect_profiles.sh on this exact bench command); None if the run is not that configuration."""
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the HIP sources of the library: ties a committed PMC summary to the kernels it measured."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "synthesis_amd", "csrc", "*.cuh")) + glob.glob(os.path.join(ROOT, "synthesis_amd", "csrc", "*.hip"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(args, key="traffic_bytes_per_launch"):
+    """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, produced
+    by tools/collect_profiles.sh on this exact bench command). The counters cannot be read inside this process, so the
+    figure comes from that committed run; it is reported ONLY when the summary was taken on this configuration AND on
+    these kernel sources (csrc hash) — otherwise None."""
     import glob
 
-    if (args.concurrent, args.games_per_step, args.explores) != (196608, 1572864, 800):
-        return None, None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    return d.get("traffic_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    if d.get("csrc_sha16") != kernel_source_hash():
+        return None, None
+    if d.get("bench_config") != [args.concurrent, args.games_per_step, args.explores]:
+        return None, None
+    return d.get(key), os.path.relpath(files[-1], ROOT)
 
 
 def host_cpu_budget():
@@ -151,13 +166,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--concurrent", type=int, default=196608,
+    ap.add_argument("--concurrent", type=int, default=262144,
                     help="concurrent games (tree slots) per GPU; BASELINE configs[1] names 4096, reported as extra")
     ap.add_argument("--games-per-step", type=int, default=1572864, help="self-play games per GPU per step")
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
+    ap.add_argument("--only-policy-cache", action="store_true",
+                    help="run nothing but the PolicyWithCache leg (the command tools/collect_profiles.sh profiles for its roofline)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the tail / replay-output / trained-weights legs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
                                                            "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 64 games per worker thread")
@@ -198,10 +216,49 @@ def main():
         local_rank, reduce_device = 0, "cpu"   # dry run: all ranks share GPU 0, scalars reduced over gloo
 
     blob = make_weights()
-    eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
-    eng.load_weights(blob)
     cfg = sa.parity_rollout_config(args.explores)
     gps = args.games_per_step
+
+    def policy_cache_leg(c_ref=None):
+        """The reference's run_n_games wraps the policy in PolicyWithCache (alpha_zero.rs:197-198), and so does the CPU
+        baseline; the headline evaluates every leaf with the network, this is the same workload with the device-side cache
+        (2^28 entries, 17 GB): one step of gps games at the headline concurrency. Its bound is the HBM line-transaction
+        rate (two thirds of the matrix work disappears), so it carries an HBM roofline object of its own."""
+        e3 = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank, policy_cache_log2=28)
+        e3.load_weights(blob)
+        e3.selfplay(cfg, base_seed=2, n_games=args.concurrent, outputs=False)
+        t1 = time.perf_counter()
+        r3 = e3.selfplay(cfg, base_seed=2, n_games=gps, first_game=args.concurrent, outputs=False)
+        dt = time.perf_counter() - t1
+        hits, misses = e3.last_cache_stats()
+        shape3 = e3.last_launch_shape()
+        # the cache never changes a tree, so the event counts are those of an uncached run of as many games: the headline's
+        # counted step when there is one, else a counted re-run
+        c3 = c_ref if c_ref is not None else e3.selfplay(cfg, base_seed=2, n_games=gps, first_game=args.concurrent,
+                                                         outputs=False, counters=True)["counters"]
+        e3.close()
+        # algorithmic bytes: the tree traffic of SURVEY §8d plus one 64-byte table entry read per Policy::eval call and
+        # one written per miss
+        alg = algorithmic_bytes(c3) + 64 * (hits + misses) + 64 * misses
+        gbs = alg / (r3["kernel_ms"] * 1e-3) / 1e9
+        traffic, src = measured_traffic(args, "cache_traffic_bytes_per_launch")
+        return {"games_per_s": gps / dt, "kernel_ms": r3["kernel_ms"], "games": gps, "concurrent_games": args.concurrent,
+                "table_entries_log2": 28, "hit_rate": hits / max(1, hits + misses),
+                "network_evals_per_s": misses / dt, "policy_eval_calls_per_s": (hits + misses) / dt,
+                "launch_shape": list(shape3),
+                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                             "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
+                             "kernel_ms_avg": r3["kernel_ms"],
+                             "mfma_frac_beside_it": misses * FLOP_PER_EVAL / (r3["kernel_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+
+    if args.only_policy_cache:
+        out = policy_cache_leg()
+        if rank == 0:
+            print(json.dumps({"with_policy_cache": out}), flush=True)
+        return
+
+    eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
+    eng.load_weights(blob)
 
     def barrier():
         torch.cuda.synchronize(local_rank)
@@ -232,7 +289,7 @@ def main():
     c = rc["counters"]
     shape, sgrid, sthreads = eng.last_launch_shape()
     kernel_name = {1: "selfplay_kernel<WPS=1>", 2: "selfplay_kernel<WPS=2>", 3: "selfplay_kernel_quads",
-                   4: "selfplay_kernel_lanes"}.get(shape, "?") + f" <<<{sgrid}, {sthreads}>>>"
+                   4: "selfplay_kernel_lanes", 5: "selfplay_kernel_pc"}.get(shape, "?") + f" <<<{sgrid}, {sthreads}>>>"
     last_ms = kernel_ms[-1]
     avg_ms = float(np.mean(kernel_ms))
 
@@ -253,7 +310,7 @@ def main():
         traffic, src = measured_traffic(args)
         for rf in (mfma, hbm):
             rf["traffic"] = traffic            # HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, guide §HBM), PMC passes
-            rf["traffic_source"] = src
+            rf["traffic_source"] = src         # the committed rocprofv3 run of this configuration and these kernel sources
         hbm["algorithmic_bytes_per_launch"] = algorithmic_bytes(c)
         near, other = (mfma, hbm) if mfma["frac"] >= hbm["frac"] else (hbm, mfma)
         out = {
@@ -271,6 +328,32 @@ def main():
             "plies_per_game": plies / total_games,
             "roofline": near, "roofline_other": other,
         }
+        if world == 1 and not args.no_extras:
+            # (1) the launch tail: a launch ends when its LAST game ends, so its final stretch runs on emptying tree slots; a
+            # step of twice the games has the same tail on twice the work. tail_share = the fraction of a default step that
+            # the tail costs against a tail-free (infinitely long) launch.
+            t1 = time.perf_counter()
+            eng.selfplay(cfg, base_seed=0, n_games=2 * gps, first_game=(args.warmup + args.steps) * gps, outputs=False)
+            dt2 = time.perf_counter() - t1
+            t_step = elapsed / args.steps
+            steady = gps / max(1e-9, dt2 - t_step)                 # games/s of the extra (tail-free) half
+            out["launch_tail"] = {"games_per_s_at_2x_games_per_step": 2 * gps / dt2, "steady_state_games_per_s": steady,
+                                  "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
+            # (2) the same step with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per
+            # game) copied to host memory inside the timed region — the PCIe-inclusive rate (never `value`)
+            try:
+                import psutil
+                room = psutil.virtual_memory().available > 3 * gps * 63 * 69
+            except Exception:
+                room = False
+            if room:
+                t1 = time.perf_counter()
+                ro = eng.selfplay(cfg, base_seed=0, n_games=gps, first_game=(args.warmup + args.steps + 2) * gps, outputs=True)
+                dt3 = time.perf_counter() - t1
+                nbytes = sum(v.nbytes for v in ro.values() if isinstance(v, np.ndarray))
+                out["with_replay_outputs_to_host"] = {"games_per_s": gps / dt3, "bytes_copied": int(nbytes),
+                                                      "seconds": dt3, "kernel_ms": ro["kernel_ms"]}
+                del ro
         if world == 1 and not args.no_4096:
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
@@ -284,22 +367,8 @@ def main():
                                                "games": 16384, "plies_per_game": float(r2["plies"].mean())}
             e2.close()
         if world == 1 and not args.no_policy_cache:
-            # the reference's run_n_games wraps the policy in PolicyWithCache (alpha_zero.rs:197-198), and so does the CPU
-            # baseline below; the headline above evaluates every leaf with the network, this is the same workload with the
-            # device-side cache (2^28 entries, 17 GB) — one step of 1,048,576 games at 131,072 concurrent games
             eng.close()
-            e3 = sa.Engine(concurrent_games=131072, max_explores=args.explores, device=local_rank, policy_cache_log2=28)
-            e3.load_weights(blob)
-            e3.selfplay(cfg, base_seed=2, n_games=131072, outputs=False)
-            t1 = time.perf_counter()
-            r3 = e3.selfplay(cfg, base_seed=2, n_games=1048576, first_game=131072, outputs=False)
-            dt = time.perf_counter() - t1
-            hits, misses = e3.last_cache_stats()
-            out["with_policy_cache"] = {"games_per_s": 1048576 / dt, "kernel_ms": r3["kernel_ms"], "games": 1048576,
-                                        "concurrent_games": 131072, "table_entries_log2": 28,
-                                        "hit_rate": hits / max(1, hits + misses),
-                                        "network_evals_per_s": misses / dt, "policy_eval_calls_per_s": (hits + misses) / dt}
-            e3.close()
+            out["with_policy_cache"] = policy_cache_leg(c)
         if world == 1 and not args.no_cpu_baseline:
             budget, quota = host_cpu_budget()
             # two worker threads per usable CPU (measured best on the 16-CPU-quota boxes: 16 -> 103, 32 -> 130 games/s)

@@ -32,7 +32,7 @@ typedef enum syn_status {
     SYN_ERR_NO_DEVICE = -2,       /* no usable gfx950 device / HIP runtime failure at create */
     SYN_ERR_HIP = -3,             /* a HIP call failed; see syn_last_error */
     SYN_ERR_NO_WEIGHTS = -4,      /* policy/value network weights not loaded yet */
-    SYN_ERR_UNSUPPORTED = -5,     /* config variant not implemented on device (e.g. Fpu::Func, Dirichlet noise) */
+    SYN_ERR_UNSUPPORTED = -5,     /* config variant not implemented on the device */
     SYN_ERR_CAPACITY = -6         /* node pool too small for the requested explores */
 } syn_status;
 
@@ -42,10 +42,13 @@ typedef enum syn_status {
 enum { SYN_EXPLORATION_UCT = 0, SYN_EXPLORATION_POLYNOMIAL_UCT = 1 };
 /* config.rs:15-19 ActionSelection */
 enum { SYN_ACTION_Q = 0, SYN_ACTION_NUM_VISITS = 1 };
-/* config.rs:21-26 Fpu (Func(fn()->f32) is a host closure: rejected with SYN_ERR_UNSUPPORTED) */
-enum { SYN_FPU_CONST = 0, SYN_FPU_PARENT_Q = 1 };
-/* config.rs:39-44 PolicyNoise (None and Equal run on the device; Dirichlet needs rand_distr's gamma sampler:
- * SYN_ERR_UNSUPPORTED for now) */
+/* config.rs:21-26 Fpu. Func(fn()->f32) is a host closure and cannot cross a C ABI; the closure the reference itself uses —
+ * Normal::new(mean, std).sample(&mut thread_rng()) (study-connect4/src/main.rs:43-47) — runs on the device as
+ * SYN_FPU_NORMAL {fpu_value = mean, fpu_std = std}: one draw per unexpanded child per select_best_child scan
+ * (mcts.rs:351-356), from a per-tree StdRng stream instead of thread_rng (reproducible; csrc/noise.cuh). */
+enum { SYN_FPU_CONST = 0, SYN_FPU_PARENT_Q = 1, SYN_FPU_NORMAL = 2 };
+/* config.rs:39-44 PolicyNoise. Dirichlet{alpha, weight} (mcts.rs:241-256) samples rand_distr's Dirichlet on the device from
+ * the tree's own stream (csrc/noise.cuh). */
 enum { SYN_NOISE_NONE = 0, SYN_NOISE_EQUAL = 1, SYN_NOISE_DIRICHLET = 2 };
 /* config.rs:1-7 ValueTarget */
 enum { SYN_VALUE_Z = 0, SYN_VALUE_Q = 1, SYN_VALUE_QZ_AVERAGE = 2, SYN_VALUE_Q_TO_Z = 3 };
@@ -61,10 +64,11 @@ typedef struct syn_mcts_config {
     int32_t select_solved_nodes;
     int32_t auto_extend;
     int32_t fpu;                      /* SYN_FPU_* */
-    float fpu_value;                  /* Fpu::Const(value) */
+    float fpu_value;                  /* Fpu::Const(value); mean of SYN_FPU_NORMAL */
     int32_t root_policy_noise;        /* SYN_NOISE_* */
     float noise_alpha;                /* Dirichlet{alpha,..} */
     float noise_weight;               /* Equal{weight} / Dirichlet{..,weight} */
+    float fpu_std;                    /* standard deviation of SYN_FPU_NORMAL (>= 0) */
 } syn_mcts_config;
 
 /* config.rs:46-56 RolloutConfig (num_workers has no meaning here: concurrency is syn_engine_config.concurrent_games) */
@@ -128,6 +132,11 @@ int syn_features_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_
 /* y[batch][O] = b + sum_i x[batch][i] * W[o][i], accumulated in ascending i with separate multiply and add. */
 int syn_linear_forward(syn_engine* h, int I, int O, const float* W, const float* b, const float* x, int batch,
                        float* y, int relu);
+/* slimnn activations as layers on x[batch][n] (slimnn/src/activations.rs:31-63): SYN_ACT_RELU = x.max(0.0); SYN_ACT_TANH =
+ * x.tanh() (a deterministic tanh shared with the oracle: Rust's f32::tanh is libm, unpinned); SYN_ACT_SOFTMAX =
+ * Softmax::apply_1d per row — exp of every element with NO max subtraction, summed in index order, divided by the total. */
+enum { SYN_ACT_RELU = 0, SYN_ACT_TANH = 1, SYN_ACT_SOFTMAX = 2 };
+int syn_activation_forward(syn_engine* h, int kind, const float* x, int batch, int n, float* y);
 /* NCHW cross-correlation; W[COUT][CIN][K][K]; x[batch][CIN][H_IN][W_IN]; y[batch][COUT][H_OUT][W_OUT]; accumulation
  * order ci -> k1 -> k2. H_OUT/W_OUT must satisfy conv.rs:50-51 or SYN_ERR_INVALID_ARGUMENT is returned. */
 int syn_conv2d_forward(syn_engine* h, int CIN, int COUT, int K, int ROW_PAD, int COL_PAD, int STRIDE, int H_IN,
@@ -289,6 +298,10 @@ int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out);
  * (IEEE-exactness checks) */
 int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
                    float* out_sqrt_a);
+
+/* fast[i] = the packed division of the lane / producer-consumer kernels' descent (device_common.cuh div2_safe_range) on
+ * a[i] / b[i]; full[i] = the device's IEEE division. Equal bit for bit for a = 0 or 2^-60 <= a <= 2^60 and 1 <= b <= 2^16. */
+int syn_debug_fast_div(syn_engine* h, const float* a, const float* b, int n, float* out_fast, float* out_full);
 
 /* PMC calibration probe (tools/calibrate_pmc.py): gathers n_spans 288-byte sibling spans of 32-byte node records at
  * record offsets d_span_off[i] from d_base (device pointers), optionally rewriting 16 bytes per touched record. */

@@ -95,4 +95,25 @@ inline float det_logf(float x) {
     return std::fmaf(fe, 0.693359375f, r);
 }
 
+// Deterministic f32 tanh for slimnn's Tanh activation (slimnn/src/activations.rs:39-44 calls Rust's f32::tanh -> platform
+// libm, unpinned). Cephes tanhf scheme with IEEE-exact operations only (same code on the device): |x| < 0.625 -> odd
+// polynomial x + x^3 P(x^2) by fma; otherwise 1 - 2 / (det_expf(2|x|) + 1) with the sign restored; |x| > 44 -> +-1.
+inline float det_tanhf(float x) {
+    if (x != x) return x;
+    const float z = x < 0.0f ? -x : x;
+    if (z > 44.0f) return x < 0.0f ? -1.0f : 1.0f;
+    if (z >= 0.625f) {
+        const float s = det_expf(z + z);
+        const float t = 1.0f - 2.0f / (s + 1.0f);
+        return x < 0.0f ? -t : t;
+    }
+    const float w = x * x;
+    float p = -5.70498872745e-3f;
+    p = std::fmaf(p, w, 2.06390887954e-2f);
+    p = std::fmaf(p, w, -5.37397155531e-2f);
+    p = std::fmaf(p, w, 1.33314422036e-1f);
+    p = std::fmaf(p, w, -3.33332819422e-1f);
+    return std::fmaf(p * w, x, x);
+}
+
 }  // namespace oracle

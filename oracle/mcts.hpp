@@ -5,7 +5,7 @@
 //   synthesis/src/mcts.rs:28-100   Node
 //   synthesis/src/mcts.rs:123-147  with_capacity / explore_n
 //   synthesis/src/mcts.rs:174-225  target_policy / target_q
-//   synthesis/src/mcts.rs:229-269  root noise (None / Equal; Dirichlet needs rand_distr's gamma sampler — not restated)
+//   synthesis/src/mcts.rs:229-269  root noise (None / Equal / Dirichlet: rand_distr's sampler restated in noise.hpp)
 //   synthesis/src/mcts.rs:273-306  best_action / solution
 //   synthesis/src/mcts.rs:310-372  explore / select_best_child / exploit_value / explore_value
 //   synthesis/src/mcts.rs:374-427  visit (expansion, auto-extend, legal-move softmax)
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "det_math.hpp"
+#include "noise.hpp"
 #include "outcome.hpp"
 
 namespace oracle {
@@ -41,7 +42,8 @@ struct MCTSConfig {
     bool auto_extend = true;
     int fpu = FPU_CONST;
     float fpu_value = 1.0f;
-    float (*fpu_fn)() = nullptr;
+    float (*fpu_fn)() = nullptr;   // Fpu::Func: an arbitrary closure, or (nullptr) the reference's own Normal(fpu_value, fpu_std)
+    float fpu_std = 0.0f;          // (study-connect4/src/main.rs:43-47) drawn from the tree's noise stream (noise.hpp)
     int noise = NOISE_NONE;
     float noise_alpha = 0.0f;
     float noise_weight = 0.0f;
@@ -93,14 +95,18 @@ struct MCTS {
     P* policy;
     MCTSConfig cfg;
     MCTSCounters* ctr = nullptr;
+    uint64_t noise_seed = 0;          // this tree's stream for Fpu::Func Normal draws / the Dirichlet sample (noise.hpp)
+    mutable uint32_t fpu_draws = 0;   // Normal draws taken so far (exploit_value is const in the reference too)
 
     // mcts.rs:123-137
     // `storage`: an empty vector whose capacity is reused (the reference allocates a fresh Vec::with_capacity per
     // move, mcts.rs:124; reusing the allocation changes no result and keeps the multi-threaded CPU baseline from
     // serialising on mmap/munmap of ~700 KB vectors).
+    // `noise_seed_`: seed of this tree's stream for the Fpu::Func Normal draws and the root's Dirichlet sample (the reference
+    // draws both from thread_rng, mcts.rs:236 / main.rs:46 — unreproducible; see noise.hpp for the discipline used here)
     MCTS(size_t capacity, const MCTSConfig& cfg_, P* policy_, const G& game, MCTSCounters* ctr_ = nullptr,
-         std::vector<Node<G>>* storage = nullptr)
-        : policy(policy_), cfg(cfg_), ctr(ctr_) {
+         std::vector<Node<G>>* storage = nullptr, uint64_t noise_seed_ = 0)
+        : policy(policy_), cfg(cfg_), ctr(ctr_), noise_seed(noise_seed_) {
         if (storage) { nodes = std::move(*storage); nodes.clear(); }
         nodes.reserve(capacity);
         nodes.push_back(unvisited(0, game, OptOutcome::none(), 0, 0.0f));
@@ -172,7 +178,7 @@ struct MCTS {
         }
     }
 
-    // mcts.rs:229-269 (Dirichlet: rand_distr gamma sampling is not restated -> unsupported here)
+    // mcts.rs:229-269
     void add_root_noise() {
         if (cfg.noise == NOISE_EQUAL) {
             Node<G>& r = nodes[root];
@@ -180,6 +186,14 @@ struct MCTS {
             float noise = 1.0f / (float)r.num_children;
             for (uint32_t c = r.first_child; c < r.last_child(); c++)
                 nodes[c].action_prob = nodes[c].action_prob * (1.0f - cfg.noise_weight) + cfg.noise_weight * noise;
+        } else if (cfg.noise == NOISE_DIRICHLET) {  // mcts.rs:241-256
+            Node<G>& r = nodes[root];
+            if (r.num_children < 2) return;
+            float noise_probs[64];
+            noise_dirichlet(noise_seed, cfg.noise_alpha, (uint32_t)r.num_children, noise_probs);
+            uint32_t k = 0;
+            for (uint32_t c = r.first_child; c < r.last_child(); c++, k++)
+                nodes[c].action_prob = nodes[c].action_prob * (1.0f - cfg.noise_weight) + cfg.noise_weight * noise_probs[k];
         }
     }
 
@@ -271,7 +285,9 @@ struct MCTS {
             switch (cfg.fpu) {
                 case FPU_CONST: return cfg.fpu_value;
                 case FPU_PARENT_Q: return parent.q();
-                default: return cfg.fpu_fn();
+                default:
+                    if (cfg.fpu_fn) return cfg.fpu_fn();
+                    return noise_fpu_normal(noise_seed, fpu_draws++, cfg.fpu_value, cfg.fpu_std);
             }
         } else {
             return -child.q();

@@ -43,7 +43,7 @@ inline void relu_inplace(float* x, int n) {
     for (int i = 0; i < n; i++) x[i] = x[i] > 0.0f ? x[i] : 0.0f;  // x.max(0.0): NaN -> 0.0 as Rust's f32::max
 }
 inline void tanh_inplace(float* x, int n) {
-    for (int i = 0; i < n; i++) x[i] = std::tanh(x[i]);
+    for (int i = 0; i < n; i++) x[i] = det_tanhf(x[i]);  // activations.rs:39-44 (x.tanh(): libm, unpinned -> det_tanhf)
 }
 // activations.rs:46-63 (exp via det_expf, see det_math.hpp)
 inline void softmax_slimnn(const float* x, float* y, int n) {

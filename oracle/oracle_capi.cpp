@@ -141,10 +141,11 @@ struct orc_mcts_config {
     int exploration;  // 0 Uct, 1 PolynomialUct
     float c;
     int solve, correct_values_on_solve, select_solved_nodes, auto_extend;
-    int fpu;  // 0 Const, 1 ParentQ
+    int fpu;  // 0 Const, 1 ParentQ, 2 Func = Normal(fpu_value, fpu_std)
     float fpu_value;
-    int noise;  // 0 None, 1 Equal
+    int noise;  // 0 None, 1 Equal, 2 Dirichlet
     float noise_alpha, noise_weight;
+    float fpu_std;
 };
 struct orc_rollout_config {
     int num_explores, random_actions_until, sample_actions_until, stop_games_when_solved;
@@ -167,6 +168,7 @@ static MCTSConfig to_cfg(const orc_mcts_config& c) {
     m.noise = c.noise;
     m.noise_alpha = c.noise_alpha;
     m.noise_weight = c.noise_weight;
+    m.fpu_std = c.fpu_std;
     return m;
 }
 static RolloutConfig to_rollout(const orc_rollout_config& c) {
@@ -290,7 +292,8 @@ void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn
     net.mode = nn_mode;
     for (int i = 0; i < n; i++) {
         Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
-        MCTS<Connect4, Connect4Net> mcts((size_t)explores + 1, cfg, &net, root);
+        // root i of a bare search: noise stream = i (the device: base_seed 0 + root index), turn 0
+        MCTS<Connect4, Connect4Net> mcts((size_t)explores + 1, cfg, &net, root, nullptr, nullptr, noise_tree_seed((uint64_t)i, 0));
         mcts.explore_n((size_t)explores);
         c4_search_collect(mcts, i, action_selection, child_N, child_W, child_P, child_sol, root_stat, root_sol, num_nodes,
                           best_action, target_pi, target_q);
@@ -497,8 +500,8 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
         for (int g = start; g < start + count; g++) {
             ChaChaRng rng = ChaChaRng::seed_from_u64(base_seed + first_game + (uint64_t)g);
             GameRecord rec;
-            if (use_cache) run_game(cfg, cached, rng, rec, &local);
-            else run_game(cfg, net, rng, rec, &local);
+            if (use_cache) run_game(cfg, cached, rng, rec, &local, base_seed + first_game + (uint64_t)g);
+            else run_game(cfg, net, rng, rec, &local, base_seed + first_game + (uint64_t)g);
             if (plies) plies[g] = rec.plies;
             if (final_kind) final_kind[g] = rec.final_kind;
             for (int k = 0; k < rec.plies; k++) {

@@ -124,8 +124,10 @@ int sample_action(const RolloutConfig& cfg, MCTS<Connect4, P>& mcts, const Conne
 }
 
 // alpha_zero.rs:229-268 + 296-338
+// `noise_stream` = base_seed + game index: with the turn it seeds each move's tree for Fpu::Func / Dirichlet draws (noise.hpp)
 template <class P>
-void run_game(const RolloutConfig& cfg, P& policy, ChaChaRng& rng, GameRecord& rec, MCTSCounters* ctr = nullptr) {
+void run_game(const RolloutConfig& cfg, P& policy, ChaChaRng& rng, GameRecord& rec, MCTSCounters* ctr = nullptr,
+              uint64_t noise_stream = 0) {
     Connect4 game = Connect4::new_game();
     OptOutcome solution = OptOutcome::none();
     float search_policy[9];
@@ -136,7 +138,8 @@ void run_game(const RolloutConfig& cfg, P& policy, ChaChaRng& rng, GameRecord& r
 
     std::vector<Node<Connect4>> storage;
     while (!solution.some) {
-        MCTS<Connect4, P> mcts((size_t)cfg.num_explores + 1, cfg.mcts_cfg, &policy, game, ctr, &storage);
+        MCTS<Connect4, P> mcts((size_t)cfg.num_explores + 1, cfg.mcts_cfg, &policy, game, ctr, &storage,
+                               noise_tree_seed(noise_stream, (uint32_t)num_turns));
         mcts.explore_n((size_t)cfg.num_explores);
 
         mcts.target_policy(search_policy);

@@ -16,11 +16,11 @@ gfx950). There is no CPU fallback: importing works anywhere, creating an Engine 
 MI355X raises.
 """
 from .config import (ActionSelection, Exploration, Fpu, MCTSConfig, PolicyNoise, RolloutConfig, ValueTarget,
-                     parity_mcts_config, parity_rollout_config)
+                     parity_mcts_config, parity_rollout_config, reference_selfplay_mcts_config)
 from .engine import Engine, SynthesisAmdError, library_path, load_library, shard_games
 
 __all__ = [
     "ActionSelection", "Exploration", "Fpu", "MCTSConfig", "PolicyNoise", "RolloutConfig", "ValueTarget",
-    "parity_mcts_config", "parity_rollout_config", "Engine", "SynthesisAmdError", "library_path", "load_library",
+    "parity_mcts_config", "parity_rollout_config", "reference_selfplay_mcts_config", "Engine", "SynthesisAmdError", "library_path", "load_library",
     "shard_games",
 ]

@@ -1,8 +1,9 @@
 """Plain-data mirrors of synthesis/src/config.rs (same names, same fields, same meaning).
 
-`Fpu.Func` (config.rs:25) is a Rust closure and cannot cross the C ABI; `PolicyNoise.Dirichlet` needs rand_distr's
-gamma sampler and is not implemented on the device yet: both are representable here and rejected by the engine with
-SYN_ERR_UNSUPPORTED, mirroring "error, not silent fallback".
+`Fpu.Func` (config.rs:25) is a Rust closure and cannot cross the C ABI; the closure the reference itself configures,
+`Normal::new(1.0, 0.1).sample(&mut thread_rng())` (study-connect4/src/main.rs:43-47), is `Fpu.Func` with `fpu_value` =
+mean and `fpu_std` = standard deviation, sampled on the device from a per-tree StdRng stream (reproducible, unlike
+thread_rng). `PolicyNoise.Dirichlet` samples rand_distr's Dirichlet on the device the same way.
 """
 import ctypes as C
 import enum
@@ -45,6 +46,7 @@ class CMctsConfig(C.Structure):           # struct syn_mcts_config
         ("auto_extend", C.c_int32),
         ("fpu", C.c_int32), ("fpu_value", C.c_float),
         ("root_policy_noise", C.c_int32), ("noise_alpha", C.c_float), ("noise_weight", C.c_float),
+        ("fpu_std", C.c_float),
     ]
 
 
@@ -77,11 +79,12 @@ class MCTSConfig:                         # config.rs:28-37
     root_policy_noise: PolicyNoise = PolicyNoise.NoNoise
     noise_alpha: float = 0.0
     noise_weight: float = 0.0
+    fpu_std: float = 0.0              # Fpu.Func = Normal(fpu_value, fpu_std)
 
     def to_c(self) -> CMctsConfig:
         return CMctsConfig(int(self.exploration), float(self.c), int(self.solve), int(self.correct_values_on_solve),
                            int(self.select_solved_nodes), int(self.auto_extend), int(self.fpu), float(self.fpu_value),
-                           int(self.root_policy_noise), float(self.noise_alpha), float(self.noise_weight))
+                           int(self.root_policy_noise), float(self.noise_alpha), float(self.noise_weight), float(self.fpu_std))
 
 
 @dataclass
@@ -108,6 +111,13 @@ def parity_mcts_config(**kw) -> MCTSConfig:
     """policy_mcts_cfg of study-connect4/src/main.rs:58-66: the deterministic variant (Fpu::Const(1.0)) of the
     reference's self-play MCTS configuration (whose Fpu::Func samples N(1, 0.1) from thread_rng, main.rs:43-47)."""
     return MCTSConfig(**kw)
+
+
+def reference_selfplay_mcts_config(**kw) -> MCTSConfig:
+    """mcts_cfg of study-connect4/src/main.rs:37-49 as written: Fpu::Func(|| Normal(1.0, 0.1)) and no root noise."""
+    d = dict(fpu=Fpu.Func, fpu_value=1.0, fpu_std=0.1)
+    d.update(kw)
+    return MCTSConfig(**d)
 
 
 def parity_rollout_config(num_explores: int = 800, **kw) -> RolloutConfig:

@@ -149,6 +149,47 @@ SYN_DEV uint32_t row_ballot(bool p) {
     return (uint32_t)(b >> (lane_id() & 48)) & 0xFFFFu;
 }
 
+// Deterministic f32 tanh (slimnn Tanh, activations.rs:39-44); same algorithm as oracle/det_math.hpp det_tanhf, bit for bit.
+SYN_DEV float det_tanhf(float x) {
+    if (x != x) return x;
+    const float z = x < 0.0f ? -x : x;
+    if (z > 44.0f) return x < 0.0f ? -1.0f : 1.0f;
+    if (z >= 0.625f) {
+        const float s = det_expf(z + z);
+        const float t = 1.0f - 2.0f / (s + 1.0f);
+        return x < 0.0f ? -t : t;
+    }
+    const float w = x * x;
+    float p = -5.70498872745e-3f;
+    p = __builtin_fmaf(p, w, 2.06390887954e-2f);
+    p = __builtin_fmaf(p, w, -5.37397155531e-2f);
+    p = __builtin_fmaf(p, w, 1.33314422036e-1f);
+    p = __builtin_fmaf(p, w, -3.33332819422e-1f);
+    return __builtin_fmaf(p * w, x, x);
+}
+
+// ------------------------------------------------------------------------------------------------ packed division
+// Two correctly rounded f32 quotients per instruction stream: the fused-multiply-add core of the hardware's own IEEE division
+// (rcp, one Newton step on the reciprocal, quotient, two residual corrections — the sequence hipcc emits between
+// v_div_scale and v_div_fixup under -fhip-fp32-correctly-rounded-divide-sqrt), written on 2-vectors so that it issues as
+// v_pk_fma_f32 / v_pk_mul_f32: 2 v_rcp + 7 packed instructions for TWO divisions instead of 2 x 12. Scaling and fix-up are
+// what the hardware sequence adds for operands near the ends of the exponent range, infinities, NaNs and zero divisors;
+// they are the identity for  a = 0 or 2^-60 <= a <= 2^60  and  1 <= b <= 2^16  (no intermediate leaves the normal range),
+// which is the ONLY range callers may use this on. tests/test_gpu_parity.py compares it with a / b bit for bit.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+SYN_DEV f32x2 div2_safe_range(f32x2 a, f32x2 b) {
+    f32x2 y = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
+    const f32x2 e = __builtin_elementwise_fma(-b, y, f32x2{1.0f, 1.0f});
+    y = __builtin_elementwise_fma(e, y, y);
+    f32x2 q = a * y;
+    f32x2 r = __builtin_elementwise_fma(-b, q, a);
+    q = __builtin_elementwise_fma(r, y, q);
+    r = __builtin_elementwise_fma(-b, q, a);
+    return __builtin_elementwise_fma(r, y, q);
+}
+// smallest non-zero prior the packed division accepts; records of smaller (or non-finite) priors carry a flag (sign bit)
+constexpr float PRIOR_SAFE_MIN = 0x1p-40f;
+
 // ------------------------------------------------------------------------------------------------ Connect4
 namespace c4 {
 constexpr int WIDTH = 9, HEIGHT = 7;
@@ -183,6 +224,33 @@ SYN_DEV bool won(uint64_t bb) {
     return (v | h | d1 | d2) != 0;
 }
 SYN_DEV int col_height(uint64_t occ, int col) { return __popcll(occ & (0x7Full << (7 * col))); }
+
+// Legal columns (bit c = column c is not full) from the occupancy board: column c is full iff its top cell, bit 6 + 7c,
+// is set. Four top-row bits at stride 7 (x bit 7i) are gathered by ONE full-rate 24-bit multiply: x * (2^18 + 2^12 + 2^6 + 1)
+// puts bit 7i on bit 18 + i, every other partial product falls outside bits 18..21 and no two coincide (no carries).
+// ~14 full-rate VALU instructions instead of nine 64-bit mask + popcount pairs.
+SYN_DEV uint32_t legal_columns(uint64_t occ) {
+    constexpr uint32_t PICK = 1u | (1u << 7) | (1u << 14) | (1u << 21), GATHER = (1u << 18) | (1u << 12) | (1u << 6) | 1u;
+    const uint32_t free_lo = ~(uint32_t)occ, free_hi = ~(uint32_t)(occ >> 32);
+    const uint32_t a = (__umul24((free_lo >> 6) & PICK, GATHER) >> 18) & 0xFu;   // columns 0..3: bits 6, 13, 20, 27
+    const uint32_t b = (__umul24((free_hi >> 2) & PICK, GATHER) >> 18) & 0xFu;   // columns 4..7: bits 34, 41, 48, 55
+    const uint32_t c = (free_hi >> 30) & 1u;                                      // column 8: bit 62
+    return a | (b << 4) | (c << 8);
+}
+
+// Cells c (one bit each) such that won(m | c): c completes a four-in-a-row with three stones of m (connect4.rs:70-83, same
+// anchor masks, so exactly the geometric lines the reference accepts). For anchor a and shift s the line is
+// {a, a+s, a+2s, a+3s}; T_k = anchors whose other three cells are in m; the winning cell is a + k*s.
+SYN_DEV uint64_t winning_cells_dir(uint64_t m, int s, uint64_t mask) {
+    const uint64_t m1 = m >> s, m2 = m >> (2 * s), m3 = m >> (3 * s);
+    const uint64_t p01 = m & m1, p23 = m2 & m3;
+    const uint64_t t3 = mask & p01 & m2, t2 = mask & p01 & m3, t1 = mask & m & p23, t0 = mask & m1 & p23;
+    return t0 | (t1 << s) | (t2 << (2 * s)) | (t3 << (3 * s));
+}
+SYN_DEV uint64_t winning_cells(uint64_t m) {
+    return winning_cells_dir(m, 6, D1_MASK) | winning_cells_dir(m, 8, D2_MASK) | winning_cells_dir(m, 7, H_MASK) |
+           winning_cells_dir(m, 1, V_MASK);
+}
 
 // Lowest empty cell of every non-full column (gravity keeps columns contiguous from the bottom):
 // a cell is "next free" iff it is empty and (it is in row 0 or the cell below is occupied).

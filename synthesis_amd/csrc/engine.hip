@@ -17,6 +17,7 @@
 #include "../../include/synthesis_amd.h"
 #include "engine_kernels.cuh"
 #include "lane_kernel.cuh"
+#include "pc_kernel.cuh"
 #include "frozen_kernel.cuh"
 #include "train_kernels.cuh"
 
@@ -61,6 +62,8 @@ struct syn_engine {
     size_t train_data_cap = 0, train_data_n = 0;
     uint4* d_path = nullptr;   // lane kernel's per-wave descent logs
     size_t path_bytes = 0;
+    unsigned char* d_vw = nullptr;  // producer/consumer kernel: per-virtual-wave parked state + network outputs
+    size_t vw_bytes = 0;
     unsigned long long* d_counters = nullptr;
     // self-play output buffers (device), grown on demand
     int out_games = 0;
@@ -151,14 +154,17 @@ static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) 
     if (!c) return fail(h, SYN_ERR_INVALID_ARGUMENT, "mcts config is NULL");
     if (c->exploration != SYN_EXPLORATION_UCT && c->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration %d", c->exploration);
-    if (c->fpu != SYN_FPU_CONST && c->fpu != SYN_FPU_PARENT_Q)
-        return fail(h, SYN_ERR_UNSUPPORTED, "Fpu::Func is a host closure and cannot run on the device");
-    if (c->root_policy_noise == SYN_NOISE_DIRICHLET)
-        return fail(h, SYN_ERR_UNSUPPORTED, "PolicyNoise::Dirichlet is not implemented on the device yet");
-    if (c->root_policy_noise != SYN_NOISE_NONE && c->root_policy_noise != SYN_NOISE_EQUAL)
+    if (c->fpu != SYN_FPU_CONST && c->fpu != SYN_FPU_PARENT_Q && c->fpu != SYN_FPU_NORMAL)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu %d (an arbitrary Fpu::Func closure cannot cross the C ABI; "
+                                                 "SYN_FPU_NORMAL is the reference's own Normal(mean, std) closure)", c->fpu);
+    if (c->fpu == SYN_FPU_NORMAL && !(c->fpu_std >= 0.0f && c->fpu_std < 1e30f && c->fpu_value == c->fpu_value))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_FPU_NORMAL needs a finite mean and a standard deviation >= 0 (Normal::new)");
+    if (c->root_policy_noise != SYN_NOISE_NONE && c->root_policy_noise != SYN_NOISE_EQUAL && c->root_policy_noise != SYN_NOISE_DIRICHLET)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown root policy noise %d", c->root_policy_noise);
-    if (c->root_policy_noise == SYN_NOISE_EQUAL && !(c->noise_weight >= 0.0f))
-        return fail(h, SYN_ERR_INVALID_ARGUMENT, "PolicyNoise::Equal weight must be >= 0");
+    if (c->root_policy_noise != SYN_NOISE_NONE && !(c->noise_weight >= 0.0f))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "PolicyNoise weight must be >= 0");
+    if (c->root_policy_noise == SYN_NOISE_DIRICHLET && !(c->noise_alpha > 0.0f && c->noise_alpha < 1e30f))
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "PolicyNoise::Dirichlet alpha must be > 0 (Dirichlet::new_with_size)");
     d.exploration = c->exploration;
     d.c = c->c;
     d.solve = c->solve != 0;
@@ -169,6 +175,10 @@ static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) 
     d.fpu_value = c->fpu_value;
     d.noise = c->root_policy_noise;
     d.noise_weight = c->noise_weight;
+    d.fpu_std = c->fpu_std;
+    d.noise_alpha = c->noise_alpha;
+    // (c * prior * sqrt(N)) / (1 + n) goes through div2_safe_range only when the numerator stays inside its exact range
+    d.fast_div = (c->c >= 0x1p-10f && c->c <= 0x1p10f) ? 1 : 0;
     return SYN_OK;
 }
 
@@ -196,14 +206,78 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // SYN_DEBUG=1 SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it (0 = never); by default it takes over once every CU can
     // be given 256 trees (4 waves; measured 41.9k games/s at 65,536 concurrent games against 31.8k for the queued
     // row-per-tree workgroups), 8 waves up to 512 trees per CU, 12 beyond (16 waves spill: measured slower).
+    // Producer/consumer kernel (pc_kernel.cuh): 12 tree waves x NV virtual waves of 64 trees + 4 matrix waves per CU. Measured
+    // slower than the symmetric lane kernel (the f32 MFMA shares the SIMD's FP32 datapath with the VALU, so
+    // dedicating waves to the matrix pipe frees nothing), so it is never chosen automatically:
+    // SYN_DEBUG=1 SYN_PC=<NV 1..3> selects it (parity tests, profiling).
+    {
+        int nv = 0;
+        if (const char* ev = debug_env("SYN_PC")) nv = std::atoi(ev);
+        if (nv >= 1 && nv <= PcGeom::NV_MAX && h->cap <= LANE_MAX_CAP) {
+            const int per_wg = 64 * PcGeom::TREE_WAVES * nv;
+            const int pgrid = (want_slots + per_wg - 1) / per_wg;
+            const size_t nvw = (size_t)pgrid * PcGeom::TREE_WAVES * nv;
+            const size_t need_path = nvw * PATH_ENTRIES * sizeof(uint4);
+            if (need_path > h->path_bytes) {
+                if (h->d_path) (void)hipFree(h->d_path);
+                h->d_path = nullptr;
+                h->path_bytes = 0;
+                hipError_t pe = hipMalloc(&h->d_path, need_path);
+                if (pe != hipSuccess) return pe;
+                h->path_bytes = need_path;
+            }
+            const size_t need_vw = nvw * PcGeom::VW_BYTES;
+            if (need_vw > h->vw_bytes) {
+                if (h->d_vw) (void)hipFree(h->d_vw);
+                h->d_vw = nullptr;
+                h->vw_bytes = 0;
+                hipError_t pe = hipMalloc(&h->d_vw, need_vw);
+                if (pe != hipSuccess) return pe;
+                h->vw_bytes = need_vw;
+            }
+            EngineParams PL = P;
+            PL.path = h->d_path;
+            PL.vw_buf = h->d_vw;
+            PL.nv = nv;
+            PL.debug_prio = 2;
+            if (const char* ev = debug_env("SYN_PC_PRIO")) PL.debug_prio = std::atoi(ev);
+            PL.debug_stub = (PROF && debug_env("SYN_PC_STUB") != nullptr) ? 1 : 0;
+            PL.lane_thresh = 48;
+            if (const char* ev = debug_env("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
+            if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
+            PL.lane_thresh &= ~15;  // whole tiles
+#define SYN_LAUNCH_PC(FAST)                                                                                        \
+    {                                                                                                              \
+        auto k = selfplay_kernel_pc<MODE, COUNT, FAST, PROF>;                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)PcLds::BYTES);         \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(pgrid), dim3(PcGeom::NT), PcLds::BYTES, h->stream, PL);                         \
+    }
+            if (fast) SYN_LAUNCH_PC(true) else SYN_LAUNCH_PC(false)
+#undef SYN_LAUNCH_PC
+            h->last_shape = 5; h->last_grid = pgrid; h->last_threads = PcGeom::NT;
+            if (out_grid) *out_grid = pgrid;
+            if (out_nt) *out_nt = PcGeom::NT;
+            return hipGetLastError();
+        }
+    }
     {
         int nw = 0;
-        if (want_slots >= h->num_cus * 256) nw = want_slots > h->num_cus * 512 ? 12 : (want_slots > h->num_cus * 256 ? 8 : 4);
+        // 4 waves per workgroup up to 256 trees per CU, 8 up to 512, 12 up to 768, 16 (hand-pipelined network tile that fits
+        // the 128-VGPR budget: mlp_tile16_pipe) beyond
+        if (want_slots >= h->num_cus * 256)
+            nw = want_slots > h->num_cus * 768 ? 16 : (want_slots > h->num_cus * 512 ? 12 : (want_slots > h->num_cus * 256 ? 8 : 4));
+        // the random draws of Fpu::Func / PolicyNoise::Dirichlet (noise.cuh) exist in the lane-per-tree kernels only
+        const bool needs_noise = P.mcts.fpu == 2 || P.mcts.noise == 2;
+        if (needs_noise && nw == 0) nw = 4;
         if (const char* ev = debug_env("SYN_LANES")) nw = std::atoi(ev);
+        if (needs_noise && !(nw == 4 || nw == 8 || nw == 12 || nw == 16)) nw = 4;
+        if (needs_noise && h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
-            const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint4);
+            const size_t need_path = (size_t)lgrid * nw * PATH_ENTRIES * sizeof(uint4);
             if (need_path > h->path_bytes) {
                 if (h->d_path) (void)hipFree(h->d_path);
                 h->d_path = nullptr;
@@ -282,7 +356,7 @@ static hipError_t launch_rollout_search(syn_engine* h, const EngineParams& P, in
     int want_slots = h->slots < jobs ? h->slots : jobs;
     int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
     if (lgrid < 1) lgrid = 1;
-    const size_t need_path = (size_t)lgrid * nw * 4096 * sizeof(uint4);
+    const size_t need_path = (size_t)lgrid * nw * PATH_ENTRIES * sizeof(uint4);
     if (need_path > h->path_bytes) {
         if (h->d_path) (void)hipFree(h->d_path);
         h->d_path = nullptr;
@@ -370,7 +444,8 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     // the launch may round the slot count up to a whole workgroup (<= 1024 trees: lane kernel)
     // + 48: the 3-quad launch rounds to multiples of 48 slots
     // (768: the 12-wave lane kernel rounds to multiples of 768 slots)
-    h->pool_slots = ((h->slots + 1023) / 1024) * 1024 + 768;
+    // (2304: the producer/consumer kernel rounds to multiples of 768 x NV slots, NV <= 3)
+    h->pool_slots = ((h->slots + 1023) / 1024) * 1024 + 2304;
     size_t nodes = (size_t)h->pool_slots * h->cap;
     if ((e = hipMalloc(&h->d_stat, nodes * 32)) != hipSuccess) return bail("hipMalloc(node pool)", e);
     h->d_edge = reinterpret_cast<uint4*>(h->d_stat);  // same records, edge half = odd 16-byte elements
@@ -396,6 +471,7 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_wimg);
     hipFree(h->d_job_next);
     hipFree(h->d_path);
+    hipFree(h->d_vw);
     hipFree(h->d_train_data);
     hipFree(h->d_cache);
     hipFree(h->d_cache_stats);
@@ -855,7 +931,23 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     if (prof) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (pgrid < 0) {  // lane kernel: per wave [A, B, C, move, rounds, tiles, active lanes, evals]
+        if (h->last_shape == 5) {  // producer/consumer kernel: per wave [role, ...] (pc_kernel.cuh)
+            const int nwv = pgrid * 16;
+            std::vector<unsigned long long> hp((size_t)nwv * 8);
+            HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(h, hipFree(d_prof));
+            d_prof = nullptr;
+            double mw = 0, mb = 0, mt = 0, nm = 0, tw = 0, ta = 0, tc = 0, tr = 0, tf = 0, ntw = 0;
+            for (int w = 0; w < nwv; w++) {
+                const unsigned long long* o = &hp[(size_t)w * 8];
+                if (o[0] == 1) { nm++; mw += (double)o[1]; mb += (double)o[2]; mt += (double)o[3]; }
+                else if (o[0] == 2) { ntw++; tw += (double)o[1]; ta += (double)o[2]; tc += (double)o[3]; tr += (double)o[4]; tf += (double)o[5]; }
+            }
+            fprintf(stderr, "[syn profile pc] grid=%d | matrix waves=%.0f: busy %.1f%% of (busy+wait), %.0f cycles per tile, %.0f tiles per wave | "
+                            "tree waves=%.0f: per visit: wait=%.0f C=%.0f A+submit=%.0f cycles, explores finished=%.2f, visits per wave=%.0f\n",
+                    pgrid, nm, 100.0 * mb / (mb + mw + 1e-9), mb / (mt + 1e-9), mt / (nm + 1e-9), ntw, tw / (tr + 1e-9), tc / (tr + 1e-9),
+                    ta / (tr + 1e-9), tf / (tr + 1e-9), tr / (ntw + 1e-9));
+        } else if (pgrid < 0) {  // lane kernel: per wave [A, B, C, move, rounds, tiles, active lanes, evals]
             int nwv = -pgrid * (pnt / 64);
             std::vector<unsigned long long> hp((size_t)nwv * 10);
             HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
@@ -1264,6 +1356,48 @@ int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out) {
     hipLaunchKernelGGL(debug_rng_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, (unsigned long long)seed, n, d);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipMemcpyAsync(out, d, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_activation_forward(syn_engine* h, int kind, const float* x, int batch, int n, float* y) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (kind < SYN_ACT_RELU || kind > SYN_ACT_SOFTMAX) return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown activation %d", kind);
+    if (batch < 0 || n < 1 || (batch > 0 && (!x || !y))) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (batch == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t cnt = (size_t)batch * (size_t)n;
+    int rc = ensure_scratch(h, cnt * 8 + 256);
+    if (rc != SYN_OK) return rc;
+    float* dx = static_cast<float*>(h->d_scratch);
+    float* dy = dx + cnt;
+    HIP_TRY(h, hipMemcpyAsync(dx, x, cnt * 4, hipMemcpyHostToDevice, h->stream));
+    const size_t threads = kind == SYN_ACT_SOFTMAX ? (size_t)batch : cnt;
+    hipLaunchKernelGGL(activation_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, kind, dx, batch, n, dy);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(y, dy, cnt * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
+int syn_debug_fast_div(syn_engine* h, const float* a, const float* b, int n, float* out_fast, float* out_full) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!a || !b || !out_fast || !out_full))) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (n == 0) return SYN_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    size_t nb = (size_t)n;
+    int rc = ensure_scratch(h, nb * 16 + 256);
+    if (rc != SYN_OK) return rc;
+    float* da = static_cast<float*>(h->d_scratch);
+    float* db = da + nb;
+    float* df = db + nb;
+    float* dd = df + nb;
+    HIP_TRY(h, hipMemcpyAsync(da, a, nb * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(db, b, nb * 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(debug_fast_div_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, da, db, n, df, dd);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(out_fast, df, nb * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_full, dd, nb * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SYN_OK;
 }

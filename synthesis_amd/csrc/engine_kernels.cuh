@@ -49,6 +49,10 @@ struct EngineParams {
     uint32_t cache_shift;          // 64 - log2(entries)
     unsigned long long* cache_stats;  // [hits, misses]
     uint4* path;                   // lane kernel: per-wave descent log [wave][level 0..63][lane 0..63]
+    unsigned char* vw_buf;         // producer/consumer kernel: parked state + network outputs per virtual wave (pc_kernel.cuh)
+    int nv;                        // producer/consumer kernel: virtual waves per tree wave
+    int debug_prio;                // producer/consumer kernel: bit 0 = matrix waves at priority 3, bit 1 = tree waves at priority 3
+    int debug_stub;                // PROF builds only: replace the network by a cheap stand-in (tree-side ceiling)
     // self-play
     unsigned long long base_seed;  // game g uses StdRng::seed_from_u64(base_seed + first_game + g)
     unsigned long long first_game;
@@ -890,6 +894,38 @@ __global__ void debug_rng_kernel(unsigned long long seed, int n, uint32_t* out) 
         StdRng r;
         r.seed_from_u64(seed);
         out[i] = r.word((uint32_t)i);
+    }
+}
+// slimnn activations as layers (slimnn/src/activations.rs:31-63) on [batch][n] rows: 0 = ReLU (x.max(0.0)), 1 = Tanh
+// (det_tanhf), 2 = Softmax::apply_1d — exp of every element (det_expf, NO max subtraction, as the reference), summed in index
+// order, each element divided by the total. One thread per row for the softmax (the sum is sequential by definition).
+__global__ void activation_kernel(int kind, const float* x, int batch, int n, float* y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kind == 2) {
+        if (i >= batch) return;
+        const float* xr = x + (size_t)i * n;
+        float* yr = y + (size_t)i * n;
+        float total = 0.0f;
+        for (int k = 0; k < n; k++) {
+            const float e = det_expf(xr[k]);
+            yr[k] = e;
+            total += e;
+        }
+        for (int k = 0; k < n; k++) yr[k] = yr[k] / total;
+        return;
+    }
+    if ((size_t)i >= (size_t)batch * n) return;
+    const float v = x[i];
+    y[i] = kind == 0 ? __builtin_fmaxf(v, 0.0f) : det_tanhf(v);
+}
+
+__global__ void debug_fast_div_kernel(const float* a, const float* b, int n, float* fast, float* full) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int j = i ^ 1;  // partner element: both halves of the packed instructions carry live data
+        const f32x2 q = div2_safe_range(f32x2{a[i], a[j < n ? j : i]}, f32x2{b[i], b[j < n ? j : i]});
+        fast[i] = q[0];
+        full[i] = a[i] / b[i];
     }
 }
 __global__ void debug_math_kernel(const float* a, const float* b, int n, float* e, float* d, float* s) {

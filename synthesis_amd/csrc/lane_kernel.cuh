@@ -21,6 +21,7 @@
 //                        search is over
 #pragma once
 #include "engine_kernels.cuh"
+#include "noise.cuh"
 
 namespace syn {
 
@@ -43,6 +44,14 @@ namespace syn {
 // q|turns} per level into a per-wave path buffer [level][lane] (coalesced 1 KB rows) and backprop replays it.
 constexpr uint32_t LANE_MAX_CAP = 1u << 16;   // blocks per tree = cap / 4 must fit the 14-bit block field
 constexpr uint32_t REC_ROOT = 0xFFFFFFFFu;
+// Path buffer of one wave: two planes of [level 0..63][lane 0..63] 16-byte entries. Plane 0 = {record, N, block|count|
+// solution (pm_*), q|turns}; plane 1 = the node's own sums {W_lose, W_draw, W_win} as the descent saw them in the line it
+// read anyway (flag PM_HAS_W in plane 0's .z). Backprop then needs NO random line read for a level it only adds to: a
+// dirtied line costs the memory system one more line transaction, a re-read line another (tools/ubench/rw_lines.hip:
+// ~50 G random line reads/s, ~23 G read+dirty visits/s) — the re-reads were 3.4 of 15 line transactions per explore.
+constexpr uint32_t PATH_PLANE = 4096;         // entries per plane
+constexpr uint32_t PATH_ENTRIES = 2 * PATH_PLANE;
+constexpr uint32_t PM_HAS_W = 1u << 21;
 
 SYN_DEV uint32_t nf_make(uint32_t n, bool solved, uint32_t blk, uint32_t kind) {
     return n | ((solved ? 1u : 0u) << 15) | (blk << 16) | (kind << 30);
@@ -62,23 +71,20 @@ SYN_DEV uint32_t pm_kind(uint32_t m) { return (m >> 19) & 3u; }
 // exploit_value of a solved child (mcts.rs:343-350): outcome.reversed().value() — child Win -> -1, Draw -> 0,
 // Lose -> +1 (game.rs:29-43) — or -inf when solved nodes are not to be selected
 SYN_DEV float pw_q_solved(uint32_t kind, bool select_solved) {
-    return select_solved ? (kind == 2u ? -1.0f : (kind == 1u ? 0.0f : 1.0f)) : -__builtin_inff();
+    return select_solved ? 1.0f - (float)kind : -__builtin_inff();  // kind 0 Lose -> +1, 1 Draw -> 0, 2 Win -> -1 (exact)
 }
 SYN_DEV unsigned char* blk_ptr(unsigned char* slab, uint32_t b) { return slab + (size_t)b * 128u; }
 SYN_DEV unsigned char* rec_ptr(unsigned char* slab, uint32_t rec) {
     return slab + (size_t)(rec >> 4) * 128u + 16u + (rec & 15u) * 12u;
 }
-SYN_DEV uint32_t legal_mask_of(uint64_t occ) {
-    uint32_t lm = 0;
-#pragma unroll
-    for (int c = 0; c < 9; c++)
-        if (c4::col_height(occ, c) < c4::HEIGHT) lm |= 1u << c;
-    return lm;
-}
+SYN_DEV uint32_t legal_mask_of(uint64_t occ) { return c4::legal_columns(occ); }
 typedef uint32_t lu3 __attribute__((ext_vector_type(3)));
 SYN_DEV void st_rec(unsigned char* slab, uint32_t rec, uint32_t qt, float P, uint32_t nf) {
     *reinterpret_cast<lu3*>(rec_ptr(slab, rec)) = lu3{qt, f32_bits(P), nf};
 }
+// Records of a block's unused slots (a node with fewer than nine legal columns): exploit value -inf, prior 0, no visits — the
+// descent scans all nine slots without a count check and such a slot can never win the strict `>` of select_best_child.
+SYN_DEV void st_rec_none(unsigned char* slab, uint32_t rec) { st_rec(slab, rec, 0xFF800000u, 0.0f, 0u); }
 SYN_DEV lu3 ld_rec(unsigned char* slab, uint32_t rec) { return *reinterpret_cast<const lu3*>(rec_ptr(slab, rec)); }
 
 struct LaneTree {
@@ -92,6 +98,7 @@ struct LaneTree {
     int job;                  // game / root index, -1 = idle
     int turn;
     uint32_t rng_index;
+    uint32_t fpu_draws;       // Fpu::Func Normal draws this tree has taken (noise.cuh); 0 at every new root
 };
 
 // Descent state of a lane. It persists across rounds: a round ends as soon as `thresh` lanes of the wave stand on a
@@ -131,6 +138,7 @@ SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
     T.root_sol = 0;
     T.root_my = 0;
     T.root_op = 0;
+    T.fpu_draws = 0;
     if (MODE == MODE_SEARCH && T.job >= 0) {
         T.root_my = P.in_my[T.job];
         T.root_op = P.in_op[T.job];
@@ -147,11 +155,18 @@ SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
     return b;
 }
 
+// Out of line: the draws sit on the slow (runtime-switched) configuration path, nine call sites per level of the descent
+__device__ __attribute__((noinline)) float lane_fpu_draw(uint64_t tree_seed, uint32_t j, float mean, float std) {
+    return noise_fpu_normal(tree_seed, j, mean, std);
+}
+
 // ---------------------------------------------------------------------------------------------- phase A
 // pl = this lane's column of the wave's path buffer: level L lives at pl[L * 64]
-template <bool COUNT, bool FAST>
+// ROOT_IN_T: the root position is live in T.root_my / T.root_op (pc_kernel.cuh) instead of parked in LDS at pk[]
+template <bool COUNT, bool FAST, bool ROOT_IN_T = false>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
-                                uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride) {
+                                uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride,
+                                uint64_t noise_seed = 0) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
@@ -174,8 +189,13 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
         rec = REC_ROOT;
         level = 0;
         // the root position is parked in LDS between searches (it is only needed here and at the end of a search)
-        my = (uint64_t)pk[0] | ((uint64_t)pk[pk_stride] << 32);
-        op = (uint64_t)pk[2 * pk_stride] | ((uint64_t)pk[3 * pk_stride] << 32);
+        if (ROOT_IN_T) {
+            my = T.root_my;
+            op = T.root_op;
+        } else {
+            my = (uint64_t)pk[0] | ((uint64_t)pk[pk_stride] << 32);
+            op = (uint64_t)pk[2 * pk_stride] | ((uint64_t)pk[3 * pk_stride] << 32);
+        }
         nsolved = false;
         kind = 0;
         qt = 0;
@@ -187,12 +207,13 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
         } else {
             blk = 1;           // the root's block
             pN = (float)T.iter;
-            if (!cfg.fpu_const()) {  // Fpu::ParentQ at the first level needs the root's q
+            if (!cfg.fpu_const() && !cfg.fpu_normal()) {  // Fpu::ParentQ at the first level needs the root's q
                 const float4 a = *reinterpret_cast<const float4*>(blk_ptr(slab, 1));
                 qt = f32_bits(-((a.z - a.x) / pN));
             }
         }
-        pl[0] = make_uint4(REC_ROOT, f32_bits(pN), pm_make(blk, (uint32_t)__popc(legal_mask_of(my | op)), false, 0), 0u);
+        pl[0] = make_uint4(REC_ROOT, f32_bits(pN),
+                           pm_make(blk, (uint32_t)__popc(legal_mask_of(my | op)), false, 0) | (blk != 0u ? PM_HAS_W : 0u), 0u);
         desc = true;
     }
 
@@ -200,6 +221,9 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     // A round ends when `thresh` lanes (a whole number of 16-position tiles) stand on a leaf that needs the network, or
     // when nobody is descending any more.
     bool hit_solved = false, at_leaf = pending;
+    // legal columns of the current position: computed once per round and updated as the descent drops stones (a column
+    // leaves the mask when its seventh stone lands); the children of a node are its legal columns in ascending order
+    uint32_t lm = legal_mask_of(my | op);
     for (;;) {
         if (desc) {
             if (nsolved) { hit_solved = true; desc = false; at_leaf = true; }
@@ -207,48 +231,97 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
         }
         if (__ballot(desc) == 0ull || __popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
         if (desc) {
-            const uint32_t lm = legal_mask_of(my | op);
             const uint32_t nc = (uint32_t)__popc(lm);
             const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, blk));
+            const uint4 hdr = line[0];  // the node's own sums: logged for backprop (same line, no extra transaction)
             uint32_t d[28];
 #pragma unroll
             for (int j = 0; j < 7; j++) {
                 const uint4 t = line[1 + j];
                 d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
             }
+            pl[PATH_PLANE + level * 64] = hdr;  // (the entry's PM_HAS_W flag was set when the descent arrived here)
             const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(qt);  // parent.q() = -(stored q)
             const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
-            // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces)
-            float best_v = 0.0f;
-            uint32_t best_i = 0, b_qt = 0, b_nf = 0, b_act = 0;
-            uint32_t m = lm;
+            // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
+            // the last child hold -inf / prior 0 (st_rec_none), so all nine are scored without a count check.
+            // what an unexpanded, unsolved child scores under a non-constant FPU: the parent's q (Fpu::ParentQ), or one
+            // Normal(mean, std) draw per such child per scan, in child order (Fpu::Func, mcts.rs:351-356)
+            float qf[9];
 #pragma unroll
-            for (uint32_t i = 0; i < 9; i++) {
-                const uint32_t act = (uint32_t)(__ffs((int)m) - 1);  // child i = the i-th legal column
-                m &= m - 1u;
-                const uint32_t cq = d[3 * i], nf = d[3 * i + 2];
-                const float cP = bits_f32(d[3 * i + 1]);
-                const float cN = nf_N(nf);
-                // exploit_value: solved -> its outcome; unvisited under Fpu::ParentQ -> parent's q; else the q slot
-                float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? q_fpu : bits_f32(cq);
-                q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
-                float u;
-                if (cfg.puct()) u = cfg.cc() * cP * visits / (1.0f + cN);
-                else u = visits / sqrtf(cN);
-                const float v = q + u;
-                const bool take = i == 0u || (i < nc && v > best_v);
-                best_v = take ? v : best_v;
+            for (uint32_t i = 0; i < 9; i++) qf[i] = q_fpu;
+            if (cfg.fpu_normal()) {
+                uint32_t draws = T.fpu_draws;
+#pragma unroll
+                for (uint32_t i = 0; i < 9; i++) {
+                    const uint32_t nf = d[3 * i + 2];
+                    if (i < nc && !nf_solved(nf) && nf_blk(nf) == 0u) qf[i] = lane_fpu_draw(noise_seed, draws++, cfg.fpu_value(), cfg_.fpu_std);
+                }
+                T.fpu_draws = draws;
+            }
+            float vv[9];
+            if (cfg.puct()) {
+                // explore_value = ((c * P) * sqrt(N_parent)) / (1 + n) (mcts.rs:361-372), two children per instruction.
+                // hdr.w != 0: this node has a prior outside the packed division's exact range (lane_create_children).
+                const bool exact_fast = cfg_.fast_div != 0 && __ballot(hdr.w != 0u) == 0ull;
+                f32x2 uu[5];
+                if (exact_fast) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 9; i += 2) {
+                        const uint32_t j = i + 1 < 9 ? i + 1 : i;
+                        f32x2 a = f32x2{cfg.cc(), cfg.cc()} * f32x2{bits_f32(d[3 * i + 1]), bits_f32(d[3 * j + 1])};
+                        a = a * f32x2{visits, visits};
+                        uu[i >> 1] = div2_safe_range(a, f32x2{1.0f, 1.0f} + f32x2{nf_N(d[3 * i + 2]), nf_N(d[3 * j + 2])});
+                    }
+                } else {
+#pragma unroll
+                    for (uint32_t i = 0; i < 9; i += 2) {
+                        const uint32_t j = i + 1 < 9 ? i + 1 : i;
+                        const float a0 = cfg.cc() * bits_f32(d[3 * i + 1]) * visits, a1 = cfg.cc() * bits_f32(d[3 * j + 1]) * visits;
+                        uu[i >> 1] = f32x2{a0 / (1.0f + nf_N(d[3 * i + 2])), a1 / (1.0f + nf_N(d[3 * j + 2]))};
+                    }
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 9; i++) {
+                    const uint32_t nf = d[3 * i + 2];
+                    // exploit_value: solved -> its outcome; unvisited under Fpu::ParentQ -> parent's q; else the q slot
+                    float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? qf[i] : bits_f32(d[3 * i]);
+                    q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
+                    vv[i] = q + uu[i >> 1][i & 1];
+                }
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 9; i++) {
+                    const uint32_t nf = d[3 * i + 2];
+                    float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? qf[i] : bits_f32(d[3 * i]);
+                    q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
+                    vv[i] = q + visits / sqrtf(nf_N(nf));
+                }
+            }
+            if (!cfg.fpu_const()) {  // Fpu::ParentQ gives an unused slot (no block) the parent's q: mask by the child count instead
+#pragma unroll
+                for (uint32_t i = 1; i < 9; i++) vv[i] = i < nc ? vv[i] : -__builtin_inff();
+            }
+            float best_v = vv[0];
+            uint32_t best_i = 0, b_qt = d[0], b_nf = d[2], b_m = lm;
+            uint32_t m = lm & (lm - 1u);  // child i = the i-th legal column = the lowest set bit of m
+#pragma unroll
+            for (uint32_t i = 1; i < 9; i++) {
+                const bool take = vv[i] > best_v;
+                best_v = take ? vv[i] : best_v;
                 best_i = take ? i : best_i;
-                b_qt = take ? cq : b_qt;
-                b_nf = take ? nf : b_nf;
-                b_act = take ? act : b_act;
+                b_qt = take ? d[3 * i] : b_qt;
+                b_nf = take ? d[3 * i + 2] : b_nf;
+                b_m = take ? m : b_m;
+                m &= m - 1u;
             }
             if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
-            const int a = (int)b_act;
+            const int a = __ffs((int)b_m) - 1;
             const int ha = c4::col_height(my | op, a);
             const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
             my = nmy;
             op = nop;
+            lm = ha == c4::HEIGHT - 1 ? lm & ~(1u << a) : lm;
             rec = blk * 16u + best_i;
             blk = nf_blk(b_nf);
             nsolved = nf_solved(b_nf);
@@ -256,7 +329,10 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
             qt = b_qt;
             pN = nf_N(b_nf);
             level++;
-            pl[level * 64] = make_uint4(rec, f32_bits(pN), pm_make(blk, (uint32_t)__popc(legal_mask_of(my | op)), nsolved, kind), qt);
+            // an expanded, unsolved node is descended through: its line (and with it its own sums) gets read and logged
+            pl[level * 64] = make_uint4(rec, f32_bits(pN),
+                                        pm_make(blk, (uint32_t)__popc(lm), nsolved, kind) |
+                                            ((!nsolved && blk != 0u) ? PM_HAS_W : 0u), qt);
         }
     }
 
@@ -300,6 +376,8 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
                     nsolved = over;
                     qt = over ? 0u : f32_bits(y_unvisited);
                     st_rec(slab, rec, qt, 1.0f, nf_make(0u, over, 0u, over ? kind : 0u));
+#pragma unroll
+                    for (uint32_t k = 1; k < 9; k++) st_rec_none(slab, rec + k);
                     blk = 0;
                     my = nmy;
                     op = nop;
@@ -340,8 +418,13 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
 // ---------------------------------------------------------------------------------------------- phase C
 // The rest of visit() for the node expanded in phase A (mcts.rs:389-423): writes its block — zero sums and one record per
 // legal column (terminal children already solved), priors = legal-move softmax of the nine raw logits. Returns any_solved.
+// `hdr_flag` (out): the value for word 3 of the block's header — non-zero iff some prior lies outside the range the descent's
+// packed division is exact on (tiny but non-zero, or not finite); backprop writes the header (sums + this word).
+// Root noise (mcts.rs:229-269) applies when `noise_kind` != 0 (the caller passes it for the root's own expansion only):
+// 1 = PolicyNoise::Equal{weight}, 2 = PolicyNoise::Dirichlet{alpha, weight} sampled from the tree's stream (noise.cuh).
 SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
-                                  const float (&lg)[9], float equal_noise_weight, float y_unvisited) {
+                                  const float (&lg)[9], int noise_kind, float noise_weight, float noise_alpha, uint64_t noise_seed,
+                                  float y_unvisited, uint32_t& hdr_flag) {
     const uint32_t lmask = X.legal_mask;
     float mx = -__builtin_inff();
 #pragma unroll
@@ -356,25 +439,46 @@ SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneL
     }
     const uint32_t nc = (uint32_t)__popc(lmask);
     const float noise = 1.0f / (float)nc;
+    float dir[9];
+#pragma unroll
+    for (int c = 0; c < 9; c++) dir[c] = 0.0f;
+    if (__ballot(noise_kind == 2 && nc >= 2u) != 0ull) {
+        if (noise_kind == 2 && nc >= 2u) noise_dirichlet(noise_seed, noise_alpha, nc, dir);  // dir[i] = noise of child i
+    }
     const uint64_t my = leaf_my, occ = leaf_my | leaf_op;
-    *reinterpret_cast<float4*>(blk_ptr(slab, blk)) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    // (the block's header — its own sums — is written by the backprop that follows every expansion)
+    // every cell that would give the mover four in a row, computed once for the whole expansion instead of one won() per
+    // child; the cell a child's stone lands on is the column's lowest free cell
+    const uint64_t wins = c4::winning_cells(my), drop = c4::next_free_cells(occ);
     uint32_t idx = 0;
-    bool any_solved = false;
+    bool any_solved = false, flag = false;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         if ((lmask >> c) & 1u) {
             float p = e[c] / total;
-            if (equal_noise_weight >= 0.0f && nc >= 2u) p = p * (1.0f - equal_noise_weight) + equal_noise_weight * noise;
-            const int h = c4::col_height(occ, c);
-            const uint64_t bit = 1ull << (h + 7 * c);
-            const bool w = c4::won(my | bit);  // child.op_bb = the mover's stones (connect4.rs:224-229)
+            if (noise_kind == 1 && nc >= 2u) p = p * (1.0f - noise_weight) + noise_weight * noise;
+            if (noise_kind == 2 && nc >= 2u) {
+                float dn = 0.0f;
+#pragma unroll
+                for (uint32_t k = 0; k < 9; k++) dn = (k == idx) ? dir[k] : dn;
+                p = p * (1.0f - noise_weight) + noise_weight * dn;
+            }
+            const uint64_t bit = drop & (0x7Full << (7 * c));
+            const bool w = (wins & bit) != 0ull;  // won(child.op_bb): the mover's stones plus this one (connect4.rs:224-229)
             const bool over = w || (occ | bit) == c4::FULL;
             // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost; turns 0
+            flag = flag || !(p == 0.0f || (p >= PRIOR_SAFE_MIN && p <= 2.0f));
             st_rec(slab, blk * 16u + idx, over ? 0u : f32_bits(y_unvisited), p, nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u));
             any_solved = any_solved || over;
             idx++;
         }
     }
+    if (__ballot(nc < 9u) != 0ull) {  // late game: some columns are full
+#pragma unroll
+        for (uint32_t k = 1; k < 9; k++)
+            if (k >= nc) st_rec_none(slab, blk * 16u + k);
+    }
+    hdr_flag = flag ? 1u : 0u;
     return any_solved;
 }
 
@@ -392,11 +496,14 @@ SYN_DEV int wave_max_i32(int v) {
 //            line — the node's block holds its sums and its children's solutions — fetched together with the next
 //            level's path entry: one memory round trip per level.
 //   phase 2 (whole wave, four levels per step): every remaining level just adds the leaf's outcome distribution
-//            (win/lose swapped once per level climbed) and one visit, so the levels are independent: the four path rows
-//            and then the four block headers are fetched together — two round trips per four levels.
+//            (win/lose swapped once per level climbed) and one visit, so the levels are independent; the node's sums
+//            come from the path log's second plane (the descent read them with the line it needed anyway), so four
+//            levels cost ONE round trip of coalesced rows and no random line read — only the dirtied lines remain.
 template <bool COUNT, bool FAST>
+// `leaf_flag`: header word 3 of the node expanded in this pass (lane_create_children), 0 otherwise; every other visited node
+// keeps the word it has (a node that was never backpropagated into has no header yet: 0).
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
-                           bool active, const uint4* pl, uint32_t* ctr, unsigned long long* t_mid = nullptr) {
+                           bool active, const uint4* pl, uint32_t* ctr, uint32_t leaf_flag, unsigned long long* t_mid = nullptr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     if (COUNT && active) {
@@ -463,7 +570,8 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
             W1 += d1;
             W2 += d2;
             N += 1.0f;
-            *reinterpret_cast<float4*>(blk_ptr(slab, blk)) = make_float4(W0, W1, W2, 0.0f);
+            const uint32_t w3 = N != 1.0f ? hdr.w : (L == depth ? leaf_flag : 0u);  // (N was incremented above)
+            *reinterpret_cast<float4*>(blk_ptr(slab, blk)) = make_float4(W0, W1, W2, bits_f32(w3));
             if (rec != REC_ROOT) {
                 // the node is (still) solved: its q slot carries the turn count, its record the outcome
                 unsigned char* r = rec_ptr(slab, rec);
@@ -490,17 +598,17 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
             pe[j] = pl[(Lj < 0 ? 0 : Lj) * 64];
+            // the node's sums as the descent logged them (coalesced row of the second plane)
+            a[j] = *reinterpret_cast<const float4*>(pl + PATH_PLANE + (Lj < 0 ? 0 : Lj) * 64);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
             const bool ok = Lj >= 0 && Lj <= L;
-            // a node that was never backpropagated into (N == 0: the fresh leaf of most explores) has no sums to read,
-            // and idle lanes have no node: both fetch their own path entry instead — a valid address that is hot in
-            // L2 — so neither costs an HBM line
-            const unsigned char* src = (ok && pe[j].y != 0u) ? blk_ptr(slab, pm_blk(pe[j].z))
-                                                             : reinterpret_cast<const unsigned char*>(pl + (Lj < 0 ? 0 : Lj) * 64);
-            a[j] = *reinterpret_cast<const float4*>(src);
+            // Only a visited node the descent did not read through lacks logged sums: a solved leaf that was visited before,
+            // reached with the solver switched off (with it on, phase 1 has handled that level). It reads its header.
+            if (ok && pe[j].y != 0u && (pe[j].z & PM_HAS_W) == 0u)
+                a[j] = *reinterpret_cast<const float4*>(blk_ptr(slab, pm_blk(pe[j].z)));
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -512,8 +620,9 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 const float W0 = (N == 0.0f ? 0.0f : a[j].x) + (flip ? d2 : d0);
                 const float W1 = (N == 0.0f ? 0.0f : a[j].y) + d1;
                 const float W2 = (N == 0.0f ? 0.0f : a[j].z) + (flip ? d0 : d2);
+                const uint32_t w3 = N != 0.0f ? f32_bits(a[j].w) : (Lj == depth ? leaf_flag : 0u);
                 N += 1.0f;
-                *reinterpret_cast<float4*>(blk_ptr(slab, pm_blk(meta))) = make_float4(W0, W1, W2, 0.0f);
+                *reinterpret_cast<float4*>(blk_ptr(slab, pm_blk(meta))) = make_float4(W0, W1, W2, bits_f32(w3));
                 if (rec != REC_ROOT) {
                     unsigned char* r = rec_ptr(slab, rec);
                     // a solved node (explore() hit it, or the solver is off) keeps its turn count in the q slot
@@ -709,6 +818,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
         T.iter = 0;
         T.root_solved = false;
         T.root_sol = 0;
+        T.fpu_draws = 0;
         return;
     }
 
@@ -968,7 +1078,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     const size_t slot = (size_t)blockIdx.x * NT + (size_t)tid;
     T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
     // this lane's column of its wave's path buffer ([level 0..63][lane 0..63] entries of 16 bytes)
-    uint4* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * 4096 + (size_t)lane;
+    uint4* const pl = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * PATH_ENTRIES + (size_t)lane;
     const uint32_t bcap = P.cap / 4u;  // 128-byte blocks in this lane's slab
     lane_start_job<MODE>(P, T);
     // Cold per-lane state lives in LDS between the ends of searches (5 dwords per lane, lane-linear): the root position and
@@ -1004,12 +1114,19 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     unsigned long long pA = 0, pB = 0, pC = 0, pC1 = 0, pC2 = 0, pM = 0, pT = 0, pTiles = 0, pRounds = 0, pLanes = 0, pEvals = 0;
 #define SYN_STAMP() (PROF ? (unsigned long long)__builtin_readcyclecounter() : 0ull)
 #define SYN_LAP(acc) if (PROF) { unsigned long long n_ = SYN_STAMP(); acc += n_ - pT; pT = n_; }
+    // seed of this lane's current tree for Fpu::Func / Dirichlet draws (noise.cuh): stream = seed + game (or root) index,
+    // turn from the parked game state; only the runtime-switched configurations evaluate it
+    auto lane_noise_seed = [&]() -> uint64_t {
+        if (FAST || (P.mcts.fpu != 2 && P.mcts.noise != 2)) return 0ull;
+        const uint64_t stream = P.base_seed + (MODE == MODE_SELFPLAY ? P.first_game : 0ull) + (uint64_t)(uint32_t)T.job;
+        return noise_tree_seed(stream, MODE == MODE_SELFPLAY ? (pk[4 * NT] & 0xFFu) : 0u);
+    };
     for (;;) {
         const bool active = T.job >= 0;
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT);
+        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT, lane_noise_seed());
         SYN_LAP(pA)
         // PROF: timeline of the three waves of SIMD 0 of workgroup 0 (rounds 2000..2015): [A end = B start, B end, C end]
         const bool tl = PROF && P.prof && blockIdx.x == 0 && (wave & 3) == 0 && pRounds >= 2000 && pRounds < 2016;
@@ -1064,7 +1181,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
             const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
             const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
-            f32x4 o = NW >= 16 ? mlp_tile16_lowreg(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+            f32x4 o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             const int q = lane >> 4;
             if (q == 2) {
                 float a = o[1], b = o[2], c = o[3];
@@ -1097,16 +1214,18 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 
         // ---- phase C
         bool solved = X.solved;
+        uint32_t leaf_flag = 0;
         if (need || hit) {
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
             solved = lane_create_children(T.slab, Wk.blk, X, Wk.my, Wk.op, lg,
-                                          (P.mcts.noise == 1 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise_weight : -1.0f,
-                                          cv.fpu_const() ? cv.fpu_value() : 0.0f);
+                                          (!FAST && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
+                                          P.mcts.noise_alpha, lane_noise_seed(),
+                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
         }
         SYN_LAP(pC1)
         unsigned long long tmid = 0;
-        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, PROF ? &tmid : nullptr);
+        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, PROF ? &tmid : nullptr);
         if (PROF) { pC2 += tmid - pT; pT = tmid; }
         SYN_LAP(pC)
         if (fin) {

@@ -32,10 +32,12 @@ struct DevMctsCfg {
     int exploration;   // 0 Uct, 1 PolynomialUct
     float c;
     int solve, correct_values, select_solved, auto_extend;
-    int fpu;           // 0 Const, 1 ParentQ
+    int fpu;           // 0 Const, 1 ParentQ, 2 Func = Normal(fpu_value, fpu_std) (noise.cuh; lane-per-tree kernels only)
     float fpu_value;
-    int noise;         // 0 None, 1 Equal
+    int noise;         // 0 None, 1 Equal, 2 Dirichlet(noise_alpha) (noise.cuh; lane-per-tree kernels only)
     float noise_weight;
+    float fpu_std, noise_alpha;
+    int fast_div;      // lane / producer-consumer kernels: c is inside the range the packed division is exact on (host-checked)
 };
 struct DevRolloutCfg {
     int num_explores, random_until, sample_until, stop_when_solved;
@@ -52,6 +54,7 @@ struct CfgView {
     const DevMctsCfg& c;
     SYN_DEV bool puct() const { return FAST ? true : c.exploration == 1; }
     SYN_DEV bool fpu_const() const { return FAST ? true : c.fpu == 0; }
+    SYN_DEV bool fpu_normal() const { return FAST ? false : c.fpu == 2; }
     SYN_DEV bool select_solved() const { return FAST ? true : c.select_solved != 0; }
     SYN_DEV bool solve() const { return FAST ? true : c.solve != 0; }
     SYN_DEV bool correct_values() const { return FAST ? true : c.correct_values != 0; }

@@ -120,6 +120,12 @@ SYN_DEV void mlp_layer(const float* __restrict__ wimg, const float* __restrict__
     }
 }
 
+SYN_DEV f32x4 relu4_(f32x4 v) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.0f);  // x.max(0.0): NaN -> 0
+    return v;
+}
+
 template <int NOB>
 SYN_DEV void relu_inplace(f32x4 (&acc)[NOB]) {
 #pragma unroll
@@ -212,6 +218,108 @@ SYN_DEV f32x4 mlp_tile16_lowreg(const float* __restrict__ wimg, const float* __r
     f32x4 out[1];
     mlp_layer<4, 1, 3>(wimg, bimg, lane, [&](int s4) { return h4[s4]; }, out);
     return out[0];
+}
+
+// ---- software-pipelined single-wave tile for the dedicated matrix waves of the producer/consumer kernel ------------------
+// Same operands and the same per-output fma chains as mlp_tile16 (bit-identical outputs), but scheduled by hand: a matrix
+// wave is ALONE on its SIMD's matrix pipe, so nobody else's MFMAs hide its LDS latency or its dependent-accumulator
+// latency. The network is cut into 59 groups of (layer part, 4 k-steps): while the 4*NB MFMAs of group g run (NB
+// independent accumulators, interleaved), the NB weight fragments (+ the biases of a part's first group) of group g+1
+// are already on their way from LDS into the other half of a register double buffer. `sched_barrier`s pin that order —
+// left alone under the 128-VGPR budget, the compiler serialises "one fragment -> wait -> 4 dependent MFMAs".
+struct PipeGroup { int layer, nob, ob0, nb, s4, ns4; };
+constexpr PipeGroup pipe_group(int gi) {
+    if (gi < 16) return {0, 8, (gi / 4) * 2, 2, gi % 4, 4};                   // L1: 4 parts of 2 blocks
+    if (gi < 40) return {1, 6, ((gi - 16) / 8) * 2, 2, (gi - 16) % 8, 8};     // L2: 3 parts of 2 blocks
+    if (gi < 52) return {2, 4, ((gi - 40) / 6) * 2, 2, (gi - 40) % 6, 6};     // L3: 2 parts of 2 blocks
+    if (gi < 56) return {3, 3, 0, 3, gi - 52, 4};                             // L4: 3 blocks
+    return {4, 1, 0, 1, gi - 56, 3};                                          // L5: 1 block
+}
+constexpr int PIPE_GROUPS = 59;
+
+struct PipeRegs {
+    f32x4 a[2][3];   // weight fragments: double buffer, up to 3 blocks per group
+    f32x4 bb[3];     // biases of the part that starts with the next group
+    f32x4 acc[3];    // accumulators of the current part
+    f32x4 fq[2];     // layer-1 B operands of this group and the next (4 features per lane each)
+    f32x4 h1[8], h2[6], h3[4], h4[3];
+};
+
+template <int GI>
+SYN_DEV void pipe_prefetch(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane, PipeRegs& R) {
+    if constexpr (GI < PIPE_GROUPS) {
+        constexpr PipeGroup G = pipe_group(GI);
+        const float* wl = wimg + MlpGeom::W_OFF[G.layer] + lane * 4;
+#pragma unroll
+        for (int ob = 0; ob < G.nb; ob++)
+            R.a[GI & 1][ob] = *reinterpret_cast<const f32x4*>(wl + (G.s4 * G.nob + G.ob0 + ob) * 256);
+        if constexpr (G.s4 == 0) {
+            const int q = lane >> 4;
+#pragma unroll
+            for (int ob = 0; ob < G.nb; ob++)
+                R.bb[ob] = *reinterpret_cast<const f32x4*>(bimg + MlpGeom::B_OFF[G.layer] + ((G.ob0 + ob) * 4 + q) * 4);
+        }
+    }
+}
+
+template <int GI>
+SYN_DEV void pipe_features(const FeatureTable& FT, uint64_t hi, uint64_t lo, PipeRegs& R) {
+    if constexpr (GI < PIPE_GROUPS) {
+        constexpr PipeGroup G = pipe_group(GI);
+        if constexpr (G.layer == 0) {
+            if constexpr (G.s4 == 0) R.fq[GI & 1] = feature_quad<0>(FT, hi, lo);
+            else if constexpr (G.s4 == 1) R.fq[GI & 1] = feature_quad<1>(FT, hi, lo);
+            else if constexpr (G.s4 == 2) R.fq[GI & 1] = feature_quad<2>(FT, hi, lo);
+            else R.fq[GI & 1] = feature_quad<3>(FT, hi, lo);
+        }
+    }
+}
+
+template <int GI>
+SYN_DEV void pipe_group_run(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane, const FeatureTable& FT,
+                            uint64_t hi, uint64_t lo, PipeRegs& R) {
+    constexpr PipeGroup G = pipe_group(GI);
+    pipe_prefetch<GI + 1>(wimg, bimg, lane, R);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (G.s4 == 0) {
+#pragma unroll
+        for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = R.bb[ob];
+    }
+    f32x4 b;
+    if constexpr (G.layer == 0) b = R.fq[GI & 1];
+    else if constexpr (G.layer == 1) b = R.h1[G.s4];
+    else if constexpr (G.layer == 2) b = R.h2[G.s4];
+    else if constexpr (G.layer == 3) b = R.h3[G.s4];
+    else b = R.h4[G.s4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int ob = 0; ob < G.nb; ob++)
+            R.acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.a[GI & 1][ob][r], b[r], R.acc[ob], 0, 0, 0);
+    // the next layer-1 group's operands are built from the boards in the shadow of this group's MFMAs
+    pipe_features<GI + 1>(FT, hi, lo, R);
+    if constexpr (G.s4 == G.ns4 - 1 && G.layer < 4) {
+#pragma unroll
+        for (int ob = 0; ob < G.nb; ob++) {
+            const f32x4 v = relu4_(R.acc[ob]);
+            if constexpr (G.layer == 0) R.h1[G.ob0 + ob] = v;
+            else if constexpr (G.layer == 1) R.h2[G.ob0 + ob] = v;
+            else if constexpr (G.layer == 2) R.h3[G.ob0 + ob] = v;
+            else R.h4[G.ob0 + ob] = v;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (GI + 1 < PIPE_GROUPS) pipe_group_run<GI + 1>(wimg, bimg, lane, FT, hi, lo, R);
+}
+
+// Lane l = (j = l&15, q = l>>4) passes the two feature boards of position j; returns the last layer's D registers (raw).
+SYN_DEV f32x4 mlp_tile16_pipe(const float* __restrict__ wimg, const float* __restrict__ bimg, int lane,
+                              const FeatureTable& FT, uint64_t hi, uint64_t lo) {
+    PipeRegs R;
+    pipe_prefetch<0>(wimg, bimg, lane, R);
+    pipe_features<0>(FT, hi, lo, R);
+    pipe_group_run<0>(wimg, bimg, lane, FT, hi, lo, R);
+    return R.acc[0];
 }
 
 // policies.rs:54-57: softmax over the three outcome logits (libtorch: max-subtracted), exp = det_expf,

@@ -17,8 +17,8 @@ NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/p
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
-    "syn_debug_math", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
+    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
 
@@ -100,6 +100,7 @@ def load_library():
                                        C.c_void_p, C.c_int]
     lib.syn_conv2d_forward.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                                       C.c_void_p, C.c_int]
+    lib.syn_activation_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.syn_mcts_search.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]
     lib.syn_mcts_search_rollout.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int,
@@ -112,6 +113,7 @@ def load_library():
     lib.syn_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.syn_last_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.syn_debug_stdrng_u32.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
+    lib.syn_debug_fast_div.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
     lib.syn_debug_calibrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -222,6 +224,14 @@ class Engine:
         self._check(self._lib.syn_linear_forward(self._h, W.shape[1], W.shape[0], _p(W), _p(b), _p(x), x.shape[0],
                                                  _p(y), int(relu)))
         return y
+
+    def activation(self, kind, x):
+        """slimnn activation layer on x[batch][n]: kind 0 ReLU, 1 Tanh, 2 Softmax::apply_1d per row (activations.rs:31-63)."""
+        x = np.ascontiguousarray(x, np.float32)
+        x2 = x.reshape(1, -1) if x.ndim == 1 else x.reshape(x.shape[0], -1)
+        y = np.zeros_like(x2)
+        self._check(self._lib.syn_activation_forward(self._h, int(kind), _p(x2), int(x2.shape[0]), int(x2.shape[1]), _p(y)))
+        return y.reshape(x.shape)
 
     def conv2d(self, W, b, x, row_pad=0, col_pad=0, stride=1, relu=False, out_hw=None):
         W = np.ascontiguousarray(W, np.float32)
@@ -397,6 +407,13 @@ class Engine:
         out = np.zeros(int(n), np.uint32)
         self._check(self._lib.syn_debug_stdrng_u32(self._h, int(seed), int(n), _p(out)))
         return out
+
+    def debug_fast_div(self, a, b):
+        a = np.ascontiguousarray(a, np.float32).ravel()
+        b = np.ascontiguousarray(b, np.float32).ravel()
+        f = np.zeros_like(a); d = np.zeros_like(a)
+        self._check(self._lib.syn_debug_fast_div(self._h, _p(a), _p(b), int(a.size), _p(f), _p(d)))
+        return f, d
 
     def debug_math(self, a, b):
         a = np.ascontiguousarray(a, np.float32).ravel()

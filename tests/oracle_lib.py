@@ -21,6 +21,7 @@ class MctsConfig(C.Structure):
         ("auto_extend", C.c_int),
         ("fpu", C.c_int), ("fpu_value", C.c_float),
         ("noise", C.c_int), ("noise_alpha", C.c_float), ("noise_weight", C.c_float),
+        ("fpu_std", C.c_float),
     ]
 
 
@@ -37,7 +38,7 @@ class RolloutConfig(C.Structure):
 def parity_mcts_config(**kw):
     """policy_mcts_cfg of study-connect4/src/main.rs:58-66 (the deterministic variant of the self-play config)."""
     d = dict(exploration=1, c=3.0, solve=1, correct_values_on_solve=1, select_solved_nodes=1, auto_extend=1,
-             fpu=0, fpu_value=1.0, noise=0, noise_alpha=0.0, noise_weight=0.0)
+             fpu=0, fpu_value=1.0, noise=0, noise_alpha=0.0, noise_weight=0.0, fpu_std=0.0)
     d.update(kw)
     return MctsConfig(**d)
 
@@ -145,6 +146,17 @@ class Oracle:
         x = np.ascontiguousarray(x, np.float32).ravel()
         y = np.zeros_like(x)
         self.lib.orc_det_logf(_p(x), _p(y), int(x.size))
+        return y
+
+    def tanh(self, x):
+        y = np.ascontiguousarray(x, np.float32).ravel().copy()
+        self.lib.orc_tanh(_p(y), int(y.size))
+        return y.reshape(np.shape(x))
+
+    def softmax_slimnn(self, x):
+        x = np.ascontiguousarray(x, np.float32).ravel()
+        y = np.zeros_like(x)
+        self.lib.orc_softmax_slimnn(_p(x), _p(y), int(x.size))
         return y
 
     def softmax_stable(self, x):

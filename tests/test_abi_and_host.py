@@ -50,7 +50,7 @@ def test_struct_layouts_match_header():
     assert fields("syn_search_result") == [f[0] for f in CSearchResult._fields_]
     assert fields("syn_counters") == [f[0] for f in CCounters._fields_]
     assert fields("syn_train_config") == [f[0] for f in CTrainConfig._fields_] and C.sizeof(CTrainConfig) == 24
-    assert C.sizeof(CMctsConfig) == 44 and C.sizeof(CRolloutConfig) == 36 + 44
+    assert C.sizeof(CMctsConfig) == 48 and C.sizeof(CRolloutConfig) == 36 + 48
     assert C.sizeof(CSearchResult) == 4 * (9 + 27 + 9 + 27 + 1 + 3 + 3 + 1 + 1 + 9 + 3)
     assert C.sizeof(CCounters) == 96
 

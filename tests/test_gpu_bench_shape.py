@@ -1,9 +1,10 @@
 """GPU tests of the headline launch shape AT ITS OWN SIZE and of the multi-rank / multi-engine plumbing.
 
-* bench shape: 196,608 concurrent games (768 per CU), the engine's own launch selection (no developer knob), at least one
-  full wave of games plus refill, replay outputs on — sampled games equal the oracle game for game and every game's length
-  equals the 4,096-slot engine's (row-per-tree kernel), i.e. the 45 GB pool (14-bit block ids, > 4 GB offsets) computes
-  the same games as the small engines the other parity tests use (alpha_zero.rs:120-169: the fan-out over workers).
+* bench shape: 262,144 concurrent games (1,024 per CU: the 16-wave lane-per-tree launch of bench.py) and 196,608 (12 waves),
+  the engine's own launch selection (no developer knob), at least one full wave of games plus refill, replay outputs on —
+  sampled games equal the oracle game for game and every game's length, last position and result equal the 4,096-slot
+  engine's (row-per-tree kernel), i.e. the 60 GB / 45 GB pools (14-bit block ids, > 4 GB offsets) compute the same
+  games as the small engines the other parity tests use (alpha_zero.rs:120-169: the fan-out over workers).
 * two engines on one device driven from two host threads (one handle per host thread: SURVEY §8b threading row).
 * `python bench.py --gpus 2 --dist-backend gloo` started bare: two ranks (both on GPU 0), one JSON line with n_gpus 2.
 """
@@ -26,20 +27,21 @@ def blob(golden_dir):
     return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
 
 
-def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch):
+@pytest.mark.parametrize("conc,expect", [(262144, (4, 256, 1024)), (196608, (4, 256, 768))])
+def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, conc, expect):
     import synthesis_amd as sa
     from tests.oracle_lib import parity_rollout_config
     from tests.test_gpu_parity import assert_selfplay_equal
 
-    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE"):
+    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE", "SYN_PC"):
         monkeypatch.delenv(k, raising=False)
-    conc, n_games, seed = 196608, 196608 + 12288, 20260
+    n_games, seed = conc + 12288, 20260
     cfg = sa.parity_rollout_config(800)
     big = sa.Engine(concurrent_games=conc, max_explores=800, device=0)
     big.load_weights(blob)
     got = big.selfplay(cfg, base_seed=seed, n_games=n_games)   # counters off: the very kernel instantiation bench.py times
     shape, grid, threads = big.last_launch_shape()
-    assert (shape, grid, threads) == (4, 256, 768), "the bench's launch shape: lane-per-tree, 256 workgroups x 12 waves"
+    assert (shape, grid, threads) == expect, "262,144 slots: the bench's launch shape (lane-per-tree, 256 workgroups x 16 waves); 196,608: 12 waves"
     big.close()
     assert got["plies"].min() >= 7 and got["plies"].max() <= 63
 

@@ -66,6 +66,41 @@ def test_device_math_is_ieee_exact(engine, oracle):
     assert np.array_equal(s[pos].view(np.uint32), np.sqrt(a[pos]).view(np.uint32))  # correctly rounded sqrt
 
 
+def test_slimnn_activation_layers_match_oracle(engine, oracle):
+    """slimnn/src/activations.rs:31-63 as device layers: ReLU, Tanh (deterministic det_tanhf shared with the oracle) and the
+    un-stabilised Softmax::apply_1d (exp / sum in index order, no max subtraction) — bit for bit the oracle's."""
+    rng = np.random.RandomState(3)
+    x = np.concatenate([rng.uniform(-6, 6, 40000), rng.uniform(-60, 60, 20000), [0.0, -0.0, 0.625, -0.625, 44.5, -44.5]]).astype(np.float32)
+    assert np.array_equal(engine.activation(1, x).view(np.uint32), oracle.tanh(x).view(np.uint32))
+    assert np.array_equal(engine.activation(0, x), np.maximum(x, np.float32(0)))
+    assert np.abs(engine.activation(1, x) - np.tanh(x.astype(np.float64))).max() < 2.5e-7
+    rows = rng.uniform(-5, 5, (500, 12)).astype(np.float32)
+    rows[7] = [100.0] + [0.0] * 11   # overflow: inf / inf = NaN in the reference too
+    got = engine.activation(2, rows)
+    ref = np.stack([oracle.softmax_slimnn(r) for r in rows])
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.isnan(got[7]).any()   # (NaN sign/payload is not compared)
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok].view(np.uint32), ref[ok].view(np.uint32))
+    with pytest.raises(Exception):
+        engine.activation(7, rows)
+
+
+def test_packed_division_is_ieee_exact_on_its_range(engine):
+    """device_common.cuh div2_safe_range (two quotients per v_pk_fma stream, used by the descent's explore_value): equal to the
+    IEEE quotient bit for bit for a = 0 or 2^-60 <= a <= 2^60 and integer-valued 1 <= b <= 2^16 — the only range it is used on
+    (numerator c * prior * sqrt(N), denominator 1 + n; priors below 2^-40 are flagged and take the full division)."""
+    rng = np.random.RandomState(7)
+    n = 4_000_000
+    a = np.exp2(rng.uniform(-60, 60, n)).astype(np.float32)
+    a[: n // 4] = (rng.uniform(0, 1, n // 4) * rng.uniform(1, 30, n // 4) * 3.0).astype(np.float32)   # the descent's own range
+    a[:1000] = 0.0
+    b = rng.randint(1, 802, n).astype(np.float32)
+    b[n // 2:] = rng.randint(1, 65537, n - n // 2).astype(np.float32)
+    fast, full = engine.debug_fast_div(a, b)
+    assert np.array_equal(full.view(np.uint32), (a / b).view(np.uint32))
+    assert np.array_equal(fast.view(np.uint32), full.view(np.uint32))
+
+
 def test_device_logf_matches_oracle(engine, oracle):
     a = np.concatenate([np.arange(1, 5000), np.random.RandomState(2).uniform(1e-30, 1e30, 100000)]).astype(np.float32)
     _, _, s = engine.debug_math(a, -np.ones_like(a))
@@ -441,6 +476,129 @@ def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
     got = eng.selfplay(sa.parity_rollout_config(800), base_seed=5, n_games=6)
     ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 5, 6, threads=8, nn_mode=oracle.ACC_FMA)
     assert_selfplay_equal(got, ref, f"lanes={waves} 800 explores")
+    eng.close()
+
+
+@pytest.mark.parametrize("nv", [1, 2, 3])
+def test_producer_consumer_kernel_matches_oracle(blob, oracle, monkeypatch, nv):
+    """The headline launch shape (pc_kernel.cuh: 12 tree waves time-slicing `nv` virtual waves of 64 trees each, 4 matrix
+    waves fed through an LDS ring, per-tree state parked in global memory between visits) is normally chosen from
+    393,216 concurrent games; force it on a small engine (partial virtual waves, idle tree waves) and hold it to the same
+    bit-exact bar as every other shape: searches incl. late-game solver positions, every config family, whole self-play
+    games with refill and all value targets."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
+    monkeypatch.setenv("SYN_PC", str(nv))
+    eng = sa.Engine(concurrent_games=1100, max_explores=800)
+    eng.load_weights(blob)
+    my, op = random_positions(oracle, 300, seed=31, max_moves=60)
+    got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
+    assert eng.last_launch_shape()[0] == 5 and eng.last_launch_shape()[2] == 1024
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, f"pc nv={nv} search")
+    for kw in (dict(exploration=0, c=1.4), dict(fpu=1), dict(solve=0), dict(correct_values_on_solve=0),
+               dict(select_solved_nodes=0), dict(auto_extend=0), dict(noise=1, noise_weight=0.25)):
+        ocfg = parity_mcts_config(**kw)
+        scfg = sa.MCTSConfig(exploration=sa.Exploration(ocfg.exploration), c=ocfg.c, solve=bool(ocfg.solve),
+                             correct_values_on_solve=bool(ocfg.correct_values_on_solve),
+                             select_solved_nodes=bool(ocfg.select_solved_nodes), auto_extend=bool(ocfg.auto_extend),
+                             fpu=sa.Fpu(ocfg.fpu), fpu_value=ocfg.fpu_value,
+                             root_policy_noise=sa.PolicyNoise(ocfg.noise), noise_weight=ocfg.noise_weight)
+        got = eng.mcts_search(scfg, my[:120], op[:120], 90, action_selection=0)
+        ref = oracle.c4_mcts_search(ocfg, blob, my[:120], op[:120], 90, action_selection=0, nn_mode=oracle.ACC_FMA)
+        assert_search_equal(got, ref, f"pc nv={nv} variant {kw}")
+    got = eng.selfplay(sa.parity_rollout_config(50), base_seed=77, n_games=2500, counters=True)
+    assert eng.last_launch_shape()[0] == 5
+    ref = oracle.c4_selfplay(parity_rollout_config(50), blob, 77, 2500, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"pc nv={nv} self-play")
+    for k in ("explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals",
+              "backprop_levels", "solver_children", "solved_hits", "max_depth"):
+        assert got["counters"][k] == ref["counters"][k], (nv, k)
+    assert got["counters"]["games"] == 2500 and got["counters"]["moves"] == int(got["plies"].sum())
+    for sv, ov in ((dict(value_target=sa.ValueTarget.Z), dict(value_target=0)),
+                   (dict(value_target=sa.ValueTarget.QZaverage, value_target_p=0.3), dict(value_target=2, vt_p=0.3)),
+                   (dict(value_target=sa.ValueTarget.QtoZ, value_target_from=0.1, value_target_to=0.9),
+                    dict(value_target=3, vt_from=0.1, vt_to=0.9)),
+                   (dict(stop_games_when_solved=True, action=sa.ActionSelection.Q, random_actions_until=3),
+                    dict(stop_games_when_solved=1, action=0, random_actions_until=3))):
+        got = eng.selfplay(sa.parity_rollout_config(40, **sv), base_seed=9, n_games=64)
+        ref = oracle.c4_selfplay(parity_rollout_config(40, **ov), blob, 9, 64, threads=8, nn_mode=oracle.ACC_FMA)
+        assert_selfplay_equal(got, ref, f"pc nv={nv} {sv}")
+    got = eng.selfplay(sa.parity_rollout_config(800), base_seed=5, n_games=6)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), blob, 5, 6, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"pc nv={nv} 800 explores")
+    eng.close()
+
+
+def test_producer_consumer_kernel_with_policy_cache(blob, oracle, monkeypatch):
+    """PolicyWithCache on the producer/consumer kernel (hits skip the ring; their outputs wait in the virtual wave's own
+    buffer): results are the oracle's bit for bit, with a tiny contended table and with one that hits."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
+    monkeypatch.setenv("SYN_PC", "2")
+    my, op = random_positions(oracle, 300, seed=31, max_moves=60)
+    sref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
+    gref = oracle.c4_selfplay(parity_rollout_config(50), blob, 77, 2500, threads=8, nn_mode=oracle.ACC_FMA)
+    for log2 in (10, 22):
+        eng = sa.Engine(concurrent_games=1100, max_explores=800, policy_cache_log2=log2)
+        eng.load_weights(blob)
+        for rep in range(2):
+            got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
+            assert_search_equal(got, sref, f"pc cache 2^{log2} search pass {rep}")
+        assert eng.last_launch_shape()[0] == 5
+        hits, misses = eng.last_cache_stats()
+        assert hits + misses > 0 and (log2 == 10 or hits > misses)
+        got = eng.selfplay(sa.parity_rollout_config(50), base_seed=77, n_games=2500, counters=True)
+        assert_selfplay_equal(got, gref, f"pc cache 2^{log2} self-play")
+        hits, misses = eng.last_cache_stats()
+        assert hits + misses == got["counters"]["policy_evals"] == gref["counters"]["policy_evals"]
+        if log2 == 22:
+            assert hits > 0.3 * (hits + misses)
+        eng.close()
+
+
+@pytest.mark.parametrize("conc", [300, 1100])
+def test_fpu_normal_and_dirichlet_noise_match_oracle(blob, oracle, conc):
+    """The reference's own self-play MCTS configuration (study-connect4/src/main.rs:37-49: Fpu::Func(|| Normal(1.0, 0.1)))
+    and PolicyNoise::Dirichlet (mcts.rs:241-256) on the device: rand_distr's samplers (ziggurat normal, Marsaglia-Tsang gamma)
+    on a per-tree StdRng stream, bit for bit the oracle's — searches, whole self-play games, and the reference's property that
+    the root's priors still sum to 1 after the noise (mcts.rs:834-868). Neither configuration returns SYN_ERR_UNSUPPORTED."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    eng = sa.Engine(concurrent_games=conc, max_explores=400)
+    eng.load_weights(blob)
+    my, op = random_positions(oracle, 120, seed=77, max_moves=50)
+    my[0] = 0; op[0] = 0
+    variants = [
+        (sa.reference_selfplay_mcts_config(), dict(fpu=2, fpu_value=1.0, fpu_std=0.1)),
+        (sa.MCTSConfig(fpu=sa.Fpu.Func, fpu_value=0.5, fpu_std=0.3, exploration=sa.Exploration.Uct, c=1.4),
+         dict(fpu=2, fpu_value=0.5, fpu_std=0.3, exploration=0, c=1.4)),
+        (sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25),
+         dict(noise=2, noise_alpha=0.3, noise_weight=0.25)),
+        (sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=1.0, noise_weight=0.5, fpu=sa.Fpu.Func, fpu_value=1.0,
+                       fpu_std=0.1), dict(noise=2, noise_alpha=1.0, noise_weight=0.5, fpu=2, fpu_value=1.0, fpu_std=0.1)),
+        (sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=2.5, noise_weight=0.25, auto_extend=False),
+         dict(noise=2, noise_alpha=2.5, noise_weight=0.25, auto_extend=0)),
+    ]
+    for scfg, okw in variants:
+        for explores in (0, 150):
+            got = eng.mcts_search(scfg, my, op, explores)
+            assert eng.last_launch_shape()[0] == 4   # the draws live in the lane-per-tree kernels
+            ref = oracle.c4_mcts_search(parity_mcts_config(**okw), blob, my, op, explores, nn_mode=oracle.ACC_FMA)
+            assert_search_equal(got, ref, f"noise variant {okw} explores {explores}")
+            if explores == 0:
+                np.testing.assert_allclose(got["child_P"].sum(axis=1), 1.0, atol=1e-6)
+    for scfg, okw in variants[:1] + variants[3:4]:
+        got = eng.selfplay(sa.parity_rollout_config(60, mcts_cfg=scfg), base_seed=31, n_games=300, first_game=7, counters=True)
+        ref = oracle.c4_selfplay(parity_rollout_config(60, mcts=parity_mcts_config(**okw)), blob, 31, 300, first_game=7, threads=8,
+                                 nn_mode=oracle.ACC_FMA)
+        assert_selfplay_equal(got, ref, f"self-play with {okw}")
+        assert got["counters"]["policy_evals"] == ref["counters"]["policy_evals"]
     eng.close()
 
 

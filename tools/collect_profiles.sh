@@ -1,49 +1,42 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + the two PMC passes the MI355X guide prescribes (FETCH_SIZE
-# and WRITE_SIZE cannot share a pass: TCC has 4 slots, they need 3 + 2), all on the SAME bench.py command, and distils
-# them into gpurun_out/profiles_<tag>/ for copying into profiles/ (tracked).
-#   usage: tools/collect_profiles.sh r01
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + the PMC passes the MI355X guide prescribes (FETCH_SIZE and
+# WRITE_SIZE cannot share a pass: TCC has 4 slots, they need 3 + 2), all on the SAME bench.py command, plus the same two
+# passes on the PolicyWithCache leg and the SQ / TA / L2 counter passes the design discussion quotes; distilled into
+# gpurun_out/profiles_<tag>/ for copying into profiles/ (tracked).
+#   usage: tools/collect_profiles.sh r02
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=$PWD
 OUT=$R/gpurun_out/profiles_$TAG
-mkdir -p $OUT $R/gpurun_out/prof_trace $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write
+mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $BENCH > $OUT/bench_under_trace.log 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $BENCH > $OUT/bench_under_fetch.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $BENCH > $OUT/bench_under_write.log 2>&1
+BENCH="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache --no-extras"
+CACHE="bench.py --only-policy-cache"
+run() {  # name, rocprof args..., -- program
+  local name=$1; shift
+  rm -rf $R/gpurun_out/prof_$name; mkdir -p $R/gpurun_out/prof_$name
+  timeout -k 5 900 rocprofv3 "$@" > $OUT/log_$name.txt 2>&1
+}
+run trace --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_trace -- python3 $BENCH
+run fetch --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_fetch -- python3 $BENCH
+run write --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_write -- python3 $BENCH
+run cfetch --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_cfetch -- python3 $CACHE
+run cwrite --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_cwrite -- python3 $CACHE
+run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/prof_sq1 -- python3 $BENCH
+run sq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/gpurun_out/prof_sq2 -- python3 $BENCH
+run ta --pmc TA_TA_BUSY_sum TA_BUSY_avr --output-format csv -d $R/gpurun_out/prof_ta -- python3 $BENCH
+run l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $R/gpurun_out/prof_l2 -- python3 $BENCH
+run lat --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum --output-format csv -d $R/gpurun_out/prof_lat -- python3 $BENCH
 cp $(ls -t $R/gpurun_out/prof_trace/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv
 head -1 $(ls -t $R/gpurun_out/prof_trace/*/*_kernel_trace.csv | head -1) > $OUT/${TAG}_kernel_trace_selfplay.csv
 grep selfplay_kernel $(ls -t $R/gpurun_out/prof_trace/*/*_kernel_trace.csv | head -1) >> $OUT/${TAG}_kernel_trace_selfplay.csv
-for c in fetch write; do
-  f=$(ls -t $R/gpurun_out/prof_$c/*/*_counter_collection.csv | head -1)
+for c in fetch write cfetch cwrite sq1 sq2 ta l2 lat; do
+  f=$(ls -t $R/gpurun_out/prof_$c/*/*_counter_collection.csv 2>/dev/null | head -1)
+  [ -z "$f" ] && continue
   head -1 $f > $OUT/${TAG}_pmc_$c.csv
   grep selfplay_kernel $f >> $OUT/${TAG}_pmc_$c.csv
 done
-grep -h '"metric"' $OUT/bench_under_*.log > $OUT/${TAG}_bench_lines_under_profiler.jsonl
-python3 - "$OUT" "$TAG" <<'PY'
-import csv, json, sys
-out, tag = sys.argv[1], sys.argv[2]
-def rows(path):
-    return list(csv.DictReader(open(path)))
-def timed(rs):  # the un-instrumented (COUNT = false) launches of the headline kernel (timed steps + warm-up)
-    return [r for r in rs if "selfplay_kernel_lanes<0, false" in r["Kernel_Name"]]
-f = timed(rows(f"{out}/{tag}_pmc_fetch.csv")); w = timed(rows(f"{out}/{tag}_pmc_write.csv"))
-fetch_kb = sum(float(r["Counter_Value"]) for r in f) / max(1, len(f))
-write_kb = sum(float(r["Counter_Value"]) for r in w) / max(1, len(w))
-ks = [r for r in rows(f"{out}/{tag}_kernel_stats.csv") if "selfplay_kernel_lanes<0, false" in r["Name"]]
-summary = {
-    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache",
-    "kernel": ks[0]["Name"] if ks else None,
-    "kernel_calls": int(ks[0]["Calls"]) if ks else None,
-    "kernel_avg_ms": float(ks[0]["AverageNs"]) / 1e6 if ks else None,
-    "FETCH_SIZE_kb_per_launch": fetch_kb, "WRITE_SIZE_kb_per_launch": write_kb,
-    # MI355X guide §HBM: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> doubled; WRITE_SIZE exact
-    "traffic_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
-    "traffic_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024.0,
-}
-json.dump(summary, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
-print(json.dumps(summary))
-PY
+grep -h '"metric"' $OUT/log_trace.txt $OUT/log_fetch.txt $OUT/log_write.txt > $OUT/${TAG}_bench_lines_under_profiler.jsonl
+grep -h 'with_policy_cache' $OUT/log_cfetch.txt $OUT/log_cwrite.txt > $OUT/${TAG}_cache_lines_under_profiler.jsonl
+python3 tools/summarize_profiles.py "$OUT" "$TAG"
 ls -la $OUT

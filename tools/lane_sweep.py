@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool: throughput of the lane-per-tree kernel. Args: conc:nw[:games[:policy_cache_log2]] ... (nw = waves per
-workgroup, 0 = the engine's own choice)"""
+"""Developer tool: throughput of the lane-per-tree / producer-consumer kernels. Args: conc:nw[:games[:policy_cache_log2]] ...
+(nw = waves per workgroup of the lane kernel, 0 = the engine's own choice, negative = producer/consumer kernel with -nw
+virtual waves per tree wave)"""
 import os
 os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, time
@@ -17,8 +18,9 @@ for c in combos:
     conc, nw = c[0], c[1]
     n = c[2] if len(c) > 2 else 2 * conc
     clog = c[3] if len(c) > 3 else 0
-    if nw: os.environ["SYN_LANES"] = str(nw)
-    else: os.environ.pop("SYN_LANES", None)
+    os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None)
+    if nw > 0: os.environ["SYN_LANES"] = str(nw); os.environ["SYN_PC"] = "0"
+    elif nw < 0: os.environ["SYN_PC"] = str(-nw)
     eng = sa.Engine(concurrent_games=conc, max_explores=800, policy_cache_log2=clog)
     eng.load_weights(blob)
     eng.selfplay(cfg, 0, 256, outputs=False)
@@ -27,5 +29,5 @@ for c in combos:
     dt = time.perf_counter() - t0
     hits, misses = eng.last_cache_stats()
     extra = f"  policy cache 2^{clog}: {hits / max(1, hits + misses):.3f} hit rate" if clog else ""
-    print(f"concurrent={conc} lanes_nw={nw}: {n} games in {dt:.3f} s = {n / dt:.0f} games/s  (mean plies {r['plies'].mean():.2f}){extra}", flush=True)
+    print(f"concurrent={conc} lanes_nw={nw} shape={eng.last_launch_shape()}: {n} games in {dt:.3f} s = {n / dt:.0f} games/s  (mean plies {r['plies'].mean():.2f}){extra}", flush=True)
     eng.close()

@@ -4,6 +4,8 @@
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int SHAPE>
 __global__ __launch_bounds__(512) void k(int mode, int iters, unsigned long long* out, float* sink) {
     const int wave = threadIdx.x >> 6;
     // mode bit0: waves 0-3 run MFMA; bit1: waves 4-7 run VALU; bit2: waves 4-7 run MFMA too; bit3: waves 0-3 run VALU
@@ -15,7 +17,14 @@ __global__ __launch_bounds__(512) void k(int mode, int iters, unsigned long long
     const float w = 1.0001f + threadIdx.x * 1e-7f, b = 0.5f;
     __syncthreads();
     unsigned long long t0 = __builtin_readcyclecounter();
-    if (do_mfma) {
+    f32x16 c0 = {0}, c1 = c0;
+    if (do_mfma && SHAPE == 1) {
+        for (int i = 0; i < iters; i++) {  // 2 x 32x32x2 = 128 pipe cycles (16 passes each)
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w, b, c1, 0, 0, 0);
+        }
+        a0[0] += c0[0] + c1[5];
+    } else if (do_mfma) {
         for (int i = 0; i < iters; i++) {
             a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, a0, 0, 0, 0);
             a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w, b, a1, 0, 0, 0);
@@ -41,11 +50,15 @@ int main() {
     hipMalloc(&d, 8 * 8); hipMalloc(&s, 512 * 4);
     const int iters = 20000;
     const char* names[] = {"", "MFMA on waves 0-3 only", "VALU on waves 4-7 only", "MFMA(0-3) + VALU(4-7)", "", "MFMA on all 8 waves", "", "", "", "", "VALU on all 8 waves"};
+    for (int shape = 0; shape < 2; shape++)
     for (int mode : {1, 2, 3, 5, 10}) {
+        if (shape == 1 && (mode == 2 || mode == 10)) continue;
         for (int rep = 0; rep < 2; rep++) {
-            hipLaunchKernelGGL(k, dim3(1), dim3(512), 0, 0, mode, iters, d, s);
+            if (shape == 0) hipLaunchKernelGGL(k<0>, dim3(1), dim3(512), 0, 0, mode, iters, d, s);
+            else hipLaunchKernelGGL(k<1>, dim3(1), dim3(512), 0, 0, mode, iters, d, s);
             hipDeviceSynchronize();
         }
+        if (shape == 1) printf("[32x32x2] ");
         unsigned long long h[8];
         hipMemcpy(h, d, 64, hipMemcpyDeviceToHost);
         printf("mode %2d %-28s cycles/iter: wave0 %.1f  wave4 %.1f   (iter = 4 MFMA 16x16x4 f32 = 128 pipe cycles | 32 v_fma = 128 issue cycles)\n",
