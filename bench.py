@@ -354,6 +354,28 @@ def main():
                 out["with_replay_outputs_to_host"] = {"games_per_s": gps / dt3, "bytes_copied": int(nbytes),
                                                       "seconds": dt3, "kernel_ms": ro["kernel_ms"]}
                 del ro
+            # (3) a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
+            # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
+            # random-init network (SURVEY §8d asks for both); same step, same kernel
+            tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
+            if os.path.exists(tpath):
+                eng.load_weights(np.load(tpath))
+                base = (args.warmup + args.steps + 3) * gps
+                eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=base, outputs=False)
+                t1 = time.perf_counter()
+                rt = eng.selfplay(cfg, base_seed=0, n_games=gps, first_game=base + args.concurrent, outputs=False)
+                dt4 = time.perf_counter() - t1
+                ct = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=base + args.concurrent, outputs=False, counters=True)["counters"]
+                out["with_trained_weights"] = {
+                    "games_per_s": gps / dt4, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                    "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
+                    "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
+                    "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
+                    "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
+                    "mfma_frac": (ct["policy_evals"] / 65536.0) * (gps / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
+                                                   "max_depth": c["max_depth"]}}
+                eng.load_weights(blob)
         if world == 1 and not args.no_4096:
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration

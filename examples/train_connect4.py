@@ -7,11 +7,15 @@ permutation (BatchRandSampler, data.rs:6-64, drop_last = true).
 
     python examples/train_connect4.py --iterations 3 --games-per-train 4096 --explores 200
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_connect4.py ...
-        (one rank per GPU: every rank plays its share of the games; the optimiser step is data-parallel with a gradient
-         all-reduce over RCCL, synthesis_amd/learner.py)
+        (one rank per GPU: every rank plays its share of the games (remainders included), the new games are all-gathered so
+         every rank holds the SAME replay buffer and de-duplicates it to the same unique states (data.rs:196-235 on the global
+         buffer, as the reference); every global batch of --batch-size samples is split evenly over the ranks, so the
+         effective batch and the number of optimiser steps — hence the number of collectives — are identical on every rank;
+         the step is data-parallel with a gradient all-reduce over RCCL, synthesis_amd/learner.py)
 
-Differences from the reference, all forced by determinism on a GPU: Fpu::Const(1.0) instead of Fpu::Func(N(1, 0.1))
-(main.rs:43-47), one StdRng stream per game, torch's randperm replaced by numpy's seeded permutation.
+Differences from the reference: one StdRng stream per game, torch's randperm replaced by numpy's seeded permutation, and by
+default the deterministic Fpu::Const(1.0) of the parity configuration; --reference-fpu selects the reference's own
+Fpu::Func(|| Normal(1.0, 0.1)) (main.rs:43-47), sampled on the device from per-tree StdRng streams instead of thread_rng.
 """
 import argparse
 import json
@@ -49,6 +53,9 @@ def main():
     ap.add_argument("--eval-explores", type=int, default=0, help="explores of the network player in evaluation (0 = --explores)")
     ap.add_argument("--eval-opponents", default="200,800", help="explores of the VanillaMCTS opponents")
     ap.add_argument("--out", default="")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (every rank on GPU 0: tests)")
+    ap.add_argument("--reference-fpu", action="store_true", help="self-play with Fpu::Func(|| Normal(1.0, 0.1)) (main.rs:43-47)")
+    ap.add_argument("--dump-weights", default="", help="write the final weights of every rank to <prefix>.rank<r>.npy")
     args = ap.parse_args()
 
     import torch  # noqa: F401  (before the engine: one HIP runtime per process)
@@ -59,9 +66,16 @@ def main():
     from synthesis_amd.learner import DataParallelLearner
 
     rank, local_rank, world = dist_util.rank_info()
-    dist = dist_util.init_process_group("nccl", local_rank) if world > 1 else None
+    dist = dist_util.init_process_group(args.dist_backend, local_rank) if world > 1 else None
+    if args.dist_backend != "nccl":
+        local_rank = 0
+    if args.batch_size % world != 0:
+        raise SystemExit(f"--batch-size {args.batch_size} must be a multiple of the world size {world}: every global batch is "
+                         f"split evenly over the ranks so that the effective batch stays the reference's")
     lr_schedule = [(1, 1e-3), (20, 5e-4), (40, 1e-4), (60, 5e-5), (80, 1e-5)]  # main.rs:18
     cfg = sa.parity_rollout_config(args.explores)
+    if args.reference_fpu:
+        cfg.mcts_cfg = sa.reference_selfplay_mcts_config()
 
     eng = sa.Engine(concurrent_games=min(args.concurrent, max(16, args.games_per_train // world)), max_explores=args.explores,
                     device=local_rank)
@@ -78,15 +92,20 @@ def main():
     for it in range(args.iterations):
         t0 = time.perf_counter()
         # ---- gather_experience (alpha_zero.rs:120-179): this rank's share of the new games, seeds never reused
-        first, count = dist_util.step_game_range(it, rank, world, args.games_per_train // world)
+        off, count = sa.shard_games(args.games_per_train, rank, world)   # contiguous shards, remainders spread over the ranks
+        first = it * args.games_per_train + off                           # global game index = seed offset, never reused
         sp = eng.selfplay(cfg, base_seed=args.seed, n_games=count, first_game=first)
         t_play = time.perf_counter() - t0
         n = sp["plies"]
         mask = np.arange(63)[None, :] < n[:, None]
-        gid = (games_played + first - it * args.games_per_train + np.arange(count))[:, None].repeat(63, 1)[mask]
-        R = dict(my=np.concatenate([R["my"], sp["states_bb"][..., 0][mask]]), op=np.concatenate([R["op"], sp["states_bb"][..., 1][mask]]),
-                 pi=np.concatenate([R["pi"], sp["pis"][mask]]), v=np.concatenate([R["v"], sp["vs"][mask]]),
-                 gid=np.concatenate([R["gid"], gid]))
+        new = dict(my=sp["states_bb"][..., 0][mask], op=sp["states_bb"][..., 1][mask], pi=sp["pis"][mask], v=sp["vs"][mask],
+                   gid=(first + np.arange(count))[:, None].repeat(63, 1)[mask])
+        if dist is not None:
+            # every rank appends ALL ranks' new games in rank order: one global replay buffer, identical everywhere
+            parts = [None] * world
+            dist.all_gather_object(parts, new)
+            new = {k: np.concatenate([p_[k] for p_ in parts]) for k in new}
+        R = {k: np.concatenate([R[k], new[k]]) for k in R}
         games_played += args.games_per_train
         keep = R["gid"] >= games_played - args.games_to_keep  # keep_last_n_games
         R = {k: a[keep] for k, a in R.items()}
@@ -103,16 +122,17 @@ def main():
         if world == 1:
             eng.train_set_data(D["my_bb"], D["op_bb"], D["pis"], D["vs"])  # one upload per iteration
         for ep in range(args.epochs):
-            perm = np.random.default_rng([args.seed, it, ep, rank]).permutation(n_unique)
-            n_steps = n_unique // args.batch_size  # drop_last = true
+            perm = np.random.default_rng([args.seed, it, ep]).permutation(n_unique)   # the same permutation on every rank
+            n_steps = n_unique // args.batch_size  # drop_last = true; n_unique is global, so every rank runs the same steps
             if world == 1:
                 # one call per epoch: batches are gathered on the device, no host round trip between the steps
                 sl = eng.train_epoch(perm[: n_steps * args.batch_size], args.batch_size, lr)
                 el = sl.astype(np.float64).sum(axis=0)
             else:
                 el = np.zeros(2, np.float64)
+                share = args.batch_size // world
                 for b in range(0, n_steps * args.batch_size, args.batch_size):
-                    idx = perm[b:b + args.batch_size]
+                    idx = perm[b + rank * share:b + (rank + 1) * share]   # this rank's slice of the global batch
                     el += learner.step(D["my_bb"][idx], D["op_bb"][idx], D["pis"][idx], D["vs"][idx], lr)
             steps += n_steps
             epoch_losses.append((el * args.batch_size / n_unique).tolist())
@@ -136,16 +156,18 @@ def main():
                 r2, _ = match.play_match(eval_eng, opp, me, args.eval_games, seed=1000 * it + 500)
                 w, d, l, s, elo = match.score(np.concatenate([r1, -r2]))
                 evaluation[opp.name] = dict(wins=w, draws=d, losses=l, score=round(s, 4), elo_diff=round(elo, 1))
-        rec = dict(iteration=it + 1, lr=lr, games=int(count * world), steps_in_buffer=int(R["my"].size), unique=int(n_unique),
+        rec = dict(iteration=it + 1, lr=lr, games=int(args.games_per_train), steps_in_buffer=int(R["my"].size), unique=int(n_unique),
                    plies_per_game=float(n.mean()), draws=float((sp["final_kind"] == 1).mean()), optimiser_steps=steps,
                    epoch_losses=epoch_losses, seconds=dict(selfplay=round(t_play, 3), dedup=round(t_dedup, 3), train=round(t_train, 3)),
-                   selfplay_games_per_s=count * world / t_play, train_steps_per_s=steps / max(t_train, 1e-9),
+                   selfplay_games_per_s=args.games_per_train / t_play, train_steps_per_s=steps / max(t_train, 1e-9),
                    evaluation=evaluation)
         log.append(rec)
         if rank == 0:
             print(json.dumps(rec), flush=True)
     if rank == 0 and args.out:
         json.dump(log, open(args.out, "w"), indent=1)
+    if args.dump_weights:
+        np.save(f"{args.dump_weights}.rank{rank}.npy", learner.state()["weights"])
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -20,6 +20,7 @@
 #include "pc_kernel.cuh"
 #include "frozen_kernel.cuh"
 #include "train_kernels.cuh"
+#include "train_mfma.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -86,6 +87,8 @@ struct syn_engine {
     float* d_tv = nullptr;
     float* d_tgrad = nullptr;
     float* d_tloss = nullptr;
+    float* d_twimg = nullptr;  // the trainer's weights in the inference fragment order (forward A operands; = the published image)
+    float* d_ttimg = nullptr;  // ... and transposed fragments for the activation gradients (train_mfma.cuh)
     long long train_step = 0;
     DevTrainHyper train_hp{};
     bool has_trainer = false;
@@ -205,7 +208,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // Lane-per-tree kernel (lane_kernel.cuh): one tree per lane, NW waves per workgroup, one workgroup per CU.
     // SYN_DEBUG=1 SYN_LANES=<waves per workgroup: 4, 8, 12 or 16> forces it (0 = never); by default it takes over once every CU can
     // be given 256 trees (4 waves; measured 41.9k games/s at 65,536 concurrent games against 31.8k for the queued
-    // row-per-tree workgroups), 8 waves up to 512 trees per CU, 12 beyond (16 waves spill: measured slower).
+    // row-per-tree workgroups), 8 waves up to 512 trees per CU, 12 up to 768, 16 beyond (selection below).
     // Producer/consumer kernel (pc_kernel.cuh): 12 tree waves x NV virtual waves of 64 trees + 4 matrix waves per CU. Measured
     // slower than the symmetric lane kernel (the f32 MFMA shares the SIMD's FP32 datapath with the VALU, so
     // dedicating waves to the matrix pipe frees nothing), so it is never chosen automatically:
@@ -489,6 +492,8 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_tv);
     hipFree(h->d_tgrad);
     hipFree(h->d_tloss);
+    hipFree(h->d_twimg);
+    hipFree(h->d_ttimg);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -592,12 +597,16 @@ int syn_features_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_
     size_t total = nb * 63;
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(features_kernel, dim3(grid), dim3(256), 0, h->stream,
                        reinterpret_cast<const unsigned long long*>(d_my),
                        reinterpret_cast<const unsigned long long*>(d_op), n, d_out);
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out, d_out, total * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
     return SYN_OK;
 }
 
@@ -620,10 +629,14 @@ int syn_linear_forward(syn_engine* h, int I, int O, const float* W, const float*
     HIP_TRY(h, hipMemcpyAsync(dx, x, nx * 4, hipMemcpyHostToDevice, h->stream));
     int grid = (int)((ny + 255) / 256);
     if (grid > 2048) grid = 2048;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(linear_kernel, dim3(grid), dim3(256), 0, h->stream, I, O, dW, db, dx, batch, dy, relu);
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(y, dy, ny * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
     return SYN_OK;
 }
 
@@ -652,11 +665,15 @@ int syn_conv2d_forward(syn_engine* h, int CIN, int COUT, int K, int RP, int CP, 
     HIP_TRY(h, hipMemcpyAsync(dx, x, nx * 4, hipMemcpyHostToDevice, h->stream));
     int grid = (int)((ny + 255) / 256);
     if (grid > 2048) grid = 2048;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(conv2d_kernel, dim3(grid), dim3(256), 0, h->stream, CIN, COUT, K, RP, CP, S, H_IN, W_IN, H_OUT,
                        W_OUT, dW, db, dx, batch, dy, relu);
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(y, dy, ny * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
     return SYN_OK;
 }
 
@@ -1035,6 +1052,23 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
         HIP_TRY(h, hipMalloc(&h->d_tv, bytes));
         HIP_TRY(h, hipMalloc(&h->d_tgrad, bytes));
         HIP_TRY(h, hipMalloc(&h->d_tloss, 64));
+        HIP_TRY(h, hipMalloc(&h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4));
+        HIP_TRY(h, hipMalloc(&h->d_ttimg, (size_t)TrainImg::T_FLOATS * 4));
+    }
+    {
+        // the two fragment-order images the matrix-core learner reads its A operands from (train_mfma.cuh); adam_image_kernel
+        // keeps them in step with the canonical weights afterwards
+        std::vector<float> img, timg((size_t)TrainImg::T_FLOATS, 0.0f);
+        build_weight_image(blob, img);
+        for (int p = 0; p < TrainGeom::NUM_PARAMS; p++) {
+            int fwd, tr;
+            train_image_slots(p, fwd, tr);
+            if (img[(size_t)fwd] != blob[p]) return fail(h, SYN_ERR_HIP, "internal: image slot table disagrees with build_weight_image at %d", p);
+            if (tr >= 0) timg[(size_t)tr] = blob[p];
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->d_twimg, img.data(), img.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(h->d_ttimg, timg.data(), timg.size() * 4, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     HIP_TRY(h, hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_tm, 0, bytes, h->stream));
@@ -1049,9 +1083,14 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
 static int launch_grads(syn_engine* h, const unsigned long long* d_my, const unsigned long long* d_op,
                         const float* d_tpi, const float* d_tv, int batch, float* d_grads, float* d_losses = nullptr,
                         const int* d_idx = nullptr) {
-    auto k = train_grad_kernel;
-    const size_t lds = (size_t)TrainGeom::LDS_FLOATS * 4;
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the matrix-core kernel (train_mfma.cuh); SYN_DEBUG=1 SYN_TRAIN_VALU=1 runs the VALU kernel it replaced (A/B, same bits)
+    static const bool valu = debug_env("SYN_TRAIN_VALU") != nullptr;
+    const size_t lds = valu ? (size_t)TrainGeom::LDS_FLOATS * 4 : (size_t)TrainGeom::WL_OFF * 4;
+    if (valu) {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    } else {
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_grad_kernel_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     // SYN_TRAIN_PROFILE=1: diagnostic stamps of the kernel's phases (first chunk), printed to stderr
     static const bool prof = debug_env("SYN_TRAIN_PROFILE") != nullptr;
     unsigned long long* d_prof = nullptr;
@@ -1059,8 +1098,12 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
         HIP_TRY(h, hipMalloc(&d_prof, 4096));
         HIP_TRY(h, hipMemsetAsync(d_prof, 0, 4096, h->stream));
     }
-    hipLaunchKernelGGL(k, dim3(1), dim3(1024), lds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
-                       d_grads, d_losses ? d_losses : h->d_tloss, d_idx, d_prof);
+    if (valu)
+        hipLaunchKernelGGL(train_grad_kernel, dim3(1), dim3(1024), lds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
+                           d_grads, d_losses ? d_losses : h->d_tloss, d_idx, d_prof);
+    else
+        hipLaunchKernelGGL(train_grad_kernel_mfma, dim3(1), dim3(1024), lds, h->stream, h->d_tw, h->d_twimg, h->d_ttimg, d_my, d_op,
+                           d_tpi, d_tv, batch, h->train_hp, d_grads, d_losses ? d_losses : h->d_tloss, d_idx, d_prof);
     HIP_TRY(h, hipGetLastError());
     if (prof) {
         unsigned long long t[8] = {0};
@@ -1080,8 +1123,8 @@ static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
     const int n = TrainGeom::NUM_PARAMS;
-    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads,
-                       n, h->train_hp, step_size, inv_sqrt_bc2, grad_scale);
+    hipLaunchKernelGGL(adam_image_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads,
+                       n, h->train_hp, step_size, inv_sqrt_bc2, grad_scale, h->d_twimg, h->d_ttimg);
     HIP_TRY(h, hipGetLastError());
     return SYN_OK;
 }
@@ -1228,10 +1271,13 @@ int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long l
 int syn_trainer_publish_weights(syn_engine* h) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
-    std::vector<float> blob(TrainGeom::NUM_PARAMS);
-    int rc = syn_trainer_get_state(h, blob.data(), nullptr, nullptr, nullptr, nullptr);
-    if (rc != SYN_OK) return rc;
-    return syn_load_weights(h, blob.data(), blob.size());
+    // the trainer keeps its weights in the inference fragment order as well (train_mfma.cuh): publishing is one device copy
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpyAsync(h->d_wimg, h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));  // new network: empty PolicyWithCache
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->has_weights = true;
+    return SYN_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ deduplicate
@@ -1373,10 +1419,14 @@ int syn_activation_forward(syn_engine* h, int kind, const float* x, int batch, i
     float* dy = dx + cnt;
     HIP_TRY(h, hipMemcpyAsync(dx, x, cnt * 4, hipMemcpyHostToDevice, h->stream));
     const size_t threads = kind == SYN_ACT_SOFTMAX ? (size_t)batch : cnt;
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(activation_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, h->stream, kind, dx, batch, n, dy);
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(y, dy, cnt * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+    h->last_launches = 1;
     return SYN_OK;
 }
 

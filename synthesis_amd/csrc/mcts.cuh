@@ -63,7 +63,7 @@ struct CfgView {
     SYN_DEV float fpu_value() const { return c.fpu_value; }
 };
 inline bool cfg_is_fast(const DevMctsCfg& c) {
-    return c.exploration == 1 && c.fpu == 0 && c.select_solved && c.solve && c.correct_values && c.auto_extend;
+    return c.exploration == 1 && c.fpu == 0 && c.select_solved && c.solve && c.correct_values && c.auto_extend && c.noise == 0;
 }
 
 struct DevCounters {  // index order = syn_counters

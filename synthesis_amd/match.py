@@ -85,6 +85,11 @@ def play_match(engine, first: Player, second: Player, n_games, seed=0, seeds=Non
     (game.reward(first_player), evaluator.rs:160) and the number of plies. Game g's rollout generator is
     StdRng::seed_from_u64(seeds[g]) (default seed + g), shared by both sides and alive for the whole game when the players
     are vanilla players (evaluator.rs:171-172, 207-208). `record`: optional dict that receives "moves" [n_games, 63]."""
+    net = [p for p in (first, second) if not p.frozen and not p.rollout]
+    if len(net) == 2 and (net[0].weights is None) != (net[1].weights is None):
+        # the engine cannot hand back the weights it currently holds, so after the first swap a `weights=None` player would
+        # silently search with its opponent's network
+        raise ValueError("play_match: give both network players explicit weights, or neither (both then use the engine's network)")
     my = np.zeros(n_games, np.uint64); op = np.zeros(n_games, np.uint64)
     alive = np.ones(n_games, bool)
     reward = np.zeros(n_games, np.float32)

@@ -218,6 +218,18 @@ def test_match_host_rules_follow_the_oracle(oracle):
     assert p.rollout and p.mcts_cfg.auto_extend is False and p.name == "RolloutMCTS800"
 
 
+def test_play_match_rejects_mixed_weight_sources():
+    """A network player without weights beside one with explicit weights would search with the other's network after the
+    first swap: refused up front."""
+    from synthesis_amd import match
+    import synthesis_amd as sa
+
+    a = match.Player("a", 10, sa.MCTSConfig(), sa.ActionSelection.NumVisits)
+    b = match.Player("b", 10, sa.MCTSConfig(), sa.ActionSelection.NumVisits, weights=np.zeros(30492, np.float32))
+    with pytest.raises(ValueError):
+        match.play_match(None, a, b, 4)
+
+
 def test_pgn_records_match_the_reference_format():
     """utils.rs:31-52: three tag lines and the result line per game"""
     from synthesis_amd import match

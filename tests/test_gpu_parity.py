@@ -210,6 +210,44 @@ def test_mcts_search_visit_exact(engine, oracle, blob):
     assert got["num_nodes"].max() <= 1 + 9 * 801
 
 
+@pytest.mark.parametrize("shape", ["rows", "lanes8", "lanes16", "pc2"])
+def test_trained_checkpoint_deep_trees_match_oracle(golden_dir, oracle, monkeypatch, shape):
+    """A TRAINED network (tests/golden/c4net_trained_f32.npy, produced on the device by examples/train_connect4.py; see
+    tests/golden/README.md) makes sharp priors, hence deep narrow trees with long backprop paths and near-ties in PUCT — the
+    regime the random-init blob never reaches. Searches at 800 explores and whole self-play games stay identical to
+    the oracle on every launch shape, and the trees really are deeper than with the random-init network."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    path = os.path.join(golden_dir, "c4net_trained_f32.npy")
+    if not os.path.exists(path):
+        pytest.skip("no trained checkpoint fixture yet")
+    trained = np.load(path)
+    if shape != "rows":
+        monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
+        if shape == "pc2":
+            monkeypatch.setenv("SYN_PC", "2")
+        else:
+            monkeypatch.setenv("SYN_LANES", shape[5:])
+    eng = sa.Engine(concurrent_games=1100, max_explores=800)
+    eng.load_weights(trained)
+    my, op = random_positions(oracle, 64, seed=19, max_moves=40)
+    my[0] = 0; op[0] = 0
+    got = eng.mcts_search(sa.parity_mcts_config(), my, op, 800)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), trained, my, op, 800, nn_mode=oracle.ACC_FMA)
+    assert_search_equal(got, ref, f"trained weights, {shape}, 800 explores")
+    got = eng.selfplay(sa.parity_rollout_config(800), base_seed=3, n_games=8, counters=True)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), trained, 3, 8, threads=8, nn_mode=oracle.ACC_FMA)
+    assert_selfplay_equal(got, ref, f"trained weights, {shape}, self-play")
+    for k in ("explores", "select_levels", "backprop_levels", "policy_evals", "max_depth"):
+        assert got["counters"][k] == ref["counters"][k], k
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    rnd = oracle.c4_selfplay(parity_rollout_config(800), blob, 3, 8, threads=8, nn_mode=oracle.ACC_FMA)["counters"]
+    deep, shallow = got["counters"]["select_levels"] / got["counters"]["explores"], rnd["select_levels"] / rnd["explores"]
+    assert deep > shallow + 0.5, (deep, shallow)
+    eng.close()
+
+
 def test_mcts_search_reference_default_1600_explores(oracle, blob):
     """The reference's own default budget (num_explores: 1600, study-connect4/src/main.rs:30): slab of 1 + 9*1601 nodes
     per tree, still visit-exact; plus one full self-play game at 1600 explores."""
@@ -319,12 +357,15 @@ def test_engine_error_behaviour(blob):
     with pytest.raises(sa.SynthesisAmdError) as e:
         eng.mcts_search(sa.parity_mcts_config(), [0], [0], 33)
     assert e.value.code == -6  # SYN_ERR_CAPACITY
+    # Fpu::Func = Normal(mean, std) and PolicyNoise::Dirichlet run on the device (round 2); malformed parameters are rejected
     with pytest.raises(sa.SynthesisAmdError) as e:
-        eng.mcts_search(sa.MCTSConfig(fpu=sa.Fpu.Func), [0], [0], 8)
-    assert e.value.code == -5  # SYN_ERR_UNSUPPORTED
+        eng.mcts_search(sa.MCTSConfig(fpu=sa.Fpu.Func, fpu_std=-1.0), [0], [0], 8)
+    assert e.value.code == -1  # SYN_ERR_INVALID_ARGUMENT (Normal::new rejects std < 0)
     with pytest.raises(sa.SynthesisAmdError) as e:
-        eng.mcts_search(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet), [0], [0], 8)
-    assert e.value.code == -5
+        eng.mcts_search(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.0, noise_weight=0.25), [0], [0], 8)
+    assert e.value.code == -1  # Dirichlet::new_with_size rejects alpha <= 0
+    eng.mcts_search(sa.MCTSConfig(fpu=sa.Fpu.Func, fpu_value=1.0, fpu_std=0.1), [0], [0], 8)
+    eng.mcts_search(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25), [0], [0], 8)
     r = eng.selfplay(sa.parity_rollout_config(8), 0, 0)
     assert r["plies"].size == 0
     # roots the reference itself could not search: overlapping stones, a floating stone, a full board

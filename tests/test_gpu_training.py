@@ -1,5 +1,6 @@
 """GPU parity of the learner step and the replay de-duplication against the oracle (bit-exact: same
 fixed-order f32 arithmetic) and against the torch float64 goldens (1e-5; no reference test covers this step)."""
+import json
 import os
 
 import numpy as np
@@ -203,3 +204,29 @@ def test_data_parallel_learner_two_ranks(oracle, blob, gold, tmp_path):
     X = np.stack([oracle.c4_features(gold["my_bb"][s], gold["op_bb"][s]) for s in range(4)])
     wf, _, _, _, _ = oracle.train_steps(blob, hp, X, gold["target_pi"][:4], gold["target_v"][:4], gold["lrs"][:4])
     assert np.abs(r0["weights"] - wf).max() < 1e-5
+
+
+def test_training_example_keeps_two_ranks_identical(tmp_path):
+    """examples/train_connect4.py with two ranks (gloo, both on GPU 0): the new games are all-gathered into ONE global replay
+    buffer, de-duplicated identically on both ranks, every global batch is split evenly, so both ranks issue the same
+    number of collectives and end with bit-identical weights (per-shard buffers made the step counts differ
+    and the all-reduces mismatch). Uneven game counts (601 games over 2 ranks) exercise the remainder handling."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = str(tmp_path / "w")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+         "--master-port", "29547", os.path.join(root, "examples", "train_connect4.py"), "--iterations", "2", "--games-per-train",
+         "601", "--explores", "40", "--epochs", "1", "--concurrent", "512", "--dist-backend", "gloo", "--dump-weights", prefix],
+        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert out.returncode == 0, out.stdout.decode()[-3000:]
+    w0, w1 = np.load(prefix + ".rank0.npy"), np.load(prefix + ".rank1.npy")
+    assert np.array_equal(w0.view(np.uint32), w1.view(np.uint32))
+    from bench import make_weights
+    assert not np.array_equal(w0, make_weights(20211003))   # the weights did train
+    lines = [json.loads(l) for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 2 and lines[0]["games"] == 601 and lines[1]["optimiser_steps"] > 0

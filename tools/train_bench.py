@@ -31,3 +31,12 @@ for B in (32, 256, 1024):
         eng.train_step(d["my_bb"][idx[i]], d["op_bb"][idx[i]], d["pis"][idx[i]], d["vs"][idx[i]], 1e-3)
     dt = (time.perf_counter() - t) / n
     print(f"train_step B={B}: {dt*1e6:.1f} us/step (host batch in, losses out) = {B/dt:.0f} samples/s")
+# device-resident epochs (syn_train_set_data + syn_train_epoch): the path the learning loop uses
+eng.train_set_data(d["my_bb"], d["op_bb"], d["pis"], d["vs"])
+nu = d["num"].size
+perm = np.random.default_rng(1).permutation(nu)
+steps = nu // 32
+eng.train_epoch(perm[: 256 * 32], 32, 1e-3)
+t = time.perf_counter(); eng.train_epoch(perm[: steps * 32], 32, 1e-3); dt = time.perf_counter() - t
+print(f"train_epoch B=32: {steps} steps in {dt*1e3:.1f} ms = {dt/steps*1e6:.2f} us/step = {steps/dt:.0f} steps/s "
+      f"({'VALU kernel' if os.environ.get('SYN_TRAIN_VALU') else 'matrix-core kernel'})")
