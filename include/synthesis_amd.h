@@ -33,7 +33,8 @@ typedef enum syn_status {
     SYN_ERR_HIP = -3,             /* a HIP call failed; see syn_last_error */
     SYN_ERR_NO_WEIGHTS = -4,      /* policy/value network weights not loaded yet */
     SYN_ERR_UNSUPPORTED = -5,     /* config variant not implemented on the device */
-    SYN_ERR_CAPACITY = -6         /* node pool too small for the requested explores */
+    SYN_ERR_CAPACITY = -6,        /* node pool too small for the requested explores */
+    SYN_ERR_CANCELLED = -7        /* syn_cancel was called while the call ran: results of the games that finished are valid */
 } syn_status;
 
 /* ---- plain-data mirrors of synthesis/src/config.rs ---------------------------------------------------------- */
@@ -290,6 +291,16 @@ int syn_last_cache_stats(const syn_engine* h, uint64_t* hits, uint64_t* misses);
  * with two workgroups per CU, 3 = quad-async row kernel (several 16-tree quads per workgroup), 4 = lane-per-tree kernel
  * (one tree per lane), 5 = the evaluator baseline's lane-per-tree kernel; grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
 int syn_last_launch_shape(const syn_engine* h, int* shape, int* grid, int* threads);
+
+/* A self-play launch plays its whole batch inside ONE kernel (seconds to tens of seconds). These two entry points may be called
+ * from ANOTHER host thread while syn_selfplay_run / syn_mcts_search runs on the handle (they use a stream of their own):
+ * syn_progress: *started = jobs handed to tree slots so far (capped at the call's job count), *finished = self-play games
+ *   completed so far.
+ * syn_cancel: no further job is handed out; the running call returns SYN_ERR_CANCELLED once the games already started have
+ *   finished (at most one game's duration). Their outputs are valid; plies[g] = 0 marks a game that never started.
+ * The reference has no counterpart (its workers are joined at the end of gather_experience, alpha_zero.rs:156-170). */
+int syn_progress(syn_engine* h, int* started, int* finished);
+int syn_cancel(syn_engine* h);
 
 /* Device-side RNG / math primitives exposed for parity tests against the oracle (no reference counterpart):
  * out[i] = i-th u32 of StdRng::seed_from_u64(seed) as generated on the GPU. */

@@ -44,6 +44,10 @@ struct syn_engine {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // syn_progress / syn_cancel: independent of the launch stream
+    int* h_pin = nullptr;              // 64 pinned bytes for their transfers
+    volatile int cancel_requested = 0;
+    volatile int running_jobs = 0;     // job count of the call in flight (0 = none)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int slots = 0;
     int last_shape = 0, last_grid = 0, last_threads = 0;
@@ -442,6 +446,8 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     h->cap = (uint32_t)(1 + 9 * (cfg->max_explores + 1));
     h->cap = (h->cap + 3u) & ~3u;
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), 64)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     // the launch may round the slot count up to a whole workgroup (<= 1024 trees: lane kernel)
@@ -497,6 +503,8 @@ int syn_engine_destroy(syn_engine* h) {
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
+    if (h->aux_stream) hipStreamDestroy(h->aux_stream);
+    if (h->h_pin) hipHostFree(h->h_pin);
     delete h;
     return SYN_OK;
 }
@@ -932,6 +940,10 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_cache_stats, 0, 16, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_plies, 0, (size_t)n_games * 4, h->stream));  // plies = 0: a game that never started (syn_cancel)
+    h->cancel_requested = 0;
+    h->running_jobs = n_games;
+    struct RunningGuard { syn_engine* e; ~RunningGuard() { e->running_jobs = 0; } } running_guard{h};
     // SYN_PROFILE=1: diagnostic build of the kernel with s_memtime stamps around each phase (never timed/benched)
     const bool prof = !counters && debug_env("SYN_PROFILE") != nullptr;
     int pgrid = 0, pnt = 0;
@@ -1035,6 +1047,29 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
+    if (h->cancel_requested) return fail(h, SYN_ERR_CANCELLED, "cancelled by syn_cancel: the games that had started were played to the end");
+    return SYN_OK;
+}
+
+int syn_progress(syn_engine* h, int* started, int* finished) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(h->device) != hipSuccess) return SYN_ERR_HIP;
+    if (hipMemcpyAsync(h->h_pin, h->d_job_next, 8, hipMemcpyDeviceToHost, h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
+    if (hipStreamSynchronize(h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
+    const int jobs = h->running_jobs;
+    if (started) *started = (jobs > 0 && h->h_pin[0] > jobs) ? jobs : h->h_pin[0];
+    if (finished) *finished = h->h_pin[1];
+    return SYN_OK;
+}
+
+int syn_cancel(syn_engine* h) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (hipSetDevice(h->device) != hipSuccess) return SYN_ERR_HIP;
+    h->cancel_requested = 1;
+    // every later job fetch (an atomic add on this word) now returns an index past the call's job count: no new game starts
+    h->h_pin[8] = 0x40000000;
+    if (hipMemcpyAsync(h->d_job_next, h->h_pin + 8, 4, hipMemcpyHostToDevice, h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
+    if (hipStreamSynchronize(h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
     return SYN_OK;
 }
 

@@ -40,7 +40,7 @@ struct EngineParams {
     uint4* edge;
     uint32_t cap;            // nodes per tree slab
     int n_jobs;              // games (self-play) or roots (search)
-    int* job_next;           // global job counter
+    int* job_next;           // [0] global job counter (syn_cancel raises it past n_jobs), [1] games finished, [8] error word
     unsigned long long* counters;  // DevCounters (may be null)
     unsigned long long* prof;      // PROF builds: per-wave cycle sums [A, wait1, B, wait2, C, iterations]
     int* error;                    // set to 1 by a quad whose bounded spin gave up (quad-async kernel)
@@ -322,6 +322,7 @@ SYN_DEV void selfplay_move_step(const EngineParams& P, TreeCtx& T, GameCtx& G, i
     if (gl == 0) {
         P.plies[G.job] = n;
         P.final_kind[G.job] = (unsigned char)sol_kind;
+        atomicAdd(P.job_next + 1, 1);  // games finished so far (syn_progress)
     }
     if (COUNT) ctr[CTR_GAMES]++;
     start_job<MODE_SELFPLAY>(P, T, G, gl);

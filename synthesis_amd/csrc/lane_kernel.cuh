@@ -849,6 +849,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     }
     P.plies[T.job] = n;
     P.final_kind[T.job] = (unsigned char)sol_kind;
+    atomicAdd(P.job_next + 1, 1);  // games finished so far (syn_progress)
     if (COUNT) ctr[CTR_GAMES]++;
     lane_start_job<MODE_SELFPLAY>(P, T);
 }

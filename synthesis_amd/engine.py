@@ -17,7 +17,7 @@ NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/p
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -109,6 +109,8 @@ def load_library():
                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.syn_selfplay_run.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int] + \
                                     [C.c_void_p] * 8
+    lib.syn_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.syn_cancel.argtypes = [C.c_void_p]
     lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.syn_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.syn_last_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -309,14 +311,28 @@ class Engine:
                      root_nodes=np.zeros((n, 63), np.uint32), final_kind=np.zeros(n, np.uint8))
         ctr = CCounters() if counters else None
         c = cfg.to_c()
-        self._check(self._lib.syn_selfplay_run(
+        rc = self._lib.syn_selfplay_run(
             self._h, C.byref(c), int(base_seed), int(first_game), n, _p(r["plies"]), _p(r.get("states_bb")),
             _p(r.get("pis")), _p(r.get("vs")), _p(r.get("actions")), _p(r.get("root_nodes")), _p(r.get("final_kind")),
-            C.cast(C.byref(ctr), C.c_void_p) if ctr is not None else None))
+            C.cast(C.byref(ctr), C.c_void_p) if ctr is not None else None)
+        if rc == -7:    # SYN_ERR_CANCELLED (Engine.cancel from another thread): the games that finished are valid, plies == 0 otherwise
+            r["cancelled"] = True
+        else:
+            self._check(rc)
         if ctr is not None:
             r["counters"] = {name: int(getattr(ctr, name)) for name, _ in CCounters._fields_}
         r["kernel_ms"] = self.last_kernel_ms()
         return r
+
+    def progress(self):
+        """(jobs started, games finished) of the call running on this engine — callable from another thread while it runs."""
+        a, b = C.c_int(), C.c_int()
+        self._check(self._lib.syn_progress(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
+    def cancel(self):
+        """No further game starts; the running selfplay() raises SynthesisAmdError(-7) once the started games have finished."""
+        self._check(self._lib.syn_cancel(self._h))
 
     def last_cache_stats(self):
         """(hits, misses) of the device PolicyWithCache during the last search / self-play call."""

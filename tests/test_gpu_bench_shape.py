@@ -114,3 +114,53 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["config"]["games_per_step_per_gpu"] == 16384
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 16384) < 1.0   # value = games of BOTH ranks / time
     assert 7 <= line["plies_per_game"] <= 63
+
+
+def test_progress_and_cancel_from_another_thread(blob, oracle):
+    """One self-play launch is a single kernel of seconds to tens of seconds: syn_progress reports jobs started / games finished
+    while it runs, syn_cancel stops the hand-out of new games — the call returns SYN_ERR_CANCELLED after the started games have
+    finished, their outputs identical to the oracle's, plies == 0 for games that never started."""
+    import time
+
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+    from tests.test_gpu_parity import assert_selfplay_equal
+
+    eng = sa.Engine(concurrent_games=4096, max_explores=200, device=0)
+    eng.load_weights(blob)
+    n = 400000   # ~10 s of work at this size if left alone
+    box = {}
+
+    def run():
+        box["r"] = eng.selfplay(sa.parity_rollout_config(200), base_seed=5, n_games=n)
+
+    t = threading.Thread(target=run)
+    t0 = time.perf_counter()
+    t.start()
+    seen = []
+    while time.perf_counter() - t0 < 60:
+        started, finished = eng.progress()
+        seen.append((started, finished))
+        if finished >= 6000:
+            break
+        time.sleep(0.02)
+    eng.cancel()
+    t.join(timeout=120)
+    dt = time.perf_counter() - t0
+    assert not t.is_alive() and "r" in box
+    r = box["r"]
+    assert r.get("cancelled") is True and dt < 30
+    assert all(b[0] >= a[0] and b[1] >= a[1] for a, b in zip(seen, seen[1:])) and seen[-1][0] >= seen[-1][1] >= 6000
+    played = np.nonzero(r["plies"])[0]
+    assert 6000 <= played.size < n and played.max() < seen[-1][0] + 4096 + 16   # nothing started after the cancel (+ slots in flight)
+    assert eng.progress()[1] == played.size
+    first = int(played[100])
+    block = [g for g in range(first, first + 6) if r["plies"][g] > 0]
+    ref = oracle.c4_selfplay(parity_rollout_config(200), blob, 5, 6, first_game=first, threads=6, nn_mode=oracle.ACC_FMA)
+    sub = {k: r[k][first:first + 6] for k in ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind")}
+    if len(block) == 6:
+        assert_selfplay_equal(sub, ref, "cancelled run, finished games")
+    # the engine is usable afterwards
+    r2 = eng.selfplay(sa.parity_rollout_config(200), base_seed=5, n_games=64)
+    assert "cancelled" not in r2 and (r2["plies"] > 0).all()
+    eng.close()
