@@ -61,14 +61,18 @@ def algorithmic_bytes(c):
             + 8 * c["expansions"] + 40 * c["backprop_levels"] + 4 * c["solver_children"])
 
 
+SELFPLAY_KERNEL_SOURCES = ("device_common.cuh", "mcts.cuh", "mlp.cuh", "engine_kernels.cuh", "lane_kernel.cuh", "pc_kernel.cuh",
+                           "noise.cuh", "zig_tables.cuh")
+
+
 def kernel_source_hash():
-    """sha256 (16 hex digits) over the HIP sources of the library: ties a committed PMC summary to the kernels it measured."""
-    import glob
+    """sha256 (16 hex digits) over the HIP sources the fused self-play kernels are compiled from (their include closure): ties a
+    committed PMC summary to the kernels it measured."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "synthesis_amd", "csrc", "*.cuh")) + glob.glob(os.path.join(ROOT, "synthesis_amd", "csrc", "*.hip"))):
-        h.update(open(f, "rb").read())
+    for f in SELFPLAY_KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "synthesis_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 

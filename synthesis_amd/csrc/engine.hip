@@ -638,7 +638,14 @@ int syn_linear_forward(syn_engine* h, int I, int O, const float* W, const float*
     int grid = (int)((ny + 255) / 256);
     if (grid > 2048) grid = 2048;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(linear_kernel, dim3(grid), dim3(256), 0, h->stream, I, O, dW, db, dx, batch, dy, relu);
+    if (nW * 4 <= 64 * 1024) {
+        // weights in LDS, transposed (the usual case: every layer of Connect4Net is <= 48 KB); few, long-lived workgroups so
+        // that the staging is amortised
+        if (grid > 4 * h->num_cus) grid = 4 * h->num_cus;
+        hipLaunchKernelGGL(linear_kernel_lds, dim3(grid), dim3(256), nW * 4, h->stream, I, O, dW, db, dx, batch, dy, relu);
+    } else {
+        hipLaunchKernelGGL(linear_kernel, dim3(grid), dim3(256), 0, h->stream, I, O, dW, db, dx, batch, dy, relu);
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(y, dy, ny * 4, hipMemcpyDeviceToHost, h->stream));
@@ -1276,6 +1283,9 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
                        reinterpret_cast<const float*>(base + n * 16), reinterpret_cast<const float*>(base + n * 52), g_my,
                        g_op, g_tpi, g_tv);
     HIP_TRY(h, hipGetLastError());
+    // (a single-launch epoch kernel — the same workgroup applying Adam after its gradients — was built and measured: 64 us per
+    //  step against 45 us for these queued launches, because one workgroup's Adam over 30,492 parameters and two scattered
+    //  image writes costs more than the launch gap it removes)
     for (size_t s = 0; s < n_steps; s++) {  // steps are dependent (weights of step s feed step s+1): queued, never synced
         const size_t o = s * (size_t)batch;
         rc = launch_grads(h, g_my + o, g_op + o, g_tpi + o * 9, g_tv + o * 3, batch, h->d_tgrad, d_losses + 2 * s);

@@ -835,6 +835,29 @@ __global__ void linear_kernel(int I, int O, const float* __restrict__ W, const f
     }
 }
 
+// The same layer with the weights transposed into LDS once per workgroup ([input][output]: the lanes of a wave read consecutive
+// outputs, conflict-free) and the input row read as a wave-uniform broadcast: per multiply-add one LDS read instead of 64
+// divergent global look-ups. Same arithmetic: separate multiply and add, ascending input index. Needs I * O * 4 bytes of LDS.
+__global__ void linear_kernel_lds(int I, int O, const float* __restrict__ W, const float* __restrict__ b,
+                                  const float* __restrict__ x, int batch, float* __restrict__ y, int relu) {
+    extern __shared__ float wt[];
+    for (int idx = threadIdx.x; idx < I * O; idx += blockDim.x) {
+        const int o = idx / I, k = idx - o * I;
+        wt[k * O + o] = W[idx];
+    }
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)batch * O;
+    for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t nb = i / O;
+        const int o = (int)(i - nb * O);
+        float acc = b[o];
+        const float* xr = x + nb * I;
+        for (int k = 0; k < I; k++) acc += xr[k] * wt[k * O + o];
+        y[i] = relu ? __builtin_fmaxf(acc, 0.0f) : acc;
+    }
+}
+
 // slimnn::Conv2d::forward (conv.rs:45-85): accumulation order ci -> k1 -> k2 per output element
 __global__ void conv2d_kernel(int CIN, int COUT, int K, int RP, int CP, int S, int H_IN, int W_IN, int H_OUT,
                               int W_OUT, const float* __restrict__ W, const float* __restrict__ b,

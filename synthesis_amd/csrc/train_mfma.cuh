@@ -202,14 +202,11 @@ SYN_DEV void tm_bias_grads(const float* __restrict__ lds, float* __restrict__ gr
     }
 }
 
-__global__ __launch_bounds__(1024) void train_grad_kernel_mfma(const float* __restrict__ w, const float* __restrict__ wimg,
-                                                               const float* __restrict__ timg,
-                                                               const unsigned long long* __restrict__ my_bb,
-                                                               const unsigned long long* __restrict__ op_bb,
-                                                               const float* __restrict__ tpi, const float* __restrict__ tv, int B,
-                                                               DevTrainHyper hp, float* __restrict__ grads, float* __restrict__ losses,
-                                                               const int* __restrict__ idx = nullptr,
-                                                               unsigned long long* __restrict__ prof = nullptr) {
+// Gradients of one minibatch by the whole 1024-thread workgroup (the body of train_grad_kernel_mfma).
+SYN_DEV void tm_gradients(const float* wimg, const float* timg, const unsigned long long* __restrict__ my_bb,
+                          const unsigned long long* __restrict__ op_bb, const float* __restrict__ tpi,
+                          const float* __restrict__ tv, int B, DevTrainHyper hp, float* grads, float* losses,
+                          const int* __restrict__ idx, unsigned long long* __restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using G = TrainGeom;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -342,6 +339,19 @@ __global__ __launch_bounds__(1024) void train_grad_kernel_mfma(const float* __re
         losses[1] = bm * v_acc;
     }
 #undef SYN_TSTAMP
+}
+
+// grads[NUM_PARAMS] (device) receives d(loss)/d(param) of the minibatch; losses[0..1] = pi_loss, v_loss.
+__global__ __launch_bounds__(1024) void train_grad_kernel_mfma(const float* __restrict__ w, const float* __restrict__ wimg,
+                                                               const float* __restrict__ timg,
+                                                               const unsigned long long* __restrict__ my_bb,
+                                                               const unsigned long long* __restrict__ op_bb,
+                                                               const float* __restrict__ tpi, const float* __restrict__ tv, int B,
+                                                               DevTrainHyper hp, float* __restrict__ grads, float* __restrict__ losses,
+                                                               const int* __restrict__ idx = nullptr,
+                                                               unsigned long long* __restrict__ prof = nullptr) {
+    (void)w;
+    tm_gradients(wimg, timg, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, prof);
 }
 
 }  // namespace syn
