@@ -13,7 +13,7 @@ Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7
            deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
            SoA MCTS node pool) at 262,144 concurrent games per GPU (1,024 per CU: the 16-wave lane-per-tree kernel);
            configs[1]'s 4096 concurrent games is measured in the same run and reported under "at_4096_concurrent_games".
-Step     : one pass of the hot path over one batch = GAMES_PER_STEP self-play games per GPU played to completion by
+Step     : one pass of the hot path over one batch = GAMES_PER_STEP (2,097,152 = 8 per tree slot) self-play games per GPU played to completion by
            ONE launch of the fused kernel (finished games hand their tree slot to the next game index, so the slots stay busy).
 Scaling  : weak — every rank plays its own GAMES_PER_STEP games per step (games share nothing; no collective on the
            data path). Timed region = barrier + device sync on both sides, max over ranks.
@@ -172,7 +172,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--concurrent", type=int, default=262144,
                     help="concurrent games (tree slots) per GPU; BASELINE configs[1] names 4096, reported as extra")
-    ap.add_argument("--games-per-step", type=int, default=1572864, help="self-play games per GPU per step")
+    ap.add_argument("--games-per-step", type=int, default=2097152, help="self-play games per GPU per step (8 per tree slot)")
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -337,11 +337,11 @@ def main():
             # step of twice the games has the same tail on twice the work. tail_share = the fraction of a default step that
             # the tail costs against a tail-free (infinitely long) launch.
             t1 = time.perf_counter()
-            eng.selfplay(cfg, base_seed=0, n_games=2 * gps, first_game=(args.warmup + args.steps) * gps, outputs=False)
+            eng.selfplay(cfg, base_seed=0, n_games=gps + gps // 2, first_game=(args.warmup + args.steps) * gps, outputs=False)
             dt2 = time.perf_counter() - t1
             t_step = elapsed / args.steps
-            steady = gps / max(1e-9, dt2 - t_step)                 # games/s of the extra (tail-free) half
-            out["launch_tail"] = {"games_per_s_at_2x_games_per_step": 2 * gps / dt2, "steady_state_games_per_s": steady,
+            steady = (gps // 2) / max(1e-9, dt2 - t_step)          # games/s of the extra (tail-free) half step
+            out["launch_tail"] = {"games_per_s_at_1_5x_games_per_step": (gps + gps // 2) / dt2, "steady_state_games_per_s": steady,
                                   "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
             # (2) the same step with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per
             # game) copied to host memory inside the timed region — the PCIe-inclusive rate (never `value`)
@@ -367,16 +367,17 @@ def main():
                 base = (args.warmup + args.steps + 3) * gps
                 eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=base, outputs=False)
                 t1 = time.perf_counter()
-                rt = eng.selfplay(cfg, base_seed=0, n_games=gps, first_game=base + args.concurrent, outputs=False)
+                gt = min(gps, 4 * args.concurrent)
+                rt = eng.selfplay(cfg, base_seed=0, n_games=gt, first_game=base + args.concurrent, outputs=False)
                 dt4 = time.perf_counter() - t1
                 ct = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=base + args.concurrent, outputs=False, counters=True)["counters"]
                 out["with_trained_weights"] = {
-                    "games_per_s": gps / dt4, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                    "games_per_s": gt / dt4, "games": gt, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
                     "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
                     "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
                     "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
                     "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
-                    "mfma_frac": (ct["policy_evals"] / 65536.0) * (gps / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                    "mfma_frac": (ct["policy_evals"] / 65536.0) * (gt / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
                     "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
                                                    "max_depth": c["max_depth"]}}
                 eng.load_weights(blob)

@@ -68,6 +68,27 @@ def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, 
     assert np.array_equal(got["root_nodes"][idx, last], ref["root_nodes"][idx, last])
 
 
+def test_policy_cache_at_bench_scale_changes_no_game(blob):
+    """PolicyWithCache at the bench's own size: 262,144 concurrent games hammering one lock-free table (2^24 entries: heavily
+    contended, torn and overwritten entries must read as misses) play exactly the games of the uncached run."""
+    import synthesis_amd as sa
+
+    cfg = sa.parity_rollout_config(800)
+    n = 262144 + 4096
+    plain = sa.Engine(concurrent_games=262144, max_explores=800, device=0)
+    plain.load_weights(blob)
+    a = plain.selfplay(cfg, base_seed=99, n_games=n, outputs=False)
+    plain.close()
+    cached = sa.Engine(concurrent_games=262144, max_explores=800, device=0, policy_cache_log2=24)
+    cached.load_weights(blob)
+    b = cached.selfplay(cfg, base_seed=99, n_games=n, outputs=False)
+    hits, misses = cached.last_cache_stats()
+    assert cached.last_launch_shape() == (4, 256, 1024)
+    cached.close()
+    assert np.array_equal(a["plies"], b["plies"])
+    assert hits > 0.2 * (hits + misses)
+
+
 def test_two_engines_on_one_device_from_two_threads(blob, oracle):
     """One handle per host thread: two engines on cuda:0, each driven by its own thread at the same time
     (ctypes releases the GIL during the call), play disjoint game ranges; both equal the oracle's games."""
