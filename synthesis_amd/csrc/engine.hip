@@ -21,6 +21,7 @@
 #include "frozen_kernel.cuh"
 #include "train_kernels.cuh"
 #include "train_mfma.cuh"
+#include "train_epoch.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -93,6 +94,8 @@ struct syn_engine {
     float* d_tloss = nullptr;
     float* d_twimg = nullptr;  // the trainer's weights in the inference fragment order (forward A operands; = the published image)
     float* d_ttimg = nullptr;  // ... and transposed fragments for the activation gradients (train_mfma.cuh)
+    float* d_timg2 = nullptr;  // the second buffer of both images for the persistent epoch kernel (train_epoch.cuh): [fwd][transposed]
+    unsigned* d_tsync = nullptr;  // its arrival counter and status word
     long long train_step = 0;
     DevTrainHyper train_hp{};
     bool has_trainer = false;
@@ -500,6 +503,8 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_tloss);
     hipFree(h->d_twimg);
     hipFree(h->d_ttimg);
+    hipFree(h->d_timg2);
+    hipFree(h->d_tsync);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1096,6 +1101,8 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
         HIP_TRY(h, hipMalloc(&h->d_tloss, 64));
         HIP_TRY(h, hipMalloc(&h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4));
         HIP_TRY(h, hipMalloc(&h->d_ttimg, (size_t)TrainImg::T_FLOATS * 4));
+        HIP_TRY(h, hipMalloc(&h->d_timg2, (size_t)(MlpGeom::IMG_FLOATS + TrainImg::T_FLOATS) * 4));
+        HIP_TRY(h, hipMalloc(&h->d_tsync, 256));
     }
     {
         // the two fragment-order images the matrix-core learner reads its A operands from (train_mfma.cuh); adam_image_kernel
@@ -1283,9 +1290,79 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
                        reinterpret_cast<const float*>(base + n * 16), reinterpret_cast<const float*>(base + n * 52), g_my,
                        g_op, g_tpi, g_tv);
     HIP_TRY(h, hipGetLastError());
-    // (a single-launch epoch kernel — the same workgroup applying Adam after its gradients — was built and measured: 64 us per
-    //  step against 45 us for these queued launches, because one workgroup's Adam over 30,492 parameters and two scattered
-    //  image writes costs more than the launch gap it removes)
+    // One persistent launch for the whole epoch (train_epoch.cuh) when the batch fits one 32-sample chunk — the reference's
+    // batch_size. SYN_DEBUG=1 SYN_TRAIN_QUEUED=1 keeps the two launches per step below (A/B, same bits), as do larger batches.
+    static const bool queued = debug_env("SYN_TRAIN_QUEUED") != nullptr;
+    if (!queued && batch <= TrainGeom::CHUNK) {
+        // per-step Adam scalars, in double on the host like libtorch (launch_adam)
+        std::vector<float> sc(2 * n_steps);
+        for (size_t s = 0; s < n_steps; s++) {
+            const double t = (double)(h->train_step + (long long)s + 1);
+            const double bc1 = 1.0 - std::pow((double)h->train_hp.beta1, t);
+            const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, t);
+            sc[s] = (float)((double)lr / bc1);
+            sc[n_steps + s] = (float)(1.0 / std::sqrt(bc2));
+        }
+        float* d_sc = nullptr;
+        HIP_TRY(h, hipMalloc(&d_sc, sc.size() * 4 + 4096));
+        unsigned long long* d_prof = reinterpret_cast<unsigned long long*>(d_sc + ((sc.size() + 1) & ~(size_t)1));
+        static const bool prof = debug_env("SYN_TRAIN_PROFILE") != nullptr;
+        int rc2 = SYN_OK;
+        unsigned status[4] = {0u, 0u, 0u, 0u};
+        unsigned long long stamps[16 * EP_WGS] = {0};
+        do {
+            hipError_t e;
+#define EP_TRY(expr) if ((e = (expr)) != hipSuccess) { rc2 = fail(h, SYN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); break; }
+            EP_TRY(hipMemcpyAsync(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, h->stream));
+            EP_TRY(hipMemsetAsync(d_prof, 0, 2048, h->stream));
+            EP_TRY(hipMemsetAsync(h->d_tsync, 0, 256, h->stream));
+            float* img2 = h->d_timg2;
+            float* timg2 = h->d_timg2 + MlpGeom::IMG_FLOATS;
+            // both buffers start as the current network: the kernel rewrites every parameter's slot, never the padding
+            EP_TRY(hipMemcpyAsync(img2, h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
+            EP_TRY(hipMemcpyAsync(timg2, h->d_ttimg, (size_t)TrainImg::T_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
+            EpochParams ep{};
+            ep.w = h->d_tw; ep.m = h->d_tm; ep.v = h->d_tv;
+            ep.img[0] = h->d_twimg; ep.img[1] = img2;
+            ep.timg[0] = h->d_ttimg; ep.timg[1] = timg2;
+            ep.my_bb = g_my; ep.op_bb = g_op; ep.tpi = g_tpi; ep.tv = g_tv;
+            ep.step_size = d_sc; ep.inv_sqrt_bc2 = d_sc + n_steps;
+            ep.losses = d_losses; ep.grads = h->d_tgrad; ep.sync = h->d_tsync;
+            ep.prof = prof ? d_prof : nullptr;
+            ep.n_steps = (int)n_steps; ep.batch = batch; ep.hp = h->train_hp;
+            static const bool device_scope = debug_env("SYN_TRAIN_DEVICE_SCOPE") != nullptr;
+            ep.force_device_scope = device_scope ? 1 : 0;
+            const size_t lds = (size_t)TrainGeom::WL_OFF * 4;
+            EP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(train_epoch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(train_epoch_kernel, dim3(EP_WGS * EP_XCDS), dim3(EP_THREADS), lds, h->stream, ep);
+            EP_TRY(hipGetLastError());
+            if (n_steps & 1) {  // the final network sits in the second buffer: bring the first one (the published image) up to date
+                EP_TRY(hipMemcpyAsync(h->d_twimg, img2, (size_t)MlpGeom::IMG_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
+                EP_TRY(hipMemcpyAsync(h->d_ttimg, timg2, (size_t)TrainImg::T_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
+            }
+            if (step_losses) EP_TRY(hipMemcpyAsync(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost, h->stream));
+            EP_TRY(hipMemcpyAsync(status, h->d_tsync, 16, hipMemcpyDeviceToHost, h->stream));
+            if (prof) EP_TRY(hipMemcpyAsync(stamps, d_prof, sizeof(stamps), hipMemcpyDeviceToHost, h->stream));
+            EP_TRY(hipStreamSynchronize(h->stream));
+#undef EP_TRY
+        } while (0);
+        (void)hipFree(d_sc);
+        if (rc2 != SYN_OK) return rc2;
+        if (status[1] != 0u)
+            return fail(h, SYN_ERR_HIP, "the %d workgroups of the epoch kernel were not resident together (device busy?): the trainer "
+                        "state is undefined, call syn_trainer_init again", EP_WGS);
+        if (prof) {
+            // stamps of step 2, workgroup g at [16 g ..]: top, features, forward L0..L4, heads, act-grads L4..L1, parameter jobs, step barrier
+            fprintf(stderr, "[syn train profile] epoch kernel (%s), step 2, cycles per phase\n", status[3] ? "workers on one XCD" : "device-scope barrier");
+            for (int g = 0; g < EP_WGS; g++) {
+                fprintf(stderr, "  wg %d (start %+lld):", g, (long long)(stamps[16 * g] - stamps[0]));
+                for (int i = 1; i < 14; i++) fprintf(stderr, " %llu", stamps[16 * g + i] - stamps[16 * g + i - 1]);
+                fprintf(stderr, "\n");
+            }
+        }
+        h->train_step += (long long)n_steps;
+        return SYN_OK;
+    }
     for (size_t s = 0; s < n_steps; s++) {  // steps are dependent (weights of step s feed step s+1): queued, never synced
         const size_t o = s * (size_t)batch;
         rc = launch_grads(h, g_my + o, g_op + o, g_tpi + o * 9, g_tv + o * 3, batch, h->d_tgrad, d_losses + 2 * s);

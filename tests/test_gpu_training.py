@@ -99,6 +99,44 @@ def test_device_resident_epoch_equals_step_by_step(engine, oracle, blob, gold):
         engine.train_epoch(np.array([n] * B, np.int32), B, 1e-3)  # index outside the uploaded buffer
 
 
+@pytest.mark.parametrize("B,steps_per_epoch", [(32, (5, 4, 1)), (7, (3, 2)), (1, (2,))])
+def test_persistent_epoch_kernel_chains_epochs(engine, oracle, blob, gold, B, steps_per_epoch):
+    """The one-launch epoch kernel (train_epoch.cuh): consecutive epochs of odd and even length (the final network ends in either
+    image buffer), short batches, non-default hyper-parameters and a changing learning rate — weights, moments, losses and the
+    last step's gradients equal the oracle's, and the published network is the trained one."""
+    from tests.oracle_lib import default_train_hyper
+
+    my = gold["my_bb"].reshape(-1); op = gold["op_bb"].reshape(-1)
+    tpi = gold["target_pi"].reshape(-1, 9); tv = gold["target_v"].reshape(-1, 3)
+    n = my.size
+    hp = default_train_hyper(weight_decay=1e-3, policy_weight=0.7, value_weight=1.9)
+    engine.trainer_init(blob, weight_decay=1e-3, policy_weight=0.7, value_weight=1.9)
+    engine.train_set_data(my, op, tpi, tv)
+    X = oracle.c4_features(my, op)
+    rng = np.random.default_rng(100 + B)
+    all_idx, lrs, losses = [], [], []
+    for e, steps in enumerate(steps_per_epoch):
+        perm = rng.integers(0, n, size=steps * B).astype(np.int32)
+        lr = 1e-3 * (e + 1)
+        losses.append(engine.train_epoch(perm, B, lr))
+        all_idx.append(perm.reshape(steps, B)); lrs += [lr] * steps
+    idx = np.concatenate(all_idx)
+    st = engine.trainer_state()
+    wo, mo, vo, _, lo = oracle.train_steps(blob, hp, X[idx], tpi[idx], tv[idx], lrs)
+    w_prev = oracle.train_steps(blob, hp, X[idx[:-1]], tpi[idx[:-1]], tv[idx[:-1]], lrs[:-1])[0] if len(lrs) > 1 else blob
+    go, _ = oracle.train_gradients(w_prev, hp, X[idx[-1]], tpi[idx[-1]], tv[idx[-1]])
+    assert st["step"] == len(lrs)
+    assert np.array_equal(np.concatenate(losses), lo)
+    assert np.array_equal(st["weights"], wo) and np.array_equal(st["m"], mo) and np.array_equal(st["v"], vo)
+    assert np.array_equal(st["grads"], go)
+    # the step-by-step path continues from the same state (it reads the fragment images the epoch kernel left behind)
+    l = engine.train_step(my[:B], op[:B], tpi[:B], tv[:B], 2e-3)
+    wo2, _, _, _, lo2 = oracle.train_steps(blob, hp, np.concatenate([X[idx], X[:B][None]]), np.concatenate([tpi[idx], tpi[:B][None]]),
+                                           np.concatenate([tv[idx], tv[:B][None]]), lrs + [2e-3])
+    assert np.array_equal(engine.trainer_state()["weights"], wo2) and np.array_equal(l, lo2[-1])
+    engine.load_weights(blob)
+
+
 def test_data_parallel_gradient_path(engine, oracle, blob, gold):
     """configs[4] plumbing on one GPU: two 'ranks' compute gradients of their half-batches into caller-owned device
     buffers, the sum is applied with grad_scale = 1/2 — equals (to f32 rounding) one step on the combined batch, and is
