@@ -1270,8 +1270,10 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t n = h->train_data_n, ni = n_steps * (size_t)batch;
     // scratch: [perm ni x 4][losses n_steps x 8][step-ordered batches: my, op (8 B each), pi (36 B), v (12 B) per sample]
+    //          [per-step Adam scalars n_steps x 8][diagnostic stamps 4 KB]
     const size_t perm_bytes = (ni * 4 + 255) & ~(size_t)255, loss_bytes = (n_steps * 8 + 255) & ~(size_t)255;
-    int rc = ensure_scratch(h, perm_bytes + loss_bytes + ni * 64 + 256);
+    const size_t batch_bytes = (ni * 64 + 255) & ~(size_t)255;
+    int rc = ensure_scratch(h, perm_bytes + loss_bytes + batch_bytes + loss_bytes + 4096 + 256);
     if (rc != SYN_OK) return rc;
     unsigned char* sc = static_cast<unsigned char*>(h->d_scratch);
     int* d_perm = reinterpret_cast<int*>(sc);
@@ -1295,17 +1297,16 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
     static const bool queued = debug_env("SYN_TRAIN_QUEUED") != nullptr;
     if (!queued && batch <= TrainGeom::CHUNK) {
         // per-step Adam scalars, in double on the host like libtorch (launch_adam)
-        std::vector<float> sc(2 * n_steps);
+        std::vector<float> adam_sc(2 * n_steps);
         for (size_t s = 0; s < n_steps; s++) {
             const double t = (double)(h->train_step + (long long)s + 1);
             const double bc1 = 1.0 - std::pow((double)h->train_hp.beta1, t);
             const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, t);
-            sc[s] = (float)((double)lr / bc1);
-            sc[n_steps + s] = (float)(1.0 / std::sqrt(bc2));
+            adam_sc[s] = (float)((double)lr / bc1);
+            adam_sc[n_steps + s] = (float)(1.0 / std::sqrt(bc2));
         }
-        float* d_sc = nullptr;
-        HIP_TRY(h, hipMalloc(&d_sc, sc.size() * 4 + 4096));
-        unsigned long long* d_prof = reinterpret_cast<unsigned long long*>(d_sc + ((sc.size() + 1) & ~(size_t)1));
+        float* d_sc = reinterpret_cast<float*>(sc + perm_bytes + loss_bytes + batch_bytes);
+        unsigned long long* d_prof = reinterpret_cast<unsigned long long*>(sc + perm_bytes + loss_bytes + batch_bytes + loss_bytes);
         static const bool prof = debug_env("SYN_TRAIN_PROFILE") != nullptr;
         int rc2 = SYN_OK;
         unsigned status[4] = {0u, 0u, 0u, 0u};
@@ -1313,7 +1314,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         do {
             hipError_t e;
 #define EP_TRY(expr) if ((e = (expr)) != hipSuccess) { rc2 = fail(h, SYN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); break; }
-            EP_TRY(hipMemcpyAsync(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, h->stream));
+            EP_TRY(hipMemcpyAsync(d_sc, adam_sc.data(), adam_sc.size() * 4, hipMemcpyHostToDevice, h->stream));
             EP_TRY(hipMemsetAsync(d_prof, 0, 2048, h->stream));
             EP_TRY(hipMemsetAsync(h->d_tsync, 0, 256, h->stream));
             float* img2 = h->d_timg2;
@@ -1346,7 +1347,6 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             EP_TRY(hipStreamSynchronize(h->stream));
 #undef EP_TRY
         } while (0);
-        (void)hipFree(d_sc);
         if (rc2 != SYN_OK) return rc2;
         if (status[1] != 0u)
             return fail(h, SYN_ERR_HIP, "the %d workgroups of the epoch kernel were not resident together (device busy?): the trainer "
@@ -1357,7 +1357,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             for (int g = 0; g < EP_WGS; g++) {
                 fprintf(stderr, "  wg %d (start %+lld):", g, (long long)(stamps[16 * g] - stamps[0]));
                 for (int i = 1; i < 14; i++) fprintf(stderr, " %llu", stamps[16 * g + i] - stamps[16 * g + i - 1]);
-                fprintf(stderr, "\n");
+                fprintf(stderr, " | probe fresh line %llu, cold line %llu\n", stamps[16 * g + 14], stamps[16 * g + 15]);
             }
         }
         h->train_step += (long long)n_steps;

@@ -64,8 +64,24 @@ SYN_DEV void adam_update(float& w, float& m, float& v, float g0, const DevTrainH
 //      workgroup: a CU's load path, ~25 B/clk, is what bounds a step once the matrix work is spread over the pipes), fragments
 //      requested ahead of the computation. The waves of consecutive layers differ (EP_FWD_BASE): the idle ones are already waiting
 //      for the next layer's fragments, and a layer's units fall on different SIMDs.
-constexpr int EP_FWD_BASE[5] = {0, 0, 6, 2, 5};   // layer L's unit u runs on wave (EP_FWD_BASE[L] + u) & 7
-constexpr int EP_BWD_BASE[5] = {0, 0, 5, 1, 6};   // activation gradients: layer L's input block kb on wave (EP_BWD_BASE[L] + kb) & 7
+constexpr int EP_FWD_BASE[5] = {0, 0, 6, 2, 5};   // layer L's slot u runs on wave (EP_FWD_BASE[L] + u) & 7
+constexpr int EP_BWD_BASE[5] = {0, 0, 5, 1, 6};   // activation gradients: layer L's slot u on wave (EP_BWD_BASE[L] + u) & 7
+// Slots of a layer: the first NF are whole units (both column blocks), then NH units are split into their two column blocks
+// (two slots each). Six-unit layers would otherwise put two whole units on two of the four SIMDs (4,096 cycles of matrix pipe
+// instead of 3,072); the one-unit last layer runs as two halves on two SIMDs.
+constexpr int EP_FWD_NF[5] = {8, 4, 4, 3, 0}, EP_FWD_NH[5] = {0, 2, 0, 0, 1};
+constexpr int EP_BWD_NF[5] = {0, 8, 4, 4, 3}, EP_BWD_NH[5] = {0, 0, 2, 0, 0};
+struct EpSlot {
+    int unit;   // output block (forward) / input block (activation gradients), -1 = this wave has no slot in the layer
+    int cb0, ncb;
+};
+SYN_DEV EpSlot ep_slot(int wave, int base, int nf, int nh) {
+    const int u = (wave - base) & (EP_WAVES - 1);
+    if (u < nf) return EpSlot{u, 0, 2};
+    if (u < nf + 2 * nh) return EpSlot{nf + ((u - nf) >> 1), (u - nf) & 1, 1};
+    return EpSlot{-1, 0, 0};
+}
+
 template <int L>
 struct EpFwd {
     f32x4 a[MlpGeom::S4[L]];
@@ -74,9 +90,10 @@ struct EpFwd {
 template <int L>
 SYN_DEV void ep_fwd_load(const float* img, int wave, int lane, EpFwd<L>& F) {
     constexpr int S4 = MlpGeom::S4[L], NOB = MlpGeom::NOB[L];
-    const int ob = (wave - EP_FWD_BASE[L]) & (EP_WAVES - 1);
-    if (ob < NOB) {
-        const int q = lane >> 4;
+    static_assert(EP_FWD_NF[L] + EP_FWD_NH[L] == NOB, "slots cover the layer");
+    const EpSlot sl = ep_slot(wave, EP_FWD_BASE[L], EP_FWD_NF[L], EP_FWD_NH[L]);
+    if (sl.unit >= 0) {
+        const int ob = sl.unit, q = lane >> 4;
         const float* wl = img + MlpGeom::W_OFF[L] + lane * 4;
 #pragma unroll
         for (int s4 = 0; s4 < S4; s4++) F.a[s4] = *reinterpret_cast<const f32x4*>(wl + (s4 * NOB + ob) * 256);
@@ -84,40 +101,57 @@ SYN_DEV void ep_fwd_load(const float* img, int wave, int lane, EpFwd<L>& F) {
     }
 }
 template <int L>
-SYN_DEV void ep_fwd_compute(const EpFwd<L>& F, float* __restrict__ lds, int wave, int lane) {
+SYN_DEV void ep_fwd_store(float* __restrict__ out, int ob, int q, const f32x4& acc) {
     using G = TrainGeom;
-    constexpr int S4 = MlpGeom::S4[L], NOB = MlpGeom::NOB[L], SA = G::stride(L), SO = G::stride(L + 1), O = G::D[L + 1];
-    const int ob = (wave - EP_FWD_BASE[L]) & (EP_WAVES - 1);
-    if (ob >= NOB) return;
-    const int j = lane & 15, q = lane >> 4;
-    f32x4 acc0 = F.bias, acc1 = F.bias;  // samples j and 16 + j: two independent chains keep the matrix pipe busy
-    const float* A = lds + G::a_off(L) + j * SA + q;
-#pragma unroll
-    for (int s4 = 0; s4 < S4; s4++) {
-        float b0[4], b1[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            b0[r] = A[16 * s4 + 4 * r];
-            b1[r] = A[16 * SA + 16 * s4 + 4 * r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b0[r], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b1[r], acc1, 0, 0, 0);
-        }
-    }
-    float* out = lds + G::a_off(L + 1) + j * SO;
+    constexpr int O = G::D[L + 1];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int u = L < G::NL - 1 ? 16 * ob + 4 * r + q : 16 * ob + 4 * q + r;
-        if (u < O) {
-            out[u] = L < G::NL - 1 ? (acc0[r] > 0.0f ? acc0[r] : 0.0f) : acc0[r];
-            out[16 * SO + u] = L < G::NL - 1 ? (acc1[r] > 0.0f ? acc1[r] : 0.0f) : acc1[r];
+        if (u < O) out[u] = L < G::NL - 1 ? (acc[r] > 0.0f ? acc[r] : 0.0f) : acc[r];
+    }
+}
+template <int L>
+SYN_DEV void ep_fwd_compute(const EpFwd<L>& F, float* __restrict__ lds, int wave, int lane) {
+    using G = TrainGeom;
+    constexpr int S4 = MlpGeom::S4[L], SA = G::stride(L), SO = G::stride(L + 1);
+    const EpSlot sl = ep_slot(wave, EP_FWD_BASE[L], EP_FWD_NF[L], EP_FWD_NH[L]);
+    if (sl.unit < 0) return;
+    const int ob = sl.unit, j = lane & 15, q = lane >> 4;
+    const float* A = lds + G::a_off(L) + (16 * sl.cb0 + j) * SA + q;
+    float* out = lds + G::a_off(L + 1) + (16 * sl.cb0 + j) * SO;
+    if (sl.ncb == 2) {
+        f32x4 acc0 = F.bias, acc1 = F.bias;  // samples j and 16 + j: two independent chains keep the matrix pipe busy
+#pragma unroll
+        for (int s4 = 0; s4 < S4; s4++) {
+            float b0[4], b1[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                b0[r] = A[16 * s4 + 4 * r];
+                b1[r] = A[16 * SA + 16 * s4 + 4 * r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b0[r], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b1[r], acc1, 0, 0, 0);
+            }
         }
+        ep_fwd_store<L>(out, ob, q, acc0);
+        ep_fwd_store<L>(out + 16 * SO, ob, q, acc1);
+    } else {
+        f32x4 acc = F.bias;
+#pragma unroll
+        for (int s4 = 0; s4 < S4; s4++) {
+            float b0[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) b0[r] = A[16 * s4 + 4 * r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b0[r], acc, 0, 0, 0);
+        }
+        ep_fwd_store<L>(out, ob, q, acc);
     }
 }
 
-// ---- activation gradients: wave-unit = input block kb of layer L, both column blocks
+// ---- activation gradients: unit = input block kb of layer L
 template <int L>
 struct EpBwd {
     f32x4 a[TrainImg::T_S4[L]];
@@ -125,48 +159,63 @@ struct EpBwd {
 template <int L>
 SYN_DEV void ep_bwd_load(const float* timg, int wave, int lane, EpBwd<L>& F) {
     constexpr int S4 = TrainImg::T_S4[L], NKB = TrainImg::T_KB[L];
-    const int kb = (wave - EP_BWD_BASE[L]) & (EP_WAVES - 1);
-    if (kb < NKB) {
+    static_assert(EP_BWD_NF[L] + EP_BWD_NH[L] == NKB, "slots cover the layer");
+    const EpSlot sl = ep_slot(wave, EP_BWD_BASE[L], EP_BWD_NF[L], EP_BWD_NH[L]);
+    if (sl.unit >= 0) {
         const float* tl = timg + TrainImg::T_OFF[L] + lane * 4;
 #pragma unroll
-        for (int s4 = 0; s4 < S4; s4++) F.a[s4] = *reinterpret_cast<const f32x4*>(tl + (s4 * NKB + kb) * 256);
+        for (int s4 = 0; s4 < S4; s4++) F.a[s4] = *reinterpret_cast<const f32x4*>(tl + (s4 * NKB + sl.unit) * 256);
     }
+}
+template <int L>
+SYN_DEV void ep_bwd_store(float* __restrict__ lds, int row, int k0, const f32x4& acc) {
+    using G = TrainGeom;
+    constexpr int SA = G::stride(L);
+    const f32x4 act = *reinterpret_cast<const f32x4*>(lds + G::a_off(L) + row * SA + k0);
+    f32x4 rr;
+#pragma unroll
+    for (int r = 0; r < 4; r++) rr[r] = act[r] > 0.0f ? acc[r] : 0.0f;
+    *reinterpret_cast<f32x4*>(lds + G::d_off(L) + row * SA + k0) = rr;
 }
 template <int L>
 SYN_DEV void ep_bwd_compute(const EpBwd<L>& F, float* __restrict__ lds, int wave, int lane) {
     using G = TrainGeom;
-    constexpr int S4 = TrainImg::T_S4[L], NKB = TrainImg::T_KB[L], SA = G::stride(L), SZ = G::stride(L + 1);
-    const int kb = (wave - EP_BWD_BASE[L]) & (EP_WAVES - 1);
-    if (kb >= NKB) return;
+    constexpr int S4 = TrainImg::T_S4[L], SZ = G::stride(L + 1);
+    const EpSlot sl = ep_slot(wave, EP_BWD_BASE[L], EP_BWD_NF[L], EP_BWD_NH[L]);
+    if (sl.unit < 0) return;
     const int j = lane & 15, q = lane >> 4;
-    f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-    const float* dZ = lds + G::d_off(L + 1) + j * SZ + q;
+    const int row = 16 * sl.cb0 + j, k0 = 16 * sl.unit + 4 * q;  // layers 1..4: every input width is a multiple of 16
+    const float* dZ = lds + G::d_off(L + 1) + row * SZ + q;
+    if (sl.ncb == 2) {
+        f32x4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
 #pragma unroll
-    for (int s4 = 0; s4 < S4; s4++) {
-        float b0[4], b1[4];
+        for (int s4 = 0; s4 < S4; s4++) {
+            float b0[4], b1[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            b0[r] = dZ[16 * s4 + 4 * r];
-            b1[r] = dZ[16 * SZ + 16 * s4 + 4 * r];
+            for (int r = 0; r < 4; r++) {
+                b0[r] = dZ[16 * s4 + 4 * r];
+                b1[r] = dZ[16 * SZ + 16 * s4 + 4 * r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b0[r], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b1[r], acc1, 0, 0, 0);
+            }
         }
+        ep_bwd_store<L>(lds, row, k0, acc0);
+        ep_bwd_store<L>(lds, row + 16, k0, acc1);
+    } else {
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b0[r], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b1[r], acc1, 0, 0, 0);
+        for (int s4 = 0; s4 < S4; s4++) {
+            float b0[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) b0[r] = dZ[16 * s4 + 4 * r];
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(F.a[s4][r], b0[r], acc, 0, 0, 0);
         }
+        ep_bwd_store<L>(lds, row, k0, acc);
     }
-    const int k0 = 16 * kb + 4 * q;  // layers 1..4: every input width is a multiple of 16
-    const float* actp = lds + G::a_off(L) + j * SA + k0;
-    float* dst = lds + G::d_off(L) + j * SA + k0;
-    const f32x4 act0 = *reinterpret_cast<const f32x4*>(actp), act1 = *reinterpret_cast<const f32x4*>(actp + 16 * SA);
-    f32x4 r0, r1;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        r0[r] = act0[r] > 0.0f ? acc0[r] : 0.0f;
-        r1[r] = act1[r] > 0.0f ? acc1[r] : 0.0f;
-    }
-    *reinterpret_cast<f32x4*>(dst) = r0;
-    *reinterpret_cast<f32x4*>(dst + 16 * SA) = r1;
 }
 
 // ---- a weight-tile job: tile (ob, s4) of layer L = the forward fragment [s4][ob]; lane (i, q) register r holds
@@ -236,6 +285,24 @@ SYN_DEV void ep_bias_job(const float* __restrict__ lds, int half, int lane, int 
     const int ob = o >> 4, c = o & 15;
     const int i = L == G::NL - 1 ? c : (c >> 2) + 4 * (c & 3);
     img_next[MlpGeom::W_FLOATS + MlpGeom::B_OFF[L] + (ob * 4 + (i >> 2)) * 4 + (i & 3)] = wb;
+}
+
+// ---- the 16 lanes of a sample's row: lane t's value in every lane (DPP row_newbcast), and the two heads' sums over the
+//      entries in ascending order (policy = lanes 0..8, outcome = lanes 9..11) — sequential adds from 0, as the reference order
+SYN_DEV void ep_row_gather(float v, float (&out)[12]) {
+    out[0] = dpp_f32<0x150>(v); out[1] = dpp_f32<0x151>(v); out[2] = dpp_f32<0x152>(v); out[3] = dpp_f32<0x153>(v);
+    out[4] = dpp_f32<0x154>(v); out[5] = dpp_f32<0x155>(v); out[6] = dpp_f32<0x156>(v); out[7] = dpp_f32<0x157>(v);
+    out[8] = dpp_f32<0x158>(v); out[9] = dpp_f32<0x159>(v); out[10] = dpp_f32<0x15A>(v); out[11] = dpp_f32<0x15B>(v);
+}
+SYN_DEV float ep_row_sum(float v, bool pol) {
+    float x[12];
+    ep_row_gather(v, x);
+    float sp = 0.0f, sv = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 9; t++) sp += x[t];
+#pragma unroll
+    for (int t = 9; t < 12; t++) sv += x[t];
+    return pol ? sp : sv;
 }
 
 struct EpJob {
@@ -351,20 +418,28 @@ __global__ __launch_bounds__(EP_THREADS) void train_epoch_kernel(EpochParams P) 
         float* img_next = (s & 1) ? P.img[0] : P.img[1];
         float* timg_next = (s & 1) ? P.timg[0] : P.timg[1];
         const bool last = s + 1 == P.n_steps;
+        if (P.prof && s == 2 && tid0 == 0) {
+            // diagnostic probes (SYN_TRAIN_PROFILE): load-to-use latency of a line another workgroup wrote in the last step, and of a
+            // line nobody touched since the launch
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            const float x = __builtin_nontemporal_load(img + MlpGeom::W_OFF[1] + 17 * 256);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(x) : "memory");
+            const unsigned long long t1 = __builtin_readcyclecounter();
+            const float y = __builtin_nontemporal_load(P.m + 12345);
+            asm volatile("s_waitcnt vmcnt(0)" ::"v"(y) : "memory");
+            const unsigned long long t2 = __builtin_readcyclecounter();
+            P.prof[g * 16 + 14] = t1 - t0;
+            P.prof[g * 16 + 15] = t2 - t1;
+        }
         EP_STAMP();
-        // ---- every fragment this wave consumes in the step, requested now in the order of use: the CU's load path streams the
-        //      211 KB of both images while the layers compute behind it
+        // ---- fragments: a wave requests what it consumes two layers later, AFTER its own matrix work of the current layer (the
+        //      CU's address path takes ~16 cycles per 1 KB wave-load, ~5,000 cycles for the 211 KB of a step: requested up front
+        //      they stall the issue of the first layer's matrix instructions by exactly that; measured). Only layers 0 and 1 are
+        //      requested at the top. A single load of a line another workgroup wrote in the last step takes ~240 cycles here.
         EpFwd<0> f0; EpFwd<1> f1; EpFwd<2> f2; EpFwd<3> f3; EpFwd<4> f4;
         EpBwd<4> b4; EpBwd<3> b3; EpBwd<2> b2; EpBwd<1> b1;
         ep_fwd_load<0>(img, wave, lane, f0);
         ep_fwd_load<1>(img, wave, lane, f1);
-        ep_fwd_load<2>(img, wave, lane, f2);
-        ep_fwd_load<3>(img, wave, lane, f3);
-        ep_fwd_load<4>(img, wave, lane, f4);
-        ep_bwd_load<4>(timg, wave, lane, b4);
-        ep_bwd_load<3>(timg, wave, lane, b3);
-        ep_bwd_load<2>(timg, wave, lane, b2);
-        ep_bwd_load<1>(timg, wave, lane, b1);
         // ---- features -> A[0] (column 63 of the padded rows and the rows of samples past nb are zero)
         {
             const int b = tid >> 4;
@@ -378,61 +453,55 @@ __global__ __launch_bounds__(EP_THREADS) void train_epoch_kernel(EpochParams P) 
             *reinterpret_cast<f32x4*>(lds + G::a_off(0) + b * G::stride(0) + (tid & 15) * 4) = x4;
         }
         const float tgt = tgt_next;
-        if (!last) request_batch(s + 1);  // behind the fragments (loads return in order), a whole step ahead of its use
+        const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;  // for the KL term of the heads, while the first fragments travel
         lds_barrier();
         EP_STAMP();  // features
         // ---- forward: at most one unit per wave and layer
         ep_fwd_compute<0>(f0, lds, wave, lane);
+        ep_fwd_load<2>(img, wave, lane, f2);
+        ep_fwd_load<3>(img, wave, lane, f3);
         lds_barrier();
         EP_STAMP();
         ep_fwd_compute<1>(f1, lds, wave, lane);
+        ep_fwd_load<4>(img, wave, lane, f4);
+        ep_bwd_load<4>(timg, wave, lane, b4);
+        ep_bwd_load<3>(timg, wave, lane, b3);
         lds_barrier();
         EP_STAMP();
         ep_fwd_compute<2>(f2, lds, wave, lane);
+        ep_bwd_load<2>(timg, wave, lane, b2);
         lds_barrier();
         EP_STAMP();
         ep_fwd_compute<3>(f3, lds, wave, lane);
+        ep_bwd_load<1>(timg, wave, lane, b1);
         lds_barrier();
         EP_STAMP();
         ep_fwd_compute<4>(f4, lds, wave, lane);
+        if (!last) request_batch(s + 1);  // behind the fragments (loads return in order), most of a step ahead of its use
         lds_barrier();
         EP_STAMP();  // forward
         // ---- heads: log_softmax + kl_div and their gradient, 16 lanes per sample, one entry per lane. The sequential sums of the
         //      reference order (entries ascending) are kept: every lane adds the row's values in that order.
+        //      A sample's 12 logits / exponentials / targets / KL terms travel between its 16 lanes as DPP row broadcasts.
         {
             const int b = tid >> 4, jx = tid & 15;
             const bool pol = jx < 9;
-            const int off = pol ? 0 : 9, n = pol ? 9 : 3;
-            const int row0 = lane & 48;  // first lane of this sample's row of 16
-            const float* x = lds + G::a_off(5) + b * G::stride(5);
-            float xv[9];
-#pragma unroll
-            for (int t = 0; t < 9; t++) xv[t] = t < n ? x[off + t] : 0.0f;
-            float mx = xv[0];
-#pragma unroll
-            for (int t = 1; t < 9; t++) mx = (t < n && xv[t] > mx) ? xv[t] : mx;
             const bool live = jx < 12 && b < nb;
-            const float xo = live ? x[jx] : 0.0f;
-            const float e = live ? det_expf(xo - mx) : 0.0f;
-            float se = 0.0f, tsum = 0.0f;
+            const float xo = live ? lds[G::a_off(5) + b * G::stride(5) + jx] : 0.0f;
+            float xs[12];
+            ep_row_gather(xo, xs);
+            float mxp = xs[0], mxv = xs[9];
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const float et = __shfl(e, row0 + ((off + t) & 15), 64);
-                const float tt = __shfl(tgt, row0 + ((off + t) & 15), 64);
-                if (t < n) {
-                    se += et;
-                    tsum += tt;
-                }
-            }
+            for (int t = 1; t < 9; t++) mxp = xs[t] > mxp ? xs[t] : mxp;
+#pragma unroll
+            for (int t = 10; t < 12; t++) mxv = xs[t] > mxv ? xs[t] : mxv;
+            const float mx = pol ? mxp : mxv;
+            const float e = live ? det_expf(xo - mx) : 0.0f;
+            const float se = ep_row_sum(e, pol), tsum = ep_row_sum(tgt, pol);
             const float lse = mx + det_logf(live ? se : 1.0f);
             const float logp = xo - lse;
-            const float term = (live && tgt > 0.0f) ? tgt * (det_logf(tgt) - logp) : 0.0f;
-            float kl = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const float kt = __shfl(term, row0 + ((off + t) & 15), 64);
-                if (t < n) kl += kt;
-            }
+            const float term = (live && tgt > 0.0f) ? tgt * (ltgt - logp) : 0.0f;
+            const float kl = ep_row_sum(term, pol);
             const float sc = (pol ? P.hp.policy_weight : P.hp.value_weight) * bm;
             if (jx < 12) lds[G::d_off(5) + b * G::stride(5) + jx] = live ? sc * (det_expf(xo - lse) * tsum - tgt) : 0.0f;
             if (jx == 0 || jx == 9) lds[G::KL_OFF + b * 2 + (pol ? 0 : 1)] = b < nb ? kl : 0.0f;

@@ -268,3 +268,38 @@ def test_training_example_keeps_two_ranks_identical(tmp_path):
     assert not np.array_equal(w0, make_weights(20211003))   # the weights did train
     lines = [json.loads(l) for l in out.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 2 and lines[0]["games"] == 601 and lines[1]["optimiser_steps"] > 0
+
+
+def test_epoch_kernel_modes_agree(tmp_path, golden_dir):
+    """The three ways an epoch can run — the persistent kernel with its workers on one XCD (L2-coherent step barrier), the
+    same kernel with the device-scope barrier it falls back to when the workers are spread over XCDs, and the queued
+    two-kernels-per-step path — leave bit-identical weights, moments and losses. The modes are debug knobs read once per
+    process, hence one child process each."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import synthesis_amd as sa\n"
+        f"g = np.load(os.path.join({golden_dir!r}, 'train_torch_goldens.npz')); blob = np.load(os.path.join({golden_dir!r}, 'c4net_blob_f32.npy'))\n"
+        "my = g['my_bb'].reshape(-1); op = g['op_bb'].reshape(-1); tpi = g['target_pi'].reshape(-1, 9); tv = g['target_v'].reshape(-1, 3)\n"
+        "eng = sa.Engine(concurrent_games=64, max_explores=16); eng.load_weights(blob); eng.trainer_init(blob)\n"
+        "eng.train_set_data(my, op, tpi, tv)\n"
+        "perm = np.random.default_rng(5).integers(0, my.size, size=11 * 32).astype(np.int32)\n"
+        "l1 = eng.train_epoch(perm, 32, 1e-3); l2 = eng.train_epoch(perm[: 6 * 32], 32, 5e-4)\n"
+        "st = eng.trainer_state()\n"
+        "np.savez(sys.argv[1], w=st['weights'], m=st['m'], v=st['v'], g=st['grads'], l=np.concatenate([l1, l2]))\n")
+    outs = {}
+    for name, knobs in (("one_xcd", {}), ("device_scope", {"SYN_DEBUG": "1", "SYN_TRAIN_DEVICE_SCOPE": "1"}),
+                        ("queued", {"SYN_DEBUG": "1", "SYN_TRAIN_QUEUED": "1"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SYN_")}
+        env.update(knobs)
+        path = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", script, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        outs[name] = np.load(path)
+    for name in ("device_scope", "queued"):
+        for k in ("w", "m", "v", "g", "l"):
+            assert np.array_equal(outs["one_xcd"][k].view(np.uint32), outs[name][k].view(np.uint32)), (name, k)
