@@ -266,7 +266,11 @@ int syn_trainer_publish_weights(syn_engine* h);
  * tensors `states / target_pis / target_vs` of alpha_zero.rs:52-58, positions as bitboards); syn_train_epoch then runs
  * n_steps optimiser steps in one call: step s trains on the states perm[s*batch .. (s+1)*batch) — the BatchRandSampler's
  * index_select (data.rs:41-62; the caller draws the permutation and applies drop_last) — and step_losses[s][0..1]
- * receives its (pi_loss, v_loss). Bit-identical to n_steps calls of syn_train_step on the gathered batches. */
+ * receives its (pi_loss, v_loss). Bit-identical to n_steps calls of syn_train_step on the gathered batches. For batch <= 32
+ * (the reference's batch_size) the whole epoch is ONE persistent kernel launch (csrc/train_epoch.cuh: 16 workgroups, the
+ * gradient of the LAST step is what syn_trainer_get_state reports); it needs 16 CUs of one XCD free for the duration and returns
+ * SYN_ERR_HIP (trainer state undefined, re-init) if its workgroups never become co-resident. Larger batches queue two launches
+ * per step. */
 int syn_train_set_data(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
                        const float* target_v, size_t n);
 int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batch, float lr, float* step_losses);
