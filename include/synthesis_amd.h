@@ -113,6 +113,15 @@ const char* syn_last_error(const syn_engine* h);
  * l_5.weight[12x48], l_5.bias[12] (VarStore names, study-connect4/src/policies.rs:20-24), row-major [out][in],
  * n_floats must be 30492. Empties the policy cache (its entries belong to the previous network). */
 int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats);
+/* The conv policy/value network BASELINE.json's north_star words — slimnn Conv2d (slimnn/src/conv.rs:45-85) over the 2x7x9
+ * bitplane state + Linear policy/value heads (slimnn/src/linear.rs:17-25) — behind the same Policy::eval surface
+ * (policies/traits.rs:4-6): x[2][7][9] = (mine, theirs) -> Conv2d<2, 16, 3, pad 1, stride 1> + ReLU -> Linear<1008, 12>, logits =
+ * out[0..9], value = softmax(out[9..12]). The reference ships the layers but no such network, so the architecture is this
+ * library's (oracle/nn.hpp Connect4ConvNet restates it). blob = conv.weight[16][2][3][3], conv.bias[16], head.weight[12][1008],
+ * head.bias[12]; n_floats must be 12412. Replaces the engine's network: syn_policy_eval_batch*, syn_mcts_search and
+ * syn_selfplay_run then evaluate this network (lane-per-tree kernels: max_explores <= 7280, else SYN_ERR_UNSUPPORTED);
+ * syn_load_weights / syn_trainer_publish_weights switch back to Connect4Net. Empties the policy cache. */
+int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats);
 
 /* ---- leaf evaluation ------------------------------------------------------------------------------------------- */
 

@@ -137,4 +137,63 @@ struct Connect4Net {
     }
 };
 
+// ---- Connect4ConvNet: the conv policy/value network BASELINE.json's north_star words ("slimnn Conv2d over the 2x9x7 bitplane
+// state + Linear policy/value heads"). The reference defines the LAYERS (slimnn Conv2d, conv.rs:45-85; Linear, linear.rs:17-25)
+// but no such network (nothing in the reference instantiates Conv2d in a policy), so the architecture is this
+// build's instantiation, fixed here:
+//     x[2][7][9]   plane 0 = stones of the side to move, plane 1 = the opponent's (1.0 / 0.0), row 0 = bottom
+//     Conv2d<IN 2, OUT 16, K 3, row_pad 1, col_pad 1, stride 1> -> [16][7][9], ReLU
+//     Linear<1008, 12> on the NCHW flattening (i = channel*63 + row*9 + col): logits = out[0..9] (raw), value = softmax(out[9..12])
+// Parameter blob: conv.weight[16][2][3][3], conv.bias[16], head.weight[12][1008], head.bias[12] = 12,412 f32.
+// Accumulation modes:
+//   ACC_SLIMNN : the layers exactly as slimnn loops them (conv taps ci -> k1 -> k2 with padded taps skipped, head inputs in
+//                flattening order, separate multiply and add) — the canonical restatement, 1e-5 tolerance against the engine;
+//   ACC_FMA    : the order the HIP engine's matrix-core chains produce bit for bit: conv taps in the same order (a padded tap is
+//                fma(w, 0, acc): the same value), head inputs position-major (p = row*9 + col ascending; inside a position the
+//                channels in the order 0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15 — the D-register order of the conv tile),
+//                one fused multiply-add per term. With 0/1 inputs the conv layer is bit-identical in both modes.
+// PARITY: the layers are pinned by slimnn's KATs; the network has no counterpart in the reference -> unpinned by construction.
+struct Connect4ConvNet {
+    static constexpr int C = 16, H = 7, W = 9, HW = 63, FLAT = C * HW, OUT = 12;
+    static constexpr size_t CONV_W = (size_t)C * 2 * 3 * 3, NUM_PARAMS = CONV_W + C + (size_t)OUT * FLAT + OUT;
+    const float* blob = nullptr;
+    int mode = ACC_SLIMNN;
+
+    const float* conv_w() const { return blob; }
+    const float* conv_b() const { return blob + CONV_W; }
+    const float* head_w() const { return blob + CONV_W + C; }
+    const float* head_b() const { return blob + CONV_W + C + (size_t)OUT * FLAT; }
+
+    static void planes(const Connect4& game, float* x /*[2][7][9]*/) {
+        for (int pl = 0; pl < 2; pl++) {
+            const uint64_t bb = pl == 0 ? game.my_bb : game.op_bb;
+            for (int r = 0; r < H; r++)
+                for (int c = 0; c < W; c++) x[(pl * H + r) * W + c] = ((bb >> (r + 7 * c)) & 1ull) ? 1.0f : 0.0f;
+        }
+    }
+    void forward(const float* x, float* out12) const {
+        float y[FLAT];
+        conv2d_forward(2, C, 3, 1, 1, 1, H, W, H, W, conv_w(), conv_b(), x, y, mode);
+        relu_inplace(y, FLAT);
+        if (mode == ACC_FMA) {
+            for (int o = 0; o < OUT; o++) out12[o] = head_b()[o];
+            for (int p = 0; p < HW; p++)
+                for (int r = 0; r < 4; r++)
+                    for (int q = 0; q < 4; q++) {
+                        const int i = (4 * q + r) * HW + p;
+                        for (int o = 0; o < OUT; o++) out12[o] = std::fmaf(y[i], head_w()[(size_t)o * FLAT + i], out12[o]);
+                    }
+        } else {
+            linear_forward(FLAT, OUT, head_w(), head_b(), y, out12, ACC_SLIMNN);
+        }
+    }
+    void eval(const Connect4& game, float logits[9], float value[3]) const {
+        float x[2 * HW], out[OUT];
+        planes(game, x);
+        forward(x, out);
+        for (int i = 0; i < 9; i++) logits[i] = out[i];
+        softmax_stable(out + 9, value, 3);
+    }
+};
+
 }  // namespace oracle

@@ -104,6 +104,23 @@ void orc_c4net_eval(const float* blob, const uint64_t* my_bb, const uint64_t* op
     for (int i = 0; i < n; i++)
         net.eval(Connect4::from_bitboards(my_bb[i], op_bb[i]), logits + (size_t)i * 9, value + (size_t)i * 3);
 }
+size_t orc_c4conv_num_params() { return Connect4ConvNet::NUM_PARAMS; }
+// Connect4ConvNet (oracle/nn.hpp): logits[n][9] raw, value[n][3] softmaxed; raw12 (optional) = the 12 raw outputs
+void orc_c4conv_eval(const float* blob, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits, float* value,
+                     float* raw12, int mode) {
+    Connect4ConvNet net;
+    net.blob = blob;
+    net.mode = mode;
+    for (int i = 0; i < n; i++) {
+        Connect4 g = Connect4::from_bitboards(my_bb[i], op_bb[i]);
+        net.eval(g, logits + (size_t)i * 9, value + (size_t)i * 3);
+        if (raw12) {
+            float x[2 * Connect4ConvNet::HW];
+            Connect4ConvNet::planes(g, x);
+            net.forward(x, raw12 + (size_t)i * 12);
+        }
+    }
+}
 void orc_c4net_forward_raw(const float* blob, const float* x63, int n, float* out12, int mode) {
     Connect4Net net;
     net.blob = blob;
@@ -280,24 +297,40 @@ static void c4_search_collect(MCTS<Connect4, P>& mcts, int i, int action_selecti
     mcts.target_policy(target_pi + i * 9);
     mcts.target_q(target_q + i * 3);
 }
+template <class Net>
+static void c4_mcts_search_impl(const orc_mcts_config* cfg_in, const float* blob, int nn_mode, const uint64_t* my_bb,
+                                const uint64_t* op_bb, int n, int explores, int action_selection, float* child_N,
+                                float* child_W, float* child_P, int* child_sol, float* root_stat, int* root_sol,
+                                unsigned* num_nodes, int* best_action, float* target_pi, float* target_q) {
+    MCTSConfig cfg = to_cfg(*cfg_in);
+    Net net;
+    net.blob = blob;
+    net.mode = nn_mode;
+    for (int i = 0; i < n; i++) {
+        Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
+        // root i of a bare search: noise stream = i (the device: base_seed 0 + root index), turn 0
+        MCTS<Connect4, Net> mcts((size_t)explores + 1, cfg, &net, root, nullptr, nullptr, noise_tree_seed((uint64_t)i, 0));
+        mcts.explore_n((size_t)explores);
+        c4_search_collect(mcts, i, action_selection, child_N, child_W, child_P, child_sol, root_stat, root_sol, num_nodes,
+                          best_action, target_pi, target_q);
+    }
+}
 extern "C" {
 
 void orc_c4_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn_mode, const uint64_t* my_bb,
                         const uint64_t* op_bb, int n, int explores, int action_selection, float* child_N,
                         float* child_W, float* child_P, int* child_sol, float* root_stat, int* root_sol,
                         unsigned* num_nodes, int* best_action, float* target_pi, float* target_q) {
-    MCTSConfig cfg = to_cfg(*cfg_in);
-    Connect4Net net;
-    net.blob = blob;
-    net.mode = nn_mode;
-    for (int i = 0; i < n; i++) {
-        Connect4 root = Connect4::from_bitboards(my_bb[i], op_bb[i]);
-        // root i of a bare search: noise stream = i (the device: base_seed 0 + root index), turn 0
-        MCTS<Connect4, Connect4Net> mcts((size_t)explores + 1, cfg, &net, root, nullptr, nullptr, noise_tree_seed((uint64_t)i, 0));
-        mcts.explore_n((size_t)explores);
-        c4_search_collect(mcts, i, action_selection, child_N, child_W, child_P, child_sol, root_stat, root_sol, num_nodes,
-                          best_action, target_pi, target_q);
-    }
+    c4_mcts_search_impl<Connect4Net>(cfg_in, blob, nn_mode, my_bb, op_bb, n, explores, action_selection, child_N, child_W, child_P,
+                                     child_sol, root_stat, root_sol, num_nodes, best_action, target_pi, target_q);
+}
+// the same search with Connect4ConvNet (oracle/nn.hpp) as the policy
+void orc_c4conv_mcts_search(const orc_mcts_config* cfg_in, const float* blob, int nn_mode, const uint64_t* my_bb,
+                            const uint64_t* op_bb, int n, int explores, int action_selection, float* child_N,
+                            float* child_W, float* child_P, int* child_sol, float* root_stat, int* root_sol,
+                            unsigned* num_nodes, int* best_action, float* target_pi, float* target_q) {
+    c4_mcts_search_impl<Connect4ConvNet>(cfg_in, blob, nn_mode, my_bb, op_bb, n, explores, action_selection, child_N, child_W,
+                                         child_P, child_sol, root_stat, root_sol, num_nodes, best_action, target_pi, target_q);
 }
 
 // MCTS<Connect4, RolloutPolicy> — the pairing the reference's own MCTS tests use (mcts.rs:691-868, there with
@@ -473,7 +506,9 @@ float orc_c4_eval_against_old(const orc_mcts_config* policy_cfg, int policy_expl
 // Outputs are indexed by (game - first_game): plies[n], states_bb[n][63][2], pis[n][63][9], vs[n][63][3],
 // actions[n][63], root_nodes[n][63], final_kind[n]. counters[9] = MCTSCounters fields summed; counters[9..10] =
 // cache hits, misses; counters[11] = max backprop depth. Returns wall seconds.
-double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
+}  // extern "C"
+template <class Net>
+static double c4_selfplay_impl(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
                        uint64_t first_game, int n_games, int threads, int use_cache, int* plies, uint64_t* states_bb,
                        float* pis, float* vs, uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind,
                        uint64_t* counters) {
@@ -490,10 +525,10 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
             count = left / (threads - i);
             left -= count;
         }
-        Connect4Net net;
+        Net net;
         net.blob = blob;
         net.mode = nn_mode;
-        PolicyWithCache<Connect4Net> cached((size_t)Connect4::MAX_TURNS * (size_t)(count > 0 ? count : 1), &net);
+        PolicyWithCache<Net> cached((size_t)Connect4::MAX_TURNS * (size_t)(count > 0 ? count : 1), &net);
         // counters live on the worker's own stack while it runs: neighbouring elements of `ctrs` share cache lines, and
         // hundreds of threads incrementing them would time false sharing instead of the search
         MCTSCounters local;
@@ -535,6 +570,24 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
         }
     }
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+extern "C" {
+
+double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
+                       uint64_t first_game, int n_games, int threads, int use_cache, int* plies, uint64_t* states_bb,
+                       float* pis, float* vs, uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind,
+                       uint64_t* counters) {
+    return c4_selfplay_impl<Connect4Net>(cfg_in, blob, nn_mode, base_seed, first_game, n_games, threads, use_cache, plies, states_bb,
+                                         pis, vs, actions, root_nodes, final_kind, counters);
+}
+// the same games with Connect4ConvNet (oracle/nn.hpp) as the policy
+double orc_c4conv_selfplay(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
+                           uint64_t first_game, int n_games, int threads, int use_cache, int* plies, uint64_t* states_bb,
+                           float* pis, float* vs, uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind,
+                           uint64_t* counters) {
+    return c4_selfplay_impl<Connect4ConvNet>(cfg_in, blob, nn_mode, base_seed, first_game, n_games, threads, use_cache, plies,
+                                             states_bb, pis, vs, actions, root_nodes, final_kind, counters);
 }
 
 // ---------------------------------------------------------------- training step + replay de-duplication

@@ -22,6 +22,7 @@
 #include "train_kernels.cuh"
 #include "train_mfma.cuh"
 #include "train_epoch.cuh"
+#include "convnet.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -58,6 +59,7 @@ struct syn_engine {
     float4* d_stat = nullptr;
     uint4* d_edge = nullptr;
     float* d_wimg = nullptr;
+    int net_kind = 0;  // which network d_wimg holds: 0 = Connect4Net (mlp.cuh), 1 = Connect4ConvNet (convnet.cuh)
     bool has_weights = false;
     int* d_job_next = nullptr;
     uint4* d_cache = nullptr;      // PolicyWithCache table (policy_cache_log2 > 0)
@@ -223,7 +225,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     {
         int nv = 0;
         if (const char* ev = debug_env("SYN_PC")) nv = std::atoi(ev);
-        if (nv >= 1 && nv <= PcGeom::NV_MAX && h->cap <= LANE_MAX_CAP) {
+        if (nv >= 1 && nv <= PcGeom::NV_MAX && h->cap <= LANE_MAX_CAP && h->net_kind == 0) {
             const int per_wg = 64 * PcGeom::TREE_WAVES * nv;
             const int pgrid = (want_slots + per_wg - 1) / per_wg;
             const size_t nvw = (size_t)pgrid * PcGeom::TREE_WAVES * nv;
@@ -284,6 +286,13 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (const char* ev = debug_env("SYN_LANES")) nw = std::atoi(ev);
         if (needs_noise && !(nw == 4 || nw == 8 || nw == 12 || nw == 16)) nw = 4;
         if (needs_noise && h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
+        // Connect4ConvNet (convnet.cuh) is evaluated by the lane-per-tree kernels only: 8 waves per workgroup up to 512 trees
+        // per CU, 16 beyond
+        const bool conv = h->net_kind == 1;
+        if (conv) {
+            if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
+            nw = want_slots > h->num_cus * 512 ? 16 : 8;
+        }
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)
@@ -310,11 +319,24 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                       \
     }
+#define SYN_LAUNCH_LC(NW, FAST)                                                                                    \
+    {                                                                                                              \
+        auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, false, 2>;                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneLds<NW>::BYTES);   \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                      \
+    }
+            if (conv) {
+                if (nw == 8) { if (fast) SYN_LAUNCH_LC(8, true) else SYN_LAUNCH_LC(8, false) }
+                else { if (fast) SYN_LAUNCH_LC(16, true) else SYN_LAUNCH_LC(16, false) }
+            } else
             if (nw == 4) { if (fast) SYN_LAUNCH_L(4, true) else SYN_LAUNCH_L(4, false) }
             else if (nw == 8) { if (fast) SYN_LAUNCH_L(8, true) else SYN_LAUNCH_L(8, false) }
             else if (nw == 12) { if (fast) SYN_LAUNCH_L(12, true) else SYN_LAUNCH_L(12, false) }
             else { if (fast) SYN_LAUNCH_L(16, true) else SYN_LAUNCH_L(16, false) }
 #undef SYN_LAUNCH_L
+#undef SYN_LAUNCH_LC
             h->last_shape = 4; h->last_grid = lgrid; h->last_threads = 64 * nw;
             if (out_grid) *out_grid = -lgrid;  // negative: lane kernel (profile layout differs)
             if (out_nt) *out_nt = 64 * nw;
@@ -528,6 +550,26 @@ int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
     // run_n_games, alpha_zero.rs:196-198): a new network starts with an empty table
     if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));
     h->has_weights = true;
+    h->net_kind = 0;
+    return SYN_OK;
+}
+
+int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!blob) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob is NULL");
+    if (n_floats != (size_t)ConvGeom::NUM_PARAMS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4ConvNet has %d parameters, got %zu", ConvGeom::NUM_PARAMS, n_floats);
+    if (h->cap > LANE_MAX_CAP)
+        return fail(h, SYN_ERR_UNSUPPORTED, "Connect4ConvNet runs in the lane-per-tree kernels: max_explores must be <= %d",
+                    (LANE_MAX_CAP - 1) / 9 - 1);
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<float> img((size_t)ConvGeom::IMG_FLOATS);
+    build_conv_image(blob, img.data());
+    HIP_TRY(h, hipMemcpyAsync(h->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));  // a new network: empty cache
+    h->has_weights = true;
+    h->net_kind = 1;
     return SYN_OK;
 }
 
@@ -555,7 +597,15 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint
                            reinterpret_cast<const unsigned long long*>(d_my),                                        \
                            reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                 \
     }
-    if (ntiles >= h->num_cus * 12 * 4) SYN_LAUNCH_EVAL(768) else SYN_LAUNCH_EVAL(512)
+    if (h->net_kind == 1) {
+        auto k = policy_eval_conv_kernel<512>;
+        const size_t clds = (size_t)ConvGeom::IMG_FLOATS * 4;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+        int grid = (ntiles + 7) / 8;
+        if (grid > h->num_cus) grid = h->num_cus;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), clds, h->stream, h->d_wimg, reinterpret_cast<const unsigned long long*>(d_my),
+                           reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);
+    } else if (ntiles >= h->num_cus * 12 * 4) SYN_LAUNCH_EVAL(768) else SYN_LAUNCH_EVAL(512)
 #undef SYN_LAUNCH_EVAL
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -1399,6 +1449,7 @@ int syn_trainer_publish_weights(syn_engine* h) {
     if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));  // new network: empty PolicyWithCache
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->has_weights = true;
+    h->net_kind = 0;
     return SYN_OK;
 }
 

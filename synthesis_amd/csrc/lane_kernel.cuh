@@ -22,6 +22,7 @@
 #pragma once
 #include "engine_kernels.cuh"
 #include "noise.cuh"
+#include "convnet.cuh"
 
 namespace syn {
 
@@ -1047,7 +1048,8 @@ SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
-// POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (policies/rollout.rs; searches only)
+// POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (policies/rollout.rs; searches only),
+//         2 = Connect4ConvNet on the matrix cores (convnet.cuh: its image takes the first 66 KB of the Connect4Net image's LDS)
 template <int MODE, bool COUNT, bool FAST, int NW, bool PROF = false, int POLICY = 0>
 __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1060,12 +1062,13 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     float* outw = reinterpret_cast<float*>(smem_raw + LaneLds<NW>::OUT_OFF) + wave * 256;
 
     if (POLICY == 0) stage_weight_image(wimg, P.wimg, tid, NT);
+    if (POLICY == 2) stage_conv_image(wimg, P.wimg, tid, NT);
     // RolloutPolicy needs no weights: the image's LDS holds the waves' ChaCha12 block rings instead (12 KB per wave)
     RolloutRing ring;
     ring.lds = reinterpret_cast<uint32_t*>(smem_raw) + (size_t)wave * (3 * 16 * 64) + lane;
     ring.hi = 0;
     ring.job = -1;
-    static_assert(POLICY == 0 || (size_t)NW * 3 * 16 * 64 * 4 <= (size_t)MlpGeom::IMG_FLOATS * 4, "rings must fit the image region");
+    static_assert(POLICY != 1 || (size_t)NW * 3 * 16 * 64 * 4 <= (size_t)MlpGeom::IMG_FLOATS * 4, "rings must fit the image region");
     if (tid < 4) {
         const FeatureTable f = make_feature_table(tid);
         *reinterpret_cast<uint4*>(smem_raw + LaneLds<NW>::FT_OFF + tid * 16) = make_uint4(f.t[0], f.t[1], f.t[2], f.t[3]);
@@ -1091,14 +1094,14 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         pk[2 * NT] = (uint32_t)T.root_op; pk[3 * NT] = (uint32_t)(T.root_op >> 32);                          \
         pk[4 * NT] = (uint32_t)T.turn | (T.rng_index << 8);                                                  \
         T.root_my = 0; T.root_op = 0; T.turn = 0;                                                            \
-        if (POLICY == 0) T.rng_index = 0;                                                                    \
+        if (POLICY != 1) T.rng_index = 0;                                                                    \
     } while (0)
 #define SYN_UNPARK()                                                                                         \
     do {                                                                                                     \
         T.root_my = (uint64_t)pk[0] | ((uint64_t)pk[NT] << 32);                                              \
         T.root_op = (uint64_t)pk[2 * NT] | ((uint64_t)pk[3 * NT] << 32);                                     \
         T.turn = (int)(pk[4 * NT] & 0xFFu);                                                                  \
-        if (POLICY == 0) T.rng_index = pk[4 * NT] >> 8;                                                      \
+        if (POLICY != 1) T.rng_index = pk[4 * NT] >> 8;                                                      \
     } while (0)
     SYN_PARK();
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
@@ -1150,7 +1153,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         }
         bool need = want_nn && !hit;
         const unsigned long long want_mask = __ballot(need);
-        if (POLICY == 0 && P.cache != nullptr) {  // wave-uniform tallies (scalar registers), flushed once at the end of the kernel
+        if (POLICY != 1 && P.cache != nullptr) {  // wave-uniform tallies (scalar registers), flushed once at the end of the kernel
             cache_hits += (unsigned long long)__popcll(__ballot(hit));
             cache_misses += (unsigned long long)__popcll(__ballot(want_nn && !hit && !X.was_pending));
         }
@@ -1175,14 +1178,23 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             if (PROF) pTiles++;
             // everything a tile needs is re-derived here instead of living in registers across the whole matrix phase:
             // the two derived boards (10 VALU) and the lane's feature shift table (one 16-byte LDS read)
-            uint64_t hi, lo;
-            feature_boards(Wk.my, Wk.op, hi, lo);
-            const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + LaneLds<NW>::FT_OFF + (lane >> 4) * 16);
-            FeatureTable FT;
-            FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
             const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
-            const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
-            f32x4 o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+            f32x4 o;
+            if (POLICY == 2) {
+                // Connect4ConvNet reads the two bitplanes themselves
+                const uint64_t tmy = shfl_u64(Wk.my, src), top = shfl_u64(Wk.op, src);
+                uint32_t img_off = 0;  // opaque per tile: the image reads stay LDS reads next to their MFMAs
+                asm volatile("" : "+v"(img_off));
+                o = conv_tile16(wimg + img_off, lane, tmy, top);
+            } else {
+                uint64_t hi, lo;
+                feature_boards(Wk.my, Wk.op, hi, lo);
+                const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + LaneLds<NW>::FT_OFF + (lane >> 4) * 16);
+                FeatureTable FT;
+                FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
+                const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
+                o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+            }
             const int q = lane >> 4;
             if (q == 2) {
                 float a = o[1], b = o[2], c = o[3];

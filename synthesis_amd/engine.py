@@ -12,10 +12,12 @@ from .config import CEngineConfig, CMctsConfig, CRolloutConfig, MCTSConfig, Roll
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 NUM_PARAMS = 30492  # Connect4Net: 63->128->96->64->48->12 (study-connect4/src/policies.rs:20-24)
+CONV_NUM_PARAMS = 12412  # Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (include/synthesis_amd.h)
 
 # every symbol include/synthesis_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
+    "syn_load_weights_conv",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
@@ -92,6 +94,7 @@ def load_library():
     lib.syn_engine_create.argtypes = [C.POINTER(CEngineConfig), C.c_int, C.POINTER(C.c_void_p)]
     lib.syn_engine_destroy.argtypes = [C.c_void_p]
     lib.syn_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.syn_load_weights_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.syn_policy_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.syn_policy_eval_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_int]
@@ -192,6 +195,11 @@ class Engine:
     def load_weights(self, blob):
         blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
         self._check(self._lib.syn_load_weights(self._h, _p(blob), blob.size))
+
+    def load_weights_conv(self, blob):
+        """Connect4ConvNet (Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12>; include/synthesis_amd.h) becomes the engine's policy."""
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        self._check(self._lib.syn_load_weights_conv(self._h, _p(blob), blob.size))
 
     # ---- Policy::eval, batched (policies.rs:47-59)
     def policy_eval(self, my_bb, op_bb):

@@ -75,7 +75,9 @@ class Oracle:
     def __init__(self, lib):
         self.lib = lib
         lib.orc_c4_selfplay.restype = C.c_double
+        lib.orc_c4conv_selfplay.restype = C.c_double
         lib.orc_c4net_num_params.restype = C.c_size_t
+        lib.orc_c4conv_num_params.restype = C.c_size_t
         lib.orc_outcome_value.restype = C.c_float
 
     # ---- outcome
@@ -175,6 +177,16 @@ class Oracle:
         self.lib.orc_c4net_eval(_p(blob), _p(my), _p(op), n, _p(logits), _p(value), mode)
         return logits, value
 
+    # ---- Connect4ConvNet (oracle/nn.hpp)
+    def c4conv_eval(self, blob, my_bb, op_bb, mode=0, raw=False):
+        blob = np.ascontiguousarray(blob, np.float32)
+        assert blob.size == self.lib.orc_c4conv_num_params()
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
+        n = int(my.size)
+        logits = np.zeros((n, 9), np.float32); value = np.zeros((n, 3), np.float32); raw12 = np.zeros((n, 12), np.float32)
+        self.lib.orc_c4conv_eval(_p(blob), _p(my), _p(op), n, _p(logits), _p(value), _p(raw12), mode)
+        return (logits, value, raw12) if raw else (logits, value)
+
     # ---- rng
     def stdrng_u32(self, seed, n, rounds=12):
         out = np.zeros(n, np.uint32)
@@ -219,7 +231,7 @@ class Oracle:
         return np.array(pr[: n.value], np.float32)
 
     # ---- connect4 MCTS search
-    def c4_mcts_search(self, cfg, blob, my_bb, op_bb, explores, action_selection=1, nn_mode=1):
+    def c4_mcts_search(self, cfg, blob, my_bb, op_bb, explores, action_selection=1, nn_mode=1, net="mlp"):
         blob = np.ascontiguousarray(blob, np.float32)
         my = np.ascontiguousarray(my_bb, dtype=np.uint64); op = np.ascontiguousarray(op_bb, dtype=np.uint64)
         n = int(my.size)
@@ -228,10 +240,11 @@ class Oracle:
                  root_stat=np.zeros((n, 4), np.float32), root_sol=np.zeros((n, 3), np.int32),
                  num_nodes=np.zeros(n, np.uint32), best_action=np.zeros(n, np.int32),
                  target_pi=np.zeros((n, 9), np.float32), target_q=np.zeros((n, 3), np.float32))
-        self.lib.orc_c4_mcts_search(C.byref(cfg), _p(blob), nn_mode, _p(my), _p(op), n, explores, action_selection,
-                                    _p(r["child_N"]), _p(r["child_W"]), _p(r["child_P"]), _p(r["child_sol"]),
-                                    _p(r["root_stat"]), _p(r["root_sol"]), _p(r["num_nodes"]), _p(r["best_action"]),
-                                    _p(r["target_pi"]), _p(r["target_q"]))
+        fn = self.lib.orc_c4conv_mcts_search if net == "conv" else self.lib.orc_c4_mcts_search
+        fn(C.byref(cfg), _p(blob), nn_mode, _p(my), _p(op), n, explores, action_selection,
+           _p(r["child_N"]), _p(r["child_W"]), _p(r["child_P"]), _p(r["child_sol"]),
+           _p(r["root_stat"]), _p(r["root_sol"]), _p(r["num_nodes"]), _p(r["best_action"]),
+           _p(r["target_pi"]), _p(r["target_q"]))
         return r
 
     def c4_mcts_search_rollout(self, cfg, seed, my_bb, op_bb, explores, action_selection=1):
@@ -340,7 +353,7 @@ class Oracle:
 
     # ---- self-play
     def c4_selfplay(self, cfg, blob, base_seed, n_games, first_game=0, threads=1, use_cache=False, nn_mode=1,
-                    outputs=True):
+                    outputs=True, net="mlp"):
         blob = np.ascontiguousarray(blob, np.float32)
         r = dict(plies=np.zeros(n_games, np.int32), final_kind=np.zeros(n_games, np.uint8),
                  counters=np.zeros(12, np.uint64))
@@ -349,9 +362,10 @@ class Oracle:
                      vs=np.zeros((n_games, 63, 3), np.float32), actions=np.zeros((n_games, 63), np.uint8),
                      root_nodes=np.zeros((n_games, 63), np.uint32))
         g = lambda k: _p(r[k]) if k in r else None
-        secs = self.lib.orc_c4_selfplay(C.byref(cfg), _p(blob), nn_mode, C.c_uint64(base_seed), C.c_uint64(first_game),
-                                        n_games, threads, int(use_cache), _p(r["plies"]), g("states_bb"), g("pis"),
-                                        g("vs"), g("actions"), g("root_nodes"), _p(r["final_kind"]), _p(r["counters"]))
+        fn = self.lib.orc_c4conv_selfplay if net == "conv" else self.lib.orc_c4_selfplay
+        secs = fn(C.byref(cfg), _p(blob), nn_mode, C.c_uint64(base_seed), C.c_uint64(first_game),
+                  n_games, threads, int(use_cache), _p(r["plies"]), g("states_bb"), g("pis"),
+                  g("vs"), g("actions"), g("root_nodes"), _p(r["final_kind"]), _p(r["counters"]))
         r["seconds"] = secs
         names = ["explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals",
                  "backprop_levels", "solver_children", "solved_hits", "cache_hits", "cache_misses", "max_depth"]

@@ -1,0 +1,140 @@
+"""GPU parity of the conv policy/value network (Connect4ConvNet: slimnn Conv2d over the 2x7x9 bitplanes + Linear heads; the layers
+are the reference's — slimnn/src/conv.rs:45-85, linear.rs:17-25 — the architecture is this build's, oracle/nn.hpp) behind the same
+Policy::eval surface: batched evaluation, MCTS searches and whole self-play games against the CPU oracle.
+
+Bars: network outputs EXACTLY equal to the oracle's ACC_FMA mode (the fma chains the matrix cores compute) and within 1e-5 of
+the canonical slimnn loop order (north_star); visit counts / trajectories bit-exact."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import NN_TOL, assert_search_equal, assert_selfplay_equal, random_positions
+
+pytestmark = pytest.mark.gpu
+
+
+def conv_blob(seed=20260101):
+    """Fixed-seed initialisation: U(+-1/sqrt(fan_in)) per layer (fan_in 18 for the conv, 1008 for the heads)."""
+    import synthesis_amd as sa
+    from synthesis_amd.engine import CONV_NUM_PARAMS
+
+    rng = np.random.default_rng(seed)
+    conv_w = rng.uniform(-1, 1, 288) / np.sqrt(18.0)
+    conv_b = rng.uniform(-1, 1, 16) / np.sqrt(18.0)
+    head_w = rng.uniform(-1, 1, 12 * 1008) / np.sqrt(1008.0) * 4.0  # (x4: sharper priors -> deeper trees than a flat prior)
+    head_b = rng.uniform(-1, 1, 12) / np.sqrt(1008.0)
+    blob = np.concatenate([conv_w, conv_b, head_w, head_b]).astype(np.float32)
+    assert blob.size == CONV_NUM_PARAMS
+    return blob
+
+
+@pytest.fixture(scope="module")
+def cblob():
+    return conv_blob()
+
+
+@pytest.fixture(scope="module")
+def engine(cblob):
+    import synthesis_amd as sa
+
+    eng = sa.Engine(concurrent_games=1100, max_explores=800, device=0)
+    eng.load_weights_conv(cblob)
+    yield eng
+    eng.close()
+
+
+def test_conv_policy_eval_parity(engine, oracle, cblob):
+    my, op = random_positions(oracle, 3000, seed=5, max_moves=62)
+    my[0] = 0; op[0] = 0
+    # edge and corner stones exercise the padding taps
+    my[1] = (1 << 0) | (1 << 6) | (1 << 56) | (1 << 62); op[1] = (1 << 1) | (1 << 55)
+    for n in (1, 15, 16, 17, 3000):
+        lg, v = engine.policy_eval(my[:n], op[:n])
+        ref_l, ref_v = oracle.c4conv_eval(cblob, my[:n], op[:n], mode=oracle.ACC_FMA)
+        assert np.array_equal(lg.view(np.uint32), ref_l.view(np.uint32)), n
+        assert np.array_equal(v.view(np.uint32), ref_v.view(np.uint32)), n
+    can_l, can_v = oracle.c4conv_eval(cblob, my, op, mode=oracle.ACC_SLIMNN)
+    assert np.abs(lg - can_l).max() <= NN_TOL and np.abs(v - can_v).max() <= NN_TOL
+    assert np.abs(lg).max() > 0.05  # a real network, not zeros
+
+
+def test_conv_mcts_search_visit_exact(engine, oracle, cblob):
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config
+
+    my, op = random_positions(oracle, 200, seed=17, max_moves=60)
+    my[0] = 0; op[0] = 0
+    for explores in (0, 1, 37, 200):
+        got = engine.mcts_search(sa.parity_mcts_config(), my, op, explores)
+        assert engine.last_launch_shape()[0] == 4  # lane-per-tree kernel
+        ref = oracle.c4_mcts_search(parity_mcts_config(), cblob, my, op, explores, nn_mode=oracle.ACC_FMA, net="conv")
+        assert_search_equal(got, ref, f"conv explores={explores}")
+    got = engine.mcts_search(sa.parity_mcts_config(), my[:16], op[:16], 800)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), cblob, my[:16], op[:16], 800, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_search_equal(got, ref, "conv explores=800")
+    # a non-FAST config family (ParentQ first-play urgency, plain UCT) goes through the general kernel variant
+    ocfg = parity_mcts_config(exploration=0, c=1.4, fpu=1)
+    scfg = sa.MCTSConfig(exploration=sa.Exploration(0), c=1.4, fpu=sa.Fpu(1))
+    got = engine.mcts_search(scfg, my[:64], op[:64], 90, action_selection=0)
+    ref = oracle.c4_mcts_search(ocfg, cblob, my[:64], op[:64], 90, action_selection=0, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_search_equal(got, ref, "conv uct/parent-q")
+
+
+def test_conv_selfplay_matches_oracle(engine, oracle, cblob):
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+
+    got = engine.selfplay(sa.parity_rollout_config(60), base_seed=21, n_games=2300, counters=True)
+    assert engine.last_launch_shape()[0] == 4 and engine.last_launch_shape()[2] == 512
+    ref = oracle.c4_selfplay(parity_rollout_config(60), cblob, 21, 2300, threads=8, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_selfplay_equal(got, ref, "conv self-play")
+    for k in ("explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals", "backprop_levels",
+              "solver_children", "solved_hits", "max_depth"):
+        assert got["counters"][k] == ref["counters"][k], k
+    got = engine.selfplay(sa.parity_rollout_config(800), base_seed=4, n_games=4)
+    ref = oracle.c4_selfplay(parity_rollout_config(800), cblob, 4, 4, threads=4, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_selfplay_equal(got, ref, "conv 800 explores")
+
+
+def test_conv_16_wave_shape_and_policy_cache(oracle, cblob):
+    """More than 512 trees per CU: the 16-wave workgroups (128-VGPR budget) — sampled games equal the oracle's; and the policy
+    cache stays semantics-neutral with the conv network."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+
+    eng = sa.Engine(concurrent_games=140000, max_explores=24)
+    eng.load_weights_conv(cblob)
+    got = eng.selfplay(sa.parity_rollout_config(24), base_seed=8, n_games=140000)
+    assert eng.last_launch_shape()[0] == 4 and eng.last_launch_shape()[2] == 1024
+    for first in (0, 70000, 139968):
+        ref = oracle.c4_selfplay(parity_rollout_config(24), cblob, 8, 32, first_game=first, threads=8, nn_mode=oracle.ACC_FMA,
+                                 net="conv")
+        sub = {k: got[k][first:first + 32] for k in ("plies", "final_kind", "states_bb", "pis", "vs", "actions", "root_nodes")}
+        assert_selfplay_equal(sub, ref, f"conv 16 waves, games {first}..")
+    eng.close()
+    eng = sa.Engine(concurrent_games=1100, max_explores=100, policy_cache_log2=14)
+    eng.load_weights_conv(cblob)
+    got = eng.selfplay(sa.parity_rollout_config(100), base_seed=5, n_games=1500)
+    ref = oracle.c4_selfplay(parity_rollout_config(100), cblob, 5, 1500, threads=8, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_selfplay_equal(got, ref, "conv with policy cache")
+    hits, misses = eng.last_cache_stats()
+    assert hits > 0 and misses > 0
+    eng.close()
+
+
+def test_conv_and_mlp_networks_switch(engine, oracle, cblob, golden_dir):
+    """syn_load_weights / syn_load_weights_conv replace the engine's network in place; wrong sizes are rejected."""
+    import os
+    import synthesis_amd as sa
+
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    my, op = random_positions(oracle, 64, seed=2)
+    engine.load_weights(blob)
+    lg, v = engine.policy_eval(my, op)
+    ref_l, ref_v = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    assert np.array_equal(lg, ref_l) and np.array_equal(v, ref_v)
+    with pytest.raises(sa.SynthesisAmdError):
+        engine.load_weights_conv(blob)  # 30,492 floats is not a Connect4ConvNet
+    engine.load_weights_conv(cblob)
+    lg, v = engine.policy_eval(my, op)
+    ref_l, ref_v = oracle.c4conv_eval(cblob, my, op, mode=oracle.ACC_FMA)
+    assert np.array_equal(lg, ref_l) and np.array_equal(v, ref_v)
