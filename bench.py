@@ -53,6 +53,20 @@ def make_weights(seed=20211003):
     return np.concatenate(parts)
 
 
+CONV_FLOP_PER_EVAL = 54592      # Connect4ConvNet as slimnn executes it: 2 * (16 * 2 * 475 in-board conv taps + 1008 * 12)
+
+
+def make_conv_weights(seed=20260101):
+    """Connect4ConvNet (include/synthesis_amd.h: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12>), fixed-seed U(+-1/sqrt(fan_in))
+    init; the head weights x4 so that the priors are not flat. Blob: conv.weight, conv.bias, head.weight, head.bias."""
+    rng = np.random.default_rng(seed)
+    conv_w = rng.uniform(-1, 1, 288) / np.sqrt(18.0)
+    conv_b = rng.uniform(-1, 1, 16) / np.sqrt(18.0)
+    head_w = rng.uniform(-1, 1, 12 * 1008) / np.sqrt(1008.0) * 4.0
+    head_b = rng.uniform(-1, 1, 12) / np.sqrt(1008.0)
+    return np.concatenate([conv_w, conv_b, head_w, head_b]).astype(np.float32)
+
+
 def algorithmic_bytes(c):
     """SURVEY.md §8(d), per event: select level = 12 B parent + 20 B per child scanned; expand = 16 B state +
     48 B per new node + 8 B parent update; NN I/O = 64 B per leaf evaluation (0 when fused — counted as 0 here);
@@ -62,7 +76,7 @@ def algorithmic_bytes(c):
 
 
 SELFPLAY_KERNEL_SOURCES = ("device_common.cuh", "mcts.cuh", "mlp.cuh", "engine_kernels.cuh", "lane_kernel.cuh", "pc_kernel.cuh",
-                           "noise.cuh", "zig_tables.cuh")
+                           "noise.cuh", "zig_tables.cuh", "convnet.cuh")
 
 
 def kernel_source_hash():
@@ -381,6 +395,25 @@ def main():
                     "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
                                                    "max_depth": c["max_depth"]}}
                 eng.load_weights(blob)
+            # (4) the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
+            # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)
+            eng.load_weights_conv(make_conv_weights())
+            base = (args.warmup + args.steps + 5) * gps
+            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=base, outputs=False)
+            t1 = time.perf_counter()
+            gt = min(gps, 4 * args.concurrent)
+            rt = eng.selfplay(cfg, base_seed=0, n_games=gt, first_game=base + args.concurrent, outputs=False)
+            dt5 = time.perf_counter() - t1
+            cc = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=base + args.concurrent, outputs=False, counters=True)["counters"]
+            evals_per_s = (cc["policy_evals"] / 65536.0) * (gt / dt5)
+            out["with_conv_policy"] = {
+                "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
+                "games_per_s": gt / dt5, "games": gt, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
+                "flop_per_eval": CONV_FLOP_PER_EVAL,
+                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "launch_shape": list(eng.last_launch_shape())}
+            eng.load_weights(blob)
         if world == 1 and not args.no_4096:
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration

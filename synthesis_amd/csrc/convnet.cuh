@@ -103,14 +103,23 @@ SYN_DEV f32x4 conv_tile16(const float* __restrict__ img, int lane, uint64_t my, 
     const float* hw = img + G::HEAD_OFF + lane * 4;
 #pragma unroll 1
     for (int r = 0; r < 7; r++) {
+        // this row's cells sit at bits r + 7 c: shift the five boards by r once, then every cell is a compile-time bit of a
+        // 32-bit half (bit-field extract + convert per tap)
+        uint32_t lo[5], hi[5];
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            const uint64_t v = S[s] >> r;
+            lo[s] = (uint32_t)v;
+            hi[s] = (uint32_t)(v >> 32);
+        }
 #pragma unroll
         for (int c = 0; c < 9; c++) {
-            const int b = r + 7 * c, p = r * 9 + c;
+            const int p = r * 9 + c;
             f32x4 acc = cb;
 #pragma unroll
             for (int s = 0; s < 5; s++) {
-                const float x = (float)((uint32_t)(S[s] >> b) & 1u);
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], x, acc, 0, 0, 0);
+                const uint32_t bit = 7 * c < 32 ? __builtin_amdgcn_ubfe(lo[s], 7 * c, 1) : __builtin_amdgcn_ubfe(hi[s], 7 * c - 32, 1);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)bit, acc, 0, 0, 0);
             }
             const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + p * 256);
 #pragma unroll

@@ -286,12 +286,12 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (const char* ev = debug_env("SYN_LANES")) nw = std::atoi(ev);
         if (needs_noise && !(nw == 4 || nw == 8 || nw == 12 || nw == 16)) nw = 4;
         if (needs_noise && h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
-        // Connect4ConvNet (convnet.cuh) is evaluated by the lane-per-tree kernels only: 8 waves per workgroup up to 512 trees
-        // per CU, 16 beyond
+        // Connect4ConvNet (convnet.cuh) is evaluated by the lane-per-tree kernels only: 4 waves per workgroup up to 256 trees
+        // per CU, 8 up to 512, 16 beyond
         const bool conv = h->net_kind == 1;
         if (conv) {
             if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
-            nw = want_slots > h->num_cus * 512 ? 16 : 8;
+            nw = want_slots > h->num_cus * 512 ? 16 : (want_slots > h->num_cus * 256 ? 8 : 4);
         }
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
@@ -328,7 +328,8 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                      \
     }
             if (conv) {
-                if (nw == 8) { if (fast) SYN_LAUNCH_LC(8, true) else SYN_LAUNCH_LC(8, false) }
+                if (nw == 4) { if (fast) SYN_LAUNCH_LC(4, true) else SYN_LAUNCH_LC(4, false) }
+                else if (nw == 8) { if (fast) SYN_LAUNCH_LC(8, true) else SYN_LAUNCH_LC(8, false) }
                 else { if (fast) SYN_LAUNCH_LC(16, true) else SYN_LAUNCH_LC(16, false) }
             } else
             if (nw == 4) { if (fast) SYN_LAUNCH_L(4, true) else SYN_LAUNCH_L(4, false) }

@@ -13,16 +13,11 @@ pytestmark = pytest.mark.gpu
 
 
 def conv_blob(seed=20260101):
-    """Fixed-seed initialisation: U(+-1/sqrt(fan_in)) per layer (fan_in 18 for the conv, 1008 for the heads)."""
-    import synthesis_amd as sa
+    """Fixed-seed initialisation (bench.make_conv_weights: U(+-1/sqrt(fan_in)) per layer, head weights x4)."""
+    from bench import make_conv_weights
     from synthesis_amd.engine import CONV_NUM_PARAMS
 
-    rng = np.random.default_rng(seed)
-    conv_w = rng.uniform(-1, 1, 288) / np.sqrt(18.0)
-    conv_b = rng.uniform(-1, 1, 16) / np.sqrt(18.0)
-    head_w = rng.uniform(-1, 1, 12 * 1008) / np.sqrt(1008.0) * 4.0  # (x4: sharper priors -> deeper trees than a flat prior)
-    head_b = rng.uniform(-1, 1, 12) / np.sqrt(1008.0)
-    blob = np.concatenate([conv_w, conv_b, head_w, head_b]).astype(np.float32)
+    blob = make_conv_weights(seed)
     assert blob.size == CONV_NUM_PARAMS
     return blob
 
@@ -84,7 +79,7 @@ def test_conv_selfplay_matches_oracle(engine, oracle, cblob):
     from tests.oracle_lib import parity_rollout_config
 
     got = engine.selfplay(sa.parity_rollout_config(60), base_seed=21, n_games=2300, counters=True)
-    assert engine.last_launch_shape()[0] == 4 and engine.last_launch_shape()[2] == 512
+    assert engine.last_launch_shape()[0] == 4 and engine.last_launch_shape()[2] == 256   # 4 waves up to 256 trees per CU
     ref = oracle.c4_selfplay(parity_rollout_config(60), cblob, 21, 2300, threads=8, nn_mode=oracle.ACC_FMA, net="conv")
     assert_selfplay_equal(got, ref, "conv self-play")
     for k in ("explores", "select_levels", "children_scanned", "expansions", "new_nodes", "policy_evals", "backprop_levels",
@@ -96,21 +91,22 @@ def test_conv_selfplay_matches_oracle(engine, oracle, cblob):
 
 
 def test_conv_16_wave_shape_and_policy_cache(oracle, cblob):
-    """More than 512 trees per CU: the 16-wave workgroups (128-VGPR budget) — sampled games equal the oracle's; and the policy
+    """The 16- and 8-wave workgroup shapes (more than 512 / 256 trees per CU) — sampled games equal the oracle's; and the policy
     cache stays semantics-neutral with the conv network."""
     import synthesis_amd as sa
     from tests.oracle_lib import parity_rollout_config
 
-    eng = sa.Engine(concurrent_games=140000, max_explores=24)
-    eng.load_weights_conv(cblob)
-    got = eng.selfplay(sa.parity_rollout_config(24), base_seed=8, n_games=140000)
-    assert eng.last_launch_shape()[0] == 4 and eng.last_launch_shape()[2] == 1024
-    for first in (0, 70000, 139968):
-        ref = oracle.c4_selfplay(parity_rollout_config(24), cblob, 8, 32, first_game=first, threads=8, nn_mode=oracle.ACC_FMA,
-                                 net="conv")
-        sub = {k: got[k][first:first + 32] for k in ("plies", "final_kind", "states_bb", "pis", "vs", "actions", "root_nodes")}
-        assert_selfplay_equal(sub, ref, f"conv 16 waves, games {first}..")
-    eng.close()
+    for slots, threads in ((140000, 1024), (70000, 512)):   # > 512 trees per CU: 16 waves; > 256: 8 waves
+        eng = sa.Engine(concurrent_games=slots, max_explores=24)
+        eng.load_weights_conv(cblob)
+        got = eng.selfplay(sa.parity_rollout_config(24), base_seed=8, n_games=slots)
+        assert eng.last_launch_shape()[0] == 4 and eng.last_launch_shape()[2] == threads
+        for first in (0, slots // 2, slots - 32):
+            ref = oracle.c4_selfplay(parity_rollout_config(24), cblob, 8, 32, first_game=first, threads=8, nn_mode=oracle.ACC_FMA,
+                                     net="conv")
+            sub = {k: got[k][first:first + 32] for k in ("plies", "final_kind", "states_bb", "pis", "vs", "actions", "root_nodes")}
+            assert_selfplay_equal(sub, ref, f"conv {threads // 64} waves, games {first}..")
+        eng.close()
     eng = sa.Engine(concurrent_games=1100, max_explores=100, policy_cache_log2=14)
     eng.load_weights_conv(cblob)
     got = eng.selfplay(sa.parity_rollout_config(100), base_seed=5, n_games=1500)

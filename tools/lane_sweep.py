@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: throughput of the lane-per-tree / producer-consumer kernels. Args: conc:nw[:games[:policy_cache_log2]] ...
 (nw = waves per workgroup of the lane kernel, 0 = the engine's own choice, negative = producer/consumer kernel with -nw
-virtual waves per tree wave)"""
+virtual waves per tree wave). A first argument "conv" runs Connect4ConvNet (convnet.cuh) instead of Connect4Net; "eval" appended
+measures the stand-alone batched Policy::eval of the chosen network on 4M positions as well."""
 import os
 os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
 import os, sys, time
@@ -10,9 +11,14 @@ import torch  # noqa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import synthesis_amd as sa
-from bench import make_weights
-blob = make_weights()
-combos = [tuple(map(int, a.split(":"))) for a in sys.argv[1:]] or [(65536, 16), (131072, 16), (262144, 16)]
+from bench import make_conv_weights, make_weights
+argv = sys.argv[1:]
+conv = bool(argv) and argv[0] == "conv"
+if conv: argv = argv[1:]
+do_eval = bool(argv) and argv[-1] == "eval"
+if do_eval: argv = argv[:-1]
+blob = make_conv_weights() if conv else make_weights()
+combos = [tuple(map(int, a.split(":"))) for a in argv] or [(65536, 16), (131072, 16), (262144, 16)]
 cfg = sa.parity_rollout_config(800)
 for c in combos:
     conc, nw = c[0], c[1]
@@ -22,7 +28,7 @@ for c in combos:
     if nw > 0: os.environ["SYN_LANES"] = str(nw); os.environ["SYN_PC"] = "0"
     elif nw < 0: os.environ["SYN_PC"] = str(-nw)
     eng = sa.Engine(concurrent_games=conc, max_explores=800, policy_cache_log2=clog)
-    eng.load_weights(blob)
+    (eng.load_weights_conv if conv else eng.load_weights)(blob)
     eng.selfplay(cfg, 0, 256, outputs=False)
     t0 = time.perf_counter()
     r = eng.selfplay(cfg, 0, n, first_game=conc, outputs=False)
@@ -30,4 +36,16 @@ for c in combos:
     hits, misses = eng.last_cache_stats()
     extra = f"  policy cache 2^{clog}: {hits / max(1, hits + misses):.3f} hit rate" if clog else ""
     print(f"concurrent={conc} lanes_nw={nw} shape={eng.last_launch_shape()}: {n} games in {dt:.3f} s = {n / dt:.0f} games/s  (mean plies {r['plies'].mean():.2f}){extra}", flush=True)
+    eng.close()
+if do_eval:
+    eng = sa.Engine(concurrent_games=256, max_explores=16)
+    (eng.load_weights_conv if conv else eng.load_weights)(blob)
+    rng = np.random.default_rng(0)
+    n = 1 << 22
+    my = rng.integers(0, 1 << 62, n, dtype=np.uint64); op = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ~my
+    eng.policy_eval(my[:65536], op[:65536])
+    eng.policy_eval(my, op)
+    ms = eng.last_kernel_ms()
+    ms = ms[0] if isinstance(ms, (tuple, list)) else ms
+    print(f"policy_eval {'Connect4ConvNet' if conv else 'Connect4Net'}: {n} positions, kernel {ms:.2f} ms = {n / ms / 1e6:.3f} G evals/s", flush=True)
     eng.close()
