@@ -4,7 +4,8 @@
 // The reference defines the layers (slimnn/src/conv.rs:45-85 Conv2d::forward, slimnn/src/linear.rs:17-25 Linear::forward) but no
 // such network; the architecture is this build's instantiation, fixed in oracle/nn.hpp (Connect4ConvNet):
 //     x[2][7][9] bitplanes (mine, theirs)  ->  Conv2d<2, 16, 3, pad 1, stride 1> + ReLU  ->  Linear<1008, 12>
-//     logits = out[0..9] raw, value = softmax(out[9..12])            12,412 parameters, 2 x 30,240 FLOP per evaluation
+//     logits = out[0..9] raw, value = softmax(out[9..12])            12,412 parameters; 54,592 FLOP per evaluation as slimnn
+//     executes it (in-board taps only), 60,480 as the matrix cores do (padded taps multiply zeros)
 // Parameter blob: conv.weight[16][2][3][3], conv.bias[16], head.weight[12][1008], head.bias[12].
 //
 // MI355X mapping — one wave evaluates a tile of 16 positions, everything in its registers, no im2col buffer, no activations
@@ -12,14 +13,16 @@
 //   conv    D[channel][position] = bias + sum over the 18 taps:  A = conv weights (16 channels x 20 taps, taps 18, 19 zero) —
 //           five registers per lane for the whole tile; B[tap][position] = ONE BIT of the position's bitboards, taken from five
 //           per-lane pre-shifted boards (tap (ci, k1, k2) reads plane ci shifted by (k1 - 1) + 7 (k2 - 1), rows that would wrap
-//           into the neighbouring column masked out): shift, and, convert — the "LDS-staged board tile" of north_star is a pair
-//           of 64-bit registers here. 5 MFMAs, taps in slimnn's order ci -> k1 -> k2; a padded tap is fma(w, 0, acc) = acc.
+//           into the neighbouring column masked out; shifted once more per board row, so that a cell is a compile-time bit of a
+//           32-bit half: v_bfe_u32 + v_cvt per tap) — the "LDS-staged board tile" of north_star is a pair of 64-bit registers
+//           here. 5 MFMAs, taps in slimnn's order ci -> k1 -> k2; a padded tap is fma(w, 0, acc) = acc.
 //   heads   the conv tile's D registers after ReLU ARE the B operands of the head GEMM for that cell (lane (j, q) register r =
 //           channel 4 q + r of position j = k-element q of step r): out[o][position] += Wh[o][channel*63 + p] * act, 4 MFMAs
 //           with the A fragments ([p][lane][r], one ds_read_b128 per lane and cell) from the 64.5 KB LDS image.
 // 567 v_mfma_f32_16x16x4_f32 per tile (Connect4Net: 476). Every output is one k-ordered fma chain, restated by oracle/nn.hpp's
 // ACC_FMA mode bit for bit (head inputs position-major, channels 0,4,8,12, 1,5,9,13, ... inside a position); against slimnn's
-// own loop order (ACC_SLIMNN) the outputs agree to ~1e-6 (tests: 1e-5).
+// own loop order (ACC_SLIMNN) the outputs agree to ~1e-6 (tests: 1e-5). Measured (MI355X): 1.32 G evaluations/s stand-alone (46 % of
+// the f32 MFMA peak in algorithmic FLOP; Connect4Net 1.83 G), 61.0k self-play games/s at 262,144 concurrent games (Connect4Net 72.6k).
 #pragma once
 #include "mlp.cuh"
 

@@ -472,7 +472,14 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     h->cap = (uint32_t)(1 + 9 * (cfg->max_explores + 1));
     h->cap = (h->cap + 3u) & ~3u;
     if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    {
+        // the progress / cancel stream must never share a hardware queue with the launch stream (it would wait behind the running
+        // kernel): the runtime deals streams of one priority round-robin over a few queues, so after enough streams in a process
+        // two of them coincide — a different priority class has its own queues
+        int lo = 0, hi = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&lo, &hi)) != hipSuccess) return bail("hipDeviceGetStreamPriorityRange", e);
+        if ((e = hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, hi)) != hipSuccess) return bail("hipStreamCreate", e);
+    }
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&h->h_pin), 64)) != hipSuccess) return bail("hipHostMalloc", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&h->ev1)) != hipSuccess) return bail("hipEventCreate", e);
