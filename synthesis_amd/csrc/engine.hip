@@ -500,6 +500,7 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     if ((e = hipMalloc(&h->d_cache_stats, 16)) != hipSuccess) return bail("hipMalloc(cache stats)", e);
     if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
     if ((e = hipMalloc(&h->d_job_next, 64)) != hipSuccess) return bail("hipMalloc(job)", e);
+    if ((e = hipMemset(h->d_job_next, 0, 64)) != hipSuccess) return bail("hipMemset(job)", e);  // syn_progress before the first launch reads zeros
     if ((e = hipMalloc(&h->d_counters, sizeof(DevCounters))) != hipSuccess) return bail("hipMalloc(counters)", e);
     *out = h;
     return SYN_OK;

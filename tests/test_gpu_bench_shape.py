@@ -149,6 +149,7 @@ def test_progress_and_cancel_from_another_thread(blob, oracle):
 
     eng = sa.Engine(concurrent_games=4096, max_explores=200, device=0)
     eng.load_weights(blob)
+    assert eng.progress() == (0, 0)   # nothing launched yet: zeros, not whatever the allocation held
     n = 400000   # ~10 s of work at this size if left alone
     box = {}
 
