@@ -404,6 +404,7 @@ def main():
             gt = min(gps, 4 * args.concurrent)
             rt = eng.selfplay(cfg, base_seed=0, n_games=gt, first_game=base + args.concurrent, outputs=False)
             dt5 = time.perf_counter() - t1
+            conv_shape = list(eng.last_launch_shape())
             cc = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=base + args.concurrent, outputs=False, counters=True)["counters"]
             evals_per_s = (cc["policy_evals"] / 65536.0) * (gt / dt5)
             out["with_conv_policy"] = {
@@ -412,7 +413,7 @@ def main():
                 "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
                 "flop_per_eval": CONV_FLOP_PER_EVAL,
                 "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "launch_shape": list(eng.last_launch_shape())}
+                "launch_shape": conv_shape}
             eng.load_weights(blob)
         if world == 1 and not args.no_4096:
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
