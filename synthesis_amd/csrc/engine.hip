@@ -23,6 +23,7 @@
 #include "train_mfma.cuh"
 #include "train_epoch.cuh"
 #include "convnet.cuh"
+#include "layer_kernels.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -670,9 +671,17 @@ int syn_features_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(features_kernel, dim3(grid), dim3(256), 0, h->stream,
-                       reinterpret_cast<const unsigned long long*>(d_my),
-                       reinterpret_cast<const unsigned long long*>(d_op), n, d_out);
+    if (n <= (1 << 25)) {
+        grid = (int)((total / 4 + 256) / 256);
+        if (grid > 16 * h->num_cus) grid = 16 * h->num_cus;
+        hipLaunchKernelGGL(features4_kernel, dim3(grid), dim3(256), 0, h->stream,   // four features per thread, 16-byte stores
+                           reinterpret_cast<const unsigned long long*>(d_my),
+                           reinterpret_cast<const unsigned long long*>(d_op), n, d_out);
+    } else {
+        hipLaunchKernelGGL(features_kernel, dim3(grid), dim3(256), 0, h->stream,
+                           reinterpret_cast<const unsigned long long*>(d_my),
+                           reinterpret_cast<const unsigned long long*>(d_op), n, d_out);
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out, d_out, total * 4, hipMemcpyDeviceToHost, h->stream));
@@ -702,7 +711,14 @@ int syn_linear_forward(syn_engine* h, int I, int O, const float* W, const float*
     int grid = (int)((ny + 255) / 256);
     if (grid > 2048) grid = 2048;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    if (nW * 4 <= 64 * 1024) {
+    if (linear_tiled_lds_bytes(I, O) + 16 <= 64 * 1024 && batch >= LIN_SB) {
+        // weights and a 64-sample input tile in LDS, 8 samples per thread (layer_kernels.cuh): VALU-bound, as slimnn's two-rounding
+        // multiply-add demands
+        int g2 = (batch + LIN_SB - 1) / LIN_SB;
+        if (g2 > 4 * h->num_cus) g2 = 4 * h->num_cus;
+        hipLaunchKernelGGL(linear_tiled_kernel, dim3(g2), dim3(256), linear_tiled_lds_bytes(I, O) + 16, h->stream, I, O, dW, db, dx,
+                           batch, dy, relu);
+    } else if (nW * 4 <= 64 * 1024) {
         // weights in LDS, transposed (the usual case: every layer of Connect4Net is <= 48 KB); few, long-lived workgroups so
         // that the staging is amortised
         if (grid > 4 * h->num_cus) grid = 4 * h->num_cus;
@@ -745,8 +761,21 @@ int syn_conv2d_forward(syn_engine* h, int CIN, int COUT, int K, int RP, int CP, 
     int grid = (int)((ny + 255) / 256);
     if (grid > 2048) grid = 2048;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(conv2d_kernel, dim3(grid), dim3(256), 0, h->stream, CIN, COUT, K, RP, CP, S, H_IN, W_IN, H_OUT,
-                       W_OUT, dW, db, dx, batch, dy, relu);
+    {
+        // input planes of SB samples + the weights in LDS (layer_kernels.cuh) when they fit 64 KB, else element-per-thread from global
+        const size_t per_in = (size_t)CIN * H_IN * W_IN;
+        size_t sb = (60 * 1024 - nW * 4) / (per_in * 4);
+        if (nW * 4 < 48 * 1024 && sb >= 4) {
+            if (sb > 64) sb = 64;
+            int g2 = (int)(((size_t)batch + sb - 1) / sb);
+            if (g2 > 8 * h->num_cus) g2 = 8 * h->num_cus;
+            hipLaunchKernelGGL(conv2d_tiled_kernel, dim3(g2), dim3(256), (nW + sb * per_in) * 4, h->stream, CIN, COUT, K, RP, CP, S,
+                               H_IN, W_IN, H_OUT, W_OUT, (int)sb, dW, db, dx, batch, dy, relu);
+        } else {
+            hipLaunchKernelGGL(conv2d_kernel, dim3(grid), dim3(256), 0, h->stream, CIN, COUT, K, RP, CP, S, H_IN, W_IN, H_OUT,
+                               W_OUT, dW, db, dx, batch, dy, relu);
+        }
+    }
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     HIP_TRY(h, hipMemcpyAsync(y, dy, ny * 4, hipMemcpyDeviceToHost, h->stream));

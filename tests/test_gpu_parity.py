@@ -173,6 +173,18 @@ def test_slimnn_layer_kats_on_gpu(engine, oracle, golden_dir):
     Wc = rng.randn(8, 2, 3, 3).astype(np.float32); bc = rng.randn(8).astype(np.float32); xc = rng.randn(5, 2, 7, 9).astype(np.float32)
     assert np.array_equal(engine.conv2d(Wc, bc, xc, 1, 0, 3), oracle.conv2d(Wc, bc, xc, 1, 0, 3))
     assert np.array_equal(engine.conv2d(Wc, bc, xc, 1, 1, 1), oracle.conv2d(Wc, bc, xc, 1, 1, 1))
+    # the LDS-tiled kernels (layer_kernels.cuh) take over from 64 samples: ragged last tiles, narrow and wide layers, strides
+    for (O, I, n) in ((128, 63, 1000), (12, 48, 777), (96, 128, 64), (5, 7, 4097)):
+        W = rng.randn(O, I).astype(np.float32); b = rng.randn(O).astype(np.float32); x = rng.randn(n, I).astype(np.float32)
+        assert np.array_equal(engine.linear(W, b, x), oracle.linear(W, b, x)), (O, I, n)
+        assert np.array_equal(engine.linear(W, b, x, relu=True), np.maximum(oracle.linear(W, b, x), 0)), (O, I, n)
+    xc = rng.randn(333, 2, 7, 9).astype(np.float32)
+    for (rp, cp, st) in ((1, 1, 1), (1, 0, 3), (0, 0, 2), (2, 1, 1)):
+        assert np.array_equal(engine.conv2d(Wc, bc, xc, rp, cp, st), oracle.conv2d(Wc, bc, xc, rp, cp, st)), (rp, cp, st)
+    W5 = rng.randn(3, 4, 5, 5).astype(np.float32); b5 = rng.randn(3).astype(np.float32); x5 = rng.randn(70, 4, 11, 6).astype(np.float32)
+    assert np.array_equal(engine.conv2d(W5, b5, x5, 2, 2, 1, relu=True), np.maximum(oracle.conv2d(W5, b5, x5, 2, 2, 1), 0))
+    my, op = random_positions(oracle, 1001, seed=9)   # 63 * 1001 floats: not a multiple of the 4-float store groups
+    assert np.array_equal(engine.features(my, op), oracle.c4_features(my, op))
     import synthesis_amd as sa
     with pytest.raises(sa.SynthesisAmdError):  # conv.rs:50-51 asserts on inconsistent output dims
         engine.conv2d(Wc, bc, xc, 1, 0, 3, out_hw=(4, 3))

@@ -36,7 +36,7 @@ n = 4_000_000
 my = rng.integers(0, 1 << 62, n, dtype=np.uint64); op = (~my) & np.uint64((1 << 62) - 1)
 eng.features(my[:1000], op[:1000])
 eng.features(my, op)
-line("features_kernel", n * (16 + 63 * 4), eng.last_kernel_ms(), {"positions": n})
+line("features4_kernel", n * (16 + 63 * 4), eng.last_kernel_ms(), {"positions": n})
 eng.policy_eval(my, op)
 ms = eng.last_kernel_ms()
 line("policy_eval_kernel (compute-bound: f32 MFMA)", n * 64, ms, {"positions": n, "tflops": n * 60288 / (ms * 1e-3) / 1e12,
@@ -45,11 +45,17 @@ B = 1_000_000
 W = rng.standard_normal((128, 63), dtype=np.float32); b = rng.standard_normal(128, dtype=np.float32)
 x = rng.standard_normal((B, 63), dtype=np.float32)
 eng.linear(W, b, x[:100]); eng.linear(W, b, x)
-line("linear_kernel 63->128", B * (63 + 128) * 4, eng.last_kernel_ms(), {"batch": B})
+ms = eng.last_kernel_ms()
+# slimnn's two-rounding multiply-add cannot use fma or the matrix cores: 2 FLOP per MAC at the packed non-fused VALU rate
+# (v_pk_mul_f32 + v_pk_add_f32: 256 CUs x 64 lanes x 2 x 2.4 GHz = 78.6 TFLOP/s) is the roof that binds, long before HBM
+line("linear_tiled_kernel 63->128", B * (63 + 128) * 4, ms, {"batch": B, "valu_tflops": B * 63 * 128 * 2 / (ms * 1e-3) / 1e12,
+                                                              "valu_frac_of_78.6_tflops": B * 63 * 128 * 2 / (ms * 1e-3) / 1e12 / 78.6})
 Wc = rng.standard_normal((4, 2, 3, 3), dtype=np.float32); bc = rng.standard_normal(4, dtype=np.float32)
 xc = rng.standard_normal((B, 2, 7, 9), dtype=np.float32)
 yc = eng.conv2d(Wc, bc, xc, row_pad=1, col_pad=1)
-line("conv2d_kernel 2->4 3x3 pad 1 on 7x9", B * (2 * 63 + 4 * 63) * 4, eng.last_kernel_ms(), {"batch": B})
+ms = eng.last_kernel_ms()
+line("conv2d_tiled_kernel 2->4 3x3 pad 1 on 7x9", B * (2 * 63 + 4 * 63) * 4, ms,
+     {"batch": B, "valu_tflops": B * 4 * 2 * 475 * 2 / (ms * 1e-3) / 1e12, "note": "475 in-board taps per (channel, plane); index and bounds arithmetic dominates"})
 xa = rng.standard_normal((B, 12), dtype=np.float32)
 eng.activation(1, xa); eng.activation(1, xa)
 line("activation_kernel tanh", B * 12 * 8, eng.last_kernel_ms())
