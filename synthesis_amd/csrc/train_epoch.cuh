@@ -379,7 +379,7 @@ __global__ __launch_bounds__(EP_THREADS) void train_epoch_kernel(EpochParams P) 
         unsigned spins = 0;
         while (__hip_atomic_load(P.sync + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)EP_WGS) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22)) {
+            if (++spins > (1u << 24)) {
                 __hip_atomic_store(P.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ep_abort = 1u;
                 break;
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(EP_THREADS) void train_epoch_kernel(EpochParams P) 
                                                   : __hip_atomic_load(P.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
                     if (have >= want) break;
                     __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 22) || __hip_atomic_load(P.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    if (++spins > (1u << 24) || __hip_atomic_load(P.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                         __hip_atomic_store(P.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ep_abort = 1u;
                         break;

@@ -41,6 +41,15 @@ eng.policy_eval(my, op)
 ms = eng.last_kernel_ms()
 line("policy_eval_kernel (compute-bound: f32 MFMA)", n * 64, ms, {"positions": n, "tflops": n * 60288 / (ms * 1e-3) / 1e12,
                                                                     "mfma_frac": n * 60288 / (ms * 1e-3) / 1e12 / 157.3})
+# the conv policy/value network's stand-alone evaluation (convnet.cuh), on its own engine (it replaces the engine's network)
+from bench import CONV_FLOP_PER_EVAL, make_conv_weights  # noqa: E402
+ce = sa.Engine(concurrent_games=256, max_explores=16)
+ce.load_weights_conv(make_conv_weights())
+ce.policy_eval(my[:65536], op[:65536]); ce.policy_eval(my, op)
+ms = ce.last_kernel_ms()
+line("policy_eval_conv_kernel (compute-bound: f32 MFMA)", n * 64, ms, {"positions": n, "tflops": n * CONV_FLOP_PER_EVAL / (ms * 1e-3) / 1e12,
+                                                                         "mfma_frac": n * CONV_FLOP_PER_EVAL / (ms * 1e-3) / 1e12 / 157.3})
+ce.close()
 B = 1_000_000
 W = rng.standard_normal((128, 63), dtype=np.float32); b = rng.standard_normal(128, dtype=np.float32)
 x = rng.standard_normal((B, 63), dtype=np.float32)
