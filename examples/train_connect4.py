@@ -56,12 +56,14 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (every rank on GPU 0: tests)")
     ap.add_argument("--reference-fpu", action="store_true", help="self-play with Fpu::Func(|| Normal(1.0, 0.1)) (main.rs:43-47)")
     ap.add_argument("--dump-weights", default="", help="write the final weights of every rank to <prefix>.rank<r>.npy")
+    ap.add_argument("--net", default="mlp", choices=["mlp", "conv"], help="mlp = the reference's Connect4Net; conv = Connect4ConvNet "
+                    "(north_star's Conv2d over the bitplanes + Linear heads; one GPU, no evaluation matches)")
     args = ap.parse_args()
 
     import torch  # noqa: F401  (before the engine: one HIP runtime per process)
 
     import synthesis_amd as sa
-    from bench import make_weights
+    from bench import make_conv_weights, make_weights
     from synthesis_amd import dist_util
     from synthesis_amd.learner import DataParallelLearner
 
@@ -79,10 +81,19 @@ def main():
 
     eng = sa.Engine(concurrent_games=min(args.concurrent, max(16, args.games_per_train // world)), max_explores=args.explores,
                     device=local_rank)
-    blob = make_weights(args.seed + 20211003)  # P::new(&vs): fixed-seed init, identical on every rank
-    eng.load_weights(blob)
-    learner = DataParallelLearner(eng, blob, dist=dist, device=local_rank, weight_decay=1e-6, policy_weight=1.0,
-                                  value_weight=1.0)
+    conv = args.net == "conv"
+    if conv and (world > 1 or args.eval_games > 0):
+        raise SystemExit("--net conv: one GPU, no evaluation matches (the match player and the data-parallel learner are Connect4Net's)")
+    if conv:
+        blob = make_conv_weights(args.seed + 20260101)
+        eng.load_weights_conv(blob)
+        eng.trainer_init_conv(blob, weight_decay=1e-6, policy_weight=1.0, value_weight=1.0)
+        learner = None
+    else:
+        blob = make_weights(args.seed + 20211003)  # P::new(&vs): fixed-seed init, identical on every rank
+        eng.load_weights(blob)
+        learner = DataParallelLearner(eng, blob, dist=dist, device=local_rank, weight_decay=1e-6, policy_weight=1.0,
+                                      value_weight=1.0)
     # replay buffer: positions as bitboards + targets + the game each step came from
     R = dict(my=np.zeros(0, np.uint64), op=np.zeros(0, np.uint64), pi=np.zeros((0, 9), np.float32),
              v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
@@ -137,7 +148,8 @@ def main():
             steps += n_steps
             epoch_losses.append((el * args.batch_size / n_unique).tolist())
         t_train = time.perf_counter() - t2
-        learner.publish()  # model_{i+1}: the next iteration's self-play runs on the trained network
+        if conv: eng.trainer_publish_weights()
+        else: learner.publish()  # model_{i+1}: the next iteration's self-play runs on the trained network
         evaluation = {}
         if args.eval_games > 0 and rank == 0:
             # evaluator.rs:52-77: the new model against every rollout baseline, as first and as second player
@@ -167,7 +179,7 @@ def main():
     if rank == 0 and args.out:
         json.dump(log, open(args.out, "w"), indent=1)
     if args.dump_weights:
-        np.save(f"{args.dump_weights}.rank{rank}.npy", learner.state()["weights"])
+        np.save(f"{args.dump_weights}.rank{rank}.npy", (eng.trainer_state() if conv else learner.state())["weights"])
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -256,6 +256,12 @@ typedef struct syn_train_config {
 /* Replaces: P::new(&vs) + Adam::default().build(&vs, lr) (alpha_zero.rs:31-36): parameters (same blob order as
  * syn_load_weights) and zeroed Adam moments on the device. */
 int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg);
+/* The same for Connect4ConvNet (syn_load_weights_conv's network and blob order, 12412 floats): the trainer then runs that
+ * network through syn_train_step / syn_train_gradients_device + syn_train_apply_device / syn_train_set_data + syn_train_epoch
+ * (minibatches of at most 32 positions, else SYN_ERR_UNSUPPORTED), syn_trainer_get_state copies 12412 floats per array, and
+ * syn_trainer_publish_weights makes the trained conv network the engine's policy. f32, the arithmetic order of
+ * oracle/train.hpp::ConvTrainer (checked against torch float64 goldens); an engine trains one network at a time. */
+int syn_trainer_init_conv(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg);
 /* Replaces: one iteration of the minibatch loop alpha_zero.rs:76-92 (forward, log_softmax, kl_div(Sum)/batch for both
  * heads, loss, backward_step). States are given as bitboards; losses[2] = {pi_loss, v_loss} (may be NULL). */
 int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,

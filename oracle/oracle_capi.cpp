@@ -627,6 +627,29 @@ void orc_train_steps(float* blob_io, const orc_train_hyper* hp, const float* X, 
     if (v_io) std::memcpy(v_io, t.v.data(), t.v.size() * sizeof(float));
     if (step_io) *step_io = t.step;
 }
+// The same two entry points for Connect4ConvNet (train.hpp ConvTrainer); positions as bitboards, blob / grads 12,412 floats.
+void orc_convtrain_gradients(const float* blob, const orc_train_hyper* hp, const uint64_t* my_bb, const uint64_t* op_bb,
+                             const float* tpi, const float* tv, int B, float* grad_out, float* losses) {
+    ConvTrainer t(blob, to_hyper(*hp));
+    t.gradients(my_bb, op_bb, tpi, tv, B, losses);
+    std::memcpy(grad_out, t.grad.data(), t.grad.size() * sizeof(float));
+}
+void orc_convtrain_steps(float* blob_io, const orc_train_hyper* hp, const uint64_t* my_bb, const uint64_t* op_bb, const float* tpi,
+                         const float* tv, int B, int n_steps, const float* lrs, float* m_io, float* v_io, long long* step_io,
+                         float* losses) {
+    ConvTrainer t(blob_io, to_hyper(*hp));
+    if (m_io) std::memcpy(t.m.data(), m_io, t.m.size() * sizeof(float));
+    if (v_io) std::memcpy(t.v.data(), v_io, t.v.size() * sizeof(float));
+    if (step_io) t.step = *step_io;
+    for (int s = 0; s < n_steps; s++) {
+        t.gradients(my_bb + (size_t)s * B, op_bb + (size_t)s * B, tpi + (size_t)s * B * 9, tv + (size_t)s * B * 3, B, losses + 2 * s);
+        t.adam(lrs[s]);
+    }
+    std::memcpy(blob_io, t.w.data(), t.w.size() * sizeof(float));
+    if (m_io) std::memcpy(m_io, t.m.data(), t.m.size() * sizeof(float));
+    if (v_io) std::memcpy(v_io, t.v.data(), t.v.size() * sizeof(float));
+    if (step_io) *step_io = t.step;
+}
 // Adam only (after an external gradient all-reduce)
 void orc_train_adam(float* blob_io, const orc_train_hyper* hp, const float* grad, float lr, float* m_io, float* v_io,
                     long long* step_io) {

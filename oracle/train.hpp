@@ -151,6 +151,149 @@ struct Trainer {
     }
 };
 
+// ---- the same step for Connect4ConvNet (oracle/nn.hpp: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12>; the network of north_star).
+// The reference has neither this network nor a learner for it (its learner is libtorch's autograd over whatever NNPolicy is
+// given): the published semantics restated above apply unchanged; every f32 chain below runs in one fixed order that the HIP
+// kernel (synthesis_amd/csrc/train_conv.cuh) reproduces bit for bit:
+//   forward   conv taps in slimnn's order ci -> k1 -> k2 (in-board taps only), head inputs in NCHW flattening order, fma per term
+//   dWh[o][i] over the samples ascending; dAct[b][i] over the outputs ascending; dWc[c][tap] over the samples ascending and, inside
+//   a sample, the cells ascending (row-major, in-board taps only), as four partial chains over the sample quarters [8q, 8q + 8)
+//   that are then added in order; bias gradients as plain sums in the same orders.
+// (The training forward uses the flattening order for the head — the inference tile's cell-major order exists for the matrix
+// cores only; the two agree to ~1e-6.) Checked against this container's torch in float64 (tests/golden/conv_train_torch_goldens.npz).
+struct ConvTrainer {
+    using Net = Connect4ConvNet;
+    std::vector<float> w, m, v, grad;
+    int64_t step = 0;
+    TrainHyper hp;
+
+    explicit ConvTrainer(const float* blob, TrainHyper h = TrainHyper())
+        : w(blob, blob + Net::NUM_PARAMS), m(Net::NUM_PARAMS, 0.0f), v(Net::NUM_PARAMS, 0.0f), grad(Net::NUM_PARAMS, 0.0f), hp(h) {}
+
+    // in-board source cell of tap (k1, k2) for output cell (r, c), or -1
+    static int tap_src(int r, int c, int k1, int k2) {
+        const int rr = r + k1 - 1, cc = c + k2 - 1;
+        return (rr >= 0 && rr < Net::H && cc >= 0 && cc < Net::W) ? rr * Net::W + cc : -1;
+    }
+
+    // my_bb / op_bb [B], tpi[B][9], tv[B][3]
+    void gradients(const uint64_t* my_bb, const uint64_t* op_bb, const float* tpi, const float* tv, int B, float losses[2]) {
+        const float* cw = w.data();
+        const float* cb = cw + Net::CONV_W;
+        const float* hw = cb + Net::C;
+        const float* hb = hw + (size_t)Net::OUT * Net::FLAT;
+        std::vector<float> X((size_t)B * 2 * Net::HW), A((size_t)B * Net::FLAT), out((size_t)B * 12), dz((size_t)B * 12, 0.0f);
+        for (int b = 0; b < B; b++) {
+            Connect4 g = Connect4::from_bitboards(my_bb[b], op_bb[b]);
+            Net::planes(g, &X[(size_t)b * 2 * Net::HW]);
+            const float* x = &X[(size_t)b * 2 * Net::HW];
+            for (int c = 0; c < Net::C; c++)
+                for (int r = 0; r < Net::H; r++)
+                    for (int col = 0; col < Net::W; col++) {
+                        float acc = cb[c];
+                        for (int ci = 0; ci < 2; ci++)
+                            for (int k1 = 0; k1 < 3; k1++)
+                                for (int k2 = 0; k2 < 3; k2++) {
+                                    const int src = tap_src(r, col, k1, k2);
+                                    if (src >= 0) acc = std::fmaf(cw[((c * 2 + ci) * 3 + k1) * 3 + k2], x[ci * Net::HW + src], acc);
+                                }
+                        A[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col] = acc > 0.0f ? acc : 0.0f;
+                    }
+            for (int o = 0; o < 12; o++) {
+                float acc = hb[o];
+                for (int i = 0; i < Net::FLAT; i++) acc = std::fmaf(A[(size_t)b * Net::FLAT + i], hw[(size_t)o * Net::FLAT + i], acc);
+                out[(size_t)b * 12 + o] = acc;
+            }
+        }
+        // heads (identical to Trainer::gradients)
+        const float bm = 1.0f / (float)B;
+        float pi_loss = 0.0f, v_loss = 0.0f;
+        for (int b = 0; b < B; b++)
+            for (int head = 0; head < 2; head++) {
+                const int off = head == 0 ? 0 : 9, n = head == 0 ? 9 : 3;
+                const float* x = &out[(size_t)b * 12 + off];
+                const float* t = head == 0 ? tpi + (size_t)b * 9 : tv + (size_t)b * 3;
+                const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
+                float mx = x[0];
+                for (int j = 1; j < n; j++) mx = x[j] > mx ? x[j] : mx;
+                float se = 0.0f;
+                for (int j = 0; j < n; j++) se += det_expf(x[j] - mx);
+                const float lse = mx + det_logf(se);
+                float kl = 0.0f, tsum = 0.0f;
+                for (int j = 0; j < n; j++) {
+                    float logp = x[j] - lse;
+                    if (t[j] > 0.0f) kl += t[j] * (det_logf(t[j]) - logp);
+                    tsum += t[j];
+                }
+                (head == 0 ? pi_loss : v_loss) += kl;
+                const float s = weight * bm;
+                for (int j = 0; j < n; j++) dz[(size_t)b * 12 + off + j] = s * (det_expf(x[j] - lse) * tsum - t[j]);
+            }
+        losses[0] = bm * pi_loss;
+        losses[1] = bm * v_loss;
+        // backward: heads
+        float* gcw = grad.data();
+        float* gcb = gcw + Net::CONV_W;
+        float* ghw = gcb + Net::C;
+        float* ghb = ghw + (size_t)Net::OUT * Net::FLAT;
+        for (int o = 0; o < 12; o++) {
+            float acc = 0.0f;
+            for (int b = 0; b < B; b++) acc += dz[(size_t)b * 12 + o];
+            ghb[o] = acc;
+            for (int i = 0; i < Net::FLAT; i++) {
+                float a = 0.0f;
+                for (int b = 0; b < B; b++) a = std::fmaf(dz[(size_t)b * 12 + o], A[(size_t)b * Net::FLAT + i], a);
+                ghw[(size_t)o * Net::FLAT + i] = a;
+            }
+        }
+        // activation gradients through the ReLU: dY[b][i]
+        std::vector<float> dY((size_t)B * Net::FLAT);
+        for (int b = 0; b < B; b++)
+            for (int i = 0; i < Net::FLAT; i++) {
+                float a = 0.0f;
+                for (int o = 0; o < 12; o++) a = std::fmaf(dz[(size_t)b * 12 + o], hw[(size_t)o * Net::FLAT + i], a);
+                dY[(size_t)b * Net::FLAT + i] = A[(size_t)b * Net::FLAT + i] > 0.0f ? a : 0.0f;
+            }
+        // conv parameters: four partial chains over the sample quarters [8 q, 8 q + 8) (samples ascending, cells row-major inside a
+        // sample), then ((p0 + p1) + p2) + p3 — the order in which the HIP kernel's four thread groups produce them
+        for (int c = 0; c < Net::C; c++) {
+            float sq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int b = 0; b < B; b++)
+                for (int p = 0; p < Net::HW; p++) sq[b >> 3] += dY[(size_t)b * Net::FLAT + c * Net::HW + p];
+            gcb[c] = ((sq[0] + sq[1]) + sq[2]) + sq[3];
+            for (int ci = 0; ci < 2; ci++)
+                for (int k1 = 0; k1 < 3; k1++)
+                    for (int k2 = 0; k2 < 3; k2++) {
+                        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        for (int b = 0; b < B; b++)
+                            for (int r = 0; r < Net::H; r++)
+                                for (int col = 0; col < Net::W; col++) {
+                                    const int src = tap_src(r, col, k1, k2);
+                                    if (src >= 0)
+                                        a[b >> 3] = std::fmaf(dY[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col],
+                                                              X[(size_t)b * 2 * Net::HW + ci * Net::HW + src], a[b >> 3]);
+                                }
+                        gcw[((c * 2 + ci) * 3 + k1) * 3 + k2] = ((a[0] + a[1]) + a[2]) + a[3];
+                    }
+        }
+    }
+
+    void adam(float lr) {  // as Trainer::adam
+        step += 1;
+        const double bc1 = 1.0 - std::pow((double)hp.beta1, (double)step);
+        const double bc2 = 1.0 - std::pow((double)hp.beta2, (double)step);
+        const float step_size = (float)((double)lr / bc1);
+        const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+        for (size_t i = 0; i < w.size(); i++) {
+            float g = hp.weight_decay != 0.0f ? std::fmaf(hp.weight_decay, w[i], grad[i]) : grad[i];
+            m[i] = std::fmaf(1.0f - hp.beta1, g, hp.beta1 * m[i]);
+            v[i] = std::fmaf((1.0f - hp.beta2) * g, g, hp.beta2 * v[i]);
+            float denom = std::sqrt(v[i]) * inv_sqrt_bc2 + hp.eps;
+            w[i] = w[i] - step_size * (m[i] / denom);
+        }
+    }
+};
+
 // data.rs:196-235: average the targets of identical states. Output order of the reference is HashMap iteration order
 // (unspecified); here: ascending (my_bb, op_bb). Sums run in buffer order, then one division by the count.
 struct DedupEntry {

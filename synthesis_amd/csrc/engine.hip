@@ -24,6 +24,7 @@
 #include "train_epoch.cuh"
 #include "convnet.cuh"
 #include "layer_kernels.cuh"
+#include "train_conv.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -102,6 +103,7 @@ struct syn_engine {
     long long train_step = 0;
     DevTrainHyper train_hp{};
     bool has_trainer = false;
+    int trainer_kind = 0;  // 0 = Connect4Net (train_mfma.cuh / train_epoch.cuh), 1 = Connect4ConvNet (train_conv.cuh)
 };
 
 static int fail(syn_engine* h, int code, const char* fmt, ...) {
@@ -1221,12 +1223,57 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
     h->train_hp = DevTrainHyper{cfg->weight_decay, cfg->policy_weight, cfg->value_weight, cfg->beta1, cfg->beta2, cfg->eps};
     h->train_step = 0;
     h->has_trainer = true;
+    h->trainer_kind = 0;
+    return SYN_OK;
+}
+
+int syn_trainer_init_conv(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!blob || !cfg) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob/cfg is NULL");
+    if (n_floats != (size_t)ConvGeom::NUM_PARAMS)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4ConvNet has %d parameters, got %zu", ConvGeom::NUM_PARAMS, n_floats);
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t cap_bytes = (size_t)TrainGeom::NUM_PARAMS * 4;  // the buffers are shared with the Connect4Net trainer (larger)
+    static_assert(ConvGeom::NUM_PARAMS <= TrainGeom::NUM_PARAMS, "trainer buffers are sized for Connect4Net");
+    if (!h->d_tw) {
+        HIP_TRY(h, hipMalloc(&h->d_tw, cap_bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tm, cap_bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tv, cap_bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tgrad, cap_bytes));
+        HIP_TRY(h, hipMalloc(&h->d_tloss, 64));
+        HIP_TRY(h, hipMalloc(&h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4));
+        HIP_TRY(h, hipMalloc(&h->d_ttimg, (size_t)TrainImg::T_FLOATS * 4));
+        HIP_TRY(h, hipMalloc(&h->d_timg2, (size_t)(MlpGeom::IMG_FLOATS + TrainImg::T_FLOATS) * 4));
+        HIP_TRY(h, hipMalloc(&h->d_tsync, 256));
+    }
+    const size_t bytes = (size_t)ConvGeom::NUM_PARAMS * 4;
+    HIP_TRY(h, hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tm, 0, cap_bytes, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tv, 0, cap_bytes, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tgrad, 0, cap_bytes, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->train_hp = DevTrainHyper{cfg->weight_decay, cfg->policy_weight, cfg->value_weight, cfg->beta1, cfg->beta2, cfg->eps};
+    h->train_step = 0;
+    h->has_trainer = true;
+    h->trainer_kind = 1;
     return SYN_OK;
 }
 
 static int launch_grads(syn_engine* h, const unsigned long long* d_my, const unsigned long long* d_op,
                         const float* d_tpi, const float* d_tv, int batch, float* d_grads, float* d_losses = nullptr,
                         const int* d_idx = nullptr) {
+    if (h->trainer_kind == 1) {
+        // Connect4ConvNet (train_conv.cuh): one workgroup, the minibatch's activations resident in LDS
+        if (batch > ConvTrainGeom::CHUNK)
+            return fail(h, SYN_ERR_UNSUPPORTED, "the Connect4ConvNet learner takes minibatches of at most %d positions (got %d)",
+                        ConvTrainGeom::CHUNK, batch);
+        const size_t clds = (size_t)ConvTrainGeom::LDS_FLOATS * 4;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_conv_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+        hipLaunchKernelGGL(train_conv_grad_kernel, dim3(1), dim3(1024), clds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
+                           h->train_hp, d_grads, d_losses ? d_losses : h->d_tloss, d_idx);
+        HIP_TRY(h, hipGetLastError());
+        return SYN_OK;
+    }
     // the matrix-core kernel (train_mfma.cuh); SYN_DEBUG=1 SYN_TRAIN_VALU=1 runs the VALU kernel it replaced (A/B, same bits)
     static const bool valu = debug_env("SYN_TRAIN_VALU") != nullptr;
     const size_t lds = valu ? (size_t)TrainGeom::LDS_FLOATS * 4 : (size_t)TrainGeom::WL_OFF * 4;
@@ -1266,6 +1313,13 @@ static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad
     const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, (double)h->train_step);
     const float step_size = (float)((double)lr / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+    if (h->trainer_kind == 1) {
+        const int nc = ConvGeom::NUM_PARAMS;
+        hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads, nc,
+                           h->train_hp, step_size, inv_sqrt_bc2, grad_scale);
+        HIP_TRY(h, hipGetLastError());
+        return SYN_OK;
+    }
     const int n = TrainGeom::NUM_PARAMS;
     hipLaunchKernelGGL(adam_image_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads,
                        n, h->train_hp, step_size, inv_sqrt_bc2, grad_scale, h->d_twimg, h->d_ttimg);
@@ -1390,7 +1444,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
     // One persistent launch for the whole epoch (train_epoch.cuh) when the batch fits one 32-sample chunk — the reference's
     // batch_size. SYN_DEBUG=1 SYN_TRAIN_QUEUED=1 keeps the two launches per step below (A/B, same bits), as do larger batches.
     static const bool queued = debug_env("SYN_TRAIN_QUEUED") != nullptr;
-    if (!queued && batch <= TrainGeom::CHUNK) {
+    if (!queued && batch <= TrainGeom::CHUNK && h->trainer_kind == 0) {
         // per-step Adam scalars, in double on the host like libtorch (launch_adam)
         std::vector<float> adam_sc(2 * n_steps);
         for (size_t s = 0; s < n_steps; s++) {
@@ -1474,7 +1528,7 @@ int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long l
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
+    const size_t bytes = (size_t)(h->trainer_kind == 1 ? ConvGeom::NUM_PARAMS : TrainGeom::NUM_PARAMS) * 4;
     if (blob) HIP_TRY(h, hipMemcpyAsync(blob, h->d_tw, bytes, hipMemcpyDeviceToHost, h->stream));
     if (m) HIP_TRY(h, hipMemcpyAsync(m, h->d_tm, bytes, hipMemcpyDeviceToHost, h->stream));
     if (v) HIP_TRY(h, hipMemcpyAsync(v, h->d_tv, bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1488,8 +1542,19 @@ int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long l
 int syn_trainer_publish_weights(syn_engine* h) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
-    // the trainer keeps its weights in the inference fragment order as well (train_mfma.cuh): publishing is one device copy
     HIP_TRY(h, hipSetDevice(h->device));
+    if (h->trainer_kind == 1) {
+        // Connect4ConvNet: the fragment image of convnet.cuh is rebuilt from the canonical parameters on the device
+        if (h->cap > LANE_MAX_CAP) return fail(h, SYN_ERR_UNSUPPORTED, "Connect4ConvNet runs in the lane-per-tree kernels only");
+        hipLaunchKernelGGL(conv_image_kernel, dim3((ConvGeom::IMG_FLOATS + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_wimg);
+        HIP_TRY(h, hipGetLastError());
+        if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->has_weights = true;
+        h->net_kind = 1;
+        return SYN_OK;
+    }
+    // the trainer keeps its weights in the inference fragment order as well (train_mfma.cuh): publishing is one device copy
     HIP_TRY(h, hipMemcpyAsync(h->d_wimg, h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
     if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));  // new network: empty PolicyWithCache
     HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "syn_load_weights_conv",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
-    "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_train_step", "syn_train_gradients_device",
+    "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
 
@@ -123,6 +123,7 @@ def load_library():
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
     lib.syn_debug_calibrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.syn_trainer_init.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(CTrainConfig)]
+    lib.syn_trainer_init_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(CTrainConfig)]
     lib.syn_train_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float,
                                    C.c_void_p]
     lib.syn_train_gradients_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -366,6 +367,15 @@ class Engine:
         blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
         cfg = CTrainConfig(weight_decay, policy_weight, value_weight, beta1, beta2, eps)
         self._check(self._lib.syn_trainer_init(self._h, _p(blob), blob.size, C.byref(cfg)))
+        self._trainer_params = NUM_PARAMS
+
+    def trainer_init_conv(self, blob, weight_decay=1e-6, policy_weight=1.0, value_weight=1.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        """The learner for Connect4ConvNet (load_weights_conv's network and blob order): train_step / train_epoch /
+        trainer_state / trainer_publish_weights then work on that network (minibatches of at most 32 positions)."""
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        cfg = CTrainConfig(weight_decay, policy_weight, value_weight, beta1, beta2, eps)
+        self._check(self._lib.syn_trainer_init_conv(self._h, _p(blob), blob.size, C.byref(cfg)))
+        self._trainer_params = CONV_NUM_PARAMS
 
     def train_step(self, my_bb, op_bb, target_pi, target_v, lr):
         my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
@@ -388,7 +398,8 @@ class Engine:
         self._check(self._lib.syn_train_apply_device(self._h, C.c_void_p(d_grads), float(lr), float(grad_scale)))
 
     def trainer_state(self):
-        blob = np.zeros(NUM_PARAMS, np.float32); m = np.zeros_like(blob); v = np.zeros_like(blob); g = np.zeros_like(blob)
+        blob = np.zeros(getattr(self, "_trainer_params", NUM_PARAMS), np.float32)
+        m = np.zeros_like(blob); v = np.zeros_like(blob); g = np.zeros_like(blob)
         step = C.c_longlong()
         self._check(self._lib.syn_trainer_get_state(self._h, _p(blob), _p(m), _p(v), C.byref(step), _p(g)))
         return dict(weights=blob, m=m, v=v, step=int(step.value), grads=g)

@@ -333,6 +333,30 @@ class Oracle:
                                  C.byref(st), _p(losses))
         return blob, m, v, st.value, losses
 
+    # ---- the learner step for Connect4ConvNet (oracle/train.hpp ConvTrainer)
+    def convtrain_gradients(self, blob, hp, my_bb, op_bb, tpi, tv):
+        blob = np.ascontiguousarray(blob, np.float32)
+        my = np.ascontiguousarray(my_bb, np.uint64).ravel(); op = np.ascontiguousarray(op_bb, np.uint64).ravel()
+        tpi = np.ascontiguousarray(tpi, np.float32); tv = np.ascontiguousarray(tv, np.float32)
+        g = np.zeros(blob.size, np.float32); losses = np.zeros(2, np.float32)
+        self.lib.orc_convtrain_gradients(_p(blob), C.byref(hp), _p(my), _p(op), _p(tpi), _p(tv), int(my.size), _p(g), _p(losses))
+        return g, losses
+
+    def convtrain_steps(self, blob, hp, my_bb, op_bb, tpi, tv, lrs, m=None, v=None, step=0):
+        """my_bb / op_bb [n_steps][B], tpi [n_steps][B][9], tv [n_steps][B][3]; returns (blob', m', v', step', losses[n_steps][2])."""
+        blob = np.array(blob, np.float32).copy()
+        my = np.ascontiguousarray(my_bb, np.uint64); op = np.ascontiguousarray(op_bb, np.uint64)
+        tpi = np.ascontiguousarray(tpi, np.float32); tv = np.ascontiguousarray(tv, np.float32)
+        n_steps, B = my.shape[0], my.shape[1]
+        lrs = np.ascontiguousarray(np.broadcast_to(np.asarray(lrs, np.float32), (n_steps,)))
+        m = np.zeros_like(blob) if m is None else np.array(m, np.float32).copy()
+        v = np.zeros_like(blob) if v is None else np.array(v, np.float32).copy()
+        st = C.c_longlong(step)
+        losses = np.zeros((n_steps, 2), np.float32)
+        self.lib.orc_convtrain_steps(_p(blob), C.byref(hp), _p(my), _p(op), _p(tpi), _p(tv), B, n_steps, _p(lrs), _p(m), _p(v),
+                                     C.byref(st), _p(losses))
+        return blob, m, v, st.value, losses
+
     def train_adam(self, blob, hp, grad, lr, m, v, step):
         blob = np.array(blob, np.float32).copy(); m = np.array(m, np.float32).copy(); v = np.array(v, np.float32).copy()
         grad = np.ascontiguousarray(grad, np.float32)

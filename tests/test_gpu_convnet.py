@@ -134,3 +134,54 @@ def test_conv_and_mlp_networks_switch(engine, oracle, cblob, golden_dir):
     lg, v = engine.policy_eval(my, op)
     ref_l, ref_v = oracle.c4conv_eval(cblob, my, op, mode=oracle.ACC_FMA)
     assert np.array_equal(lg, ref_l) and np.array_equal(v, ref_v)
+
+
+def test_conv_learner_matches_oracle_and_feeds_selfplay(oracle, cblob, golden_dir):
+    """The learner step of Connect4ConvNet (train_conv.cuh + adam_kernel): gradients, losses, weights and Adam moments after
+    several steps bit-identical to oracle/train.hpp::ConvTrainer (itself checked against torch float64 goldens) — through
+    syn_train_step with full and ragged batches, through syn_train_set_data + syn_train_epoch, and through the data-parallel
+    pair gradients_device / apply_device; the trained network, published on the device, then plays the oracle's games."""
+    import os
+    import synthesis_amd as sa
+    from tests.oracle_lib import default_train_hyper, parity_rollout_config
+
+    g = np.load(os.path.join(golden_dir, "conv_train_torch_goldens.npz"))
+    my, op, tpi, tv, lrs = g["my_bb"], g["op_bb"], g["target_pi"], g["target_v"], g["lrs"]
+    eng = sa.Engine(concurrent_games=256, max_explores=64)
+    eng.load_weights_conv(cblob)
+    hp = default_train_hyper(weight_decay=1e-3, policy_weight=0.7, value_weight=1.9)
+    for B in (32, 31, 5, 1):
+        eng.trainer_init_conv(cblob, weight_decay=1e-3, policy_weight=0.7, value_weight=1.9)
+        l = eng.train_step(my[0][:B], op[0][:B], tpi[0][:B], tv[0][:B], 2e-3)
+        st = eng.trainer_state()
+        go, lo = oracle.convtrain_gradients(cblob, hp, my[0][:B], op[0][:B], tpi[0][:B], tv[0][:B])
+        assert st["weights"].size == 12412
+        assert np.array_equal(st["grads"].view(np.uint32), go.view(np.uint32)), B
+        assert np.array_equal(l, lo), B
+        wo, mo, vo, _, _ = oracle.convtrain_steps(cblob, hp, my[0][None, :B], op[0][None, :B], tpi[0][None, :B], tv[0][None, :B], [2e-3])
+        assert np.array_equal(st["weights"], wo) and np.array_equal(st["m"], mo) and np.array_equal(st["v"], vo), B
+    with pytest.raises(sa.SynthesisAmdError):
+        eng.train_step(np.zeros(33, np.uint64), np.zeros(33, np.uint64), np.zeros((33, 9), np.float32), np.zeros((33, 3), np.float32), 1e-3)
+    # the 8 golden steps one by one, then as one device-resident epoch
+    eng.trainer_init_conv(cblob)
+    ls = np.stack([eng.train_step(my[s], op[s], tpi[s], tv[s], float(lrs[s])) for s in range(8)])
+    st = eng.trainer_state()
+    wo, mo, vo, so, lo = oracle.convtrain_steps(cblob, default_train_hyper(), my, op, tpi, tv, lrs)
+    assert st["step"] == 8 and np.array_equal(ls, lo)
+    assert np.array_equal(st["weights"], wo) and np.array_equal(st["m"], mo) and np.array_equal(st["v"], vo)
+    assert np.abs(st["weights"] - g["final_weights_f64"]).max() <= 1e-5   # and the torch float64 run
+    eng.trainer_init_conv(cblob)
+    eng.train_set_data(my.reshape(-1), op.reshape(-1), tpi.reshape(-1, 9), tv.reshape(-1, 3))
+    le = eng.train_epoch(np.arange(128, dtype=np.int32), 32, 1e-3)
+    wo4, _, _, _, lo4 = oracle.convtrain_steps(cblob, default_train_hyper(), my[:4], op[:4], tpi[:4], tv[:4], [1e-3] * 4)
+    assert np.array_equal(le, lo4) and np.array_equal(eng.trainer_state()["weights"], wo4)
+    # publish: the trained conv network becomes the self-play policy without a host round trip
+    eng.trainer_publish_weights()
+    got = eng.selfplay(sa.parity_rollout_config(48), base_seed=6, n_games=40)
+    ref = oracle.c4_selfplay(parity_rollout_config(48), wo4, 6, 40, threads=8, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_selfplay_equal(got, ref, "self-play with the published trained conv network")
+    # switching the trainer back to Connect4Net keeps working
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    eng.trainer_init(blob)
+    assert eng.trainer_state()["weights"].size == 30492
+    eng.close()

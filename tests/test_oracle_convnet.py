@@ -50,3 +50,20 @@ def test_convnet_is_the_composition_of_the_pinned_layers(oracle):
         assert np.abs(out64 - raw[i]).max() <= 1e-5, i
         e = np.exp(out64[9:] - out64[9:].max())
         assert np.abs(e / e.sum() - v[i]).max() <= 1e-5 and np.array_equal(lg[i], raw[i][:9])
+
+
+def test_conv_trainer_matches_torch_float64_goldens(oracle, golden_dir):
+    """oracle/train.hpp::ConvTrainer (forward, log_softmax + kl_div, backward, Adam — all in fixed f32 orders) against this
+    container's torch in float64 (tests/golden/make_conv_train_golden.py): first gradient, per-step losses, weights after 8 steps."""
+    import os
+    from tests.oracle_lib import default_train_hyper
+
+    g = np.load(os.path.join(golden_dir, "conv_train_torch_goldens.npz"))
+    blob = conv_blob()
+    hp = default_train_hyper()
+    grad, losses = oracle.convtrain_gradients(blob, hp, g["my_bb"][0], g["op_bb"][0], g["target_pi"][0], g["target_v"][0])
+    assert np.abs(grad - g["first_grad_f64"]).max() <= 1e-6 and np.abs(losses - g["losses_f64"][0]).max() <= 1e-6
+    w, m, v, step, ls = oracle.convtrain_steps(blob, hp, g["my_bb"], g["op_bb"], g["target_pi"], g["target_v"], g["lrs"])
+    assert step == 8 and np.abs(ls - g["losses_f64"]).max() <= 1e-6
+    assert np.abs(w - g["final_weights_f64"]).max() <= 1e-5
+    assert np.abs(w - blob).max() > 1e-3  # the weights did move

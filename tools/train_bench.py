@@ -40,3 +40,12 @@ eng.train_epoch(perm[: 256 * 32], 32, 1e-3)
 t = time.perf_counter(); eng.train_epoch(perm[: steps * 32], 32, 1e-3); dt = time.perf_counter() - t
 print(f"train_epoch B=32: {steps} steps in {dt*1e3:.1f} ms = {dt/steps*1e6:.2f} us/step = {steps/dt:.0f} steps/s "
       f"({'VALU kernel' if os.environ.get('SYN_TRAIN_VALU') else 'matrix-core kernel'})")
+
+# the learner of the conv policy/value network (Connect4ConvNet, train_conv.cuh): queued gradient + Adam launches per step
+from bench import make_conv_weights  # noqa: E402
+eng.trainer_init_conv(make_conv_weights())
+eng.train_set_data(d["my_bb"], d["op_bb"], d["pis"], d["vs"])
+eng.train_epoch(perm[: 64 * 32], 32, 1e-3)
+csteps = min(steps, 2000)
+t = time.perf_counter(); eng.train_epoch(perm[: csteps * 32], 32, 1e-3); dt = time.perf_counter() - t
+print(f"train_epoch Connect4ConvNet B=32: {csteps} steps in {dt*1e3:.1f} ms = {dt/csteps*1e6:.2f} us/step = {csteps/dt:.0f} steps/s (VALU kernel)")
