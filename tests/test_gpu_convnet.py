@@ -139,8 +139,8 @@ def test_conv_and_mlp_networks_switch(engine, oracle, cblob, golden_dir):
 def test_conv_learner_matches_oracle_and_feeds_selfplay(oracle, cblob, golden_dir):
     """The learner step of Connect4ConvNet (train_conv.cuh + adam_kernel): gradients, losses, weights and Adam moments after
     several steps bit-identical to oracle/train.hpp::ConvTrainer (itself checked against torch float64 goldens) — through
-    syn_train_step with full and ragged batches, through syn_train_set_data + syn_train_epoch, and through the data-parallel
-    pair gradients_device / apply_device; the trained network, published on the device, then plays the oracle's games."""
+    syn_train_step with full and ragged batches and through syn_train_set_data + syn_train_epoch; the trained network,
+    published on the device, then plays the oracle's games."""
     import os
     import synthesis_amd as sa
     from tests.oracle_lib import default_train_hyper, parity_rollout_config
