@@ -134,6 +134,14 @@ def test_conv_and_mlp_networks_switch(engine, oracle, cblob, golden_dir):
     lg, v = engine.policy_eval(my, op)
     ref_l, ref_v = oracle.c4conv_eval(cblob, my, op, mode=oracle.ACC_FMA)
     assert np.array_equal(lg, ref_l) and np.array_equal(v, ref_v)
+    # the conv network lives in the lane-per-tree kernels: node pools past their 16-bit block addressing are refused, not mis-run
+    big = sa.Engine(concurrent_games=64, max_explores=8000)
+    with pytest.raises(sa.SynthesisAmdError) as ei:
+        big.load_weights_conv(cblob)
+    assert ei.value.code == -5   # SYN_ERR_UNSUPPORTED
+    with pytest.raises(sa.SynthesisAmdError):
+        big.trainer_init_conv(blob)  # wrong parameter count
+    big.close()
 
 
 def test_conv_learner_matches_oracle_and_feeds_selfplay(oracle, cblob, golden_dir):
