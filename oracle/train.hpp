@@ -157,7 +157,7 @@ struct Trainer {
 // kernel (synthesis_amd/csrc/train_conv.cuh) reproduces bit for bit:
 //   forward   conv taps in slimnn's order ci -> k1 -> k2 (in-board taps only), head inputs in NCHW flattening order, fma per term
 //   dWh[o][i] over the samples ascending; dAct[b][i] over the outputs ascending; dWc[c][tap] over the samples ascending and, inside
-//   a sample, the cells ascending (row-major, in-board taps only), as four partial chains over the sample quarters [8q, 8q + 8)
+//   a sample, the cells ascending (row-major, in-board taps only), as eight partial chains over the sample groups [4g, 4g + 4)
 //   that are then added in order; bias gradients as plain sums in the same orders.
 // (The training forward uses the flattening order for the head — the inference tile's cell-major order exists for the matrix
 // cores only; the two agree to ~1e-6.) Checked against this container's torch in float64 (tests/golden/conv_train_torch_goldens.npz).
@@ -254,26 +254,30 @@ struct ConvTrainer {
                 for (int o = 0; o < 12; o++) a = std::fmaf(dz[(size_t)b * 12 + o], hw[(size_t)o * Net::FLAT + i], a);
                 dY[(size_t)b * Net::FLAT + i] = A[(size_t)b * Net::FLAT + i] > 0.0f ? a : 0.0f;
             }
-        // conv parameters: four partial chains over the sample quarters [8 q, 8 q + 8) (samples ascending, cells row-major inside a
-        // sample), then ((p0 + p1) + p2) + p3 — the order in which the HIP kernel's four thread groups produce them
+        // conv parameters: eight partial chains over the sample groups [4 g, 4 g + 4) (samples ascending, cells row-major inside a
+        // sample), then added in order — the order in which the HIP kernel's thread groups produce them
         for (int c = 0; c < Net::C; c++) {
-            float sq[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float sq[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
             for (int b = 0; b < B; b++)
-                for (int p = 0; p < Net::HW; p++) sq[b >> 3] += dY[(size_t)b * Net::FLAT + c * Net::HW + p];
-            gcb[c] = ((sq[0] + sq[1]) + sq[2]) + sq[3];
+                for (int p = 0; p < Net::HW; p++) sq[b >> 2] += dY[(size_t)b * Net::FLAT + c * Net::HW + p];
+            float sb = sq[0];
+            for (int g = 1; g < 8; g++) sb += sq[g];
+            gcb[c] = sb;
             for (int ci = 0; ci < 2; ci++)
                 for (int k1 = 0; k1 < 3; k1++)
                     for (int k2 = 0; k2 < 3; k2++) {
-                        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                        float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                         for (int b = 0; b < B; b++)
                             for (int r = 0; r < Net::H; r++)
                                 for (int col = 0; col < Net::W; col++) {
                                     const int src = tap_src(r, col, k1, k2);
                                     if (src >= 0)
-                                        a[b >> 3] = std::fmaf(dY[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col],
-                                                              X[(size_t)b * 2 * Net::HW + ci * Net::HW + src], a[b >> 3]);
+                                        a[b >> 2] = std::fmaf(dY[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col],
+                                                              X[(size_t)b * 2 * Net::HW + ci * Net::HW + src], a[b >> 2]);
                                 }
-                        gcw[((c * 2 + ci) * 3 + k1) * 3 + k2] = ((a[0] + a[1]) + a[2]) + a[3];
+                        float sa = a[0];
+                        for (int g = 1; g < 8; g++) sa += a[g];
+                        gcw[((c * 2 + ci) * 3 + k1) * 3 + k2] = sa;
                     }
         }
     }

@@ -8,8 +8,8 @@
 //   head forward   per (sample, output): bias, then the 1008 activations in NCHW flattening order, fma per term
 //   dWh[o][i]      fma chain over the samples ascending;  dbh[o] plain sum over the samples
 //   dY[b][i]       relu'(act) * (fma chain over the 12 outputs ascending)       (overwrites the activations in LDS)
-//   dWc[c][tap]    four partial fma chains over the sample quarters [8 q, 8 q + 8) (samples ascending, cells row-major inside a
-//                  sample), added as ((p0 + p1) + p2) + p3; dbc[c] plain sums in the same order
+//   dWc[c][tap]    eight partial fma chains over the sample groups [4 g, 4 g + 4) (samples ascending, cells row-major inside a
+//                  sample), added in order ((p0 + p1) + p2) + ...; dbc[c] plain sums in the same order
 // Everything runs on the VALU with the 32 x 1008 activations resident in LDS (129 KB): a (sample, cell)'s 18 tap inputs are
 // extracted once for all 16 channels in the forward pass, the tap inputs of dWc are bits of convnet.cuh's pre-shifted boards, a
 // thread owns one head input column for all 12 outputs in dWh. The matrix-core forms (the inference tile for the forward, a
@@ -22,16 +22,18 @@ namespace syn {
 
 struct ConvTrainGeom {
     static constexpr int CHUNK = 32, FLAT = ConvGeom::FLAT, HW = ConvGeom::HW, C = ConvGeom::C;
+    static constexpr int ASTR = FLAT + 1;   // LDS row stride of a sample's activations: odd, so that lanes = samples hit 32 banks
+    static constexpr int NPART = 8;         // dWc / dbc: partial chains over the sample groups [4 g, 4 g + 4), added in order
     // LDS (floats): activations / dY, the 12 raw outputs, their gradients, per-sample KL terms, conv parameters, boards
     static constexpr int ACT_OFF = 0;
-    static constexpr int OUT_OFF = ACT_OFF + CHUNK * FLAT;
+    static constexpr int OUT_OFF = ACT_OFF + CHUNK * ASTR;
     static constexpr int DZ_OFF = OUT_OFF + CHUNK * 12;
     static constexpr int KL_OFF = DZ_OFF + CHUNK * 12;
     static constexpr int CW_OFF = KL_OFF + CHUNK * 2;
     static constexpr int CB_OFF = CW_OFF + ConvGeom::CONV_W;
     static constexpr int BB_OFF = (CB_OFF + C + 1) & ~1;          // [CHUNK][2] u64
-    static constexpr int PART_OFF = BB_OFF + CHUNK * 4;           // [4 sample quarters][288 + 16] partial conv gradients
-    static constexpr int LDS_FLOATS = PART_OFF + 4 * (ConvGeom::CONV_W + C);
+    static constexpr int PART_OFF = BB_OFF + CHUNK * 4;           // [NPART sample groups][288 + 16] partial conv gradients
+    static constexpr int LDS_FLOATS = PART_OFF + NPART * (ConvGeom::CONV_W + C);
     // canonical parameter offsets
     static constexpr int P_CW = 0, P_CB = ConvGeom::CONV_W, P_HW = P_CB + C, P_HB = P_HW + 12 * FLAT;
 };
@@ -59,15 +61,12 @@ __global__ __launch_bounds__(1024) void train_conv_grad_kernel(const float* __re
     float* act = lds + G::ACT_OFF;
     float* out = lds + G::OUT_OFF;
     float* dz = lds + G::DZ_OFF;
-    float* cw = lds + G::CW_OFF;
-    float* cb = lds + G::CB_OFF;
     uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
     const float* hw = w + G::P_HW;
     const float* hb = w + G::P_HB;
     const float bm = 1.0f / (float)B;
 
-    // ---- stage the conv parameters and the boards; the targets of the (sample, head) threads
-    for (int i = tid; i < ConvGeom::CONV_W + G::C; i += 1024) cw[i] = w[i];  // cw, cb are contiguous in the blob and in LDS
+    // ---- stage the boards; the targets of the (sample, head) threads
     if (tid < 2 * B) {
         const int b = tid >> 1;
         const size_t si = idx ? (size_t)idx[b] : (size_t)b;
@@ -107,26 +106,30 @@ __global__ __launch_bounds__(1024) void train_conv_grad_kernel(const float* __re
                     xf[(ci * 3 + k1) * 3 + k2] = in ? (float)((uint32_t)(plane >> (rr + 7 * cc)) & 1u) : 0.0f;
                 }
         }
-        float* ab = act + b * G::FLAT + p;
+        float* ab = act + b * G::ASTR + p;
 #pragma unroll 4
         for (int c = 0; c < G::C; c++) {
-            float acc = cb[c];
+            // the weights are wave-uniform: read through the scalar cache, they reach the fma as scalar operands
+            float acc = w[G::P_CB + c];
 #pragma unroll
-            for (int t = 0; t < 18; t++) acc = __builtin_fmaf(cw[c * 18 + t], xf[t], acc);
+            for (int t = 0; t < 18; t++) acc = __builtin_fmaf(w[G::P_CW + c * 18 + t], xf[t], acc);
             ab[c * G::HW] = acc > 0.0f ? acc : 0.0f;
         }
     }
     __syncthreads();
 
-    // ---- head forward: one (sample, output) chain of 1008 terms per thread
-    if (tid < B * 12) {
-        const int b = tid / 12, o = tid - 12 * b;
-        const float* a = act + b * G::FLAT;
-        const float* wr = hw + (size_t)o * G::FLAT;
-        float acc = hb[o];
-#pragma unroll 8
-        for (int i = 0; i < G::FLAT; i++) acc = __builtin_fmaf(a[i], wr[i], acc);
-        out[tid] = acc;
+    // ---- head forward: wave o (12 of the 16) runs output o for all samples, lane = sample: the weight row is wave-uniform (scalar
+    //      loads, scalar fma operand), the activations come from LDS rows whose odd stride spreads the lanes over the banks
+    {
+        const int o = tid >> 6, b = tid & 63;
+        if (o < 12 && b < B) {
+            const float* a = act + b * G::ASTR;
+            const float* wr = hw + (size_t)o * G::FLAT;
+            float acc = hb[o];
+#pragma unroll 16
+            for (int i = 0; i < G::FLAT; i++) acc = __builtin_fmaf(a[i], wr[i], acc);
+            out[b * 12 + o] = acc;
+        }
     }
     __syncthreads();
 
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(1024) void train_conv_grad_kernel(const float* __re
 #pragma unroll
         for (int o = 0; o < 12; o++) acc[o] = 0.0f;
         for (int b = 0; b < B; b++) {
-            const float a = act[b * G::FLAT + tid];
+            const float a = act[b * G::ASTR + tid];
 #pragma unroll
             for (int o = 0; o < 12; o++) acc[o] = __builtin_fmaf(dz[b * 12 + o], a, acc[o]);
         }
@@ -197,50 +200,58 @@ __global__ __launch_bounds__(1024) void train_conv_grad_kernel(const float* __re
     }
     __syncthreads();
 
-    // ---- activation gradients through the ReLU, in place: dY[b][i]
-    for (int it = tid; it < B * G::FLAT; it += 1024) {
-        const int b = it / G::FLAT, i = it - b * G::FLAT;
-        float a = 0.0f;
+    // ---- activation gradients through the ReLU, in place: dY[b][i]; a thread owns column i: its 12 head weights are loaded once
+    if (tid < G::FLAT) {
+        float wcol[12];
 #pragma unroll
-        for (int o = 0; o < 12; o++) a = __builtin_fmaf(dz[b * 12 + o], hw[(size_t)o * G::FLAT + i], a);
-        act[it] = act[it] > 0.0f ? a : 0.0f;
+        for (int o = 0; o < 12; o++) wcol[o] = hw[(size_t)o * G::FLAT + tid];
+        for (int b = 0; b < B; b++) {
+            float a = 0.0f;
+#pragma unroll
+            for (int o = 0; o < 12; o++) a = __builtin_fmaf(dz[b * 12 + o], wcol[o], a);
+            float* p = act + b * G::ASTR + tid;
+            *p = *p > 0.0f ? a : 0.0f;
+        }
     }
     __syncthreads();
 
-    // ---- conv parameter gradients: thread (quarter q, channel, tap) runs the partial chain over the samples [8 q, 8 q + 8) and
-    //      their cells row-major (the tap's input for a cell is one bit of the pre-shifted board of convnet.cuh: conv_tap_board);
-    //      the four partials meet in LDS and are added in order. 64 more threads do the same for the conv bias.
+    // ---- conv parameter gradients: a partial chain per (sample group g of 4, channel, tap) over the group's samples and their cells
+    //      row-major (the tap's input for a cell is one bit of the pre-shifted board of convnet.cuh, conv_tap_board: a set bit adds
+    //      dY — fma(dY, 1, a) —, a clear one adds +0); the eight partials meet in LDS and are added in order. The conv bias likewise.
     float* part = lds + G::PART_OFF;
-    for (int it = tid; it < 4 * (ConvGeom::CONV_W + G::C); it += 1024) {  // 1,216 partial chains for 1,024 threads
-        const int q = it / (ConvGeom::CONV_W + G::C), j = it - q * (ConvGeom::CONV_W + G::C);
+    constexpr int NCH = ConvGeom::CONV_W + G::C;
+    for (int it = tid; it < G::NPART * NCH; it += 1024) {
+        const int gq = it / NCH, j = it - gq * NCH;
         float a = 0.0f;
-        const int b1 = 8 * q + 8 < B ? 8 * q + 8 : B;
+        const int b1 = 4 * gq + 4 < B ? 4 * gq + 4 : B;
         if (j < ConvGeom::CONV_W) {
             const int c = j / 18, t = j - 18 * c;
-            for (int b = 8 * q; b < b1; b++) {
+            for (int b = 4 * gq; b < b1; b++) {
                 const uint64_t S = conv_tap_board(bb[2 * b], bb[2 * b + 1], t);
-                const float* dY = act + b * G::FLAT + c * G::HW;
+                const float* dY = act + b * G::ASTR + c * G::HW;
                 for (int r = 0; r < 7; r++) {
                     const uint64_t Sr = S >> r;
                     const uint32_t lo = (uint32_t)Sr, hi = (uint32_t)(Sr >> 32);
 #pragma unroll
                     for (int col = 0; col < 9; col++) {
-                        const uint32_t bit = 7 * col < 32 ? __builtin_amdgcn_ubfe(lo, 7 * col, 1) : __builtin_amdgcn_ubfe(hi, 7 * col - 32, 1);
-                        a = __builtin_fmaf(dY[r * 9 + col], (float)bit, a);  // (a cell whose tap is outside the board or empty adds 0)
+                        // sign-extended 1-bit field: 0 or ~0 — the mask of the term
+                        const int m = 7 * col < 32 ? __builtin_amdgcn_sbfe((int)lo, 7 * col, 1) : __builtin_amdgcn_sbfe((int)hi, 7 * col - 32, 1);
+                        a += bits_f32(f32_bits(dY[r * 9 + col]) & (uint32_t)m);
                     }
                 }
             }
         } else {
             const int c = j - ConvGeom::CONV_W;
-            for (int b = 8 * q; b < b1; b++)
-                for (int p = 0; p < G::HW; p++) a += act[b * G::FLAT + c * G::HW + p];
+            for (int b = 4 * gq; b < b1; b++)
+                for (int p = 0; p < G::HW; p++) a += act[b * G::ASTR + c * G::HW + p];
         }
         part[it] = a;
     }
     __syncthreads();
-    if (tid < ConvGeom::CONV_W + G::C) {
-        const int n = ConvGeom::CONV_W + G::C;
-        const float v = ((part[tid] + part[n + tid]) + part[2 * n + tid]) + part[3 * n + tid];
+    if (tid < NCH) {
+        float v = part[tid];
+#pragma unroll
+        for (int gq = 1; gq < G::NPART; gq++) v += part[gq * NCH + tid];
         grads[tid < ConvGeom::CONV_W ? G::P_CW + tid : G::P_CB + (tid - ConvGeom::CONV_W)] = v;
     }
 }
