@@ -415,6 +415,33 @@ def main():
                 "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "launch_shape": conv_shape}
             eng.load_weights(blob)
+        if world == 1 and not args.no_extras:
+            # (5) the step after the path: optimiser steps per second of the learner at the reference's batch of 32, on
+            # de-duplicated positions of a small self-play run — Connect4Net through the persistent epoch kernel, Connect4ConvNet
+            # through its queued gradient + Adam launches
+            try:
+                e3 = sa.Engine(concurrent_games=4096, max_explores=64, device=local_rank)
+                e3.load_weights(blob)
+                r3 = e3.selfplay(sa.parity_rollout_config(64), base_seed=1, n_games=8192)
+                sel = np.arange(63)[None, :] < r3["plies"][:, None]
+                d3 = e3.replay_deduplicate(r3["states_bb"][..., 0][sel], r3["states_bb"][..., 1][sel], r3["pis"][sel], r3["vs"][sel])
+                nu = int(d3["num"].size)
+                perm = np.random.default_rng(1).permutation(nu).astype(np.int32)
+                st3 = min(nu // 32, 3000)
+                learner = {"batch": 32, "unique_positions": nu}
+                for name, init, w0, n_steps in (("connect4net", e3.trainer_init, blob, st3),
+                                                ("connect4convnet", e3.trainer_init_conv, make_conv_weights(), min(st3, 1000))):
+                    init(w0)
+                    e3.train_set_data(d3["my_bb"], d3["op_bb"], d3["pis"], d3["vs"])
+                    e3.train_epoch(perm[: 64 * 32], 32, 1e-3)
+                    t1 = time.perf_counter()
+                    e3.train_epoch(perm[: n_steps * 32], 32, 1e-3)
+                    dt6 = time.perf_counter() - t1
+                    learner[name] = {"steps": n_steps, "steps_per_s": n_steps / dt6, "us_per_step": dt6 / n_steps * 1e6}
+                out["learner"] = learner
+                e3.close()
+            except Exception as ex:  # the learner is not the benchmarked path: never lose the bench line over it
+                out["learner"] = {"error": repr(ex)}
         if world == 1 and not args.no_4096:
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
