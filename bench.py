@@ -180,6 +180,7 @@ def spawn_ranks(n, argv):
 
 
 def main():
+    t_run0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -194,6 +195,8 @@ def main():
     ap.add_argument("--only-policy-cache", action="store_true",
                     help="run nothing but the PolicyWithCache leg (the command tools/collect_profiles.sh profiles for its roofline)")
     ap.add_argument("--no-extras", action="store_true", help="skip the tail / replay-output / trained-weights legs")
+    ap.add_argument("--time-budget-s", type=float, default=870.0, help="wall-clock budget of the whole run: the extra legs (never the timed "
+                    "steps, the roofline or the CPU baseline) are skipped, least important first, once they would overrun it")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
                                                            "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
     ap.add_argument("--cpu-sample-games", type=int, default=0, help="0 = 64 games per worker thread")
@@ -346,77 +349,38 @@ def main():
             "plies_per_game": plies / total_games,
             "roofline": near, "roofline_other": other,
         }
-        if world == 1 and not args.no_extras:
-            # (1) the launch tail: a launch ends when its LAST game ends, so its final stretch runs on emptying tree slots; a
-            # step of twice the games has the same tail on twice the work. tail_share = the fraction of a default step that
-            # the tail costs against a tail-free (infinitely long) launch.
+        # ---- extra legs, most important first; each is skipped once it would overrun --time-budget-s (the driver's K = 20 / W = 5 run
+        #      spends ~760 s in the 26 full launches alone). The CPU baseline is part of the contract and always runs.
+        t_step = elapsed / args.steps
+        skipped = []
+
+        def fits(name, est_s):
+            ok = (time.perf_counter() - t_run0) + est_s <= args.time_budget_s
+            if not ok:
+                skipped.append(name)
+            return ok
+
+        if world == 1 and not args.no_cpu_baseline:
+            budget, quota = host_cpu_budget()
+            # two worker threads per usable CPU (measured best on the 16-CPU-quota boxes: 16 -> 103, 32 -> 130 games/s)
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 2 * budget)
+            sample = args.cpu_sample_games or 64 * threads  # ~15-20 s of wall time
+            out["cpu_baseline"] = cpu_baseline(blob, args.explores, sample, threads)
+            out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
+        if world == 1 and not args.no_4096 and fits("at_4096_concurrent_games", 6):
+            # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
+            # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
+            e2 = sa.Engine(concurrent_games=4096, max_explores=args.explores, device=local_rank)
+            e2.load_weights(blob)
+            e2.selfplay(cfg, base_seed=1, n_games=4096, outputs=False)
             t1 = time.perf_counter()
-            eng.selfplay(cfg, base_seed=0, n_games=gps + gps // 2, first_game=(args.warmup + args.steps) * gps, outputs=False)
-            dt2 = time.perf_counter() - t1
-            t_step = elapsed / args.steps
-            steady = (gps // 2) / max(1e-9, dt2 - t_step)          # games/s of the extra (tail-free) half step
-            out["launch_tail"] = {"games_per_s_at_1_5x_games_per_step": (gps + gps // 2) / dt2, "steady_state_games_per_s": steady,
-                                  "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
-            # (2) the same step with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per
-            # game) copied to host memory inside the timed region — the PCIe-inclusive rate (never `value`)
-            try:
-                import psutil
-                room = psutil.virtual_memory().available > 3 * gps * 63 * 69
-            except Exception:
-                room = False
-            if room:
-                t1 = time.perf_counter()
-                ro = eng.selfplay(cfg, base_seed=0, n_games=gps, first_game=(args.warmup + args.steps + 2) * gps, outputs=True)
-                dt3 = time.perf_counter() - t1
-                nbytes = sum(v.nbytes for v in ro.values() if isinstance(v, np.ndarray))
-                out["with_replay_outputs_to_host"] = {"games_per_s": gps / dt3, "bytes_copied": int(nbytes),
-                                                      "seconds": dt3, "kernel_ms": ro["kernel_ms"]}
-                del ro
-            # (3) a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
-            # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
-            # random-init network (SURVEY §8d asks for both); same step, same kernel
-            tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
-            if os.path.exists(tpath):
-                eng.load_weights(np.load(tpath))
-                base = (args.warmup + args.steps + 3) * gps
-                eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=base, outputs=False)
-                t1 = time.perf_counter()
-                gt = min(gps, 4 * args.concurrent)
-                rt = eng.selfplay(cfg, base_seed=0, n_games=gt, first_game=base + args.concurrent, outputs=False)
-                dt4 = time.perf_counter() - t1
-                ct = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=base + args.concurrent, outputs=False, counters=True)["counters"]
-                out["with_trained_weights"] = {
-                    "games_per_s": gt / dt4, "games": gt, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
-                    "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
-                    "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
-                    "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
-                    "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
-                    "mfma_frac": (ct["policy_evals"] / 65536.0) * (gt / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                    "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
-                                                   "max_depth": c["max_depth"]}}
-                eng.load_weights(blob)
-            # (4) the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
-            # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)
-            eng.load_weights_conv(make_conv_weights())
-            base = (args.warmup + args.steps + 5) * gps
-            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=base, outputs=False)
-            t1 = time.perf_counter()
-            gt = min(gps, 4 * args.concurrent)
-            rt = eng.selfplay(cfg, base_seed=0, n_games=gt, first_game=base + args.concurrent, outputs=False)
-            dt5 = time.perf_counter() - t1
-            conv_shape = list(eng.last_launch_shape())
-            cc = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=base + args.concurrent, outputs=False, counters=True)["counters"]
-            evals_per_s = (cc["policy_evals"] / 65536.0) * (gt / dt5)
-            out["with_conv_policy"] = {
-                "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
-                "games_per_s": gt / dt5, "games": gt, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
-                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
-                "flop_per_eval": CONV_FLOP_PER_EVAL,
-                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "launch_shape": conv_shape}
-            eng.load_weights(blob)
-        if world == 1 and not args.no_extras:
-            # (5) the step after the path: optimiser steps per second of the learner at the reference's batch of 32, on
+            r2 = e2.selfplay(cfg, base_seed=1, n_games=16384, first_game=4096, outputs=False)
+            dt = time.perf_counter() - t1
+            out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
+                                               "games": 16384, "plies_per_game": float(r2["plies"].mean())}
+            e2.close()
+        if world == 1 and not args.no_extras and fits("learner", 10):
+            # the step after the path: optimiser steps per second of the learner at the reference's batch of 32, on
             # de-duplicated positions of a small self-play run — Connect4Net through the persistent epoch kernel, Connect4ConvNet
             # through its queued gradient + Adam launches
             try:
@@ -442,28 +406,85 @@ def main():
                 e3.close()
             except Exception as ex:  # the learner is not the benchmarked path: never lose the bench line over it
                 out["learner"] = {"error": repr(ex)}
-        if world == 1 and not args.no_4096:
-            # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
-            # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
-            e2 = sa.Engine(concurrent_games=4096, max_explores=args.explores, device=local_rank)
-            e2.load_weights(blob)
-            e2.selfplay(cfg, base_seed=1, n_games=4096, outputs=False)
+        next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
+        if world == 1 and not args.no_extras and fits("launch_tail", 0.6 * t_step + 2):
+            # the launch tail: a launch ends when its LAST game ends, so its final stretch runs on emptying tree slots. A launch of
+            # half the games has the same tail on half the work: the difference between a full and a half launch is tail-free time.
+            # tail_share = the fraction of a default step that the tail costs against a tail-free (infinitely long) launch.
             t1 = time.perf_counter()
-            r2 = e2.selfplay(cfg, base_seed=1, n_games=16384, first_game=4096, outputs=False)
-            dt = time.perf_counter() - t1
-            out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
-                                               "games": 16384, "plies_per_game": float(r2["plies"].mean())}
-            e2.close()
-        if world == 1 and not args.no_policy_cache:
-            eng.close()
+            eng.selfplay(cfg, base_seed=0, n_games=gps // 2, first_game=next_first, outputs=False)
+            dt2 = time.perf_counter() - t1
+            next_first += gps
+            steady = (gps - gps // 2) / max(1e-9, t_step - dt2)    # games/s of the tail-free half of a step
+            out["launch_tail"] = {"games_per_s_at_half_games_per_step": (gps // 2) / dt2, "steady_state_games_per_s": steady,
+                                  "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
+        if world == 1 and not args.no_policy_cache and fits("with_policy_cache", 1.1 * t_step + 25):
+            # (a second engine beside the first: 2 x 60 GB of node pools + the 17 GB table fit the 288 GB of HBM)
             out["with_policy_cache"] = policy_cache_leg(c)
-        if world == 1 and not args.no_cpu_baseline:
-            budget, quota = host_cpu_budget()
-            # two worker threads per usable CPU (measured best on the 16-CPU-quota boxes: 16 -> 103, 32 -> 130 games/s)
-            threads = args.cpu_threads or min(os.cpu_count() or 1, 2 * budget)
-            sample = args.cpu_sample_games or 64 * threads  # ~15-20 s of wall time
-            out["cpu_baseline"] = cpu_baseline(blob, args.explores, sample, threads)
-            out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
+        gx = min(gps, 4 * args.concurrent)   # the size of the remaining legs' launches
+        if world == 1 and not args.no_extras and fits("with_conv_policy", 0.75 * t_step * gx / gps * 1.3 + 8):
+            # the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
+            # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)
+            eng.load_weights_conv(make_conv_weights())
+            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
+            t1 = time.perf_counter()
+            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
+            dt5 = time.perf_counter() - t1
+            conv_shape = list(eng.last_launch_shape())
+            cc = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
+            next_first += args.concurrent + gx
+            evals_per_s = (cc["policy_evals"] / 65536.0) * (gx / dt5)
+            out["with_conv_policy"] = {
+                "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
+                "games_per_s": gx / dt5, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
+                "flop_per_eval": CONV_FLOP_PER_EVAL,
+                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "launch_shape": conv_shape}
+            eng.load_weights(blob)
+        tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
+        if world == 1 and not args.no_extras and os.path.exists(tpath) and fits("with_trained_weights", t_step * gx / gps * 1.6 + 8):
+            # a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
+            # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
+            # random-init network (SURVEY §8d asks for both); same kernel
+            eng.load_weights(np.load(tpath))
+            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
+            t1 = time.perf_counter()
+            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
+            dt4 = time.perf_counter() - t1
+            ct = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
+            next_first += args.concurrent + gx
+            out["with_trained_weights"] = {
+                "games_per_s": gx / dt4, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
+                "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
+                "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
+                "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
+                "mfma_frac": (ct["policy_evals"] / 65536.0) * (gx / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
+                                               "max_depth": c["max_depth"]}}
+            eng.load_weights(blob)
+        if world == 1 and not args.no_extras and fits("with_replay_outputs_to_host", t_step * gx / gps * 1.15 + 6):
+            # a launch with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per game) copied to
+            # host memory inside the timed region — the PCIe-inclusive rate (never `value`); kernel_ms is the same launch without
+            # the copies
+            try:
+                import psutil
+                room = psutil.virtual_memory().available > 3 * gx * 63 * 69
+            except Exception:
+                room = False
+            if room:
+                t1 = time.perf_counter()
+                ro = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first, outputs=True)
+                dt3 = time.perf_counter() - t1
+                next_first += gx
+                nbytes = sum(v.nbytes for v in ro.values() if isinstance(v, np.ndarray))
+                out["with_replay_outputs_to_host"] = {"games_per_s": gx / dt3, "games": gx, "bytes_copied": int(nbytes), "seconds": dt3,
+                                                      "kernel_ms": ro["kernel_ms"],
+                                                      "games_per_s_of_the_kernel_alone": gx / (ro["kernel_ms"] * 1e-3)}
+                del ro
+        if skipped:
+            out["skipped_for_time_budget"] = {"legs": skipped, "budget_s": args.time_budget_s}
         print(json.dumps(out), flush=True)
 
     try:
