@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--reference-fpu", action="store_true", help="self-play with Fpu::Func(|| Normal(1.0, 0.1)) (main.rs:43-47)")
     ap.add_argument("--dump-weights", default="", help="write the final weights of every rank to <prefix>.rank<r>.npy")
     ap.add_argument("--net", default="mlp", choices=["mlp", "conv"], help="mlp = the reference's Connect4Net; conv = Connect4ConvNet "
-                    "(north_star's Conv2d over the bitplanes + Linear heads; one GPU, no evaluation matches)")
+                    "(north_star's Conv2d over the bitplanes + Linear heads; one GPU)")
     args = ap.parse_args()
 
     import torch  # noqa: F401  (before the engine: one HIP runtime per process)
@@ -82,8 +82,8 @@ def main():
     eng = sa.Engine(concurrent_games=min(args.concurrent, max(16, args.games_per_train // world)), max_explores=args.explores,
                     device=local_rank)
     conv = args.net == "conv"
-    if conv and (world > 1 or args.eval_games > 0):
-        raise SystemExit("--net conv: one GPU, no evaluation matches (the match player and the data-parallel learner are Connect4Net's)")
+    if conv and world > 1:
+        raise SystemExit("--net conv: one GPU (the data-parallel learner wrapper is Connect4Net's)")
     if conv:
         blob = make_conv_weights(args.seed + 20260101)
         eng.load_weights_conv(blob)
@@ -160,7 +160,7 @@ def main():
             if eval_eng is None:  # its own engine: the opponents search deeper than self-play does
                 eval_eng = sa.Engine(concurrent_games=max(16, args.eval_games), max_explores=max(opponents + [my_explores]),
                                      device=local_rank)
-            eval_eng.load_weights(eng.trainer_state()["weights"])
+            (eval_eng.load_weights_conv if conv else eval_eng.load_weights)(eng.trainer_state()["weights"])
             me = match.Player(f"model_{it + 1}", my_explores, cfg.mcts_cfg, cfg.action)
             for ox in opponents:
                 opp = match.vanilla_player(ox)  # the evaluator's "VanillaMCTS<n>" baseline (FrozenMCTS over RolloutPolicy)
