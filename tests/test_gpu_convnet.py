@@ -193,3 +193,25 @@ def test_conv_learner_matches_oracle_and_feeds_selfplay(oracle, cblob, golden_di
     eng.trainer_init(blob)
     assert eng.trainer_state()["weights"].size == 30492
     eng.close()
+
+
+def test_conv_trained_checkpoint_matches_oracle(oracle, golden_dir):
+    """A TRAINED conv network (tests/golden/c4conv_trained_f32.npy, produced by examples/train_connect4.py --net conv): sharp priors,
+    deep narrow trees, many solved lines — searches and whole games still equal the oracle's."""
+    import os
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    w = np.load(os.path.join(golden_dir, "c4conv_trained_f32.npy"))
+    eng = sa.Engine(concurrent_games=1100, max_explores=800)
+    eng.load_weights_conv(w)
+    my, op = random_positions(oracle, 96, seed=23, max_moves=50)
+    my[0] = 0; op[0] = 0
+    got = eng.mcts_search(sa.parity_mcts_config(), my, op, 400)
+    ref = oracle.c4_mcts_search(parity_mcts_config(), w, my, op, 400, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_search_equal(got, ref, "trained conv, 400 explores")
+    got = eng.selfplay(sa.parity_rollout_config(200), base_seed=2, n_games=48, counters=True)
+    ref = oracle.c4_selfplay(parity_rollout_config(200), w, 2, 48, threads=8, nn_mode=oracle.ACC_FMA, net="conv")
+    assert_selfplay_equal(got, ref, "trained conv self-play")
+    assert got["counters"]["max_depth"] == ref["counters"]["max_depth"] and got["counters"]["max_depth"] >= 12
+    eng.close()
