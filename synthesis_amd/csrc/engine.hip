@@ -31,6 +31,22 @@
 
 using namespace syn;
 
+// The Connect4ConvNet instantiations of the lane-per-tree kernel are compiled in engine_conv.hip (a second translation unit, built in
+// parallel); here they are only declared.
+namespace syn {
+#define SYN_CONV_LANES(MODE, COUNT)                                                                        \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, true, 4, false, 2>(EngineParams);   \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, false, 4, false, 2>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, true, 8, false, 2>(EngineParams);   \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, false, 8, false, 2>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, true, 16, false, 2>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, false, 16, false, 2>(EngineParams);
+SYN_CONV_LANES(MODE_SEARCH, false)
+SYN_CONV_LANES(MODE_SELFPLAY, false)
+SYN_CONV_LANES(MODE_SELFPLAY, true)
+#undef SYN_CONV_LANES
+}  // namespace syn
+
 static_assert(sizeof(DevSearchResult) == sizeof(syn_search_result), "search result layout must match the C ABI");
 static_assert(sizeof(syn_counters) == sizeof(unsigned long long) * CTR_COUNT, "counter layout must match the C ABI");
 
