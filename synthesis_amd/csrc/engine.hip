@@ -17,6 +17,7 @@
 #include "../../include/synthesis_amd.h"
 #include "engine_kernels.cuh"
 #include "lane_kernel.cuh"
+#include "lane2_kernel.cuh"
 #include "pc_kernel.cuh"
 #include "frozen_kernel.cuh"
 #include "train_kernels.cuh"
@@ -45,6 +46,17 @@ SYN_CONV_LANES(MODE_SEARCH, false)
 SYN_CONV_LANES(MODE_SELFPLAY, false)
 SYN_CONV_LANES(MODE_SELFPLAY, true)
 #undef SYN_CONV_LANES
+// ... and the two-trees-per-lane kernels in engine_lanes2.hip (a third one)
+#define SYN_LANES2(MODE, COUNT)                                                                      \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 0>(EngineParams);   \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 0>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 2>(EngineParams);   \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 2>(EngineParams);
+extern template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>(EngineParams);
+SYN_LANES2(MODE_SEARCH, false)
+SYN_LANES2(MODE_SELFPLAY, false)
+SYN_LANES2(MODE_SELFPLAY, true)
+#undef SYN_LANES2
 }  // namespace syn
 
 static_assert(sizeof(DevSearchResult) == sizeof(syn_search_result), "search result layout must match the C ABI");
@@ -290,6 +302,55 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             h->last_shape = 5; h->last_grid = pgrid; h->last_threads = PcGeom::NT;
             if (out_grid) *out_grid = pgrid;
             if (out_nt) *out_nt = PcGeom::NT;
+            return hipGetLastError();
+        }
+    }
+    // Two trees per lane (lane2_kernel.cuh): 8 waves per workgroup, 1,024 trees per CU. SYN_DEBUG=1 SYN_LANES2=8 forces it,
+    // SYN_LANES2=0 switches it off.
+    {
+        int nw2 = 0;
+        const bool needs_noise2 = P.mcts.fpu == 2 || P.mcts.noise == 2;
+        if (const char* ev = debug_env("SYN_LANES2")) nw2 = std::atoi(ev);
+        if (PROF) nw2 = 0;
+        if (nw2 == 8 && h->cap <= LANE_MAX_CAP) {
+            (void)needs_noise2;
+            const int per_wg = 128 * nw2;
+            const int lgrid = (want_slots + per_wg - 1) / per_wg;
+            const size_t need_path = (size_t)lgrid * nw2 * 2 * PATH_ENTRIES * sizeof(uint4);
+            if (need_path > h->path_bytes) {
+                if (h->d_path) (void)hipFree(h->d_path);
+                h->d_path = nullptr;
+                h->path_bytes = 0;
+                hipError_t pe = hipMalloc(&h->d_path, need_path);
+                if (pe != hipSuccess) return pe;
+                h->path_bytes = need_path;
+            }
+            EngineParams PL = P;
+            PL.path = h->d_path;
+            PL.lane_thresh = 48;
+            if (const char* ev = debug_env("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
+            if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
+            PL.lane_thresh &= ~15;  // whole tiles
+#define SYN_LAUNCH_L2(NW, FAST, POL)                                                                               \
+    {                                                                                                              \
+        auto k = selfplay_kernel_lanes2<MODE, COUNT, FAST, NW, POL>;                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lane2Lds<NW>::BYTES);  \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), Lane2Lds<NW>::BYTES, h->stream, PL);                     \
+    }
+            if (h->net_kind == 1) { if (fast) SYN_LAUNCH_L2(8, true, 2) else SYN_LAUNCH_L2(8, false, 2) }
+            else if (MODE == MODE_SELFPLAY && !COUNT && fast && debug_env("SYN_L2_TILE")) {
+                auto k = selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>;
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lane2Lds<8>::BYTES);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k, dim3(lgrid), dim3(512), Lane2Lds<8>::BYTES, h->stream, PL);
+            }
+            else { if (fast) SYN_LAUNCH_L2(8, true, 0) else SYN_LAUNCH_L2(8, false, 0) }
+#undef SYN_LAUNCH_L2
+            h->last_shape = 6; h->last_grid = lgrid; h->last_threads = 64 * nw2;
+            if (out_grid) *out_grid = -lgrid;
+            if (out_nt) *out_nt = 64 * nw2;
             return hipGetLastError();
         }
     }

@@ -162,15 +162,242 @@ __device__ __attribute__((noinline)) float lane_fpu_draw(uint64_t tree_seed, uin
 }
 
 // ---------------------------------------------------------------------------------------------- phase A
-// pl = this lane's column of the wave's path buffer: level L lives at pl[L * 64]
-// ROOT_IN_T: the root position is live in T.root_my / T.root_op (pc_kernel.cuh) instead of parked in LDS at pk[]
+// The node a descent stands on: its record and own block (0 = none), solution, q slot, N and position.
+struct LaneCursor {
+    uint32_t rec, blk, kind, qt;
+    bool nsolved;
+    float pN;
+    uint64_t my, op;
+    int level;
+};
+
+// explore() starts at the root (mcts.rs:310-312). pl = this lane's column of the wave's path buffer: level L lives at
+// pl[L * 64]. ROOT_IN_T: the root position is live in T.root_my / T.root_op (pc_kernel.cuh) instead of parked in LDS at pk[].
+template <bool COUNT, bool FAST, bool ROOT_IN_T>
+SYN_DEV void lane_begin_explore(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint4* pl, uint32_t* ctr, const uint32_t* pk,
+                                int pk_stride) {
+    const CfgView<FAST> cfg{cfg_};
+    if (COUNT) ctr[CTR_EXPLORES]++;
+    C.rec = REC_ROOT;
+    C.level = 0;
+    // the root position is parked in LDS between searches (it is only needed here and at the end of a search)
+    if (ROOT_IN_T) {
+        C.my = T.root_my;
+        C.op = T.root_op;
+    } else {
+        C.my = (uint64_t)pk[0] | ((uint64_t)pk[pk_stride] << 32);
+        C.op = (uint64_t)pk[2 * pk_stride] | ((uint64_t)pk[3 * pk_stride] << 32);
+    }
+    C.nsolved = false;
+    C.kind = 0;
+    C.qt = 0;
+    if (T.next_block == 0) {
+        T.next_block = 1;  // MCTS::with_capacity pushes the root (mcts.rs:125): not expanded yet, no block
+        T.num_nodes = 1;
+        C.blk = 0;
+        C.pN = 0.0f;
+    } else {
+        C.blk = 1;           // the root's block
+        C.pN = (float)T.iter;
+        if (!cfg.fpu_const() && !cfg.fpu_normal()) {  // Fpu::ParentQ at the first level needs the root's q
+            const float4 a = *reinterpret_cast<const float4*>(blk_ptr(T.slab, 1));
+            C.qt = f32_bits(-((a.z - a.x) / C.pN));
+        }
+    }
+    pl[0] = make_uint4(REC_ROOT, f32_bits(C.pN),
+                       pm_make(C.blk, (uint32_t)__popc(legal_mask_of(C.my | C.op)), false, 0) | (C.blk != 0u ? PM_HAS_W : 0u), 0u);
+}
+
+// One level of the descent (mcts.rs:310-341: select_best_child + the step into the chosen child) = one cache line.
+// lm = legal columns of the cursor's position (updated as the descent drops stones: a column leaves the mask when its seventh
+// stone lands); the children of a node are its legal columns in ascending order.
+template <bool COUNT, bool FAST>
+SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint32_t& lm, uint4* pl, uint32_t* ctr,
+                                uint64_t noise_seed) {
+    const CfgView<FAST> cfg{cfg_};
+    unsigned char* const slab = T.slab;
+    const uint32_t nc = (uint32_t)__popc(lm);
+    const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, C.blk));
+    const uint4 hdr = line[0];  // the node's own sums: logged for backprop (same line, no extra transaction)
+    uint32_t d[28];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const uint4 t = line[1 + j];
+        d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
+    }
+    pl[PATH_PLANE + C.level * 64] = hdr;  // (the entry's PM_HAS_W flag was set when the descent arrived here)
+    const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(C.qt);  // parent.q() = -(stored q)
+    const float visits = cfg.puct() ? sqrtf(C.pN) : sqrtf(cfg.cc() * det_logf(C.pN));
+    // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
+    // the last child hold -inf / prior 0 (st_rec_none), so all nine are scored without a count check.
+    // what an unexpanded, unsolved child scores under a non-constant FPU: the parent's q (Fpu::ParentQ), or one
+    // Normal(mean, std) draw per such child per scan, in child order (Fpu::Func, mcts.rs:351-356)
+    float qf[9];
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) qf[i] = q_fpu;
+    if (cfg.fpu_normal()) {
+        uint32_t draws = T.fpu_draws;
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            const uint32_t nf = d[3 * i + 2];
+            if (i < nc && !nf_solved(nf) && nf_blk(nf) == 0u) qf[i] = lane_fpu_draw(noise_seed, draws++, cfg.fpu_value(), cfg_.fpu_std);
+        }
+        T.fpu_draws = draws;
+    }
+    float vv[9];
+    if (cfg.puct()) {
+        // explore_value = ((c * P) * sqrt(N_parent)) / (1 + n) (mcts.rs:361-372), two children per instruction.
+        // hdr.w != 0: this node has a prior outside the packed division's exact range (lane_create_children).
+        const bool exact_fast = cfg_.fast_div != 0 && __ballot(hdr.w != 0u) == 0ull;
+        f32x2 uu[5];
+        if (exact_fast) {
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i += 2) {
+                const uint32_t j = i + 1 < 9 ? i + 1 : i;
+                f32x2 a = f32x2{cfg.cc(), cfg.cc()} * f32x2{bits_f32(d[3 * i + 1]), bits_f32(d[3 * j + 1])};
+                a = a * f32x2{visits, visits};
+                uu[i >> 1] = div2_safe_range(a, f32x2{1.0f, 1.0f} + f32x2{nf_N(d[3 * i + 2]), nf_N(d[3 * j + 2])});
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i += 2) {
+                const uint32_t j = i + 1 < 9 ? i + 1 : i;
+                const float a0 = cfg.cc() * bits_f32(d[3 * i + 1]) * visits, a1 = cfg.cc() * bits_f32(d[3 * j + 1]) * visits;
+                uu[i >> 1] = f32x2{a0 / (1.0f + nf_N(d[3 * i + 2])), a1 / (1.0f + nf_N(d[3 * j + 2]))};
+            }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            const uint32_t nf = d[3 * i + 2];
+            // exploit_value: solved -> its outcome; unvisited under Fpu::ParentQ -> parent's q; else the q slot
+            float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? qf[i] : bits_f32(d[3 * i]);
+            q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
+            vv[i] = q + uu[i >> 1][i & 1];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            const uint32_t nf = d[3 * i + 2];
+            float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? qf[i] : bits_f32(d[3 * i]);
+            q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
+            vv[i] = q + visits / sqrtf(nf_N(nf));
+        }
+    }
+    if (!cfg.fpu_const()) {  // Fpu::ParentQ gives an unused slot (no block) the parent's q: mask by the child count instead
+#pragma unroll
+        for (uint32_t i = 1; i < 9; i++) vv[i] = i < nc ? vv[i] : -__builtin_inff();
+    }
+    float best_v = vv[0];
+    uint32_t best_i = 0, b_qt = d[0], b_nf = d[2], b_m = lm;
+    uint32_t m = lm & (lm - 1u);  // child i = the i-th legal column = the lowest set bit of m
+#pragma unroll
+    for (uint32_t i = 1; i < 9; i++) {
+        const bool take = vv[i] > best_v;
+        best_v = take ? vv[i] : best_v;
+        best_i = take ? i : best_i;
+        b_qt = take ? d[3 * i] : b_qt;
+        b_nf = take ? d[3 * i + 2] : b_nf;
+        b_m = take ? m : b_m;
+        m &= m - 1u;
+    }
+    if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
+    const int a = __ffs((int)b_m) - 1;
+    const int ha = c4::col_height(C.my | C.op, a);
+    const uint64_t nmy = C.op, nop = C.my | (1ull << (ha + 7 * a));
+    C.my = nmy;
+    C.op = nop;
+    lm = ha == c4::HEIGHT - 1 ? lm & ~(1u << a) : lm;
+    C.rec = C.blk * 16u + best_i;
+    C.blk = nf_blk(b_nf);
+    C.nsolved = nf_solved(b_nf);
+    C.kind = nf_kind(b_nf);
+    C.qt = b_qt;
+    C.pN = nf_N(b_nf);
+    C.level++;
+    // an expanded, unsolved node is descended through: its line (and with it its own sums) gets read and logged
+    pl[C.level * 64] = make_uint4(C.rec, f32_bits(C.pN),
+                                  pm_make(C.blk, (uint32_t)__popc(lm), C.nsolved, C.kind) |
+                                      ((!C.nsolved && C.blk != 0u) ? PM_HAS_W : 0u), C.qt);
+}
+
+// The descent stands on a leaf: a solved node (explore() returns its outcome) or an unexpanded one, which visit()
+// (mcts.rs:374-406) gives its block; the children's records are written in phase C together with their priors. Only an
+// auto-extended single child is written here (prior 1.0, no policy call). Sets X.{p0,p1,p2,solved,needs_eval,legal_mask}.
+template <bool COUNT, bool FAST>
+SYN_DEV void lane_arrive(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, LaneLeaf& X, bool hit_solved, uint4* pl,
+                         uint32_t bcap, uint32_t* ctr, int* error) {
+    const CfgView<FAST> cfg{cfg_};
+    unsigned char* const slab = T.slab;
+    const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
+    if (hit_solved) {
+        X.p0 = C.kind == 0u ? 1.0f : 0.0f;
+        X.p1 = C.kind == 1u ? 1.0f : 0.0f;
+        X.p2 = C.kind == 2u ? 1.0f : 0.0f;
+        X.solved = true;
+        if (COUNT) ctr[CTR_SOLVED_HITS]++;
+        if (C.blk == 0u) {
+            // first visit of a terminal node: it gets a block for its outcome sums
+            C.blk = lane_alloc_block(T, bcap, error);
+            *reinterpret_cast<unsigned short*>(rec_ptr(slab, C.rec) + 10) = (unsigned short)(C.blk | (C.kind << 14));
+            pl[C.level * 64].z = pm_make(C.blk, 0u, true, C.kind);
+        }
+    } else {
+        for (;;) {
+            const uint64_t occ = C.my | C.op;
+            const uint32_t lmask = legal_mask_of(occ);
+            const uint32_t n_new = (uint32_t)__popc(lmask);
+            const uint32_t nb = lane_alloc_block(T, bcap, error);
+            T.num_nodes += n_new;
+            if (C.rec != REC_ROOT) *reinterpret_cast<unsigned short*>(rec_ptr(slab, C.rec) + 10) = (unsigned short)nb;
+            C.blk = nb;
+            pl[C.level * 64].z = pm_make(nb, n_new, false, 0u);
+            if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
+
+            if (cfg.auto_extend() && n_new == 1u) {
+                const int a = __ffs((int)lmask) - 1;
+                const int ha = c4::col_height(occ, a);
+                const uint64_t abit = 1ull << (ha + 7 * a);
+                const uint64_t nmy = C.op, nop = C.my | abit;
+                const bool aw = c4::won(nop);
+                const bool over = aw || (occ | abit) == c4::FULL;
+                // the only child: slot 0 of the new block (the block's own sums are written by backprop)
+                C.rec = nb * 16u;
+                C.kind = aw ? 0u : 1u;
+                C.nsolved = over;
+                C.qt = over ? 0u : f32_bits(y_unvisited);
+                st_rec(slab, C.rec, C.qt, 1.0f, nf_make(0u, over, 0u, over ? C.kind : 0u));
+#pragma unroll
+                for (uint32_t k = 1; k < 9; k++) st_rec_none(slab, C.rec + k);
+                C.blk = 0;
+                C.my = nmy;
+                C.op = nop;
+                C.pN = 0.0f;
+                C.level++;
+                pl[C.level * 64] = make_uint4(C.rec, f32_bits(0.0f), pm_make(0u, (uint32_t)__popc(legal_mask_of(C.my | C.op)), over, over ? C.kind : 0u), C.qt);
+                if (over) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
+                    X.p0 = aw ? 1.0f : 0.0f;
+                    X.p1 = aw ? 0.0f : 1.0f;
+                    X.p2 = 0.0f;
+                    X.solved = true;
+                    C.blk = lane_alloc_block(T, bcap, error);
+                    *reinterpret_cast<unsigned short*>(rec_ptr(slab, C.rec) + 10) = (unsigned short)(C.blk | (C.kind << 14));
+                    pl[C.level * 64].z = pm_make(C.blk, 0u, true, C.kind);
+                    break;
+                }
+                continue;
+            }
+            X.needs_eval = true;
+            X.legal_mask = lmask;
+            break;
+        }
+    }
+}
+
+// Phase A of a round of the one-tree-per-lane kernels: start an explore, descend, stop on a leaf.
 template <bool COUNT, bool FAST, bool ROOT_IN_T = false>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
                                 uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride,
                                 uint64_t noise_seed = 0) {
-    const CfgView<FAST> cfg{cfg_};
-    unsigned char* const slab = T.slab;
-    const float y_unvisited = cfg.fpu_const() ? cfg.fpu_value() : 0.0f;
     const bool pending = active && Wk.pending;
     X.at_leaf = false;
     X.was_pending = pending;
@@ -178,43 +405,15 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     X.solved = false;
     X.p0 = X.p1 = X.p2 = 0.0f;
     X.legal_mask = Wk.pend_lmask;
-    uint32_t rec = Wk.rec, blk = Wk.blk, kind = Wk.kind, qt = Wk.qt;
-    bool nsolved = Wk.solved;
-    float pN = Wk.pN;
-    uint64_t my = Wk.my, op = Wk.op;
-    int level = Wk.level;
+    LaneCursor C;
+    C.rec = Wk.rec; C.blk = Wk.blk; C.kind = Wk.kind; C.qt = Wk.qt;
+    C.nsolved = Wk.solved;
+    C.pN = Wk.pN;
+    C.my = Wk.my; C.op = Wk.op;
+    C.level = Wk.level;
     bool desc = active && Wk.descending;
     if (active && !desc && !pending) {
-        // explore() starts at the root (mcts.rs:310-312)
-        if (COUNT) ctr[CTR_EXPLORES]++;
-        rec = REC_ROOT;
-        level = 0;
-        // the root position is parked in LDS between searches (it is only needed here and at the end of a search)
-        if (ROOT_IN_T) {
-            my = T.root_my;
-            op = T.root_op;
-        } else {
-            my = (uint64_t)pk[0] | ((uint64_t)pk[pk_stride] << 32);
-            op = (uint64_t)pk[2 * pk_stride] | ((uint64_t)pk[3 * pk_stride] << 32);
-        }
-        nsolved = false;
-        kind = 0;
-        qt = 0;
-        if (T.next_block == 0) {
-            T.next_block = 1;  // MCTS::with_capacity pushes the root (mcts.rs:125): not expanded yet, no block
-            T.num_nodes = 1;
-            blk = 0;
-            pN = 0.0f;
-        } else {
-            blk = 1;           // the root's block
-            pN = (float)T.iter;
-            if (!cfg.fpu_const() && !cfg.fpu_normal()) {  // Fpu::ParentQ at the first level needs the root's q
-                const float4 a = *reinterpret_cast<const float4*>(blk_ptr(slab, 1));
-                qt = f32_bits(-((a.z - a.x) / pN));
-            }
-        }
-        pl[0] = make_uint4(REC_ROOT, f32_bits(pN),
-                           pm_make(blk, (uint32_t)__popc(legal_mask_of(my | op)), false, 0) | (blk != 0u ? PM_HAS_W : 0u), 0u);
+        lane_begin_explore<COUNT, FAST, ROOT_IN_T>(cfg_, T, C, pl, ctr, pk, pk_stride);
         desc = true;
     }
 
@@ -222,198 +421,29 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     // A round ends when `thresh` lanes (a whole number of 16-position tiles) stand on a leaf that needs the network, or
     // when nobody is descending any more.
     bool hit_solved = false, at_leaf = pending;
-    // legal columns of the current position: computed once per round and updated as the descent drops stones (a column
-    // leaves the mask when its seventh stone lands); the children of a node are its legal columns in ascending order
-    uint32_t lm = legal_mask_of(my | op);
+    // legal columns of the current position: computed once per round and updated as the descent drops stones
+    uint32_t lm = legal_mask_of(C.my | C.op);
     for (;;) {
         if (desc) {
-            if (nsolved) { hit_solved = true; desc = false; at_leaf = true; }
-            else if (blk == 0u) { desc = false; at_leaf = true; }
+            if (C.nsolved) { hit_solved = true; desc = false; at_leaf = true; }
+            else if (C.blk == 0u) { desc = false; at_leaf = true; }
         }
         if (__ballot(desc) == 0ull || __popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
-        if (desc) {
-            const uint32_t nc = (uint32_t)__popc(lm);
-            const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, blk));
-            const uint4 hdr = line[0];  // the node's own sums: logged for backprop (same line, no extra transaction)
-            uint32_t d[28];
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const uint4 t = line[1 + j];
-                d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
-            }
-            pl[PATH_PLANE + level * 64] = hdr;  // (the entry's PM_HAS_W flag was set when the descent arrived here)
-            const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(qt);  // parent.q() = -(stored q)
-            const float visits = cfg.puct() ? sqrtf(pN) : sqrtf(cfg.cc() * det_logf(pN));
-            // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
-            // the last child hold -inf / prior 0 (st_rec_none), so all nine are scored without a count check.
-            // what an unexpanded, unsolved child scores under a non-constant FPU: the parent's q (Fpu::ParentQ), or one
-            // Normal(mean, std) draw per such child per scan, in child order (Fpu::Func, mcts.rs:351-356)
-            float qf[9];
-#pragma unroll
-            for (uint32_t i = 0; i < 9; i++) qf[i] = q_fpu;
-            if (cfg.fpu_normal()) {
-                uint32_t draws = T.fpu_draws;
-#pragma unroll
-                for (uint32_t i = 0; i < 9; i++) {
-                    const uint32_t nf = d[3 * i + 2];
-                    if (i < nc && !nf_solved(nf) && nf_blk(nf) == 0u) qf[i] = lane_fpu_draw(noise_seed, draws++, cfg.fpu_value(), cfg_.fpu_std);
-                }
-                T.fpu_draws = draws;
-            }
-            float vv[9];
-            if (cfg.puct()) {
-                // explore_value = ((c * P) * sqrt(N_parent)) / (1 + n) (mcts.rs:361-372), two children per instruction.
-                // hdr.w != 0: this node has a prior outside the packed division's exact range (lane_create_children).
-                const bool exact_fast = cfg_.fast_div != 0 && __ballot(hdr.w != 0u) == 0ull;
-                f32x2 uu[5];
-                if (exact_fast) {
-#pragma unroll
-                    for (uint32_t i = 0; i < 9; i += 2) {
-                        const uint32_t j = i + 1 < 9 ? i + 1 : i;
-                        f32x2 a = f32x2{cfg.cc(), cfg.cc()} * f32x2{bits_f32(d[3 * i + 1]), bits_f32(d[3 * j + 1])};
-                        a = a * f32x2{visits, visits};
-                        uu[i >> 1] = div2_safe_range(a, f32x2{1.0f, 1.0f} + f32x2{nf_N(d[3 * i + 2]), nf_N(d[3 * j + 2])});
-                    }
-                } else {
-#pragma unroll
-                    for (uint32_t i = 0; i < 9; i += 2) {
-                        const uint32_t j = i + 1 < 9 ? i + 1 : i;
-                        const float a0 = cfg.cc() * bits_f32(d[3 * i + 1]) * visits, a1 = cfg.cc() * bits_f32(d[3 * j + 1]) * visits;
-                        uu[i >> 1] = f32x2{a0 / (1.0f + nf_N(d[3 * i + 2])), a1 / (1.0f + nf_N(d[3 * j + 2]))};
-                    }
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < 9; i++) {
-                    const uint32_t nf = d[3 * i + 2];
-                    // exploit_value: solved -> its outcome; unvisited under Fpu::ParentQ -> parent's q; else the q slot
-                    float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? qf[i] : bits_f32(d[3 * i]);
-                    q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
-                    vv[i] = q + uu[i >> 1][i & 1];
-                }
-            } else {
-#pragma unroll
-                for (uint32_t i = 0; i < 9; i++) {
-                    const uint32_t nf = d[3 * i + 2];
-                    float q = (!cfg.fpu_const() && nf_blk(nf) == 0u) ? qf[i] : bits_f32(d[3 * i]);
-                    q = nf_solved(nf) ? pw_q_solved(nf_kind(nf), cfg.select_solved()) : q;
-                    vv[i] = q + visits / sqrtf(nf_N(nf));
-                }
-            }
-            if (!cfg.fpu_const()) {  // Fpu::ParentQ gives an unused slot (no block) the parent's q: mask by the child count instead
-#pragma unroll
-                for (uint32_t i = 1; i < 9; i++) vv[i] = i < nc ? vv[i] : -__builtin_inff();
-            }
-            float best_v = vv[0];
-            uint32_t best_i = 0, b_qt = d[0], b_nf = d[2], b_m = lm;
-            uint32_t m = lm & (lm - 1u);  // child i = the i-th legal column = the lowest set bit of m
-#pragma unroll
-            for (uint32_t i = 1; i < 9; i++) {
-                const bool take = vv[i] > best_v;
-                best_v = take ? vv[i] : best_v;
-                best_i = take ? i : best_i;
-                b_qt = take ? d[3 * i] : b_qt;
-                b_nf = take ? d[3 * i + 2] : b_nf;
-                b_m = take ? m : b_m;
-                m &= m - 1u;
-            }
-            if (COUNT) { ctr[CTR_SELECT_LEVELS]++; ctr[CTR_CHILDREN_SCANNED] += nc; }
-            const int a = __ffs((int)b_m) - 1;
-            const int ha = c4::col_height(my | op, a);
-            const uint64_t nmy = op, nop = my | (1ull << (ha + 7 * a));
-            my = nmy;
-            op = nop;
-            lm = ha == c4::HEIGHT - 1 ? lm & ~(1u << a) : lm;
-            rec = blk * 16u + best_i;
-            blk = nf_blk(b_nf);
-            nsolved = nf_solved(b_nf);
-            kind = nf_kind(b_nf);
-            qt = b_qt;
-            pN = nf_N(b_nf);
-            level++;
-            // an expanded, unsolved node is descended through: its line (and with it its own sums) gets read and logged
-            pl[level * 64] = make_uint4(rec, f32_bits(pN),
-                                        pm_make(blk, (uint32_t)__popc(lm), nsolved, kind) |
-                                            ((!nsolved && blk != 0u) ? PM_HAS_W : 0u), qt);
-        }
+        if (desc) lane_descend_level<COUNT, FAST>(cfg_, T, C, lm, pl, ctr, noise_seed);
     }
 
-    if (at_leaf && !pending) {
-        if (hit_solved) {
-            X.p0 = kind == 0u ? 1.0f : 0.0f;
-            X.p1 = kind == 1u ? 1.0f : 0.0f;
-            X.p2 = kind == 2u ? 1.0f : 0.0f;
-            X.solved = true;
-            if (COUNT) ctr[CTR_SOLVED_HITS]++;
-            if (blk == 0u) {
-                // first visit of a terminal node: it gets a block for its outcome sums
-                blk = lane_alloc_block(T, bcap, error);
-                *reinterpret_cast<unsigned short*>(rec_ptr(slab, rec) + 10) = (unsigned short)(blk | (kind << 14));
-                pl[level * 64].z = pm_make(blk, 0u, true, kind);
-            }
-        } else {
-            // visit() (mcts.rs:374-406): give the node its block; the children's records are written in phase C together
-            // with their priors. Only an auto-extended single child is written here (prior 1.0, no policy call).
-            for (;;) {
-                const uint64_t occ = my | op;
-                const uint32_t lmask = legal_mask_of(occ);
-                const uint32_t n_new = (uint32_t)__popc(lmask);
-                const uint32_t nb = lane_alloc_block(T, bcap, error);
-                T.num_nodes += n_new;
-                if (rec != REC_ROOT) *reinterpret_cast<unsigned short*>(rec_ptr(slab, rec) + 10) = (unsigned short)nb;
-                blk = nb;
-                pl[level * 64].z = pm_make(nb, n_new, false, 0u);
-                if (COUNT) { ctr[CTR_EXPANSIONS]++; ctr[CTR_NEW_NODES] += n_new; }
-
-                if (cfg.auto_extend() && n_new == 1u) {
-                    const int a = __ffs((int)lmask) - 1;
-                    const int ha = c4::col_height(occ, a);
-                    const uint64_t abit = 1ull << (ha + 7 * a);
-                    const uint64_t nmy = op, nop = my | abit;
-                    const bool aw = c4::won(nop);
-                    const bool over = aw || (occ | abit) == c4::FULL;
-                    // the only child: slot 0 of the new block (the block's own sums are written by backprop)
-                    rec = nb * 16u;
-                    kind = aw ? 0u : 1u;
-                    nsolved = over;
-                    qt = over ? 0u : f32_bits(y_unvisited);
-                    st_rec(slab, rec, qt, 1.0f, nf_make(0u, over, 0u, over ? kind : 0u));
-#pragma unroll
-                    for (uint32_t k = 1; k < 9; k++) st_rec_none(slab, rec + k);
-                    blk = 0;
-                    my = nmy;
-                    op = nop;
-                    pN = 0.0f;
-                    level++;
-                    pl[level * 64] = make_uint4(rec, f32_bits(0.0f), pm_make(0u, (uint32_t)__popc(legal_mask_of(my | op)), over, over ? kind : 0u), qt);
-                    if (over) {  // visit() of a solved node returns its one-hot outcome (mcts.rs:377-379)
-                        X.p0 = aw ? 1.0f : 0.0f;
-                        X.p1 = aw ? 0.0f : 1.0f;
-                        X.p2 = 0.0f;
-                        X.solved = true;
-                        blk = lane_alloc_block(T, bcap, error);
-                        *reinterpret_cast<unsigned short*>(rec_ptr(slab, rec) + 10) = (unsigned short)(blk | (kind << 14));
-                        pl[level * 64].z = pm_make(blk, 0u, true, kind);
-                        break;
-                    }
-                    continue;
-                }
-                X.needs_eval = true;
-                X.legal_mask = lmask;
-                break;
-            }
-        }
-    }
+    if (at_leaf && !pending) lane_arrive<COUNT, FAST>(cfg_, T, C, X, hit_solved, pl, bcap, ctr, error);
     X.at_leaf = at_leaf;
     Wk.descending = desc;
-    Wk.rec = rec;
-    Wk.blk = blk;
-    Wk.solved = nsolved;
-    Wk.kind = kind;
-    Wk.qt = qt;
-    Wk.pN = pN;
-    Wk.my = my;
-    Wk.op = op;
-    Wk.level = level;
+    Wk.rec = C.rec;
+    Wk.blk = C.blk;
+    Wk.solved = C.nsolved;
+    Wk.kind = C.kind;
+    Wk.qt = C.qt;
+    Wk.pN = C.pN;
+    Wk.my = C.my;
+    Wk.op = C.op;
+    Wk.level = C.level;
 }
 
 // ---------------------------------------------------------------------------------------------- phase C
