@@ -90,7 +90,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(args, key="traffic_bytes_per_launch"):
+def measured_traffic(args, key="traffic_bytes_per_launch", games=None):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc.json, produced
     by tools/collect_profiles.sh on this exact bench command). The counters cannot be read inside this process, so the
     figure comes from that committed run; it is reported ONLY when the summary was taken on this configuration AND on
@@ -104,6 +104,8 @@ def measured_traffic(args, key="traffic_bytes_per_launch"):
     if d.get("csrc_sha16") != kernel_source_hash():
         return None, None
     if d.get("bench_config") != [args.concurrent, args.games_per_step, args.explores]:
+        return None, None
+    if games is not None and d.get("extra_leg_games") != games:
         return None, None
     return d.get(key), os.path.relpath(files[-1], ROOT)
 
@@ -193,8 +195,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
     ap.add_argument("--only-policy-cache", action="store_true",
-                    help="run nothing but the PolicyWithCache leg (the command tools/collect_profiles.sh profiles for its roofline)")
-    ap.add_argument("--no-extras", action="store_true", help="skip the tail / replay-output / trained-weights legs")
+                    help="run nothing but the PolicyWithCache + reference-config legs (the command tools/collect_profiles.sh profiles for their rooflines)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the trained-weights / replay-output / reference-config / conv / tail / learner legs")
     ap.add_argument("--time-budget-s", type=float, default=870.0, help="wall-clock budget of the whole run: the extra legs (never the timed "
                     "steps, the roofline or the CPU baseline) are skipped, least important first, once they would overrun it")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
@@ -240,42 +242,75 @@ def main():
     cfg = sa.parity_rollout_config(args.explores)
     gps = args.games_per_step
 
-    def policy_cache_leg(c_ref=None):
+    def hbm_roofline(alg_bytes, kernel_ms, traffic, src, mfma_flops):
+        """HBM roofline object of a tree-bound leg. `achieved` = algorithmic bytes / kernel time (the contract's definition);
+        `frac` is the counter-backed figure whenever the PMC passes of this configuration exist and saw FEWER bytes than the
+        model charges (re-reads served by L2 / MALL are not HBM traffic: the model would overstate the HBM rate), else the model's."""
+        secs = kernel_ms * 1e-3
+        gbs = alg_bytes / secs / 1e9
+        frac_model = gbs / PEAK_HBM_GBS
+        frac_pmc = (traffic / secs / 1e9 / PEAK_HBM_GBS) if traffic else None
+        use_pmc = frac_pmc is not None and frac_pmc < frac_model
+        return {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": frac_pmc if use_pmc else frac_model, "frac_basis": "pmc" if use_pmc else "model",
+                "frac_model": frac_model, "frac_pmc": frac_pmc, "traffic": traffic, "traffic_source": src,
+                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms_avg": kernel_ms,
+                "mfma_frac_beside_it": mfma_flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS}
+
+    def policy_cache_leg(n_games, trained=None, reference_mcts=False):
         """The reference's run_n_games wraps the policy in PolicyWithCache (alpha_zero.rs:197-198), and so does the CPU
         baseline; the headline evaluates every leaf with the network, this is the same workload with the device-side cache
-        (2^28 entries, 17 GB): one step of gps games at the headline concurrency. Its bound is the HBM line-transaction
-        rate (two thirds of the matrix work disappears), so it carries an HBM roofline object of its own."""
+        (2^28 entries, 17 GB): one launch of n_games games at the headline concurrency. Its bound is the tree phases (two thirds
+        of the matrix work disappears), so it carries an HBM roofline object of its own.
+        trained + reference_mcts = the configuration the reference actually runs self-play with (study-connect4/src/main.rs:37-49:
+        a trained network behind PolicyWithCache, Fpu::Func(|| Normal(1.0, 0.1)))."""
         e3 = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank, policy_cache_log2=28)
-        e3.load_weights(blob)
-        e3.selfplay(cfg, base_seed=2, n_games=args.concurrent, outputs=False)
-        t1 = time.perf_counter()
-        r3 = e3.selfplay(cfg, base_seed=2, n_games=gps, first_game=args.concurrent, outputs=False)
-        dt = time.perf_counter() - t1
-        hits, misses = e3.last_cache_stats()
-        shape3 = e3.last_launch_shape()
-        # the cache never changes a tree, so the event counts are those of an uncached run of as many games: the headline's
-        # counted step when there is one, else a counted re-run
-        c3 = c_ref if c_ref is not None else e3.selfplay(cfg, base_seed=2, n_games=gps, first_game=args.concurrent,
-                                                         outputs=False, counters=True)["counters"]
+        out3 = {}
+        for name, w3, cfg3 in (("with_policy_cache", blob, cfg),
+                               ("reference_selfplay_config", trained,
+                                sa.parity_rollout_config(args.explores, mcts_cfg=sa.reference_selfplay_mcts_config()) if reference_mcts else None)):
+            if w3 is None or cfg3 is None:
+                continue
+            e3.load_weights(w3)   # (a new network empties the table)
+            e3.selfplay(cfg3, base_seed=2, n_games=args.concurrent, outputs=False)
+            t1 = time.perf_counter()
+            r3 = e3.selfplay(cfg3, base_seed=2, n_games=n_games, first_game=args.concurrent, outputs=False)
+            dt = time.perf_counter() - t1
+            hits, misses = e3.last_cache_stats()
+            shape3 = e3.last_launch_shape()
+            # event counts of a 32,768-game sample of the same games (the cache never changes a tree), scaled to the launch
+            ns = min(32768, n_games)
+            c3 = e3.selfplay(cfg3, base_seed=2, n_games=ns, first_game=args.concurrent, outputs=False, counters=True)["counters"]
+            scale = n_games / ns
+            # algorithmic bytes: the tree traffic of SURVEY §8d plus one 64-byte table entry read per Policy::eval call and
+            # one written per miss
+            alg = algorithmic_bytes(c3) * scale + 64 * (hits + misses) + 64 * misses
+            key = "cache_traffic_bytes_per_launch" if name == "with_policy_cache" else "reference_traffic_bytes_per_launch"
+            traffic, src = measured_traffic(args, key, n_games)
+            o = {"games_per_s": n_games / dt, "kernel_ms": r3["kernel_ms"], "games": n_games, "concurrent_games": args.concurrent,
+                 "plies_per_game": float(r3["plies"].mean()), "table_entries_log2": 28, "hit_rate": hits / max(1, hits + misses),
+                 "network_evals_per_s": misses / dt, "policy_eval_calls_per_s": (hits + misses) / dt,
+                 "select_levels_per_explore": c3["select_levels"] / max(1, c3["explores"]),
+                 "launch_shape": list(shape3),
+                 "roofline": hbm_roofline(alg, r3["kernel_ms"], traffic, src, misses * FLOP_PER_EVAL)}
+            if name == "reference_selfplay_config":
+                o["config"] = ("trained checkpoint tests/golden/c4net_trained_f32.npy + PolicyWithCache (2^28 entries) + "
+                               "Fpu::Func(Normal(1.0, 0.1)) on the device (study-connect4/src/main.rs:37-49), %d explores" % args.explores)
+                o["roofline_mfma"] = {"bound": "mfma", "achieved": misses * FLOP_PER_EVAL / (r3["kernel_ms"] * 1e-3) / 1e12,
+                                      "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": misses * FLOP_PER_EVAL / (r3["kernel_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      "kernel_ms_avg": r3["kernel_ms"], "flop_per_leaf_eval": FLOP_PER_EVAL}
+            out3[name] = o
         e3.close()
-        # algorithmic bytes: the tree traffic of SURVEY §8d plus one 64-byte table entry read per Policy::eval call and
-        # one written per miss
-        alg = algorithmic_bytes(c3) + 64 * (hits + misses) + 64 * misses
-        gbs = alg / (r3["kernel_ms"] * 1e-3) / 1e9
-        traffic, src = measured_traffic(args, "cache_traffic_bytes_per_launch")
-        return {"games_per_s": gps / dt, "kernel_ms": r3["kernel_ms"], "games": gps, "concurrent_games": args.concurrent,
-                "table_entries_log2": 28, "hit_rate": hits / max(1, hits + misses),
-                "network_evals_per_s": misses / dt, "policy_eval_calls_per_s": (hits + misses) / dt,
-                "launch_shape": list(shape3),
-                "roofline": {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                             "traffic": traffic, "traffic_source": src, "algorithmic_bytes_per_launch": alg,
-                             "kernel_ms_avg": r3["kernel_ms"],
-                             "mfma_frac_beside_it": misses * FLOP_PER_EVAL / (r3["kernel_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}
+        return out3
 
+    tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
+    trained_blob = np.load(tpath) if os.path.exists(tpath) else None
+    gx = max(args.concurrent, gps // 4)   # games of every extra leg's launch: a quarter of a step
     if args.only_policy_cache:
-        out = policy_cache_leg()
+        out = policy_cache_leg(gx, trained_blob, reference_mcts=True)
         if rank == 0:
-            print(json.dumps({"with_policy_cache": out}), flush=True)
+            print(json.dumps(out), flush=True)
         return
 
     eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
@@ -290,8 +325,11 @@ def main():
         first, count = dist_util.step_game_range(i, rank, world, gps)
         return eng.selfplay(cfg, base_seed=0, n_games=count, first_game=first, outputs=False, **kw)
 
+    # warm-up steps play a quarter of a step's games (the first of them pages the kernel in and touches the whole node pool: every
+    # tree slot plays one game; a full-size warm-up would only repeat the timed steps — at --warmup 5 that was 150 s of the driver's run)
     for i in range(args.warmup):
-        step(i)
+        first, count = dist_util.step_game_range(i, rank, world, gps)
+        eng.selfplay(cfg, base_seed=0, n_games=max(min(count, args.concurrent), count // 4), first_game=first, outputs=False)
     barrier()
     t0 = time.perf_counter()
     kernel_ms = []
@@ -310,7 +348,7 @@ def main():
     c = rc["counters"]
     shape, sgrid, sthreads = eng.last_launch_shape()
     kernel_name = {1: "selfplay_kernel<WPS=1>", 2: "selfplay_kernel<WPS=2>", 3: "selfplay_kernel_quads",
-                   4: "selfplay_kernel_lanes", 5: "selfplay_kernel_pc"}.get(shape, "?") + f" <<<{sgrid}, {sthreads}>>>"
+                   4: "selfplay_kernel_lanes", 5: "selfplay_kernel_pc", 6: "selfplay_kernel_lanes2"}.get(shape, "?") + f" <<<{sgrid}, {sthreads}>>>"
     last_ms = kernel_ms[-1]
     avg_ms = float(np.mean(kernel_ms))
 
@@ -349,9 +387,12 @@ def main():
             "plies_per_game": plies / total_games,
             "roofline": near, "roofline_other": other,
         }
-        # ---- extra legs, most important first; each is skipped once it would overrun --time-budget-s (the driver's K = 20 / W = 5 run
-        #      spends ~760 s in the 26 full launches alone). The CPU baseline is part of the contract and always runs.
+        # ---- extra legs, most important first. Every leg is one launch of a QUARTER of a step (gx games) on the headline
+        #      concurrency, so that the whole list fits beside the driver's K = 20 / W = 5 run (20 full + 5 quarter launches + the
+        #      counted re-run = ~670 s of an ~870 s budget); a leg is skipped — and named — only if it would still overrun
+        #      --time-budget-s. The CPU baseline is part of the contract and always runs.
         t_step = elapsed / args.steps
+        t_q = t_step * gx / gps          # a quarter launch of the headline configuration
         skipped = []
 
         def fits(name, est_s):
@@ -367,6 +408,85 @@ def main():
             sample = args.cpu_sample_games or 64 * threads  # ~15-20 s of wall time
             out["cpu_baseline"] = cpu_baseline(blob, args.explores, sample, threads)
             out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
+        next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
+        extras = world == 1 and not args.no_extras
+        if extras and trained_blob is not None and fits("with_trained_weights", 1.7 * t_q + 8):
+            # a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
+            # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
+            # random-init network (SURVEY §8d asks for both); same kernel
+            eng.load_weights(trained_blob)
+            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
+            t1 = time.perf_counter()
+            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
+            dt4 = time.perf_counter() - t1
+            ct = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
+            next_first += args.concurrent + gx
+            out["with_trained_weights"] = {
+                "games_per_s": gx / dt4, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
+                "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
+                "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
+                "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
+                "mfma_frac": (ct["policy_evals"] / 32768.0) * (gx / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
+                                               "max_depth": c["max_depth"]}}
+            eng.load_weights(blob)
+        if extras and fits("with_replay_outputs_to_host", 1.2 * t_q + 6):
+            # a launch with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per game) copied to
+            # host memory inside the timed region — the PCIe-inclusive rate (never `value`); kernel_ms is the same launch without
+            # the copies
+            try:
+                import psutil
+                room = psutil.virtual_memory().available > 3 * gx * 63 * 69
+            except Exception:
+                room = False
+            if room:
+                t1 = time.perf_counter()
+                ro = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first, outputs=True)
+                dt3 = time.perf_counter() - t1
+                next_first += gx
+                nbytes = sum(v.nbytes for v in ro.values() if isinstance(v, np.ndarray))
+                out["with_replay_outputs_to_host"] = {"games_per_s": gx / dt3, "games": gx, "bytes_copied": int(nbytes), "seconds": dt3,
+                                                      "kernel_ms": ro["kernel_ms"],
+                                                      "games_per_s_of_the_kernel_alone": gx / (ro["kernel_ms"] * 1e-3)}
+                del ro
+            else:
+                out["with_replay_outputs_to_host"] = {"skipped": "not enough host memory for the 4.3 KB per game of outputs"}
+        if world == 1 and not args.no_policy_cache and fits("with_policy_cache+reference_selfplay_config", 4.5 * t_q + 40):
+            # (a second engine beside the first: 2 x 60 GB of node pools + the 17 GB table fit the 288 GB of HBM)
+            out.update(policy_cache_leg(gx, trained_blob if extras else None, reference_mcts=extras))
+        if extras and fits("with_conv_policy", 1.6 * t_q + 8):
+            # the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
+            # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)
+            eng.load_weights_conv(make_conv_weights())
+            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
+            t1 = time.perf_counter()
+            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
+            dt5 = time.perf_counter() - t1
+            conv_shape = list(eng.last_launch_shape())
+            cc = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
+            next_first += args.concurrent + gx
+            evals_per_s = (cc["policy_evals"] / 32768.0) * (gx / dt5)
+            out["with_conv_policy"] = {
+                "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
+                "games_per_s": gx / dt5, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
+                "flop_per_eval": CONV_FLOP_PER_EVAL,
+                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "launch_shape": conv_shape}
+            eng.load_weights(blob)
+        if extras and fits("launch_tail", 1.1 * t_q + 2):
+            # the launch tail: a launch ends when its LAST game ends, so its final stretch runs on emptying tree slots. A launch of
+            # a quarter of the games has the same tail on a quarter of the work: the difference between a full and a quarter launch
+            # is tail-free time. tail_share = the fraction of a default step that the tail costs against a tail-free (infinitely
+            # long) launch.
+            t1 = time.perf_counter()
+            eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first, outputs=False)
+            dt2 = time.perf_counter() - t1
+            next_first += gx
+            steady = (gps - gx) / max(1e-9, t_step - dt2)    # games/s of the tail-free three quarters of a step
+            out["launch_tail"] = {"games_per_s_at_quarter_games_per_step": gx / dt2, "steady_state_games_per_s": steady,
+                                  "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
         if world == 1 and not args.no_4096 and fits("at_4096_concurrent_games", 6):
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
@@ -379,10 +499,9 @@ def main():
             out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
                                                "games": 16384, "plies_per_game": float(r2["plies"].mean())}
             e2.close()
-        if world == 1 and not args.no_extras and fits("learner", 10):
+        if extras and fits("learner", 10):
             # the step after the path: optimiser steps per second of the learner at the reference's batch of 32, on
-            # de-duplicated positions of a small self-play run — Connect4Net through the persistent epoch kernel, Connect4ConvNet
-            # through its queued gradient + Adam launches
+            # de-duplicated positions of a small self-play run — both networks through their persistent epoch kernels
             try:
                 e3 = sa.Engine(concurrent_games=4096, max_explores=64, device=local_rank)
                 e3.load_weights(blob)
@@ -406,83 +525,6 @@ def main():
                 e3.close()
             except Exception as ex:  # the learner is not the benchmarked path: never lose the bench line over it
                 out["learner"] = {"error": repr(ex)}
-        next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
-        if world == 1 and not args.no_extras and fits("launch_tail", 0.6 * t_step + 2):
-            # the launch tail: a launch ends when its LAST game ends, so its final stretch runs on emptying tree slots. A launch of
-            # half the games has the same tail on half the work: the difference between a full and a half launch is tail-free time.
-            # tail_share = the fraction of a default step that the tail costs against a tail-free (infinitely long) launch.
-            t1 = time.perf_counter()
-            eng.selfplay(cfg, base_seed=0, n_games=gps // 2, first_game=next_first, outputs=False)
-            dt2 = time.perf_counter() - t1
-            next_first += gps
-            steady = (gps - gps // 2) / max(1e-9, t_step - dt2)    # games/s of the tail-free half of a step
-            out["launch_tail"] = {"games_per_s_at_half_games_per_step": (gps // 2) / dt2, "steady_state_games_per_s": steady,
-                                  "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
-        if world == 1 and not args.no_policy_cache and fits("with_policy_cache", 1.1 * t_step + 25):
-            # (a second engine beside the first: 2 x 60 GB of node pools + the 17 GB table fit the 288 GB of HBM)
-            out["with_policy_cache"] = policy_cache_leg(c)
-        gx = min(gps, 4 * args.concurrent)   # the size of the remaining legs' launches
-        if world == 1 and not args.no_extras and fits("with_conv_policy", 0.75 * t_step * gx / gps * 1.3 + 8):
-            # the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
-            # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)
-            eng.load_weights_conv(make_conv_weights())
-            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
-            t1 = time.perf_counter()
-            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
-            dt5 = time.perf_counter() - t1
-            conv_shape = list(eng.last_launch_shape())
-            cc = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
-            next_first += args.concurrent + gx
-            evals_per_s = (cc["policy_evals"] / 65536.0) * (gx / dt5)
-            out["with_conv_policy"] = {
-                "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
-                "games_per_s": gx / dt5, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
-                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
-                "flop_per_eval": CONV_FLOP_PER_EVAL,
-                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "launch_shape": conv_shape}
-            eng.load_weights(blob)
-        tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
-        if world == 1 and not args.no_extras and os.path.exists(tpath) and fits("with_trained_weights", t_step * gx / gps * 1.6 + 8):
-            # a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
-            # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
-            # random-init network (SURVEY §8d asks for both); same kernel
-            eng.load_weights(np.load(tpath))
-            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
-            t1 = time.perf_counter()
-            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
-            dt4 = time.perf_counter() - t1
-            ct = eng.selfplay(cfg, base_seed=0, n_games=65536, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
-            next_first += args.concurrent + gx
-            out["with_trained_weights"] = {
-                "games_per_s": gx / dt4, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
-                "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
-                "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
-                "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
-                "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
-                "mfma_frac": (ct["policy_evals"] / 65536.0) * (gx / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
-                                               "max_depth": c["max_depth"]}}
-            eng.load_weights(blob)
-        if world == 1 and not args.no_extras and fits("with_replay_outputs_to_host", t_step * gx / gps * 1.15 + 6):
-            # a launch with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per game) copied to
-            # host memory inside the timed region — the PCIe-inclusive rate (never `value`); kernel_ms is the same launch without
-            # the copies
-            try:
-                import psutil
-                room = psutil.virtual_memory().available > 3 * gx * 63 * 69
-            except Exception:
-                room = False
-            if room:
-                t1 = time.perf_counter()
-                ro = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first, outputs=True)
-                dt3 = time.perf_counter() - t1
-                next_first += gx
-                nbytes = sum(v.nbytes for v in ro.values() if isinstance(v, np.ndarray))
-                out["with_replay_outputs_to_host"] = {"games_per_s": gx / dt3, "games": gx, "bytes_copied": int(nbytes), "seconds": dt3,
-                                                      "kernel_ms": ro["kernel_ms"],
-                                                      "games_per_s_of_the_kernel_alone": gx / (ro["kernel_ms"] * 1e-3)}
-                del ro
         if skipped:
             out["skipped_for_time_budget"] = {"legs": skipped, "budget_s": args.time_budget_s}
         print(json.dumps(out), flush=True)

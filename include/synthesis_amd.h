@@ -283,9 +283,10 @@ int syn_trainer_publish_weights(syn_engine* h);
  * index_select (data.rs:41-62; the caller draws the permutation and applies drop_last) — and step_losses[s][0..1]
  * receives its (pi_loss, v_loss). Bit-identical to n_steps calls of syn_train_step on the gathered batches. For batch <= 32
  * (the reference's batch_size) the whole epoch is ONE persistent kernel launch (csrc/train_epoch.cuh: 16 workgroups, the
- * gradient of the LAST step is what syn_trainer_get_state reports); it needs 16 CUs of one XCD free for the duration and returns
- * SYN_ERR_HIP (trainer state undefined, re-init) if its workgroups never become co-resident. Larger batches queue two launches
- * per step. */
+ * gradient of the LAST step is what syn_trainer_get_state reports). That kernel needs its 16 workgroups resident together; the
+ * learner's state is snapshotted before the launch, and if the workgroups never become co-resident (another kernel holds the CUs:
+ * it gives up after ~10 s) the snapshot is restored and the epoch runs through the queued per-step launches instead — same bits,
+ * the call still returns SYN_OK. Larger batches and the Connect4ConvNet learner with batch > 32 queue two launches per step. */
 int syn_train_set_data(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
                        const float* target_v, size_t n);
 int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batch, float lr, float* step_losses);
@@ -308,15 +309,21 @@ int syn_last_cache_stats(const syn_engine* h, uint64_t* hits, uint64_t* misses);
 /* Launch shape the last syn_selfplay_run / syn_mcts_search used (the engine picks it from the number of concurrent games,
  * DESIGN.md §6.1): *shape = 1 row-per-tree kernel with the weights in registers (16 trees per workgroup), 2 = the same
  * with two workgroups per CU, 3 = quad-async row kernel (several 16-tree quads per workgroup), 4 = lane-per-tree kernel
- * (one tree per lane), 5 = the evaluator baseline's lane-per-tree kernel; grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
+ * (one tree per lane), 5 = the evaluator baseline's lane-per-tree kernel / the producer-consumer debug shape, 6 = the lane-per-tree kernel
+ * with two trees per lane; grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
 int syn_last_launch_shape(const syn_engine* h, int* shape, int* grid, int* threads);
 
 /* A self-play launch plays its whole batch inside ONE kernel (seconds to tens of seconds). These two entry points may be called
- * from ANOTHER host thread while syn_selfplay_run / syn_mcts_search runs on the handle (they use a stream of their own):
- * syn_progress: *started = jobs handed to tree slots so far (capped at the call's job count), *finished = self-play games
- *   completed so far.
- * syn_cancel: no further job is handed out; the running call returns SYN_ERR_CANCELLED once the games already started have
- *   finished (at most one game's duration). Their outputs are valid; plies[g] = 0 marks a game that never started.
+ * from ANOTHER host thread while syn_selfplay_run / syn_mcts_search / syn_mcts_search_rollout runs on the handle (they use a stream
+ * of their own and never touch the handle's error string):
+ * syn_progress: *started = jobs (games / roots) handed to tree slots so far, capped at the call's job count; after a cancel, the
+ *   number handed out when the cancel was applied (a lower bound of what finally ran). *finished = self-play games completed.
+ * syn_cancel: no further job is handed out; the running call returns once the jobs already started have finished (at most one
+ *   game's duration) — with SYN_ERR_CANCELLED if anything was left out: self-play games that never started have plies[g] = 0,
+ *   roots that were not searched have all-zero results (num_nodes == 0); everything else is valid. A cancel that arrives after
+ *   the last job was handed out cancels nothing and the call returns SYN_OK. A cancel that arrives while the call is still
+ *   setting up is applied before the first job is handed out. Returns SYN_ERR_INVALID_ARGUMENT when no call is in flight.
+ *   syn_frozen_search_rollout takes its roots in a grid-stride loop: a cancel during it is accepted and has no effect.
  * The reference has no counterpart (its workers are joined at the end of gather_experience, alpha_zero.rs:156-170). */
 int syn_progress(syn_engine* h, int* started, int* finished);
 int syn_cancel(syn_engine* h);

@@ -127,8 +127,9 @@ public:
         return a;
     }
     bool step(int col) {
+        if (col < 0 || col >= WIDTH) throw Error(SYN_ERR_INVALID_ARGUMENT, "illegal Connect4 move");  // (before height(): it shifts by 7 * col)
         const int h = height(col);
-        if (col < 0 || col >= WIDTH || h >= HEIGHT) throw Error(SYN_ERR_INVALID_ARGUMENT, "illegal Connect4 move");
+        if (h >= HEIGHT) throw Error(SYN_ERR_INVALID_ARGUMENT, "illegal Connect4 move");
         const uint64_t mine = my_ | (1ull << (h + HEIGHT * col));
         my_ = op_;
         op_ = mine;

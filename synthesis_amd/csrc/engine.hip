@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -77,9 +78,15 @@ struct syn_engine {
     int num_cus = 256;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // syn_progress / syn_cancel: independent of the launch stream
-    int* h_pin = nullptr;              // 64 pinned bytes for their transfers
-    volatile int cancel_requested = 0;
-    volatile int running_jobs = 0;     // job count of the call in flight (0 = none)
+    int* h_pin = nullptr;              // 64 pinned bytes for their transfers: [0..1] syn_progress, [8] syn_cancel's word, [9] its pre-read
+    // The call in flight (syn_selfplay_run / syn_mcts_search* / syn_frozen_search_rollout) as syn_progress / syn_cancel see it.
+    // call_mu orders their state changes and serialises the users of aux_stream and h_pin.
+    std::mutex call_mu;
+    int call_state = 0;                // 0 idle, 1 launching (the job counter's reset is not enqueued yet), 2 running
+    int cancel_pending = 0;            // a syn_cancel that arrived while launching: applied right behind the counter's reset
+    int cancel_applied = 0;            // the running call's job counter was raised past its job count
+    int started_at_cancel = 0;         // jobs handed out when that happened (read just before the write)
+    int running_jobs = 0;              // job count of the call in flight (0 = none)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int slots = 0;
     int last_shape = 0, last_grid = 0, last_threads = 0;
@@ -128,7 +135,9 @@ struct syn_engine {
     float* d_ttimg = nullptr;  // ... and transposed fragments for the activation gradients (train_mfma.cuh)
     float* d_timg2 = nullptr;  // the second buffer of both images for the persistent epoch kernel (train_epoch.cuh): [fwd][transposed]
     unsigned* d_tsync = nullptr;  // its arrival counter and status word
+    float* d_tsnap = nullptr;     // snapshot of [w][m][v][fwd image][transposed image] taken before an epoch launch (restored if it aborts)
     long long train_step = 0;
+    long long epoch_fallbacks = 0;  // syn_train_epoch calls whose persistent kernel gave up and ran through the queued launches
     DevTrainHyper train_hp{};
     bool has_trainer = false;
     int trainer_kind = 0;  // 0 = Connect4Net (train_mfma.cuh / train_epoch.cuh), 1 = Connect4ConvNet (train_conv.cuh)
@@ -191,6 +200,48 @@ static void build_weight_image(const float* blob, std::vector<float>& img) {
                 }
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------ progress / cancel bracket
+// Every entry point that plays jobs from the device-side job counter (d_job_next[0]) brackets its launch with a CallScope:
+//   CallScope scope(h, n_jobs);          state = launching: a syn_cancel from another thread is remembered, nothing touches the device
+//   ... enqueue the counter's reset ...
+//   scope.armed();                       state = running; a remembered cancel is enqueued right behind the reset (same stream)
+//   ... launch, copies, synchronise ...
+//   scope.cancelled()                    did a cancel reach this call?  (the caller then decides from what actually finished)
+// and the destructor returns the engine to idle. syn_cancel on an idle engine is an error: there is nothing to cancel.
+constexpr int CANCEL_WORD = 0x40000000;
+struct CallScope {
+    syn_engine* e;
+    CallScope(syn_engine* h, int n_jobs) : e(h) {
+        std::lock_guard<std::mutex> g(e->call_mu);
+        e->call_state = 1;
+        e->cancel_pending = 0;
+        e->cancel_applied = 0;
+        e->started_at_cancel = 0;
+        e->running_jobs = n_jobs;
+    }
+    hipError_t armed() {
+        std::lock_guard<std::mutex> g(e->call_mu);
+        e->call_state = 2;
+        if (!e->cancel_pending) return hipSuccess;
+        e->cancel_pending = 0;
+        e->cancel_applied = 1;
+        e->started_at_cancel = 0;
+        e->h_pin[8] = CANCEL_WORD;
+        return hipMemcpyAsync(e->d_job_next, e->h_pin + 8, 4, hipMemcpyHostToDevice, e->stream);
+    }
+    bool cancelled() {
+        std::lock_guard<std::mutex> g(e->call_mu);
+        return e->cancel_applied != 0;
+    }
+    ~CallScope() {
+        std::lock_guard<std::mutex> g(e->call_mu);
+        e->call_state = 0;
+        e->cancel_pending = 0;
+        e->running_jobs = 0;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------ config checks
 static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) {
@@ -616,6 +667,7 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_ttimg);
     hipFree(h->d_timg2);
     hipFree(h->d_tsync);
+    hipFree(h->d_tsnap);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -907,6 +959,15 @@ static int common_params(syn_engine* h, EngineParams& P, int explores, bool need
     return SYN_OK;
 }
 
+// Fpu::Func, PolicyNoise::Dirichlet and Connect4ConvNet exist in the lane-per-tree kernels only, whose block ids are 14 bits: an
+// engine created for more than 7,280 explores cannot run them. Said before anything is enqueued.
+static int check_lane_only(syn_engine* h, const DevMctsCfg& m) {
+    if ((m.fpu == 2 || m.noise == 2 || h->net_kind == 1) && h->cap > LANE_MAX_CAP)
+        return fail(h, SYN_ERR_UNSUPPORTED, "Fpu::Func / PolicyNoise::Dirichlet / Connect4ConvNet run in the lane-per-tree kernels only: "
+                    "max_explores must be <= %u for them (this engine: %d)", (LANE_MAX_CAP - 1u) / 9u - 1u, h->max_explores);
+    return SYN_OK;
+}
+
 static int mcts_search_impl(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
                             int explores, int action_selection, syn_search_result* results, bool rollout, uint64_t seed) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
@@ -919,6 +980,7 @@ static int mcts_search_impl(syn_engine* h, const syn_mcts_config* cfg, const uin
     if (rc != SYN_OK) return rc;
     rc = convert_mcts(h, cfg, P.mcts);
     if (rc != SYN_OK) return rc;
+    if (!rollout && (rc = check_lane_only(h, P.mcts)) != SYN_OK) return rc;
     if (n == 0) return SYN_OK;
     for (int i = 0; i < n; i++)
         if (!valid_root(my_bb[i], op_bb[i]))
@@ -931,10 +993,14 @@ static int mcts_search_impl(syn_engine* h, const syn_mcts_config* cfg, const uin
     unsigned long long* d_my = static_cast<unsigned long long*>(h->d_scratch);
     unsigned long long* d_op = d_my + nb;
     DevSearchResult* d_res = reinterpret_cast<DevSearchResult*>(d_op + nb);
+    CallScope scope(h, n);
     HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    HIP_TRY(h, scope.armed());
     HIP_TRY(h, hipMemsetAsync(h->d_cache_stats, 0, 16, h->stream));
+    // a root that syn_cancel kept from being searched reads as all zeros (num_nodes == 0: a searched root has at least its own node)
+    HIP_TRY(h, hipMemsetAsync(d_res, 0, nb * sizeof(DevSearchResult), h->stream));
     P.roll.num_explores = explores;
     P.n_jobs = n;
     P.in_my = d_my;
@@ -961,6 +1027,13 @@ static int mcts_search_impl(syn_engine* h, const syn_mcts_config* cfg, const uin
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
+    if (scope.cancelled()) {
+        int missing = 0;
+        for (int i = 0; i < n; i++) missing += results[i].num_nodes == 0u ? 1 : 0;
+        if (missing)
+            return fail(h, SYN_ERR_CANCELLED, "cancelled by syn_cancel: %d of %d roots were not searched (their results are all zero)",
+                        missing, n);
+    }
     return SYN_OK;
 }
 
@@ -1032,7 +1105,10 @@ int syn_frozen_search_rollout(syn_engine* h, const syn_mcts_config* cfg, const u
     HIP_TRY(h, hipMemcpyAsync(d_seed, seeds, nb * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_words, rng_words, nb * 8, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(d_expl, explores, nb * 4, hipMemcpyHostToDevice, h->stream));
+    CallScope scope(h, n);
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    HIP_TRY(h, scope.armed());  // (this kernel takes its roots in a grid-stride loop, not from the job counter: a syn_cancel
+                                //  during the call is accepted and has no effect — every root is searched)
     FrozenParams P;
     P.pool = reinterpret_cast<uint4*>(h->d_stat);
     P.nodes_per_tree = nodes_per_tree;
@@ -1099,6 +1175,7 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (rc != SYN_OK) return rc;
     rc = convert_mcts(h, &cfg->mcts_cfg, P.mcts);
     if (rc != SYN_OK) return rc;
+    if ((rc = check_lane_only(h, P.mcts)) != SYN_OK) return rc;
     if (counters) std::memset(counters, 0, sizeof(*counters));
     if (n_games == 0) return SYN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
@@ -1123,13 +1200,12 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     P.actions = h->d_actions;
     P.root_nodes = h->d_root_nodes;
     P.final_kind = h->d_final;
+    CallScope scope(h, n_games);
     HIP_TRY(h, hipMemsetAsync(h->d_job_next, 0, 64, h->stream));
+    HIP_TRY(h, scope.armed());
     HIP_TRY(h, hipMemsetAsync(h->d_cache_stats, 0, 16, h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), h->stream));
     HIP_TRY(h, hipMemsetAsync(h->d_plies, 0, (size_t)n_games * 4, h->stream));  // plies = 0: a game that never started (syn_cancel)
-    h->cancel_requested = 0;
-    h->running_jobs = n_games;
-    struct RunningGuard { syn_engine* e; ~RunningGuard() { e->running_jobs = 0; } } running_guard{h};
     // SYN_PROFILE=1: diagnostic build of the kernel with s_memtime stamps around each phase (never timed/benched)
     const bool prof = !counters && debug_env("SYN_PROFILE") != nullptr;
     int pgrid = 0, pnt = 0;
@@ -1220,9 +1296,10 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (final_kind) HIP_TRY(h, hipMemcpyAsync(final_kind, h->d_final, g, hipMemcpyDeviceToHost, h->stream));
     if (counters)
         HIP_TRY(h, hipMemcpyAsync(counters, h->d_counters, sizeof(DevCounters), hipMemcpyDeviceToHost, h->stream));
-    int kerr = 0;
+    int kerr = 0, games_finished = 0;
     unsigned long long cstats[2] = {0, 0};
     HIP_TRY(h, hipMemcpyAsync(&kerr, h->d_job_next + 8, 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(&games_finished, h->d_job_next + 1, 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(cstats, h->d_cache_stats, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->last_cache_hits = cstats[0];
@@ -1233,29 +1310,73 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     if (kerr) return fail(h, SYN_ERR_HIP, "kernel reported a synchronisation timeout (bounded spin gave up)");
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     h->last_launches = 1;
-    if (h->cancel_requested) return fail(h, SYN_ERR_CANCELLED, "cancelled by syn_cancel: the games that had started were played to the end");
+    // decided by what finished, not by the flag: a cancel that arrives after the last game was handed out cancels nothing
+    if (scope.cancelled() && games_finished < n_games)
+        return fail(h, SYN_ERR_CANCELLED, "cancelled by syn_cancel: %d of %d games were played (to the end); the others have plies == 0",
+                    games_finished, n_games);
     return SYN_OK;
 }
 
 int syn_progress(syn_engine* h, int* started, int* finished) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(h->call_mu);
     if (hipSetDevice(h->device) != hipSuccess) return SYN_ERR_HIP;
     if (hipMemcpyAsync(h->h_pin, h->d_job_next, 8, hipMemcpyDeviceToHost, h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
     if (hipStreamSynchronize(h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
     const int jobs = h->running_jobs;
-    if (started) *started = (jobs > 0 && h->h_pin[0] > jobs) ? jobs : h->h_pin[0];
+    int st = h->h_pin[0];
+    if (st >= CANCEL_WORD) st = h->started_at_cancel;  // the counter was raised by syn_cancel: what had been handed out before
+    if (jobs > 0 && st > jobs) st = jobs;              // (every lane's last fetch overshoots the job count)
+    if (started) *started = st;
     if (finished) *finished = h->h_pin[1];
     return SYN_OK;
 }
 
 int syn_cancel(syn_engine* h) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> g(h->call_mu);
+    if (h->call_state == 0) return SYN_ERR_INVALID_ARGUMENT;  // no call in flight: nothing to cancel (the error string belongs to the calling thread's entry points and is not touched here)
+    if (h->call_state == 1) {  // the call has not reset the job counter yet: it applies the cancel itself, right behind the reset
+        h->cancel_pending = 1;
+        return SYN_OK;
+    }
+    if (h->cancel_applied) return SYN_OK;
     if (hipSetDevice(h->device) != hipSuccess) return SYN_ERR_HIP;
-    h->cancel_requested = 1;
+    // jobs handed out so far (a lower bound of what will have started: a fetch between this read and the write below still counts)
+    if (hipMemcpyAsync(h->h_pin + 9, h->d_job_next, 4, hipMemcpyDeviceToHost, h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
     // every later job fetch (an atomic add on this word) now returns an index past the call's job count: no new game starts
-    h->h_pin[8] = 0x40000000;
+    h->h_pin[8] = CANCEL_WORD;
     if (hipMemcpyAsync(h->d_job_next, h->h_pin + 8, 4, hipMemcpyHostToDevice, h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
     if (hipStreamSynchronize(h->aux_stream) != hipSuccess) return SYN_ERR_HIP;
+    h->started_at_cancel = h->h_pin[9] < h->running_jobs ? h->h_pin[9] : h->running_jobs;
+    h->cancel_applied = 1;
+    return SYN_OK;
+}
+
+// The learner's device buffers (shared by both networks' trainers; sized for Connect4Net, the larger one): all of them or none —
+// a failed allocation frees what was taken, so that a retry starts from scratch instead of skipping the allocation block.
+static int alloc_trainer_buffers(syn_engine* h) {
+    if (h->d_tw) return SYN_OK;
+    const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
+    const size_t img = (size_t)MlpGeom::IMG_FLOATS * 4, timg = (size_t)TrainImg::T_FLOATS * 4;
+    struct { void** p; size_t n; } want[] = {
+        {reinterpret_cast<void**>(&h->d_tw), bytes},      {reinterpret_cast<void**>(&h->d_tm), bytes},
+        {reinterpret_cast<void**>(&h->d_tv), bytes},      {reinterpret_cast<void**>(&h->d_tgrad), bytes},
+        {reinterpret_cast<void**>(&h->d_tloss), 64},      {reinterpret_cast<void**>(&h->d_twimg), img},
+        {reinterpret_cast<void**>(&h->d_ttimg), timg},    {reinterpret_cast<void**>(&h->d_timg2), img + timg},
+        {reinterpret_cast<void**>(&h->d_tsync), 256},     {reinterpret_cast<void**>(&h->d_tsnap), 3 * bytes + img + timg},
+    };
+    for (auto& w : want) {
+        hipError_t e = hipMalloc(w.p, w.n);
+        if (e != hipSuccess) {
+            for (auto& u : want) {
+                if (*u.p) (void)hipFree(*u.p);
+                *u.p = nullptr;
+            }
+            h->has_trainer = false;
+            return fail(h, SYN_ERR_HIP, "hipMalloc(trainer buffers) failed: %s", hipGetErrorString(e));
+        }
+    }
     return SYN_OK;
 }
 
@@ -1267,16 +1388,9 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4Net has %d parameters, got %zu", TrainGeom::NUM_PARAMS, n_floats);
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
-    if (!h->d_tw) {
-        HIP_TRY(h, hipMalloc(&h->d_tw, bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tm, bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tv, bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tgrad, bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tloss, 64));
-        HIP_TRY(h, hipMalloc(&h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4));
-        HIP_TRY(h, hipMalloc(&h->d_ttimg, (size_t)TrainImg::T_FLOATS * 4));
-        HIP_TRY(h, hipMalloc(&h->d_timg2, (size_t)(MlpGeom::IMG_FLOATS + TrainImg::T_FLOATS) * 4));
-        HIP_TRY(h, hipMalloc(&h->d_tsync, 256));
+    {
+        const int rc = alloc_trainer_buffers(h);
+        if (rc != SYN_OK) return rc;
     }
     {
         // the two fragment-order images the matrix-core learner reads its A operands from (train_mfma.cuh); adam_image_kernel
@@ -1312,16 +1426,9 @@ int syn_trainer_init_conv(syn_engine* h, const float* blob, size_t n_floats, con
     HIP_TRY(h, hipSetDevice(h->device));
     const size_t cap_bytes = (size_t)TrainGeom::NUM_PARAMS * 4;  // the buffers are shared with the Connect4Net trainer (larger)
     static_assert(ConvGeom::NUM_PARAMS <= TrainGeom::NUM_PARAMS, "trainer buffers are sized for Connect4Net");
-    if (!h->d_tw) {
-        HIP_TRY(h, hipMalloc(&h->d_tw, cap_bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tm, cap_bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tv, cap_bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tgrad, cap_bytes));
-        HIP_TRY(h, hipMalloc(&h->d_tloss, 64));
-        HIP_TRY(h, hipMalloc(&h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4));
-        HIP_TRY(h, hipMalloc(&h->d_ttimg, (size_t)TrainImg::T_FLOATS * 4));
-        HIP_TRY(h, hipMalloc(&h->d_timg2, (size_t)(MlpGeom::IMG_FLOATS + TrainImg::T_FLOATS) * 4));
-        HIP_TRY(h, hipMalloc(&h->d_tsync, 256));
+    {
+        const int rc = alloc_trainer_buffers(h);
+        if (rc != SYN_OK) return rc;
     }
     const size_t bytes = (size_t)ConvGeom::NUM_PARAMS * 4;
     HIP_TRY(h, hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream));
@@ -1541,6 +1648,18 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             hipError_t e;
 #define EP_TRY(expr) if ((e = (expr)) != hipSuccess) { rc2 = fail(h, SYN_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e)); break; }
             EP_TRY(hipMemcpyAsync(d_sc, adam_sc.data(), adam_sc.size() * 4, hipMemcpyHostToDevice, h->stream));
+            // snapshot of the learner (parameters, moments, both images: 0.85 MB of device copies): the launch below needs its 16
+            // workgroups resident together; if it gives up (another kernel holds the CUs) the state is put back and the epoch runs
+            // through the queued per-step launches instead — same bits, no co-residency requirement
+            {
+                const size_t pb = (size_t)TrainGeom::NUM_PARAMS * 4, ib = (size_t)MlpGeom::IMG_FLOATS * 4, tb = (size_t)TrainImg::T_FLOATS * 4;
+                unsigned char* sn = reinterpret_cast<unsigned char*>(h->d_tsnap);
+                EP_TRY(hipMemcpyAsync(sn, h->d_tw, pb, hipMemcpyDeviceToDevice, h->stream));
+                EP_TRY(hipMemcpyAsync(sn + pb, h->d_tm, pb, hipMemcpyDeviceToDevice, h->stream));
+                EP_TRY(hipMemcpyAsync(sn + 2 * pb, h->d_tv, pb, hipMemcpyDeviceToDevice, h->stream));
+                EP_TRY(hipMemcpyAsync(sn + 3 * pb, h->d_twimg, ib, hipMemcpyDeviceToDevice, h->stream));
+                EP_TRY(hipMemcpyAsync(sn + 3 * pb + ib, h->d_ttimg, tb, hipMemcpyDeviceToDevice, h->stream));
+            }
             EP_TRY(hipMemsetAsync(d_prof, 0, 2048, h->stream));
             EP_TRY(hipMemsetAsync(h->d_tsync, 0, 256, h->stream));
             float* img2 = h->d_timg2;
@@ -1574,10 +1693,20 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
 #undef EP_TRY
         } while (0);
         if (rc2 != SYN_OK) return rc2;
-        if (status[1] != 0u)
-            return fail(h, SYN_ERR_HIP, "the %d workgroups of the epoch kernel were not resident together (device busy?): the trainer "
-                        "state is undefined, call syn_trainer_init again", EP_WGS);
-        if (prof) {
+        const bool force_abort = debug_env("SYN_TRAIN_FORCE_ABORT") != nullptr;  // test hook: take the recovery path
+        bool aborted = status[1] != 0u || force_abort;
+        if (aborted) {
+            // the workers were not resident together: put the learner back and run the epoch through the queued launches below
+            const size_t pb = (size_t)TrainGeom::NUM_PARAMS * 4, ib = (size_t)MlpGeom::IMG_FLOATS * 4, tb = (size_t)TrainImg::T_FLOATS * 4;
+            const unsigned char* sn = reinterpret_cast<const unsigned char*>(h->d_tsnap);
+            HIP_TRY(h, hipMemcpyAsync(h->d_tw, sn, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_tm, sn + pb, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_tv, sn + 2 * pb, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_twimg, sn + 3 * pb, ib, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_ttimg, sn + 3 * pb + ib, tb, hipMemcpyDeviceToDevice, h->stream));
+            h->epoch_fallbacks++;
+        }
+        if (!aborted && prof) {
             // stamps of step 2, workgroup g at [16 g ..]: top, features, forward L0..L4, heads, act-grads L4..L1, parameter jobs, step barrier
             fprintf(stderr, "[syn train profile] epoch kernel (%s), step 2, cycles per phase\n", status[3] ? "workers on one XCD" : "device-scope barrier");
             for (int g = 0; g < EP_WGS; g++) {
@@ -1586,8 +1715,10 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
                 fprintf(stderr, " | probe fresh line %llu, cold line %llu\n", stamps[16 * g + 14], stamps[16 * g + 15]);
             }
         }
-        h->train_step += (long long)n_steps;
-        return SYN_OK;
+        if (!aborted) {
+            h->train_step += (long long)n_steps;
+            return SYN_OK;
+        }
     }
     for (size_t s = 0; s < n_steps; s++) {  // steps are dependent (weights of step s feed step s+1): queued, never synced
         const size_t o = s * (size_t)batch;

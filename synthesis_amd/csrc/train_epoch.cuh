@@ -576,7 +576,10 @@ __global__ __launch_bounds__(EP_THREADS) void train_epoch_kernel(EpochParams P) 
             }
             lds_barrier();
             if (ep_abort) return;  // a workgroup of the launch never arrived (not co-resident): the host reports the failure
-            if (one_xcd) asm volatile("buffer_inv sc0" ::: "memory");
+            // acquire: drop this CU's vector L1. sc1 = agent scope: outside threadgroup-split mode the memory model only promises
+            // that an AGENT-scope invalidate empties the L1 (a workgroup-scope one may legally keep lines); the writers' data sits in
+            // the XCD's L2 either way, so the cheap release above stays.
+            if (one_xcd) asm volatile("buffer_inv sc1" ::: "memory");
             else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             EP_STAMP();  // step barrier
         }

@@ -270,11 +270,13 @@ class Engine:
         res = (CSearchResult * max(n, 1))()
         c = cfg.to_c()
         if rollout_seed is None:
-            self._check(self._lib.syn_mcts_search(self._h, C.byref(c), _p(my), _p(op), n, int(explores),
-                                                  int(action_selection), C.cast(res, C.c_void_p)))
+            rc = self._lib.syn_mcts_search(self._h, C.byref(c), _p(my), _p(op), n, int(explores),
+                                           int(action_selection), C.cast(res, C.c_void_p))
         else:
-            self._check(self._lib.syn_mcts_search_rollout(self._h, C.byref(c), int(rollout_seed), _p(my), _p(op), n,
-                                                          int(explores), int(action_selection), C.cast(res, C.c_void_p)))
+            rc = self._lib.syn_mcts_search_rollout(self._h, C.byref(c), int(rollout_seed), _p(my), _p(op), n,
+                                                   int(explores), int(action_selection), C.cast(res, C.c_void_p))
+        if rc != -7:    # SYN_ERR_CANCELLED (Engine.cancel from another thread): searched roots are valid, the others all zero
+            self._check(rc)
         raw = np.frombuffer(res, dtype=np.uint8).reshape(max(n, 1), C.sizeof(CSearchResult))[:n]
         dt = np.dtype([("child_N", np.float32, (9,)), ("child_W", np.float32, (9, 3)), ("child_P", np.float32, (9,)),
                        ("child_sol", np.int32, (9, 3)), ("root_N", np.float32), ("root_W", np.float32, (3,)),
@@ -284,6 +286,8 @@ class Engine:
         rec = raw.copy().view(dt).reshape(n)
         out = {k: rec[k].copy() for k in dt.names}
         out["root_stat"] = np.concatenate([out.pop("root_N")[:, None], out.pop("root_W")], axis=1)
+        if rc == -7:
+            out["cancelled"] = True
         return out
 
     # ---- the evaluator's baseline: FrozenMCTS::exploit over RolloutPolicy on n roots (evaluator.rs:308-319)
@@ -340,7 +344,9 @@ class Engine:
         return int(a.value), int(b.value)
 
     def cancel(self):
-        """No further game starts; the running selfplay() raises SynthesisAmdError(-7) once the started games have finished."""
+        """No further game (or root) starts; the running selfplay() / mcts_search() returns once the started ones have finished,
+        with result["cancelled"] = True if anything was left out (plies == 0 / num_nodes == 0 mark those). Raises
+        SynthesisAmdError(SYN_ERR_INVALID_ARGUMENT) when no call is in flight on this engine."""
         self._check(self._lib.syn_cancel(self._h))
 
     def last_cache_stats(self):

@@ -175,7 +175,8 @@ def test_progress_and_cancel_from_another_thread(blob, oracle):
     assert all(b[0] >= a[0] and b[1] >= a[1] for a, b in zip(seen, seen[1:])) and seen[-1][0] >= seen[-1][1] >= 6000
     played = np.nonzero(r["plies"])[0]
     assert 6000 <= played.size < n and played.max() < seen[-1][0] + 4096 + 16   # nothing started after the cancel (+ slots in flight)
-    assert eng.progress()[1] == played.size
+    started_after, finished_after = eng.progress()
+    assert finished_after == played.size and started_after <= played.size <= started_after + 4096 + 16
     first = int(played[100])
     block = [g for g in range(first, first + 6) if r["plies"][g] > 0]
     ref = oracle.c4_selfplay(parity_rollout_config(200), blob, 5, 6, first_game=first, threads=6, nn_mode=oracle.ACC_FMA)
@@ -185,4 +186,41 @@ def test_progress_and_cancel_from_another_thread(blob, oracle):
     # the engine is usable afterwards
     r2 = eng.selfplay(sa.parity_rollout_config(200), base_seed=5, n_games=64)
     assert "cancelled" not in r2 and (r2["plies"] > 0).all()
+    # nothing in flight: there is nothing to cancel, and the next call is not affected by the refused one
+    with pytest.raises(sa.SynthesisAmdError):
+        eng.cancel()
+    r3 = eng.selfplay(sa.parity_rollout_config(200), base_seed=5, n_games=64)
+    assert "cancelled" not in r3 and np.array_equal(r3["plies"], r2["plies"])
+
+    # the same bracket around a search: roots that were never handed out come back all zero and the call says so
+    from tests.oracle_lib import parity_mcts_config
+    from tests.test_gpu_parity import assert_search_equal, random_positions
+    my, op = random_positions(oracle, 512, seed=3, max_moves=30)
+    reps = 600
+    my_all, op_all = np.tile(my, reps), np.tile(op, reps)
+    box.clear()
+
+    def search():
+        box["s"] = eng.mcts_search(sa.parity_mcts_config(), my_all, op_all, 200)
+
+    t = threading.Thread(target=search)
+    t0 = time.perf_counter()
+    t.start()
+    while time.perf_counter() - t0 < 60:
+        if eng.progress()[0] >= 8192:
+            break
+        time.sleep(0.01)
+    eng.cancel()
+    t.join(timeout=120)
+    assert not t.is_alive() and "s" in box
+    sres = box["s"]
+    done = sres["num_nodes"] > 0
+    assert sres.get("cancelled") is True and 8192 <= int(done.sum()) < my_all.size
+    assert not sres["child_N"][~done].any() and not sres["target_pi"][~done].any()
+    ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my[:64], op[:64], 200, nn_mode=oracle.ACC_FMA)
+    assert done[:64].all()
+    assert_search_equal({k: v[:64] for k, v in sres.items() if k != "cancelled"}, ref, "cancelled search, searched roots")
+    after = eng.mcts_search(sa.parity_mcts_config(), my[:64], op[:64], 200)
+    assert "cancelled" not in after
+    assert_search_equal(after, ref, "search after a cancelled one")
     eng.close()

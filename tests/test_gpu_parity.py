@@ -534,9 +534,9 @@ def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
 
 @pytest.mark.parametrize("nv", [1, 2, 3])
 def test_producer_consumer_kernel_matches_oracle(blob, oracle, monkeypatch, nv):
-    """The headline launch shape (pc_kernel.cuh: 12 tree waves time-slicing `nv` virtual waves of 64 trees each, 4 matrix
-    waves fed through an LDS ring, per-tree state parked in global memory between visits) is normally chosen from
-    393,216 concurrent games; force it on a small engine (partial virtual waves, idle tree waves) and hold it to the same
+    """The producer/consumer debug shape (pc_kernel.cuh: 12 tree waves time-slicing `nv` virtual waves of 64 trees each, 4 matrix
+    waves fed through an LDS ring, per-tree state parked in global memory between visits) is never chosen automatically
+    (measured no faster than the symmetric kernel); force it on a small engine (partial virtual waves, idle tree waves) and hold it to the same
     bit-exact bar as every other shape: searches incl. late-game solver positions, every config family, whole self-play
     games with refill and all value targets."""
     import synthesis_amd as sa

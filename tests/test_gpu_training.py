@@ -137,6 +137,39 @@ def test_persistent_epoch_kernel_chains_epochs(engine, oracle, blob, gold, B, st
     engine.load_weights(blob)
 
 
+def test_epoch_kernel_recovery_keeps_the_learner(engine, oracle, blob, gold, monkeypatch):
+    """syn_train_epoch's persistent kernel needs its 16 workgroups resident together and gives up after ~10 s when another kernel
+    holds the CUs. The call must not lose the learner then: the state snapshotted before the launch is put back and the epoch
+    runs through the queued per-step launches — same bits. SYN_TRAIN_FORCE_ABORT takes that path on purpose."""
+    from tests.oracle_lib import default_train_hyper
+
+    my = gold["my_bb"].reshape(-1); op = gold["op_bb"].reshape(-1)
+    tpi = gold["target_pi"].reshape(-1, 9); tv = gold["target_v"].reshape(-1, 3)
+    B, steps = 32, 5
+    hp = default_train_hyper()
+    engine.trainer_init(blob)
+    engine.train_set_data(my, op, tpi, tv)
+    X = oracle.c4_features(my, op)
+    perm = np.random.default_rng(7).integers(0, my.size, size=2 * steps * B).astype(np.int32)
+    idx = perm.reshape(2 * steps, B)
+    l0 = engine.train_epoch(perm[: steps * B], B, 1e-3)               # the persistent kernel
+    monkeypatch.setenv("SYN_DEBUG", "1")
+    monkeypatch.setenv("SYN_TRAIN_FORCE_ABORT", "1")
+    l1 = engine.train_epoch(perm[steps * B:], B, 1e-3)                # persistent kernel, thrown away, restored, queued launches
+    monkeypatch.delenv("SYN_TRAIN_FORCE_ABORT")
+    st = engine.trainer_state()
+    wo, mo, vo, _, lo = oracle.train_steps(blob, hp, X[idx], tpi[idx], tv[idx], [1e-3] * (2 * steps))
+    assert st["step"] == 2 * steps
+    assert np.array_equal(np.concatenate([l0, l1]), lo)
+    assert np.array_equal(st["weights"], wo) and np.array_equal(st["m"], mo) and np.array_equal(st["v"], vo)
+    # and the persistent kernel continues from what the fallback left behind (both fragment images are current)
+    l2 = engine.train_epoch(perm[: 3 * B], B, 2e-3)
+    wo2, _, _, _, lo2 = oracle.train_steps(blob, hp, np.concatenate([X[idx], X[idx[:3]]]), np.concatenate([tpi[idx], tpi[idx[:3]]]),
+                                           np.concatenate([tv[idx], tv[idx[:3]]]), [1e-3] * (2 * steps) + [2e-3] * 3)
+    assert np.array_equal(engine.trainer_state()["weights"], wo2) and np.array_equal(l2, lo2[-3:])
+    engine.load_weights(blob)
+
+
 def test_data_parallel_gradient_path(engine, oracle, blob, gold):
     """configs[4] plumbing on one GPU: two 'ranks' compute gradients of their half-batches into caller-owned device
     buffers, the sum is applied with grad_scale = 1/2 — equals (to f32 rounding) one step on the combined batch, and is
