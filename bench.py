@@ -272,14 +272,20 @@ def main():
             if w3 is None or cfg3 is None:
                 continue
             e3.load_weights(w3)   # (a new network empties the table)
-            e3.selfplay(cfg3, base_seed=2, n_games=args.concurrent, outputs=False)
+            if name == "reference_selfplay_config":
+                # Fpu::Func draws a Normal per unexpanded child and scan (one ChaCha12 block each, noise.cuh): an order of magnitude
+                # more work per explore than the constant FPU — one game per tree slot, a small warm-up
+                n_games = args.concurrent
+                e3.selfplay(cfg3, base_seed=2, n_games=4096, outputs=False)
+            else:
+                e3.selfplay(cfg3, base_seed=2, n_games=args.concurrent, outputs=False)
             t1 = time.perf_counter()
             r3 = e3.selfplay(cfg3, base_seed=2, n_games=n_games, first_game=args.concurrent, outputs=False)
             dt = time.perf_counter() - t1
             hits, misses = e3.last_cache_stats()
             shape3 = e3.last_launch_shape()
             # event counts of a 32,768-game sample of the same games (the cache never changes a tree), scaled to the launch
-            ns = min(32768, n_games)
+            ns = min(32768 if name == "with_policy_cache" else 8192, n_games)
             c3 = e3.selfplay(cfg3, base_seed=2, n_games=ns, first_game=args.concurrent, outputs=False, counters=True)["counters"]
             scale = n_games / ns
             # algorithmic bytes: the tree traffic of SURVEY §8d plus one 64-byte table entry read per Policy::eval call and
@@ -306,9 +312,10 @@ def main():
 
     tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
     trained_blob = np.load(tpath) if os.path.exists(tpath) else None
-    gx = max(args.concurrent, gps // 4)   # games of every extra leg's launch: a quarter of a step
+    gx = max(args.concurrent, gps // 4)   # games of an extra leg's launch: a quarter of a step ...
+    gh = max(args.concurrent, gps // 2)   # ... half a step for the two legs with targets of their own (policy cache, trained network)
     if args.only_policy_cache:
-        out = policy_cache_leg(gx, trained_blob, reference_mcts=True)
+        out = policy_cache_leg(gh, trained_blob, reference_mcts=True)
         if rank == 0:
             print(json.dumps(out), flush=True)
         return
@@ -387,10 +394,11 @@ def main():
             "plies_per_game": plies / total_games,
             "roofline": near, "roofline_other": other,
         }
-        # ---- extra legs, most important first. Every leg is one launch of a QUARTER of a step (gx games) on the headline
-        #      concurrency, so that the whole list fits beside the driver's K = 20 / W = 5 run (20 full + 5 quarter launches + the
-        #      counted re-run = ~670 s of an ~870 s budget); a leg is skipped — and named — only if it would still overrun
-        #      --time-budget-s. The CPU baseline is part of the contract and always runs.
+        # ---- extra legs, most important first. Every leg is one launch of a QUARTER of a step (gx games; HALF a step, gh, for the
+        #      trained-network and policy-cache legs) on the headline concurrency, so that the whole list fits beside the driver's
+        #      K = 20 / W = 5 run (20 full + 5 quarter launches + the counted re-run = ~670 s of an ~870 s budget); a leg is skipped —
+        #      and named — only if it would still overrun --time-budget-s. A shorter launch carries a larger share of tail (tree
+        #      slots emptying at its end: ~5 % at a full step, ~9 % at half, ~15 % at a quarter). The CPU baseline always runs.
         t_step = elapsed / args.steps
         t_q = t_step * gx / gps          # a quarter launch of the headline configuration
         skipped = []
@@ -410,24 +418,24 @@ def main():
             out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
         next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
         extras = world == 1 and not args.no_extras
-        if extras and trained_blob is not None and fits("with_trained_weights", 1.7 * t_q + 8):
+        if extras and trained_blob is not None and fits("with_trained_weights", 3.2 * t_q + 8):
             # a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
             # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
             # random-init network (SURVEY §8d asks for both); same kernel
             eng.load_weights(trained_blob)
             eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
             t1 = time.perf_counter()
-            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
+            rt = eng.selfplay(cfg, base_seed=0, n_games=gh, first_game=next_first + args.concurrent, outputs=False)
             dt4 = time.perf_counter() - t1
             ct = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
-            next_first += args.concurrent + gx
+            next_first += args.concurrent + gh
             out["with_trained_weights"] = {
-                "games_per_s": gx / dt4, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "games_per_s": gh / dt4, "games": gh, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
                 "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
                 "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
                 "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
                 "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
-                "mfma_frac": (ct["policy_evals"] / 32768.0) * (gx / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "mfma_frac": (ct["policy_evals"] / 32768.0) * (gh / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
                                                "max_depth": c["max_depth"]}}
             eng.load_weights(blob)
@@ -452,9 +460,9 @@ def main():
                 del ro
             else:
                 out["with_replay_outputs_to_host"] = {"skipped": "not enough host memory for the 4.3 KB per game of outputs"}
-        if world == 1 and not args.no_policy_cache and fits("with_policy_cache+reference_selfplay_config", 4.5 * t_q + 40):
+        if world == 1 and not args.no_policy_cache and fits("with_policy_cache+reference_selfplay_config", 2.6 * t_q + 75):
             # (a second engine beside the first: 2 x 60 GB of node pools + the 17 GB table fit the 288 GB of HBM)
-            out.update(policy_cache_leg(gx, trained_blob if extras else None, reference_mcts=extras))
+            out.update(policy_cache_leg(gh, trained_blob if extras else None, reference_mcts=extras))
         if extras and fits("with_conv_policy", 1.6 * t_q + 8):
             # the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
             # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)

@@ -187,6 +187,39 @@ SYN_DEV f32x2 div2_safe_range(f32x2 a, f32x2 b) {
     r = __builtin_elementwise_fma(-b, q, a);
     return __builtin_elementwise_fma(r, y, q);
 }
+// Two det_expf per instruction stream: exactly det_expf's operations on each component (IEEE mul / fma / add per component, so
+// v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32 give the same bits) for the arguments that need none of its early-outs and not the
+// two-step scaling:  -86 <= x <= 88.72283  (then n >= -124). Callers test that range wave-uniformly and fall back to det_expf.
+SYN_DEV f32x2 det_expf2_in_range(f32x2 x) {
+    const f32x2 t = x * f32x2{1.44269504f, 1.44269504f};
+    const f32x2 n = f32x2{__builtin_rintf(t[0]), __builtin_rintf(t[1])};
+    f32x2 r = __builtin_elementwise_fma(n, f32x2{-0.693145751953125f, -0.693145751953125f}, x);
+    r = __builtin_elementwise_fma(n, f32x2{-1.42860682030941723212e-6f, -1.42860682030941723212e-6f}, r);
+    f32x2 p = f32x2{1.9875691500e-4f, 1.9875691500e-4f};
+    p = __builtin_elementwise_fma(p, r, f32x2{1.3981999507e-3f, 1.3981999507e-3f});
+    p = __builtin_elementwise_fma(p, r, f32x2{8.3334519073e-3f, 8.3334519073e-3f});
+    p = __builtin_elementwise_fma(p, r, f32x2{4.1665795894e-2f, 4.1665795894e-2f});
+    p = __builtin_elementwise_fma(p, r, f32x2{1.6666665459e-1f, 1.6666665459e-1f});
+    p = __builtin_elementwise_fma(p, r, f32x2{5.0000001201e-1f, 5.0000001201e-1f});
+    const f32x2 r2 = r * r;
+    const f32x2 y = __builtin_elementwise_fma(p, r2, r) + f32x2{1.0f, 1.0f};
+    return f32x2{bits_f32(f32_bits(y[0]) + ((uint32_t)(int)n[0] << 23)), bits_f32(f32_bits(y[1]) + ((uint32_t)(int)n[1] << 23))};
+}
+// The refined reciprocal of div2_safe_range for a divisor shared by several quotients, and the quotient steps on it: a / b for
+// a = 0 or 2^-60 <= a <= 2^60, 1 <= b <= 2^16 (same sequence, same bits as div2_safe_range and as the hardware's IEEE division).
+SYN_DEV float rcp_refined_safe_range(float b) {
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    return __builtin_fmaf(e, y0, y0);
+}
+SYN_DEV f32x2 div2_by_shared(f32x2 a, float b, float y) {
+    const f32x2 nb = f32x2{-b, -b}, yy = f32x2{y, y};
+    f32x2 q = a * yy;
+    f32x2 r = __builtin_elementwise_fma(nb, q, a);
+    q = __builtin_elementwise_fma(r, yy, q);
+    r = __builtin_elementwise_fma(nb, q, a);
+    return __builtin_elementwise_fma(r, yy, q);
+}
 // smallest non-zero prior the packed division accepts; records of smaller (or non-finite) priors carry a flag (sign bit)
 constexpr float PRIOR_SAFE_MIN = 0x1p-40f;
 

@@ -52,7 +52,11 @@ SYN_CONV_LANES(MODE_SELFPLAY, true)
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 0>(EngineParams);   \
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 0>(EngineParams);  \
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 2>(EngineParams);   \
-    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 2>(EngineParams);
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 2>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 12, 0>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 12, 0>(EngineParams); \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 12, 2>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 12, 2>(EngineParams);
 extern template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>(EngineParams);
 SYN_LANES2(MODE_SEARCH, false)
 SYN_LANES2(MODE_SELFPLAY, false)
@@ -363,7 +367,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         const bool needs_noise2 = P.mcts.fpu == 2 || P.mcts.noise == 2;
         if (const char* ev = debug_env("SYN_LANES2")) nw2 = std::atoi(ev);
         if (PROF) nw2 = 0;
-        if (nw2 == 8 && h->cap <= LANE_MAX_CAP) {
+        if ((nw2 == 8 || nw2 == 12) && h->cap <= LANE_MAX_CAP) {
             (void)needs_noise2;
             const int per_wg = 128 * nw2;
             const int lgrid = (want_slots + per_wg - 1) / per_wg;
@@ -390,7 +394,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), Lane2Lds<NW>::BYTES, h->stream, PL);                     \
     }
-            if (h->net_kind == 1) { if (fast) SYN_LAUNCH_L2(8, true, 2) else SYN_LAUNCH_L2(8, false, 2) }
+            if (nw2 == 12) {
+                if (h->net_kind == 1) { if (fast) SYN_LAUNCH_L2(12, true, 2) else SYN_LAUNCH_L2(12, false, 2) }
+                else { if (fast) SYN_LAUNCH_L2(12, true, 0) else SYN_LAUNCH_L2(12, false, 0) }
+            }
+            else if (h->net_kind == 1) { if (fast) SYN_LAUNCH_L2(8, true, 2) else SYN_LAUNCH_L2(8, false, 2) }
             else if (MODE == MODE_SELFPLAY && !COUNT && fast && debug_env("SYN_L2_TILE")) {
                 auto k = selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>;
                 hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lane2Lds<8>::BYTES);
@@ -618,6 +626,7 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     // + 48: the 3-quad launch rounds to multiples of 48 slots
     // (768: the 12-wave lane kernel rounds to multiples of 768 slots)
     // (2304: the producer/consumer kernel rounds to multiples of 768 x NV slots, NV <= 3)
+    // (1536: the two-trees-per-lane kernel with 12 waves rounds to multiples of 1,536 slots)
     h->pool_slots = ((h->slots + 1023) / 1024) * 1024 + 2304;
     size_t nodes = (size_t)h->pool_slots * h->cap;
     if ((e = hipMalloc(&h->d_stat, nodes * 32)) != hipSuccess) return bail("hipMalloc(node pool)", e);

@@ -13,7 +13,11 @@ namespace syn {
     template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 0>(EngineParams);   \
     template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 0>(EngineParams);  \
     template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 2>(EngineParams);   \
-    template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 2>(EngineParams);
+    template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 2>(EngineParams);  \
+    template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 12, 0>(EngineParams);  \
+    template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 12, 0>(EngineParams); \
+    template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 12, 2>(EngineParams);  \
+    template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 12, 2>(EngineParams);
 template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>(EngineParams);
 SYN_LANES2(MODE_SEARCH, false)
 SYN_LANES2(MODE_SELFPLAY, false)

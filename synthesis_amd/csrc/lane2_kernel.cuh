@@ -14,8 +14,8 @@
 // needs fewer of them (and fewer memory round trips) per explore, and phases B / C still see one finished tree per lane and
 // round — the round ends once `thresh` lanes hold a tree that waits for the network. A tree that waits is served oldest first.
 //
-// The other tree's registers (18 dwords) are the price: the shape is built for 8 waves per workgroup (2 per SIMD, 256 VGPRs),
-// i.e. the same 1,024 trees per CU as the 16-wave one-tree-per-lane shape. Results never depend on which slot or context
+// The other tree's registers (18 dwords) are the price: the shape is built for 8 or 12 waves per workgroup (2 or 3 per SIMD: 256 /
+// 168 VGPRs), i.e. 1,024 or 1,536 trees per CU. Results never depend on which slot or context
 // plays a game (trees share nothing), so every parity test of the lane kernel holds this kernel to the oracle unchanged.
 #pragma once
 #include "lane_kernel.cuh"
@@ -25,10 +25,12 @@ namespace syn {
 template <int NW>
 struct Lane2Lds {
     static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;     // 123,264 B weight + bias image
-    static constexpr size_t IDX_OFF = OUT_OFF + (size_t)NW * 1024;        // + 1 KB result patch per wave
-    static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;           // + 64 B compaction index per wave
+    // + 768 B result patch per wave (16 positions x 12 outputs); its first 64 bytes double as the wave's compaction index (rank ->
+    //   lane), which every lane reads into a register before the first tile's results overwrite it
+    static constexpr size_t FT_OFF = OUT_OFF + (size_t)NW * 768;
     static constexpr size_t PARK_OFF = FT_OFF + 64;                       // + the four feature shift tables (16 B each)
     static constexpr size_t BYTES = PARK_OFF + (size_t)NW * 64 * 2 * 20;  // + 5 parked dwords per lane and context
+    static_assert(BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 
 // what a context is doing
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    float* outw = reinterpret_cast<float*>(smem_raw + Lane2Lds<NW>::OUT_OFF) + wave * 256;
+    float* outw = reinterpret_cast<float*>(smem_raw + Lane2Lds<NW>::OUT_OFF) + wave * 192;
 
     if (POLICY == 0) stage_weight_image(wimg, P.wimg, tid, NT);
     if (POLICY == 2) stage_conv_image(wimg, P.wimg, tid, NT);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
 
     const int n_explores = P.roll.num_explores;
     const int thresh = P.lane_thresh;
-    unsigned char* const idxw = smem_raw + Lane2Lds<NW>::IDX_OFF + wave * 64;  // compaction: rank -> lane
+    unsigned char* const idxw = reinterpret_cast<unsigned char*>(outw);  // compaction: byte (rank & 15) * 4 + (rank >> 4) = lane of that rank
     unsigned long long cache_hits = 0, cache_misses = 0;
 
     // the lanes with `c` exchange their two contexts
@@ -250,14 +252,18 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
         idxw[lane] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (need) idxw[rank] = (unsigned char)lane;
+        if (need) idxw[(rank & 15) * 4 + (rank >> 4)] = (unsigned char)lane;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // tile slot (lane & 15) of tile j evaluates the position of lane byte j of src4 (slots past the last request: lane 0, finite input)
+        const uint32_t src4 = *reinterpret_cast<const uint32_t*>(idxw + (lane & 15) * 4);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
         for (int j = 0; j * 16 < n_need; j++) {
             // everything a tile needs is re-derived here instead of living in registers across the whole matrix phase
-            const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
+            const int src = (int)((src4 >> (8 * j)) & 0xFFu);
             f32x4 o;
             if (POLICY == 2) {
                 const uint64_t tmy = shfl_u64(C.my, src), top = shfl_u64(C.op, src);
@@ -273,18 +279,14 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
                 const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
                 o = TILE == 0 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             }
+            // (raw outputs: the softmax over the three outcome logits runs per tree lane in phase C, lane_softmaxes)
             const int q = lane >> 4;
-            if (q == 2) {
-                float a = o[1], b = o[2], c = o[3];
-                value_softmax(a, b, c);
-                o[1] = a; o[2] = b; o[3] = c;
-            }
-            if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 16 + q * 4) = o;
+            if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 12 + q * 4) = o;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (need && (rank >> 4) == j) {
-                const float* mine = outw + (rank & 15) * 16;
+                const float* mine = outw + (rank & 15) * 12;
                 const f32x4 r0 = *reinterpret_cast<const f32x4*>(mine);
                 const f32x4 r1 = *reinterpret_cast<const f32x4*>(mine + 4);
                 const f32x4 r2 = *reinterpret_cast<const f32x4*>(mine + 8);
@@ -297,20 +299,22 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
 
-        if (P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, C.my, C.op, lg, v0, v1, v2);
-
         // ---- phase C
         bool solved = st == CS_SOLVED;
         uint32_t leaf_flag = 0;
         if (need || hit) {
+            // the leaf's two softmaxes, then — with the probabilities — the PolicyWithCache entry of a position the network has
+            // just evaluated
+            const uint32_t lmask = legal_mask_of(C.my | C.op);
+            float pr[9];
+            lane_softmaxes(lmask, lg, pr, need, v0, v1, v2);
+            if (P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, C.my, C.op, lg, v0, v1, v2);
             // root noise applies to the root's own expansion (mcts.rs:229-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
-            LaneLeaf X;
-            X.legal_mask = legal_mask_of(C.my | C.op);
-            solved = lane_create_children(T.slab, C.blk, X, C.my, C.op, lg,
-                                          (!FAST && T.iter == 0 && C.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
-                                          P.mcts.noise_alpha, lane_noise_seed(),
-                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
+            solved = lane_write_children(T.slab, C.blk, lmask, C.my, C.op, pr,
+                                         (!FAST && T.iter == 0 && C.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
+                                         P.mcts.noise_alpha, lane_noise_seed(),
+                                         cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
         }
         lane_backprop<COUNT, FAST>(P.mcts, T, C.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, nullptr);
         if (fin) {

@@ -447,27 +447,85 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
 }
 
 // ---------------------------------------------------------------------------------------------- phase C
-// The rest of visit() for the node expanded in phase A (mcts.rs:389-423): writes its block — zero sums and one record per
-// legal column (terminal children already solved), priors = legal-move softmax of the nine raw logits. Returns any_solved.
-// `hdr_flag` (out): the value for word 3 of the block's header — non-zero iff some prior lies outside the range the descent's
-// packed division is exact on (tiny but non-zero, or not finite); backprop writes the header (sums + this word).
-// Root noise (mcts.rs:229-269) applies when `noise_kind` != 0 (the caller passes it for the root's own expansion only):
-// 1 = PolicyNoise::Equal{weight}, 2 = PolicyNoise::Dirichlet{alpha, weight} sampled from the tree's stream (noise.cuh).
-SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
-                                  const float (&lg)[9], int noise_kind, float noise_weight, float noise_alpha, uint64_t noise_seed,
-                                  float y_unvisited, uint32_t& hdr_flag) {
-    const uint32_t lmask = X.legal_mask;
+// The two softmaxes of a fresh leaf, per lane: the legal-move softmax of the nine raw logits (mcts.rs:407-423: max over the
+// children, exp(l - max), sum in child order, divide) -> pr[c] for every legal column c (other entries unspecified), and — for a
+// lane whose outputs came from the network in this round (`do_value`) — policies.rs:54-57's softmax over the three outcome logits
+// in (v0, v1, v2). Twelve exponentials and twelve divisions per lane: they run two at a time (det_expf2_in_range, one refined
+// reciprocal per sum + div2_by_shared) whenever every argument of the wave is inside those functions' exact ranges — logit gaps
+// below 41, i.e. always for a sane network — and through det_expf / IEEE division otherwise. Same bits either way.
+SYN_DEV void lane_softmaxes(uint32_t lmask, const float (&lg)[9], float (&pr)[9], bool do_value, float& v0, float& v1, float& v2) {
     float mx = -__builtin_inff();
 #pragma unroll
     for (int c = 0; c < 9; c++)
         if ((lmask >> c) & 1u) mx = lg[c] > mx ? lg[c] : mx;
-    float e[9];
-    float total = 0.0f;
+    float vm = v0;
+    vm = v1 > vm ? v1 : vm;
+    vm = v2 > vm ? v2 : vm;
+    float x[12];
+    bool in_range = true;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
-        e[c] = det_expf(lg[c] - mx);
-        if ((lmask >> c) & 1u) total += e[c];  // summed in child (= ascending column) order
+        const bool legal = ((lmask >> c) & 1u) != 0u;
+        const float d = lg[c] - mx;
+        in_range = in_range && (!legal || d >= -41.0f);  // (a legal d is <= 0, or NaN: then the comparison fails)
+        x[c] = legal ? d : 0.0f;
     }
+    {
+        const float d0 = v0 - vm, d1 = v1 - vm, d2 = v2 - vm;
+        in_range = in_range && (!do_value || (d0 >= -41.0f && d1 >= -41.0f && d2 >= -41.0f));
+        x[9] = do_value ? d0 : 0.0f;
+        x[10] = do_value ? d1 : 0.0f;
+        x[11] = do_value ? d2 : 0.0f;
+    }
+    if (__ballot(!in_range) == 0ull) {
+        float e[12];
+#pragma unroll
+        for (int i = 0; i < 12; i += 2) {
+            const f32x2 ee = det_expf2_in_range(f32x2{x[i], x[i + 1]});
+            e[i] = ee[0];
+            e[i + 1] = ee[1];
+        }
+        float total = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; c++) total += ((lmask >> c) & 1u) ? e[c] : 0.0f;  // child (= ascending column) order; + 0.0 is exact
+        float vt = 0.0f;
+        vt += e[9];
+        vt += e[10];
+        vt += e[11];
+        // 1 <= total <= 9, 1 <= vt <= 3, every e >= exp(-41) > 2^-60: inside the packed division's exact range
+        const float ry = rcp_refined_safe_range(total), rv = rcp_refined_safe_range(vt);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f32x2 q = div2_by_shared(f32x2{e[i], e[i + 1]}, total, ry);
+            pr[i] = q[0];
+            pr[i + 1] = q[1];
+        }
+        pr[8] = div2_by_shared(f32x2{e[8], e[8]}, total, ry)[0];
+        const f32x2 qa = div2_by_shared(f32x2{e[9], e[10]}, vt, rv), qb = div2_by_shared(f32x2{e[11], e[11]}, vt, rv);
+        if (do_value) { v0 = qa[0]; v1 = qa[1]; v2 = qb[0]; }
+    } else {
+        float e[9];
+        float total = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            e[c] = det_expf(lg[c] - mx);
+            if ((lmask >> c) & 1u) total += e[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 9; c++) pr[c] = e[c] / total;
+        if (do_value) value_softmax(v0, v1, v2);
+    }
+}
+
+// The rest of visit() for the node expanded in phase A (mcts.rs:389-423): writes its block — one record per legal column
+// (terminal children already solved) with the priors `pr` of lane_softmaxes. Returns any_solved.
+// `hdr_flag` (out): the value for word 3 of the block's header — non-zero iff some prior lies outside the range the descent's
+// packed division is exact on (tiny but non-zero, or not finite); backprop writes the header (sums + this word).
+// Root noise (mcts.rs:229-269) applies when `noise_kind` != 0 (the caller passes it for the root's own expansion only):
+// 1 = PolicyNoise::Equal{weight}, 2 = PolicyNoise::Dirichlet{alpha, weight} sampled from the tree's stream (noise.cuh).
+SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lmask, uint64_t leaf_my, uint64_t leaf_op,
+                                 const float (&pr)[9], int noise_kind, float noise_weight, float noise_alpha, uint64_t noise_seed,
+                                 float y_unvisited, uint32_t& hdr_flag) {
     const uint32_t nc = (uint32_t)__popc(lmask);
     const float noise = 1.0f / (float)nc;
     float dir[9];
@@ -479,27 +537,30 @@ SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneL
     const uint64_t my = leaf_my, occ = leaf_my | leaf_op;
     // (the block's header — its own sums — is written by the backprop that follows every expansion)
     // every cell that would give the mover four in a row, computed once for the whole expansion instead of one won() per
-    // child; the cell a child's stone lands on is the column's lowest free cell
-    const uint64_t wins = c4::winning_cells(my), drop = c4::next_free_cells(occ);
+    // child; the cell a child's stone lands on is the column's lowest free cell. A child's game is over if its stone makes the
+    // four or fills the board (the last of the 63 cells).
+    const uint64_t win_drop = c4::winning_cells(my) & c4::next_free_cells(occ);
+    const bool last_cell = __popcll(occ) == 62;
+    unsigned char* const rec0 = rec_ptr(slab, blk * 16u);
     uint32_t idx = 0;
     bool any_solved = false, flag = false;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
-        if ((lmask >> c) & 1u) {
-            float p = e[c] / total;
-            if (noise_kind == 1 && nc >= 2u) p = p * (1.0f - noise_weight) + noise_weight * noise;
-            if (noise_kind == 2 && nc >= 2u) {
-                float dn = 0.0f;
+        const bool legal = ((lmask >> c) & 1u) != 0u;
+        float p = pr[c];
+        if (noise_kind == 1 && nc >= 2u) p = p * (1.0f - noise_weight) + noise_weight * noise;
+        if (noise_kind == 2 && nc >= 2u) {
+            float dn = 0.0f;
 #pragma unroll
-                for (uint32_t k = 0; k < 9; k++) dn = (k == idx) ? dir[k] : dn;
-                p = p * (1.0f - noise_weight) + noise_weight * dn;
-            }
-            const uint64_t bit = drop & (0x7Full << (7 * c));
-            const bool w = (wins & bit) != 0ull;  // won(child.op_bb): the mover's stones plus this one (connect4.rs:224-229)
-            const bool over = w || (occ | bit) == c4::FULL;
-            // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost; turns 0
+            for (uint32_t k = 0; k < 9; k++) dn = (k == idx) ? dir[k] : dn;
+            p = p * (1.0f - noise_weight) + noise_weight * dn;
+        }
+        const bool w = (win_drop & (0x7Full << (7 * c))) != 0ull;  // won(child.op_bb): the mover's stones plus this one (connect4.rs:224-229)
+        const bool over = w || last_cell;
+        // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost; turns 0
+        if (legal) {
             flag = flag || !(p == 0.0f || (p >= PRIOR_SAFE_MIN && p <= 2.0f));
-            st_rec(slab, blk * 16u + idx, over ? 0u : f32_bits(y_unvisited), p, nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u));
+            *reinterpret_cast<lu3*>(rec0 + idx * 12u) = lu3{over ? 0u : f32_bits(y_unvisited), f32_bits(p), nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u)};
             any_solved = any_solved || over;
             idx++;
         }
@@ -511,6 +572,17 @@ SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneL
     }
     hdr_flag = flag ? 1u : 0u;
     return any_solved;
+}
+
+// Both steps for callers that hold the value head's probabilities already (pc_kernel.cuh).
+SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneLeaf& X, uint64_t leaf_my, uint64_t leaf_op,
+                                  const float (&lg)[9], int noise_kind, float noise_weight, float noise_alpha, uint64_t noise_seed,
+                                  float y_unvisited, uint32_t& hdr_flag) {
+    float pr[9];
+    float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
+    lane_softmaxes(X.legal_mask, lg, pr, false, u0, u1, u2);
+    return lane_write_children(slab, blk, X.legal_mask, leaf_my, leaf_op, pr, noise_kind, noise_weight, noise_alpha, noise_seed,
+                               y_unvisited, hdr_flag);
 }
 
 SYN_DEV int wave_max_i32(int v) {
@@ -1225,12 +1297,8 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
                 o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             }
+            // (raw outputs: the softmax over the three outcome logits runs per tree lane in phase C, lane_softmaxes)
             const int q = lane >> 4;
-            if (q == 2) {
-                float a = o[1], b = o[2], c = o[3];
-                value_softmax(a, b, c);
-                o[1] = a; o[2] = b; o[3] = c;
-            }
             if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 16 + q * 4) = o;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1253,18 +1321,21 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         SYN_LAP(pB)
         if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(fin)); pEvals += (unsigned long long)n_need; }
 
-        if (P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
-
         // ---- phase C
         bool solved = X.solved;
         uint32_t leaf_flag = 0;
         if (need || hit) {
+            // the leaf's two softmaxes (RolloutPolicy delivers outcome probabilities already), then — with the probabilities —
+            // the PolicyWithCache entry of a position the network has just evaluated
+            float pr[9];
+            lane_softmaxes(X.legal_mask, lg, pr, POLICY != 1 && need, v0, v1, v2);
+            if (POLICY != 1 && P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
-            solved = lane_create_children(T.slab, Wk.blk, X, Wk.my, Wk.op, lg,
-                                          (!FAST && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
-                                          P.mcts.noise_alpha, lane_noise_seed(),
-                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
+            solved = lane_write_children(T.slab, Wk.blk, X.legal_mask, Wk.my, Wk.op, pr,
+                                         (!FAST && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
+                                         P.mcts.noise_alpha, lane_noise_seed(),
+                                         cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
         }
         SYN_LAP(pC1)
         unsigned long long tmid = 0;

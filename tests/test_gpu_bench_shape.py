@@ -27,37 +27,47 @@ def blob(golden_dir):
     return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
 
 
-@pytest.mark.parametrize("conc,expect", [(262144, (4, 256, 1024)), (196608, (4, 256, 768))])
-def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, conc, expect):
+@pytest.mark.parametrize("net,conc,expect", [("mlp", 262144, (4, 256, 1024)), ("mlp", 196608, (4, 256, 768)),
+                                             ("conv", 262144, (4, 256, 1024))])
+def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, net, conc, expect):
+    """The configuration bench.py times, at its own size and with the launch shape the engine picks by itself: Connect4Net (the
+    headline) and the conv policy/value network (the `with_conv_policy` leg; layers slimnn/src/conv.rs:45-85, linear.rs:17-25)."""
     import synthesis_amd as sa
     from tests.oracle_lib import parity_rollout_config
     from tests.test_gpu_parity import assert_selfplay_equal
 
-    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE", "SYN_PC"):
+    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_LANES2", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE", "SYN_PC"):
         monkeypatch.delenv(k, raising=False)
+    if net == "conv":
+        from tests.test_gpu_convnet import conv_blob
+        weights = conv_blob()
+    else:
+        weights = blob
+    load = (lambda e: e.load_weights_conv(weights)) if net == "conv" else (lambda e: e.load_weights(weights))
     n_games, seed = conc + 12288, 20260
     cfg = sa.parity_rollout_config(800)
     big = sa.Engine(concurrent_games=conc, max_explores=800, device=0)
-    big.load_weights(blob)
+    load(big)
     got = big.selfplay(cfg, base_seed=seed, n_games=n_games)   # counters off: the very kernel instantiation bench.py times
     shape, grid, threads = big.last_launch_shape()
-    assert (shape, grid, threads) == expect, "262,144 slots: the bench's launch shape (lane-per-tree, 256 workgroups x 16 waves); 196,608: 12 waves"
+    assert (shape, grid, threads) == expect, "the launch shape bench.py's configuration takes by default"
     big.close()
     assert got["plies"].min() >= 7 and got["plies"].max() <= 63
 
     # (1) game for game against the oracle: blocks of games from the first wave, the last slots of the pool (highest
     # slab offsets: > 40 GB into the pool) and the refill tail
     for first in (0, 65536 + 5, conc - 8, conc, n_games - 8):
-        ref = oracle.c4_selfplay(parity_rollout_config(800), blob, seed, 8, first_game=first, threads=8, nn_mode=oracle.ACC_FMA)
+        ref = oracle.c4_selfplay(parity_rollout_config(800), weights, seed, 8, first_game=first, threads=8, nn_mode=oracle.ACC_FMA,
+                                 net=net)
         sub = {k: got[k][first:first + 8] for k in ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind")}
-        assert_selfplay_equal(sub, ref, f"bench shape, games {first}..{first + 7}")
+        assert_selfplay_equal(sub, ref, f"bench shape ({net}), games {first}..{first + 7}")
 
-    # (2) every game against the 4,096-slot engine (row-per-tree kernel, another node layout): same lengths, same last
-    # positions and same final results
+    # (2) every game against a 4,096-slot engine (Connect4Net: row-per-tree kernel, another node layout; conv: the 4-wave
+    # lane-per-tree shape): same lengths, same last positions and same final results
     small = sa.Engine(concurrent_games=4096, max_explores=800, device=0)
-    small.load_weights(blob)
+    load(small)
     ref = small.selfplay(cfg, base_seed=seed, n_games=n_games)
-    assert small.last_launch_shape()[0] in (1, 2)
+    assert small.last_launch_shape()[0] in ((1, 2) if net == "mlp" else (4,))
     small.close()
     assert np.array_equal(got["plies"], ref["plies"])
     assert np.array_equal(got["final_kind"], ref["final_kind"])

@@ -23,10 +23,11 @@ def blob(golden_dir):
     return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
 
 
-@pytest.fixture()
-def lanes2(monkeypatch):
+@pytest.fixture(params=[8, 12])
+def lanes2(monkeypatch, request):
     monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
-    monkeypatch.setenv("SYN_LANES2", "8")
+    monkeypatch.setenv("SYN_LANES2", str(request.param))
+    return request.param
 
 
 @pytest.mark.parametrize("conc", [1100, 3000])
@@ -38,7 +39,7 @@ def test_lanes2_kernel_matches_oracle(blob, oracle, lanes2, conc):
     eng.load_weights(blob)
     my, op = random_positions(oracle, 300, seed=31, max_moves=60)
     got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
-    assert eng.last_launch_shape()[0] == SHAPE_LANES2 and eng.last_launch_shape()[2] == 512
+    assert eng.last_launch_shape()[0] == SHAPE_LANES2 and eng.last_launch_shape()[2] == 64 * lanes2
     ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
     assert_search_equal(got, ref, "lanes2 search")
     for explores in (0, 1, 2):
