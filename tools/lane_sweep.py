@@ -15,9 +15,12 @@ from bench import make_conv_weights, make_weights
 argv = sys.argv[1:]
 conv = bool(argv) and argv[0] == "conv"
 if conv: argv = argv[1:]
+trained = bool(argv) and argv[0] == "trained"   # the trained Connect4Net checkpoint (deep narrow trees) instead of the fixed-seed init
+if trained: argv = argv[1:]
 do_eval = bool(argv) and argv[-1] == "eval"
 if do_eval: argv = argv[:-1]
 blob = make_conv_weights() if conv else make_weights()
+if trained: blob = np.load(os.path.join(ROOT, 'tests', 'golden', 'c4net_trained_f32.npy'))
 combos = [tuple(map(int, a.split(":"))) for a in argv] or [(65536, 16), (131072, 16), (262144, 16)]
 cfg = sa.parity_rollout_config(800)
 for c in combos:
