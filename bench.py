@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-learner-loop", action="store_true", help="skip the two iterations of the N-rank learning loop (learner_loop)")
     ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
     ap.add_argument("--only-policy-cache", action="store_true",
                     help="run nothing but the PolicyWithCache + reference-config legs (the command tools/collect_profiles.sh profiles for their rooflines)")
@@ -359,6 +360,31 @@ def main():
     last_ms = kernel_ms[-1]
     avg_ms = float(np.mean(kernel_ms))
 
+    # ---- BASELINE configs[4] (self-play on every GPU + the training step): two iterations of the learning loop in the shape that
+    #      scales (synthesis_amd.learner.LearningLoop: every rank plays 8,192 games at 200 explores, rank 0 gathers, de-duplicates and
+    #      trains with the persistent epoch kernel, the 122 KB of weights are broadcast) — every rank takes part, rank 0 reports the
+    #      second iteration's seconds per phase. Not part of the timed steps.
+    loop_rec = None
+    if not args.no_learner_loop:
+        try:
+            from synthesis_amd.learner import LearningLoop
+
+            e4 = sa.Engine(concurrent_games=8192, max_explores=200, device=local_rank)
+            loop = LearningLoop(e4, "mlp", blob, dist=dist, device=local_rank, seed=7, weight_decay=1e-6)
+            cfg4 = sa.parity_rollout_config(200)
+            recs = [loop.iteration(cfg4, 8192 * world, 20000 * world, 1, 32) for _ in range(2)]
+            e4.close()
+            if rank == 0:
+                r4 = recs[-1]
+                loop_rec = {"games_per_iteration": r4["games"], "explores": 200, "ranks": world, "optimiser_steps": r4["optimiser_steps"],
+                            "unique_positions": r4["unique"], "seconds": r4["seconds"],
+                            "games_per_s_of_the_whole_iteration": r4["games"] / max(1e-9, r4["seconds"]["total"]),
+                            "collectives": "gather_object of the new positions to rank 0 + one %d-byte weight broadcast per iteration (%s)"
+                                           % (blob.size * 4, args.dist_backend if world > 1 else "none: one rank"),
+                            "note": "the 1 -> 8 GPU curve of this loop has not been measured on an 8-GPU node (one GPU per box here)"}
+        except Exception as ex:   # never lose the bench line over the learner leg
+            loop_rec = {"error": repr(ex)}
+
     if rank == 0:
         total_games = gps * world * args.steps
         games_per_s = total_games / elapsed
@@ -394,6 +420,8 @@ def main():
             "plies_per_game": plies / total_games,
             "roofline": near, "roofline_other": other,
         }
+        if loop_rec is not None:
+            out["learner_loop"] = loop_rec
         # ---- extra legs, most important first. Every leg is one launch of a QUARTER of a step (gx games; HALF a step, gh, for the
         #      trained-network and policy-cache legs) on the headline concurrency, so that the whole list fits beside the driver's
         #      K = 20 / W = 5 run (20 full + 5 quarter launches + the counted re-run = ~670 s of an ~870 s budget); a leg is skipped —

@@ -135,59 +135,6 @@ SYN_DEV f32x4 conv_tile16(const float* __restrict__ img, int lane, uint64_t my, 
     return hacc;
 }
 
-// Two tiles (32 positions) per call: the same per-output fma chains as two conv_tile16 calls — bit-identical results — but a
-// wave then carries FOUR independent accumulator chains per board cell (conv and heads of either tile) instead of two, so a
-// dependent v_mfma never waits for its predecessor's result (a 16x16x4 chain step has 40 cycles of latency for 32 of issue), and
-// every head fragment fetched from LDS feeds two tiles.
-SYN_DEV void conv_tile16x2(const float* __restrict__ img, int lane, uint64_t my0, uint64_t op0, uint64_t my1, uint64_t op1,
-                           f32x4& out0, f32x4& out1) {
-    using G = ConvGeom;
-    const int q = lane >> 4;
-    uint64_t S0[5], S1[5];
-    float ca[5];
-#pragma unroll
-    for (int s = 0; s < 5; s++) {
-        S0[s] = conv_tap_board(my0, op0, 4 * s + q);
-        S1[s] = conv_tap_board(my1, op1, 4 * s + q);
-        ca[s] = img[G::CONVA_OFF + s * 64 + lane];
-    }
-    const f32x4 cb = *reinterpret_cast<const f32x4*>(img + G::CBIAS_OFF + q * 4);
-    f32x4 h0 = *reinterpret_cast<const f32x4*>(img + G::HBIAS_OFF + q * 4);
-    f32x4 h1 = h0;
-    const float* hw = img + G::HEAD_OFF + lane * 4;
-#pragma unroll 1
-    for (int r = 0; r < 7; r++) {
-        uint32_t lo0[5], hi0[5], lo1[5], hi1[5];
-#pragma unroll
-        for (int s = 0; s < 5; s++) {
-            const uint64_t v0 = S0[s] >> r, v1 = S1[s] >> r;
-            lo0[s] = (uint32_t)v0; hi0[s] = (uint32_t)(v0 >> 32);
-            lo1[s] = (uint32_t)v1; hi1[s] = (uint32_t)(v1 >> 32);
-        }
-#pragma unroll
-        for (int c = 0; c < 9; c++) {
-            const int p = r * 9 + c;
-            f32x4 a0 = cb, a1 = cb;
-#pragma unroll
-            for (int s = 0; s < 5; s++) {
-                const uint32_t b0 = 7 * c < 32 ? __builtin_amdgcn_ubfe(lo0[s], 7 * c, 1) : __builtin_amdgcn_ubfe(hi0[s], 7 * c - 32, 1);
-                const uint32_t b1 = 7 * c < 32 ? __builtin_amdgcn_ubfe(lo1[s], 7 * c, 1) : __builtin_amdgcn_ubfe(hi1[s], 7 * c - 32, 1);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)b0, a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)b1, a1, 0, 0, 0);
-            }
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + p * 256);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float x0 = a0[k] > 0.0f ? a0[k] : 0.0f, x1 = a1[k] > 0.0f ? a1[k] : 0.0f;
-                h0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[k], x0, h0, 0, 0, 0);
-                h1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[k], x1, h1, 0, 0, 0);
-            }
-        }
-    }
-    out0 = h0;
-    out1 = h1;
-}
-
 // Batched Policy::eval with Connect4ConvNet: n positions -> logits[n][9], value[n][3] (the stand-alone form of the tile)
 template <int NT>
 __global__ __launch_bounds__(NT) void policy_eval_conv_kernel(const float* __restrict__ g_img,
@@ -198,35 +145,26 @@ __global__ __launch_bounds__(NT) void policy_eval_conv_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     stage_conv_image(smem, g_img, tid, NT);
     __syncthreads();
-    const int ntiles = (n + 15) >> 4, npairs = (ntiles + 1) >> 1;
+    const int ntiles = (n + 15) >> 4;
     const int j = lane & 15, q = lane >> 4;
-    for (int pair = blockIdx.x * (NT / 64) + wave; pair < npairs; pair += gridDim.x * (NT / 64)) {
+    for (int tile = blockIdx.x * (NT / 64) + wave; tile < ntiles; tile += gridDim.x * (NT / 64)) {
         uint32_t img_off = 0;  // opaque per iteration: the fragment reads stay next to their MFMAs (see policy_eval_kernel)
         asm volatile("" : "+v"(img_off));
-        const int pos0 = pair * 32 + j, pos1 = pos0 + 16;
-        const bool valid0 = pos0 < n, valid1 = pos1 < n;
-        const uint64_t my0 = valid0 ? my_bb[pos0] : 0ull, op0 = valid0 ? op_bb[pos0] : 0ull;
-        const uint64_t my1 = valid1 ? my_bb[pos1] : 0ull, op1 = valid1 ? op_bb[pos1] : 0ull;
-        f32x4 o0, o1;
-        if (pair * 2 + 1 < ntiles) conv_tile16x2(smem + img_off, lane, my0, op0, my1, op1, o0, o1);   // (wave-uniform)
-        else { o0 = conv_tile16(smem + img_off, lane, my0, op0); o1 = o0; }
+        const int pos = tile * 16 + j;
+        const bool valid = pos < n;
+        const uint64_t my = valid ? my_bb[pos] : 0ull, op = valid ? op_bb[pos] : 0ull;
+        f32x4 o = conv_tile16(smem + img_off, lane, my, op);
+        if (valid) {
+            if (q < 2) {
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int pos = t ? pos1 : pos0;
-            const bool valid = t ? valid1 : valid0;
-            const f32x4 o = t ? o1 : o0;
-            if (valid) {
-                if (q < 2) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) logits[(size_t)pos * 9 + q * 4 + r] = o[r];
-                } else if (q == 2) {
-                    logits[(size_t)pos * 9 + 8] = o[0];
-                    float v0 = o[1], v1 = o[2], v2 = o[3];
-                    value_softmax(v0, v1, v2);
-                    value[(size_t)pos * 3 + 0] = v0;
-                    value[(size_t)pos * 3 + 1] = v1;
-                    value[(size_t)pos * 3 + 2] = v2;
-                }
+                for (int r = 0; r < 4; r++) logits[(size_t)pos * 9 + q * 4 + r] = o[r];
+            } else if (q == 2) {
+                logits[(size_t)pos * 9 + 8] = o[0];
+                float v0 = o[1], v1 = o[2], v2 = o[3];
+                value_softmax(v0, v1, v2);
+                value[(size_t)pos * 3 + 0] = v0;
+                value[(size_t)pos * 3 + 1] = v1;
+                value[(size_t)pos * 3 + 2] = v2;
             }
         }
     }

@@ -1275,15 +1275,35 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // results of tile jj: the 12 outputs per position return through the wave's 1 KB LDS patch
-        auto deliver = [&](const f32x4& o, int jj) {
+#pragma unroll 1
+        for (int j = 0; j * 16 < n_need; j++) {
+            if (PROF) pTiles++;
+            // everything a tile needs is re-derived here instead of living in registers across the whole matrix phase:
+            // the two derived boards (10 VALU) and the lane's feature shift table (one 16-byte LDS read)
+            const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
+            f32x4 o;
+            if (POLICY == 2) {
+                // Connect4ConvNet reads the two bitplanes themselves
+                const uint64_t tmy = shfl_u64(Wk.my, src), top = shfl_u64(Wk.op, src);
+                uint32_t img_off = 0;  // opaque per tile: the image reads stay LDS reads next to their MFMAs
+                asm volatile("" : "+v"(img_off));
+                o = conv_tile16(wimg + img_off, lane, tmy, top);
+            } else {
+                uint64_t hi, lo;
+                feature_boards(Wk.my, Wk.op, hi, lo);
+                const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + LaneLds<NW>::FT_OFF + (lane >> 4) * 16);
+                FeatureTable FT;
+                FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
+                const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
+                o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+            }
             // (raw outputs: the softmax over the three outcome logits runs per tree lane in phase C, lane_softmaxes)
             const int q = lane >> 4;
             if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 16 + q * 4) = o;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (need && (rank >> 4) == jj) {
+            if (need && (rank >> 4) == j) {
                 const float* mine = outw + (rank & 15) * 16;
                 const f32x4 r0 = *reinterpret_cast<const f32x4*>(mine);
                 const f32x4 r1 = *reinterpret_cast<const f32x4*>(mine + 4);
@@ -1295,41 +1315,6 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-#pragma unroll 1
-        for (int j = 0; j * 16 < n_need; j += (POLICY == 2 ? 2 : 1)) {
-            if (PROF) pTiles++;
-            // everything a tile needs is re-derived here instead of living in registers across the whole matrix phase:
-            // the two derived boards (10 VALU) and the lane's feature shift table (one 16-byte LDS read)
-            const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
-            if (POLICY == 2) {
-                // Connect4ConvNet reads the two bitplanes themselves, and takes its tiles two at a time (conv_tile16x2)
-                const bool two = (j + 1) * 16 < n_need;  // wave-uniform
-                const int src1 = two ? (int)idxw[16 * (j + 1) + (lane & 15)] : src;
-                const uint64_t tmy = shfl_u64(Wk.my, src), top = shfl_u64(Wk.op, src);
-                const uint64_t tmy1 = shfl_u64(Wk.my, src1), top1 = shfl_u64(Wk.op, src1);
-                uint32_t img_off = 0;  // opaque per tile: the image reads stay LDS reads next to their MFMAs
-                asm volatile("" : "+v"(img_off));
-                f32x4 o0, o1;
-                if (two) {
-                    if (PROF) pTiles++;
-                    conv_tile16x2(wimg + img_off, lane, tmy, top, tmy1, top1, o0, o1);
-                    deliver(o0, j);
-                    deliver(o1, j + 1);
-                } else {
-                    o0 = conv_tile16(wimg + img_off, lane, tmy, top);
-                    deliver(o0, j);
-                }
-            } else {
-                uint64_t hi, lo;
-                feature_boards(Wk.my, Wk.op, hi, lo);
-                const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + LaneLds<NW>::FT_OFF + (lane >> 4) * 16);
-                FeatureTable FT;
-                FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
-                const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
-                const f32x4 o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
-                deliver(o, j);
-            }
         }
 
         if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 1] = SYN_STAMP();

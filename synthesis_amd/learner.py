@@ -1,61 +1,218 @@
-"""Data-parallel learner step (BASELINE configs[4]): the optimiser half of alpha_zero.rs:72-94 with the
-gradient all-reduce over RCCL/xGMI that the single-process reference does not need.
+"""The learner side of the reference's loop on N GPUs (BASELINE configs[4]):
 
-One process per GPU. Every rank holds identical weights and Adam moments on its own engine; per step each rank computes
-the gradients of ITS shard of the batch with the HIP training kernels (`syn_train_gradients_device`, loss scaled by
-1 / local batch like alpha_zero.rs:44), the 30,492-float gradient buffer (122 KB — latency-bound, one message) is
-all-reduced (sum) and every rank applies the same Adam update with `grad_scale = 1 / world`
-(`syn_train_apply_device`), i.e. the step on the mean loss of the global batch. No parameter broadcast is ever needed.
+    alpha_zero()            synthesis/src/alpha_zero.rs:16-118   iterate { gather_experience -> dedup -> Adam epochs -> save model }
+    gather_experience()     alpha_zero.rs:120-179                worker threads play games_per_train games, buffers concatenated
+    train step              alpha_zero.rs:72-94                  forward, kl_div losses, Adam
 
-torch is plumbing here: it owns the gradient buffer (so `torch.distributed` can reduce it in place — backend "nccl" is RCCL
-on ROCm) and the device copies of the batch. With the "gloo" backend (CPU tests, or several ranks sharing one GPU) the
-buffer is staged through host memory.
+`LearningLoop` is that loop in the shape that scales on one node: EVERY rank plays its share of an iteration's games (sharded by
+game index, no collective on the data path — games share nothing), rank 0 gathers the new positions, owns the replay buffer and
+trains with the persistent epoch kernel (`syn_train_epoch`: 13 us per optimiser step at the reference's batch of 32 — a
+data-parallel step at that batch size moves 122 KB over xGMI for 13 us of compute and can only be slower than one GPU), and the
+new parameters (122 KB for Connect4Net, 50 KB for Connect4ConvNet) are broadcast once per iteration. One process per GPU;
+torch.distributed is the transport (backend "nccl" is RCCL over xGMI; "gloo" in the CPU tests and when ranks share a GPU).
+With one rank it is exactly the single-GPU loop. The games an iteration plays, the replay buffer and therefore the trained
+weights do not depend on the number of ranks.
+
+`DataParallelLearner` is the other reading of configs[4] — a gradient all-reduce per optimiser step — kept for callers who want
+it (large batches): every rank computes the gradients of ITS shard of the batch (`syn_train_gradients_device`), the gradient
+buffer and the two loss sums travel in ONE all-reduce, every rank applies the same Adam update with grad_scale = 1 / world
+(`syn_train_apply_device`), so weights stay identical without a broadcast. Both networks. The data set and the epoch's
+permutation live on the device; a step gathers its shard there and the losses stay on the device until asked for.
+
+torch is plumbing in both: it owns the buffers torch.distributed moves. Nothing here touches oracle/.
 """
+import time
+
 import numpy as np
 
-from .engine import NUM_PARAMS
+from .engine import CONV_NUM_PARAMS, NUM_PARAMS, shard_games
 
 
-class DataParallelLearner:
-    def __init__(self, engine, blob, dist=None, device=0, **hyper):
+def _lr_at(schedule, i_iter):
+    """alpha_zero.rs:62-69: the last (iteration, lr) entry whose iteration is <= i_iter + 1"""
+    lr = schedule[0][1]
+    for it, v in schedule:
+        if it <= i_iter + 1:
+            lr = v
+    return lr
+
+
+class LearningLoop:
+    """alpha_zero.rs:16-118 with self-play on every rank and the learner on rank 0 (see the module docstring).
+
+    engine       this rank's sa.Engine (self-play; on rank 0 also the learner and the de-duplication)
+    net          "mlp" (Connect4Net, study-connect4/src/policies.rs:14-59) | "conv" (Connect4ConvNet)
+    blob         initial parameters — identical on every rank (P::new(&vs), alpha_zero.rs:31)
+    dist         torch.distributed (initialised) or None for one rank
+    """
+
+    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, **hyper):
         import torch
 
         self._torch = torch
         self.engine = engine
+        self.net = net
+        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.lr_schedule = list(lr_schedule)
+        self.seed = int(seed)
+        self.n_params = CONV_NUM_PARAMS if net == "conv" else NUM_PARAMS
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        assert blob.size == self.n_params
+        self._load = engine.load_weights_conv if net == "conv" else engine.load_weights
+        self._load(blob)
+        self.weights = blob.copy()
+        # the buffer the broadcast moves: on the GPU for RCCL, on the host for gloo
+        on_gpu = self.dist is not None and self.dist.get_backend() == "nccl"
+        self._wbuf = torch.zeros(self.n_params, dtype=torch.float32, device=torch.device(f"cuda:{device}") if on_gpu else "cpu")
+        if self.rank == 0:
+            (engine.trainer_init_conv if net == "conv" else engine.trainer_init)(blob, **hyper)
+        # replay buffer (rank 0): positions as bitboards + targets + the game each step came from (data.rs:107-158)
+        self.R = dict(my=np.zeros(0, np.uint64), op=np.zeros(0, np.uint64), pi=np.zeros((0, 9), np.float32),
+                      v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
+        self.games_played = 0
+        self.iterations_done = 0
+
+    def iteration(self, cfg, games_per_train, games_to_keep, epochs, batch_size):
+        """One pass of the loop body (alpha_zero.rs:42-100). Returns this rank's record of it (rank 0's has the learner's numbers)."""
+        it = self.iterations_done
+        t0 = time.perf_counter()
+        # ---- gather_experience: this rank's share of the new games; global game index = seed offset, never reused
+        off, count = shard_games(games_per_train, self.rank, self.world)
+        first = it * games_per_train + off
+        sp = self.engine.selfplay(cfg, base_seed=self.seed, n_games=count, first_game=first)
+        t_play = time.perf_counter() - t0
+        n = sp["plies"]
+        mask = np.arange(63)[None, :] < n[:, None]
+        new = dict(my=sp["states_bb"][..., 0][mask], op=sp["states_bb"][..., 1][mask], pi=sp["pis"][mask], v=sp["vs"][mask],
+                   gid=(first + np.arange(count))[:, None].repeat(63, 1)[mask])
+        t1 = time.perf_counter()
+        if self.dist is not None:
+            # the new positions go to the learner's rank only (in rank order = game order): ~18 MB per 8,192 games
+            parts = [None] * self.world if self.rank == 0 else None
+            self.dist.gather_object(new, parts, dst=0)
+            if self.rank == 0:
+                new = {k: np.concatenate([p_[k] for p_ in parts]) for k in new}
+        t_gather = time.perf_counter() - t1
+        self.games_played += games_per_train
+        lr = _lr_at(self.lr_schedule, it)
+        rec = dict(iteration=it + 1, lr=lr, games=int(games_per_train), games_this_rank=int(count),
+                   plies_per_game=float(n.mean()) if count else 0.0)
+        t_dedup = t_train = 0.0
+        if self.rank == 0:
+            R = {k: np.concatenate([self.R[k], new[k]]) for k in self.R}
+            keep = R["gid"] >= self.games_played - games_to_keep   # keep_last_n_games (data.rs:160-194)
+            self.R = {k: a[keep] for k, a in R.items()}
+            # ---- deduplicate on the GPU (data.rs:196-235)
+            t2 = time.perf_counter()
+            D = self.engine.replay_deduplicate(self.R["my"], self.R["op"], self.R["pi"], self.R["v"])
+            t_dedup = time.perf_counter() - t2
+            n_unique = int(D["num"].size)
+            # ---- epochs of optimiser steps (alpha_zero.rs:72-94): one upload, one persistent kernel launch per epoch
+            t3 = time.perf_counter()
+            self.engine.train_set_data(D["my_bb"], D["op_bb"], D["pis"], D["vs"])
+            steps, epoch_losses = 0, []
+            n_steps = n_unique // batch_size   # drop_last = true (data.rs:41-62)
+            for ep in range(epochs):
+                perm = np.random.default_rng([self.seed, it, ep]).permutation(n_unique)   # BatchRandSampler's randperm
+                if n_steps:
+                    sl = self.engine.train_epoch(perm[: n_steps * batch_size], batch_size, lr)
+                    epoch_losses.append((sl.astype(np.float64).sum(axis=0) * batch_size / n_unique).tolist())
+                steps += n_steps
+            t_train = time.perf_counter() - t3
+            self.weights = self.engine.trainer_state()["weights"]
+            rec.update(steps_in_buffer=int(self.R["my"].size), unique=n_unique, optimiser_steps=steps, epoch_losses=epoch_losses)
+        # ---- model_{i+1} (alpha_zero.rs:97,194): the trained parameters become every rank's self-play network
+        t4 = time.perf_counter()
+        if self.dist is not None:
+            if self.rank == 0:
+                self._wbuf.copy_(self._torch.from_numpy(self.weights))
+            self.dist.broadcast(self._wbuf, src=0)
+            self.weights = self._wbuf.cpu().numpy().copy()
+            self._load(self.weights)
+        elif self.rank == 0:
+            self.engine.trainer_publish_weights()   # one rank: the learner's image is copied on the device
+        t_bcast = time.perf_counter() - t4
+        self.iterations_done += 1
+        rec["seconds"] = dict(selfplay=round(t_play, 4), gather=round(t_gather, 4), dedup=round(t_dedup, 4), train=round(t_train, 4),
+                              broadcast=round(t_bcast, 4), total=round(time.perf_counter() - t0, 4))
+        return rec
+
+
+class DataParallelLearner:
+    """Gradient all-reduce per optimiser step (see the module docstring). Every rank holds identical weights and Adam moments."""
+
+    def __init__(self, engine, blob, dist=None, device=0, net="mlp", **hyper):
+        import torch
+
+        self._torch = torch
+        self.engine = engine
+        self.net = net
         self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.device = torch.device(f"cuda:{device}")
-        engine.trainer_init(blob, **hyper)
-        self.grads = torch.zeros(NUM_PARAMS, dtype=torch.float32, device=self.device)
+        self.n_params = CONV_NUM_PARAMS if net == "conv" else NUM_PARAMS
+        (engine.trainer_init_conv if net == "conv" else engine.trainer_init)(blob, **hyper)
+        # [gradients | pi-loss sum | v-loss sum]: one buffer, one all-reduce per step
+        self.buf = torch.zeros(self.n_params + 2, dtype=torch.float32, device=self.device)
         self._staged = self.dist is not None and self.dist.get_backend() != "nccl"
+        self._host = torch.zeros(self.n_params + 2, dtype=torch.float32).pin_memory() if self._staged else None
+        self._loss_sum = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._steps = 0
+        self._data = None
+
+    # ---- the data set of an iteration and an epoch's order: uploaded once, gathered on the device per step
+    def set_data(self, my_bb, op_bb, target_pi, target_v):
+        t = self._torch
+        self._data = (t.from_numpy(np.ascontiguousarray(my_bb, dtype=np.uint64).view(np.int64)).to(self.device),
+                      t.from_numpy(np.ascontiguousarray(op_bb, dtype=np.uint64).view(np.int64)).to(self.device),
+                      t.from_numpy(np.ascontiguousarray(target_pi, dtype=np.float32).reshape(-1, 9)).to(self.device),
+                      t.from_numpy(np.ascontiguousarray(target_v, dtype=np.float32).reshape(-1, 3)).to(self.device))
+
+    def step_indices(self, idx, lr):
+        """One optimiser step on the samples `idx` (THIS rank's shard of the global batch) of the uploaded data set."""
+        t = self._torch
+        ix = t.as_tensor(np.ascontiguousarray(idx, dtype=np.int64), device=self.device)
+        my, op, tpi, tv = (a.index_select(0, ix).contiguous() for a in self._data)
+        self._step_device(my, op, tpi, tv, lr)
 
     def step(self, my_bb, op_bb, target_pi, target_v, lr):
-        """One optimiser step; the arguments are THIS rank's shard of the batch. Returns the (pi_loss, v_loss) of the
-        global batch (mean over ranks of the per-shard means)."""
-        torch = self._torch
-        my = torch.from_numpy(np.ascontiguousarray(my_bb, dtype=np.uint64).view(np.int64)).to(self.device)
-        op = torch.from_numpy(np.ascontiguousarray(op_bb, dtype=np.uint64).view(np.int64)).to(self.device)
-        tpi = torch.from_numpy(np.ascontiguousarray(target_pi, dtype=np.float32)).to(self.device)
-        tv = torch.from_numpy(np.ascontiguousarray(target_v, dtype=np.float32)).to(self.device)
-        torch.cuda.synchronize(self.device)  # the engine runs on its own stream
+        """One optimiser step; the arguments are THIS rank's shard of the batch (host arrays). Returns the (pi_loss, v_loss) of
+        the global batch (mean over ranks of the per-shard means) — which costs a device synchronisation; `step_indices` +
+        `take_losses` keep that off the step's critical path."""
+        t = self._torch
+        my = t.from_numpy(np.ascontiguousarray(my_bb, dtype=np.uint64).view(np.int64)).to(self.device)
+        op = t.from_numpy(np.ascontiguousarray(op_bb, dtype=np.uint64).view(np.int64)).to(self.device)
+        tpi = t.from_numpy(np.ascontiguousarray(target_pi, dtype=np.float32)).to(self.device)
+        tv = t.from_numpy(np.ascontiguousarray(target_v, dtype=np.float32)).to(self.device)
+        self._step_device(my, op, tpi, tv, lr)
+        return (self.buf[self.n_params:] / self.world).cpu().numpy()
+
+    def _step_device(self, my, op, tpi, tv, lr):
+        t = self._torch
+        t.cuda.current_stream(self.device).synchronize()  # the engine runs on its own stream: the batch must be there
         losses = self.engine.train_gradients_device(my.data_ptr(), op.data_ptr(), tpi.data_ptr(), tv.data_ptr(),
-                                                    int(my.numel()), self.grads.data_ptr())  # returns after the kernel
+                                                    int(my.numel()), self.buf.data_ptr())  # returns after the kernel
+        self.buf[self.n_params:] = t.from_numpy(losses)   # the two loss sums ride in the same message as the gradients
         if self.dist is not None:
             if self._staged:
-                g = self.grads.cpu()
-                self.dist.all_reduce(g)
-                self.grads.copy_(g)
-                l = torch.from_numpy(losses.copy())
-                self.dist.all_reduce(l)
+                self._host.copy_(self.buf)
+                self.dist.all_reduce(self._host)
+                self.buf.copy_(self._host)
             else:
-                self.dist.all_reduce(self.grads)  # RCCL over xGMI: one 122 KB message
-                l = torch.from_numpy(losses.copy()).to(self.device)
-                self.dist.all_reduce(l)
-                l = l.cpu()
-            losses = (l / self.world).numpy()
-            torch.cuda.synchronize(self.device)
-        self.engine.train_apply_device(self.grads.data_ptr(), lr, grad_scale=1.0 / self.world)
-        return losses
+                self.dist.all_reduce(self.buf)  # RCCL over xGMI: one 122 KB message (latency-bound)
+            t.cuda.current_stream(self.device).synchronize()
+        self._loss_sum += self.buf[self.n_params:].double() / self.world
+        self._steps += 1
+        self.engine.train_apply_device(self.buf.data_ptr(), lr, grad_scale=1.0 / self.world)
+
+    def take_losses(self):
+        """(sum of the per-step global (pi_loss, v_loss), steps) since the last call — one read-back per epoch instead of per step."""
+        out = self._loss_sum.cpu().numpy().copy(), self._steps
+        self._loss_sum.zero_()
+        self._steps = 0
+        return out
 
     def publish(self):
         """The trained network becomes the engine's self-play network (model_{i+1}.ot of alpha_zero.rs:97)."""

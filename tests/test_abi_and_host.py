@@ -163,6 +163,84 @@ def test_multi_rank_reduce_under_gloo(tmp_path):
     assert int(line[3]) == (2 * 2 + 0) * 500 + (2 * 2 + 1) * 500  # SUM of the two shard offsets
 
 
+LOOP_WORKER = r'''
+import sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch  # noqa
+from synthesis_amd import dist_util
+from synthesis_amd.engine import NUM_PARAMS
+from synthesis_amd.learner import LearningLoop
+
+class StandInEngine:
+    """No GPU here: an engine-shaped object whose results are simple functions of its inputs, so that the loop's sharding,
+    gather, replay bookkeeping and broadcast can be checked under gloo with two ranks (the real engine runs in the -m gpu tests)."""
+    def __init__(self): self.w = None; self.tw = None; self.loaded = []
+    def load_weights(self, w): self.w = np.array(w, np.float32); self.loaded.append(float(self.w[0]))
+    def trainer_init(self, w, **kw): self.tw = np.array(w, np.float32); self.steps = 0
+    def selfplay(self, cfg, base_seed, n_games, first_game=0, **kw):
+        g = first_game + np.arange(n_games)
+        plies = (7 + g % 5).astype(np.int32)
+        st = np.zeros((n_games, 63, 2), np.uint64)
+        st[..., 0] = (g[:, None] * 100 + np.arange(63)[None, :]).astype(np.uint64)
+        # what the games look like depends on the network in use: a rank that missed a broadcast would be caught
+        st[..., 1] = np.uint64(int(round(float(self.w[0]) * 1000)))
+        return dict(plies=plies, states_bb=st, pis=np.full((n_games, 63, 9), 1 / 9, np.float32), vs=np.zeros((n_games, 63, 3), np.float32),
+                    final_kind=np.zeros(n_games, np.uint8))
+    def replay_deduplicate(self, my, op, pi, v):
+        key = np.stack([my, op], 1)
+        _, idx = np.unique(key, axis=0, return_index=True)
+        idx = np.sort(idx)
+        return dict(my_bb=my[idx], op_bb=op[idx], pis=pi[idx], vs=v[idx], num=np.ones(idx.size, np.uint32))
+    def train_set_data(self, my, op, pi, v): self.data_n = my.size; self.data_sum = int(my.sum() % 1000003)
+    def train_epoch(self, perm, batch, lr):
+        steps = perm.size // batch
+        self.tw = self.tw + np.float32(steps * lr) + np.float32(self.data_sum * 1e-9)
+        self.steps += steps
+        return np.ones((steps, 2), np.float32)
+    def trainer_state(self): return dict(weights=self.tw.copy(), step=self.steps)
+    def trainer_publish_weights(self): self.load_weights(self.tw)
+
+rank, local_rank, world = dist_util.rank_info()
+dist = dist_util.init_process_group("gloo") if world > 1 else None
+eng = StandInEngine()
+loop = LearningLoop(eng, "mlp", np.full(NUM_PARAMS, 0.5, np.float32), dist=dist, seed=3, lr_schedule=[(1, 1e-3), (2, 5e-4)])
+recs = [loop.iteration(None, 101, 150, 2, 32) for _ in range(3)]
+out = dict(rank=rank, world=world, w0=float(loop.weights[0]), wsum=float(loop.weights.astype(np.float64).sum()), loaded=eng.loaded,
+           games=[r["games_this_rank"] for r in recs], unique=[r.get("unique") for r in recs], steps=[r.get("optimiser_steps") for r in recs],
+           lr=[r["lr"] for r in recs], buffer=[r.get("steps_in_buffer") for r in recs])
+print("LOOP", json.dumps(out), flush=True)
+if dist is not None:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_learning_loop_collectives_under_gloo(tmp_path):
+    """synthesis_amd.learner.LearningLoop with world_size 2 on CPU (gloo) and a stand-in engine: every rank plays its shard (101
+    games: 51 + 50), rank 0 gathers, keeps the last 150 games, de-duplicates and trains, the weights are broadcast and loaded on
+    both ranks before the next iteration's games — and the result equals the single-rank run's (the loop does not depend on the
+    number of ranks)."""
+    script = tmp_path / "loop_worker.py"
+    script.write_text(LOOP_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+         "127.0.0.1", "--master-port", "29541", str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
+    two = sorted((json.loads(l.split(" ", 1)[1]) for l in out.splitlines() if l.startswith("LOOP")), key=lambda d: d["rank"])
+    one = json.loads([l for l in subprocess.check_output([sys.executable, str(script), ROOT], env=env, stderr=subprocess.STDOUT,
+                                                          timeout=300).decode().splitlines() if l.startswith("LOOP")][0].split(" ", 1)[1])
+    assert len(two) == 2 and two[0]["world"] == 2 and one["world"] == 1
+    assert two[0]["games"] == [51, 51, 51] and two[1]["games"] == [50, 50, 50] and one["games"] == [101, 101, 101]
+    assert two[0]["w0"] == two[1]["w0"] == one["w0"] and two[0]["wsum"] == two[1]["wsum"] == one["wsum"]
+    assert two[0]["loaded"] == two[1]["loaded"] and len(two[1]["loaded"]) == 4   # the initial network + one broadcast per iteration
+    assert two[0]["unique"] == one["unique"] and two[0]["steps"] == one["steps"] and two[0]["buffer"] == one["buffer"]
+    assert two[1]["unique"] == [None] * 3                                          # only rank 0 holds the replay buffer
+    assert one["lr"] == [1e-3, 5e-4, 5e-4] and one["steps"][0] > 0
+    # keep_last_n_games: 3 x 101 games played, the last 150 kept
+    assert one["buffer"][2] < one["buffer"][1] + sum(7 + g % 5 for g in range(202, 303))
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher (how the driver runs it) must start two ranks itself: the parent never
     touches the GPU, the ranks rendezvous over 127.0.0.1 and rank 0 reports world size 2 (launch plumbing only, no GPU)."""

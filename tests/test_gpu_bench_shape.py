@@ -143,6 +143,9 @@ def test_bench_two_ranks_on_one_gpu():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 1
     assert line["config"]["games_per_step_per_gpu"] == 16384
+    # BASELINE configs[4]'s loop ran on both ranks: self-play everywhere, the learner on rank 0, one weight broadcast per iteration
+    ll = line["learner_loop"]
+    assert ll["ranks"] == 2 and ll["games_per_iteration"] == 16384 and ll["optimiser_steps"] > 0 and ll["seconds"]["broadcast"] >= 0
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 16384) < 1.0   # value = games of BOTH ranks / time
     assert 7 <= line["plies_per_game"] <= 63
 
