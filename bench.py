@@ -105,7 +105,7 @@ def measured_traffic(args, key="traffic_bytes_per_launch", games=None):
         return None, None
     if d.get("bench_config") != [args.concurrent, args.games_per_step, args.explores]:
         return None, None
-    if games is not None and d.get("extra_leg_games") != games:
+    if games is not None and (d.get("extra_leg_games") or {}).get(key) != games:
         return None, None
     return d.get(key), os.path.relpath(files[-1], ROOT)
 
@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-counted", action="store_true", help="profiling passes: only the warm-up and timed launches, a reduced line")
     ap.add_argument("--no-learner-loop", action="store_true", help="skip the two iterations of the N-rank learning loop (learner_loop)")
     ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
     ap.add_argument("--only-policy-cache", action="store_true",
@@ -352,6 +353,19 @@ def main():
 
     # Event counts of exactly the games of the last timed step (trajectories are deterministic, so an instrumented
     # re-run outside the timed region gives the counts of the timed run).
+    if args.skip_counted:
+        # tools/collect_profiles.sh's counter passes only need the launches themselves: no instrumented re-run, no roofline objects
+        if rank == 0:
+            print(json.dumps({"metric": "self-play games/sec, 9x7 Connect4", "value": gps * world * args.steps / elapsed, "unit": "games/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "kernel_ms_avg": float(np.mean(kernel_ms)), "roofline": None, "profile_pass": True,
+                              "config": {"games_per_step_per_gpu": gps, "concurrent_games_per_gpu": args.concurrent,
+                                         "explores_per_move": args.explores}}), flush=True)
+        eng.close()
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     rc = step(args.warmup + args.steps - 1, counters=True)
     c = rc["counters"]
     shape, sgrid, sthreads = eng.last_launch_shape()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Distils the rocprofv3 outputs of tools/collect_profiles.sh into <tag>_pmc.json (HBM traffic per launch of the headline
-kernel and of the PolicyWithCache leg, guide-corrected) and <tag>_sq.json (SQ / TA / L2 counters per launch)."""
+"""Distils the rocprofv3 outputs of tools/collect_profiles.sh into <tag>_pmc.json (HBM traffic per launch of the headline kernel,
+of the PolicyWithCache leg and of the reference-configuration leg, guide-corrected) and <tag>_sq.json (SQ / TA / L2 counters per
+launch of the headline kernel and of the PolicyWithCache leg)."""
 import collections
 import csv
 import json
@@ -19,12 +20,18 @@ def rows(name):
     return list(csv.DictReader(open(path))) if os.path.exists(path) else []
 
 
-def per_launch(name, pick):
-    """counter -> value per launch (summed over the dispatch's counter rows, averaged over the picked dispatches)"""
+def per_launch(name, pick, largest=True):
+    """counter -> value of ONE launch: the counter rows of a dispatch summed, and among the dispatches `pick` accepts the one with
+    the largest sums (the timed launch: the warm-up launches of the same kernel play fewer games) — or their average."""
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in rows(name):
         if pick(r["Kernel_Name"]):
             acc[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    if not acc:
+        return {}, 0
+    if largest:
+        best = max(acc.values(), key=lambda d: sum(d.values()))
+        return dict(best), len(acc)
     res = collections.defaultdict(list)
     for d in acc.values():
         for k, v in d.items():
@@ -32,47 +39,84 @@ def per_launch(name, pick):
     return {k: sum(v) / len(v) for k, v in res.items()}, len(acc)
 
 
-timed = lambda n: "selfplay_kernel" in n and "<0, false" in n   # the un-instrumented (COUNT = false) self-play launches
+# the un-instrumented (COUNT = false) self-play launches: the parity configuration takes the FAST instantiation, the reference's
+# Fpu::Func configuration the general one (template arguments <MODE, COUNT, FAST, ...>)
+timed = lambda n: "selfplay_kernel" in n and "<0, false, true" in n
+timed_general = lambda n: "selfplay_kernel" in n and "<0, false, false" in n
 line = None
 for l in open(f"{out}/{tag}_bench_lines_under_profiler.jsonl"):
     line = json.loads(l)
 cfgv = [line["config"]["concurrent_games_per_gpu"], line["config"]["games_per_step_per_gpu"], line["config"]["explores_per_move"]] if line else None
+cache_line = None
+if os.path.exists(f"{out}/{tag}_cache_lines_under_profiler.jsonl"):
+    for l in open(f"{out}/{tag}_cache_lines_under_profiler.jsonl"):
+        cache_line = json.loads(l)
 f, nf = per_launch("pmc_fetch", timed)
 w, nw = per_launch("pmc_write", timed)
 cf, _ = per_launch("pmc_cfetch", timed)
 cw, _ = per_launch("pmc_cwrite", timed)
+rf, _ = per_launch("pmc_cfetch", timed_general)
+rw, _ = per_launch("pmc_cwrite", timed_general)
 ks = [r for r in csv.DictReader(open(f"{out}/{tag}_kernel_stats.csv")) if timed(r["Name"])]
 ks.sort(key=lambda r: -float(r["TotalDurationNs"]))
+
+
+def traffic(fe, wr):
+    # MI355X guide §HBM: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> doubled; WRITE_SIZE exact; KB units
+    return (2.0 * fe.get("FETCH_SIZE", 0) + wr.get("WRITE_SIZE", 0)) * 1024.0 if fe and wr else None
+
+
 summary = {
-    "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache --no-extras",
+    "command": "python3 bench.py --steps 1 --warmup 1 --skip-counted --no-learner-loop   (the timed launch of each pass)",
+    "trace_command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache --no-extras --no-learner-loop",
     "bench_config": cfgv, "csrc_sha16": kernel_source_hash(),
     "kernel": ks[0]["Name"] if ks else None, "kernel_calls": int(ks[0]["Calls"]) if ks else None,
-    "kernel_avg_ms": float(ks[0]["AverageNs"]) / 1e6 if ks else None,
+    "kernel_avg_ms_all_launches_incl_quarter_size_warmup": float(ks[0]["AverageNs"]) / 1e6 if ks else None,
+    "kernel_max_ms": float(ks[0]["MaxNs"]) / 1e6 if ks and "MaxNs" in ks[0] else None,
     "FETCH_SIZE_kb_per_launch": f.get("FETCH_SIZE"), "WRITE_SIZE_kb_per_launch": w.get("WRITE_SIZE"),
-    # MI355X guide §HBM: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) loads -> doubled; WRITE_SIZE exact
-    "traffic_bytes_per_launch": (2.0 * f.get("FETCH_SIZE", 0) + w.get("WRITE_SIZE", 0)) * 1024.0 if f and w else None,
-    "cache_command": "python3 bench.py --only-policy-cache",
+    "traffic_bytes_per_launch": traffic(f, w),
+    "cache_command": "python3 bench.py --only-policy-cache   (both legs; the largest dispatch of each kernel instantiation)",
     "cache_FETCH_SIZE_kb_per_launch": cf.get("FETCH_SIZE"), "cache_WRITE_SIZE_kb_per_launch": cw.get("WRITE_SIZE"),
-    # the cache leg launches twice at full size (timed + counted): the average over its launches of >= 1 M games
-    "cache_traffic_bytes_per_launch": (2.0 * cf.get("FETCH_SIZE", 0) + cw.get("WRITE_SIZE", 0)) * 1024.0 if cf and cw else None,
+    "cache_traffic_bytes_per_launch": traffic(cf, cw),
+    "reference_FETCH_SIZE_kb_per_launch": rf.get("FETCH_SIZE"), "reference_WRITE_SIZE_kb_per_launch": rw.get("WRITE_SIZE"),
+    "reference_traffic_bytes_per_launch": traffic(rf, rw),
+    "extra_leg_games": {
+        "cache_traffic_bytes_per_launch": (cache_line or {}).get("with_policy_cache", {}).get("games"),
+        "reference_traffic_bytes_per_launch": (cache_line or {}).get("reference_selfplay_config", {}).get("games"),
+    },
 }
 json.dump(summary, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
-sq = {}
-for name in ("pmc_sq1", "pmc_sq2", "pmc_ta", "pmc_l2", "pmc_lat"):
-    v, n = per_launch(name, timed)
-    sq.update(v)
-if sq:
+
+
+def derive(sq, waves_per_simd):
     wave = sq.get("SQ_WAVE_CYCLES")
-    d = {"counters_per_launch": sq, "csrc_sha16": kernel_source_hash(), "bench_config": cfgv}
-    if wave and ks:
-        waves_per_simd = 4 if "1024" in (ks[0]["Name"] or "") or True else 3
-        simd_cycles = wave * 4.0 / waves_per_simd       # SQ_WAVE_CYCLES counts 4-cycle units per resident wave
-        d["derived"] = {
-            "note": "fractions of SIMD time (1024 SIMDs); SQ_WAVE_CYCLES x 4 / resident waves per SIMD = SIMD cycles",
-            "mfma_pipe_busy": sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles,
-            "valu_issue_non_mfma": (sq.get("SQ_INSTS_VALU", 0) - sq.get("SQ_INSTS_MFMA", 0)) * 4.0 / simd_cycles,
-            "l2_hit_rate": sq.get("TCC_HIT_sum", 0) / max(1.0, sq.get("TCC_REQ_sum", 1.0)),
-            "l2_read_latency_cycles": sq.get("TCP_TCC_READ_REQ_LATENCY_sum", 0) / max(1.0, sq.get("TCP_TCC_READ_REQ_sum", 1.0)),
-        }
+    if not wave:
+        return None
+    simd_cycles = wave * 4.0 / waves_per_simd       # SQ_WAVE_CYCLES counts 4-cycle units per resident wave
+    return {
+        "note": "fractions of SIMD time (1024 SIMDs); SQ_WAVE_CYCLES x 4 / resident waves per SIMD = SIMD cycles",
+        "mfma_pipe_busy": sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles,
+        "valu_issue_non_mfma_if_INSTS_VALU_includes_mfma": (sq.get("SQ_INSTS_VALU", 0) - sq.get("SQ_INSTS_MFMA", 0)) * 4.0 / simd_cycles,
+        "valu_issue_if_INSTS_VALU_excludes_mfma": sq.get("SQ_INSTS_VALU", 0) * 4.0 / simd_cycles,
+        "l2_hit_rate": sq.get("TCC_HIT_sum", 0) / max(1.0, sq.get("TCC_REQ_sum", 1.0)),
+        "wait_inst_any_share_of_wave_cycles": sq.get("SQ_WAIT_INST_ANY", 0) / wave,
+        "active_inst_any_share_of_wave_cycles": sq.get("SQ_ACTIVE_INST_ANY", 0) / wave,
+    }
+
+
+d = {"csrc_sha16": kernel_source_hash(), "bench_config": cfgv}
+sq = {}
+for name in ("pmc_sq1", "pmc_sq2", "pmc_ta", "pmc_l2"):
+    sq.update(per_launch(name, timed)[0])
+if sq:
+    d["counters_per_launch"] = sq
+    d["derived"] = derive(sq, 4)
+csq = {}
+for name in ("pmc_csq1", "pmc_csq2", "pmc_cl2"):
+    csq.update(per_launch(name, timed)[0])
+if csq:
+    d["policy_cache_leg"] = {"command": "python3 bench.py --only-policy-cache (the largest FAST self-play dispatch of each pass)",
+                             "counters_per_launch": csq, "derived": derive(csq, 4)}
+if sq or csq:
     json.dump(d, open(f"{out}/{tag}_sq.json", "w"), indent=1)
 print(json.dumps(summary))
