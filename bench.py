@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-warmup", action="store_true", help="warm-up steps at full size (the kernel-trace pass: every launch of the "
+                    "kernel then has the timed steps' duration, so the trace's per-kernel average is the step's)")
     ap.add_argument("--skip-counted", action="store_true", help="profiling passes: only the warm-up and timed launches, a reduced line")
     ap.add_argument("--no-learner-loop", action="store_true", help="skip the two iterations of the N-rank learning loop (learner_loop)")
     ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
@@ -338,7 +340,8 @@ def main():
     # tree slot plays one game; a full-size warm-up would only repeat the timed steps — at --warmup 5 that was 150 s of the driver's run)
     for i in range(args.warmup):
         first, count = dist_util.step_game_range(i, rank, world, gps)
-        eng.selfplay(cfg, base_seed=0, n_games=max(min(count, args.concurrent), count // 4), first_game=first, outputs=False)
+        eng.selfplay(cfg, base_seed=0, n_games=count if args.full_warmup else max(min(count, args.concurrent), count // 4),
+                     first_game=first, outputs=False)
     barrier()
     t0 = time.perf_counter()
     kernel_ms = []
@@ -563,8 +566,11 @@ def main():
                 st3 = min(nu // 32, 3000)
                 learner = {"batch": 32, "unique_positions": nu}
                 for name, init, w0, n_steps in (("connect4net", e3.trainer_init, blob, st3),
-                                                ("connect4convnet", e3.trainer_init_conv, make_conv_weights(), min(st3, 1000))):
+                                                ("connect4convnet", e3.trainer_init_conv, make_conv_weights(), st3),
+                                                ("connect4convnet_bf16", e3.trainer_init_conv, make_conv_weights(), st3)):
                     init(w0)
+                    if name.endswith("_bf16"):
+                        e3.trainer_set_precision("bf16")   # BASELINE configs[4] "bf16 conv": bf16 matrix cores, f32 accumulation / Adam
                     e3.train_set_data(d3["my_bb"], d3["op_bb"], d3["pis"], d3["vs"])
                     e3.train_epoch(perm[: 64 * 32], 32, 1e-3)
                     t1 = time.perf_counter()

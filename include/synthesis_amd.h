@@ -272,6 +272,14 @@ int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, 
 int syn_train_gradients_device(syn_engine* h, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,
                                const float* d_target_v, int batch, float* d_grads, float* losses);
 int syn_train_apply_device(syn_engine* h, const float* d_grads, float lr, float grad_scale);
+/* Arithmetic of the Connect4ConvNet learner's gradient step (forward, dZ, backward; BASELINE configs[4] words the on-node training
+ * step "bf16 conv"): SYN_TRAIN_F32 (default after every syn_trainer_init*) = f32 matrix cores, bit-identical to the oracle;
+ * SYN_TRAIN_BF16 = every matrix operand rounded to bf16 and multiplied on the bf16 matrix cores with f32 accumulation — master
+ * weights, Adam moments, the softmax / KL head and Adam itself stay f32. Training only: inference never runs in bf16 (it cannot
+ * hold north_star's 1e-5). SYN_ERR_UNSUPPORTED for the Connect4Net learner. No counterpart in the reference (its learner is
+ * libtorch f32, alpha_zero.rs:28-37). */
+enum { SYN_TRAIN_F32 = 0, SYN_TRAIN_BF16 = 1 };
+int syn_trainer_set_precision(syn_engine* h, int precision);
 /* Copies out parameters / Adam moments / last gradient (each may be NULL) and the optimiser step count. */
 int syn_trainer_get_state(syn_engine* h, float* blob, float* m, float* v, long long* step, float* grads);
 /* Replaces: vs.save(model_{i+1}.ot) + the workers' vs.load (alpha_zero.rs:97,194): the trained parameters become the

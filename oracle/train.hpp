@@ -154,13 +154,13 @@ struct Trainer {
 // ---- the same step for Connect4ConvNet (oracle/nn.hpp: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12>; the network of north_star).
 // The reference has neither this network nor a learner for it (its learner is libtorch's autograd over whatever NNPolicy is
 // given): the published semantics restated above apply unchanged; every f32 chain below runs in one fixed order that the HIP
-// kernel (synthesis_amd/csrc/train_conv.cuh) reproduces bit for bit:
-//   forward   conv taps in slimnn's order ci -> k1 -> k2 (in-board taps only), head inputs in NCHW flattening order, fma per term
+// kernel (synthesis_amd/csrc/train_conv_mfma.cuh: every chain a k-ordered fma chain of the f32 matrix cores) reproduces bit for bit:
+//   forward   conv taps in slimnn's order ci -> k1 -> k2 (in-board taps only), fma per term; head = sixteen partial chains over
+//             the cells p = g (mod 16), channels 0,4,8,12, 1,5,9,13, ... inside a cell, added to the bias in order
 //   dWh[o][i] over the samples ascending; dAct[b][i] over the outputs ascending; dWc[c][tap] over the samples ascending and, inside
-//   a sample, the cells ascending (row-major, in-board taps only), as eight partial chains over the sample groups [4g, 4g + 4)
+//   a sample, the cells ascending (row-major, in-board taps only), as sixteen partial chains over the sample pairs [2g, 2g + 2)
 //   that are then added in order; bias gradients as plain sums in the same orders.
-// (The training forward uses the flattening order for the head — the inference tile's cell-major order exists for the matrix
-// cores only; the two agree to ~1e-6.) Checked against this container's torch in float64 (tests/golden/conv_train_torch_goldens.npz).
+// Checked against this container's torch in float64 (tests/golden/conv_train_torch_goldens.npz).
 struct ConvTrainer {
     using Net = Connect4ConvNet;
     std::vector<float> w, m, v, grad;
@@ -199,9 +199,21 @@ struct ConvTrainer {
                                 }
                         A[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col] = acc > 0.0f ? acc : 0.0f;
                     }
+            // head: sixteen partial fma chains — chain g over the cells p = g, g + 16, g + 32, g + 48 (< 63), inside a cell the
+            // channels 0,4,8,12, 1,5,9,13, ... (the k order of the matrix-core tile, convnet.cuh) — then bias + P0 + P1 + ... in order:
+            // the order in which the sixteen waves of the HIP learner (train_conv_mfma.cuh) produce them
             for (int o = 0; o < 12; o++) {
                 float acc = hb[o];
-                for (int i = 0; i < Net::FLAT; i++) acc = std::fmaf(A[(size_t)b * Net::FLAT + i], hw[(size_t)o * Net::FLAT + i], acc);
+                for (int g = 0; g < 16; g++) {
+                    float part = 0.0f;
+                    for (int p = g; p < Net::HW; p += 16)
+                        for (int r = 0; r < 4; r++)
+                            for (int q = 0; q < 4; q++) {
+                                const size_t i = (size_t)(4 * q + r) * Net::HW + p;
+                                part = std::fmaf(A[(size_t)b * Net::FLAT + i], hw[(size_t)o * Net::FLAT + i], part);
+                            }
+                    acc += part;
+                }
                 out[(size_t)b * 12 + o] = acc;
             }
         }
@@ -254,29 +266,32 @@ struct ConvTrainer {
                 for (int o = 0; o < 12; o++) a = std::fmaf(dz[(size_t)b * 12 + o], hw[(size_t)o * Net::FLAT + i], a);
                 dY[(size_t)b * Net::FLAT + i] = A[(size_t)b * Net::FLAT + i] > 0.0f ? a : 0.0f;
             }
-        // conv parameters: eight partial chains over the sample groups [4 g, 4 g + 4) (samples ascending, cells row-major inside a
-        // sample), then added in order — the order in which the HIP kernel's thread groups produce them
+        // conv parameters: sixteen partial chains over the sample pairs [2 g, 2 g + 2) (samples ascending, cells row-major inside a
+        // sample), then added in order — the order in which the HIP kernel's sixteen waves produce them (groups without a sample
+        // contribute +0)
         for (int c = 0; c < Net::C; c++) {
-            float sq[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            float sq[16];
+            for (int g = 0; g < 16; g++) sq[g] = 0.0f;
             for (int b = 0; b < B; b++)
-                for (int p = 0; p < Net::HW; p++) sq[b >> 2] += dY[(size_t)b * Net::FLAT + c * Net::HW + p];
+                for (int p = 0; p < Net::HW; p++) sq[b >> 1] += dY[(size_t)b * Net::FLAT + c * Net::HW + p];
             float sb = sq[0];
-            for (int g = 1; g < 8; g++) sb += sq[g];
+            for (int g = 1; g < 16; g++) sb += sq[g];
             gcb[c] = sb;
             for (int ci = 0; ci < 2; ci++)
                 for (int k1 = 0; k1 < 3; k1++)
                     for (int k2 = 0; k2 < 3; k2++) {
-                        float a[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                        float a[16];
+                        for (int g = 0; g < 16; g++) a[g] = 0.0f;
                         for (int b = 0; b < B; b++)
                             for (int r = 0; r < Net::H; r++)
                                 for (int col = 0; col < Net::W; col++) {
                                     const int src = tap_src(r, col, k1, k2);
                                     if (src >= 0)
-                                        a[b >> 2] = std::fmaf(dY[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col],
-                                                              X[(size_t)b * 2 * Net::HW + ci * Net::HW + src], a[b >> 2]);
+                                        a[b >> 1] = std::fmaf(dY[(size_t)b * Net::FLAT + c * Net::HW + r * Net::W + col],
+                                                              X[(size_t)b * 2 * Net::HW + ci * Net::HW + src], a[b >> 1]);
                                 }
                         float sa = a[0];
-                        for (int g = 1; g < 8; g++) sa += a[g];
+                        for (int g = 1; g < 16; g++) sa += a[g];
                         gcw[((c * 2 + ci) * 3 + k1) * 3 + k2] = sa;
                     }
         }

@@ -27,6 +27,7 @@
 #include "convnet.cuh"
 #include "layer_kernels.cuh"
 #include "train_conv.cuh"
+#include "train_conv_mfma.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -144,7 +145,8 @@ struct syn_engine {
     long long epoch_fallbacks = 0;  // syn_train_epoch calls whose persistent kernel gave up and ran through the queued launches
     DevTrainHyper train_hp{};
     bool has_trainer = false;
-    int trainer_kind = 0;  // 0 = Connect4Net (train_mfma.cuh / train_epoch.cuh), 1 = Connect4ConvNet (train_conv.cuh)
+    int trainer_kind = 0;  // 0 = Connect4Net (train_mfma.cuh / train_epoch.cuh), 1 = Connect4ConvNet (train_conv_mfma.cuh)
+    int train_bf16 = 0;    // Connect4ConvNet learner: 1 = the bf16 matrix-core variant of the gradient step (syn_trainer_set_precision)
 };
 
 static int fail(syn_engine* h, int code, const char* fmt, ...) {
@@ -1424,6 +1426,7 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
     h->train_step = 0;
     h->has_trainer = true;
     h->trainer_kind = 0;
+    h->train_bf16 = 0;
     return SYN_OK;
 }
 
@@ -1449,6 +1452,18 @@ int syn_trainer_init_conv(syn_engine* h, const float* blob, size_t n_floats, con
     h->train_step = 0;
     h->has_trainer = true;
     h->trainer_kind = 1;
+    h->train_bf16 = 0;
+    return SYN_OK;
+}
+
+int syn_trainer_set_precision(syn_engine* h, int precision) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init_conv first");
+    if (precision != SYN_TRAIN_F32 && precision != SYN_TRAIN_BF16) return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown training precision %d", precision);
+    if (precision == SYN_TRAIN_BF16 && h->trainer_kind != 1)
+        return fail(h, SYN_ERR_UNSUPPORTED, "the bf16 training variant exists for Connect4ConvNet only (BASELINE configs[4]: \"bf16 conv\"); "
+                                            "Connect4Net trains in f32, bit-exact with the oracle");
+    h->train_bf16 = precision == SYN_TRAIN_BF16 ? 1 : 0;
     return SYN_OK;
 }
 
@@ -1456,13 +1471,15 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
                         const float* d_tpi, const float* d_tv, int batch, float* d_grads, float* d_losses = nullptr,
                         const int* d_idx = nullptr) {
     if (h->trainer_kind == 1) {
-        // Connect4ConvNet (train_conv.cuh): one workgroup, the minibatch's activations resident in LDS
+        // Connect4ConvNet (train_conv_mfma.cuh): one workgroup, the minibatch's activations resident in LDS, every chain on the
+        // f32 matrix cores
         if (batch > ConvTrainGeom::CHUNK)
             return fail(h, SYN_ERR_UNSUPPORTED, "the Connect4ConvNet learner takes minibatches of at most %d positions (got %d)",
                         ConvTrainGeom::CHUNK, batch);
-        const size_t clds = (size_t)ConvTrainGeom::LDS_FLOATS * 4;
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_conv_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-        hipLaunchKernelGGL(train_conv_grad_kernel, dim3(1), dim3(1024), clds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
+        const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
+        auto kg = h->train_bf16 ? train_conv_grad_kernel_mfma<true> : train_conv_grad_kernel_mfma<false>;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+        hipLaunchKernelGGL(kg, dim3(1), dim3(1024), clds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
                            h->train_hp, d_grads, d_losses ? d_losses : h->d_tloss, d_idx);
         HIP_TRY(h, hipGetLastError());
         return SYN_OK;
@@ -1728,6 +1745,35 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             h->train_step += (long long)n_steps;
             return SYN_OK;
         }
+    }
+    if (!queued && batch <= ConvTrainGeom::CHUNK && h->trainer_kind == 1) {
+        // Connect4ConvNet: the persistent one-workgroup epoch kernel (train_conv_mfma.cuh) — gradients and Adam of every step in ONE
+        // launch, no co-residency requirement
+        std::vector<float> adam_sc(2 * n_steps);
+        for (size_t s = 0; s < n_steps; s++) {
+            const double t = (double)(h->train_step + (long long)s + 1);
+            const double bc1 = 1.0 - std::pow((double)h->train_hp.beta1, t);
+            const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, t);
+            adam_sc[s] = (float)((double)lr / bc1);
+            adam_sc[n_steps + s] = (float)(1.0 / std::sqrt(bc2));
+        }
+        float* d_sc = reinterpret_cast<float*>(sc + perm_bytes + loss_bytes + batch_bytes);
+        HIP_TRY(h, hipMemcpyAsync(d_sc, adam_sc.data(), adam_sc.size() * 4, hipMemcpyHostToDevice, h->stream));
+        ConvEpochParams ep{};
+        ep.w = h->d_tw; ep.m = h->d_tm; ep.v = h->d_tv;
+        ep.my_bb = g_my; ep.op_bb = g_op; ep.tpi = g_tpi; ep.tv = g_tv;
+        ep.step_size = d_sc; ep.inv_sqrt_bc2 = d_sc + n_steps;
+        ep.losses = d_losses; ep.grads = h->d_tgrad;
+        ep.n_steps = (int)n_steps; ep.batch = batch; ep.hp = h->train_hp;
+        const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
+        auto ke = h->train_bf16 ? train_conv_epoch_kernel<true> : train_conv_epoch_kernel<false>;
+        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+        hipLaunchKernelGGL(ke, dim3(1), dim3(1024), clds, h->stream, ep);
+        HIP_TRY(h, hipGetLastError());
+        if (step_losses) HIP_TRY(h, hipMemcpyAsync(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        h->train_step += (long long)n_steps;
+        return SYN_OK;
     }
     for (size_t s = 0; s < n_steps; s++) {  // steps are dependent (weights of step s feed step s+1): queued, never synced
         const size_t o = s * (size_t)batch;

@@ -1,0 +1,583 @@
+// synthesis_amd — the learner step for Connect4ConvNet on the f32 matrix cores: forward, log_softmax + kl_div, backward of a
+// minibatch of up to 32 positions by ONE 16-wave workgroup, every GEMM-shaped chain a k-ordered fma chain of
+// v_mfma_f32_16x16x4_f32; and the persistent epoch kernel around it (all steps of an epoch in one launch, Adam inside).
+//
+// The reference has neither this network nor a learner of its own for it (alpha_zero.rs:72-94 drives libtorch's autograd over
+// whatever NNPolicy it is given): the published semantics restated in oracle/train.hpp apply unchanged, and every f32 chain here
+// runs in the fixed order of oracle/train.hpp::ConvTrainer, so the kernels are bit-identical to it. With
+// A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[4 (lane >> 4) + r][lane & 15] (MI355X guide §3) and
+// q = lane >> 4, j = lane & 15:
+//   F   conv forward + head partials. Wave w owns the board cells p = w, w + 16, w + 32, w + 48 (< 63) for both 16-sample tiles:
+//       conv    D[channel][sample] = bias + sum over the 18 taps — A = conv weights (five registers per lane), B = one BIT of the
+//               sample's pre-shifted boards (convnet.cuh conv_tap_board), 5 MFMAs, taps in slimnn's order;
+//       ReLU -> LDS act[sample][channel * 63 + p]  (what dWh, dY and dWc read), and straight from the registers
+//       head    D[output][sample] += Wh[output][channel * 63 + p] * act — 4 MFMAs per cell, channels 0,4,8,12, 1,5,9,13, ...;
+//               the wave's partial sums over its cells go to LDS, bias + P0 + P1 + ... + P15 in order makes the 12 outputs.
+//   H   log_softmax / kl_div / dz per (sample, head) on the VALU (det_expf / det_logf), as train_kernels.cuh.
+//   G1  dWh[o][i] = chain over the samples: A = dz^T (outputs x samples), B = act (samples x 16 input columns): 8 MFMAs per
+//       16-column tile, 63 tiles dealt over the waves; dbh plain sums.
+//   G2  dY[b][i] = relu'(act) * chain over the 12 outputs: A = Wh (16 input columns x outputs), B = dz^T (outputs x 16 samples):
+//       3 MFMAs per (column tile, sample tile); overwrites act in LDS.
+//   G3  dWc[c][tap] and dbc[c]: wave w owns the sample pair 2 w, 2 w + 1: A = dY (channels x 4 cells), B = the tap's input bit
+//       of those cells (taps 0..15 in one column tile, taps 16, 17 and an all-ones "bias tap" in a second): 16 k-steps per sample
+//       and tile (cell 63 is padding: A = 0); the sixteen partial results meet in LDS and are added in order.
+// 72 + 32 + 24 + 64 MFMAs per wave and step. Measured in DESIGN.md §6.4.
+#pragma once
+#include "train_conv.cuh"
+
+namespace syn {
+
+struct ConvMfmaGeom {
+    static constexpr int CHUNK = 32, FLAT = ConvGeom::FLAT, HW = ConvGeom::HW, C = ConvGeom::C;
+    static constexpr int ASTR = FLAT + 1;                          // LDS row stride of a sample's activations (odd)
+    static constexpr int ACT_OFF = 0;
+    static constexpr int OUT_OFF = ACT_OFF + CHUNK * ASTR;         // [32][12] raw outputs
+    static constexpr int DZ_OFF = OUT_OFF + CHUNK * 12;            // [32][12] d(loss)/d(output); rows >= B stay zero
+    static constexpr int KL_OFF = DZ_OFF + CHUNK * 12;             // [32][2]
+    static constexpr int BB_OFF = (KL_OFF + CHUNK * 2 + 1) & ~1;   // [32][2] u64 boards; rows >= B zero
+    // one region, two uses: the head's partial outputs [wave 16][sample 32][12] (phase F -> H), then the conv gradients'
+    // partial sums [wave 16][channel 16][20: taps 0..17, bias, pad] (phase G3 -> G4)
+    static constexpr int PART_OFF = BB_OFF + CHUNK * 4;
+    static constexpr int PART_FLOATS = 16 * CHUNK * 12;
+    static constexpr int LDS_FLOATS = PART_OFF + PART_FLOATS;      // 39,392 floats = 157,568 B
+    static constexpr int P_CW = 0, P_CB = ConvGeom::CONV_W, P_HW = P_CB + C, P_HB = P_HW + 12 * FLAT;
+};
+static_assert(16 * 16 * 20 <= ConvMfmaGeom::PART_FLOATS, "conv-gradient partials fit the head-partial region");
+static_assert(ConvMfmaGeom::LDS_FLOATS * 4 <= 160 * 1024, "one workgroup: 160 KB of LDS");
+
+// One minibatch (B <= 32 samples; sample b = my_bb[idx ? idx[b] : b]): grads[12412] <- d(loss)/d(param), losses[0..1] <- pi / v
+// loss. Called by all 1024 threads of a workgroup; ends with every gradient written (no trailing barrier).
+SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
+                                 const unsigned long long* __restrict__ op_bb, const float* __restrict__ tpi,
+                                 const float* __restrict__ tv, int B, const DevTrainHyper& hp, float* __restrict__ grads,
+                                 float* __restrict__ losses, const int* __restrict__ idx, float* lds, int tid) {
+    using G = ConvMfmaGeom;
+    const int lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    float* act = lds + G::ACT_OFF;
+    float* out = lds + G::OUT_OFF;
+    float* dz = lds + G::DZ_OFF;
+    float* part = lds + G::PART_OFF;
+    uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
+    const float bm = 1.0f / (float)B;
+
+    // ---- stage the boards (samples >= B: empty boards, zero dz rows -> exact zeros in every gradient chain); targets
+    if (tid < 2 * G::CHUNK) {
+        const int b = tid >> 1;
+        unsigned long long v = 0ull;
+        if (b < B) {
+            const size_t si = idx ? (size_t)idx[b] : (size_t)b;
+            v = (tid & 1) ? op_bb[si] : my_bb[si];
+        }
+        bb[tid] = v;
+    }
+    if (tid < G::CHUNK * 12) dz[tid] = 0.0f;
+    float tgt[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) tgt[i] = 0.0f;
+    if (tid < 2 * G::CHUNK && (tid >> 1) < B) {
+        const int b = tid >> 1;
+        const size_t si = idx ? (size_t)idx[b] : (size_t)b;
+        if ((tid & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) tgt[i] = tpi[si * 9 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) tgt[i] = tv[si * 3 + i];
+        }
+    }
+    __syncthreads();
+
+    // ---- F: conv forward + ReLU + head partials
+    {
+        float ca[5];
+#pragma unroll
+        for (int s = 0; s < 5; s++) ca[s] = 4 * s + q < 18 ? w[G::P_CW + j * 18 + 4 * s + q] : 0.0f;   // A[channel j][tap 4 s + q]
+        const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);                         // D rows: channels 4 q + r
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            const int sample = 16 * t + j;
+            const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
+            uint64_t S[5];
+#pragma unroll
+            for (int s = 0; s < 5; s++) S[s] = conv_tap_board(my, op, 4 * s + q);
+            f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+            for (int p = wv; p < G::HW; p += 16) {
+                const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
+                f32x4 acc = cbv;
+#pragma unroll
+                for (int s = 0; s < 5; s++)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)((uint32_t)(S[s] >> pos) & 1u), acc, 0, 0, 0);
+                float hwv[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) hwv[r] = j < 12 ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float a = acc[r] > 0.0f ? acc[r] : 0.0f;
+                    act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a;
+                    hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(hwv[r], a, hacc, 0, 0, 0);
+                }
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) part[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- H: the 12 outputs (bias + the sixteen partials in order), then log_softmax + kl_div and their gradient
+    if (tid < G::CHUNK * 12) {
+        const int b = tid / 12, o = tid - 12 * b;
+        float a = w[G::P_HB + o];
+#pragma unroll
+        for (int g = 0; g < 16; g++) a += part[(g * G::CHUNK + b) * 12 + o];
+        out[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 2 * G::CHUNK) {
+        const int b = tid >> 1, head = tid & 1;
+        const int off = head == 0 ? 0 : 9, n = head == 0 ? 9 : 3;
+        float kl = 0.0f;
+        if (b < B) {
+            const float* x = out + b * 12 + off;
+            const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
+            float xv[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) xv[i] = i < n ? x[i] : 0.0f;
+            float mx = xv[0];
+#pragma unroll
+            for (int i = 1; i < 9; i++) mx = (i < n && xv[i] > mx) ? xv[i] : mx;
+            float se = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < n) se += det_expf(xv[i] - mx);
+            const float lse = mx + det_logf(se);
+            float tsum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                if (i < n) {
+                    const float logp = xv[i] - lse;
+                    if (tgt[i] > 0.0f) kl += tgt[i] * (det_logf(tgt[i]) - logp);
+                    tsum += tgt[i];
+                }
+            }
+            const float s = weight * bm;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < n) dz[b * 12 + off + i] = s * (det_expf(xv[i] - lse) * tsum - tgt[i]);
+        }
+        lds[G::KL_OFF + b * 2 + head] = kl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float pi_acc = 0.0f, v_acc = 0.0f;
+        for (int b = 0; b < B; b++) {
+            pi_acc += lds[G::KL_OFF + b * 2 + 0];
+            v_acc += lds[G::KL_OFF + b * 2 + 1];
+        }
+        losses[0] = bm * pi_acc;
+        losses[1] = bm * v_acc;
+    }
+
+    // ---- G1: head parameter gradients
+    {
+        float dza[8];   // A[output j][sample 4 s + q]
+#pragma unroll
+        for (int s = 0; s < 8; s++) dza[s] = j < 12 ? dz[(4 * s + q) * 12 + j] : 0.0f;
+#pragma unroll 1
+        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+            const int col = 16 * ct + j;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s = 0; s < 8; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dza[s], act[(4 * s + q) * G::ASTR + col], acc, 0, 0, 0);
+            if (q < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + col] = acc[r];
+            }
+        }
+        if (tid >= 1024 - 12) {   // dbh: plain sums over the samples (threads of the last wave, which has the fewest tiles)
+            const int o = tid - (1024 - 12);
+            float a = 0.0f;
+            for (int b = 0; b < B; b++) a += dz[b * 12 + o];
+            grads[G::P_HB + o] = a;
+        }
+    }
+    __syncthreads();
+
+    // ---- G2: activation gradients through the ReLU, in place
+    {
+        float dzb[2][3];   // B[output 4 s + q][sample 16 bt + j]
+#pragma unroll
+        for (int bt = 0; bt < 2; bt++)
+#pragma unroll
+            for (int s = 0; s < 3; s++) dzb[bt][s] = dz[(16 * bt + j) * 12 + 4 * s + q];
+#pragma unroll 1
+        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+            float wa[3];   // A[input column 16 ct + j][output 4 s + q]
+#pragma unroll
+            for (int s = 0; s < 3; s++) wa[s] = w[G::P_HW + (size_t)(4 * s + q) * G::FLAT + 16 * ct + j];
+#pragma unroll
+            for (int bt = 0; bt < 2; bt++) {
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s = 0; s < 3; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], dzb[bt][s], acc, 0, 0, 0);
+                float* pa = act + (16 * bt + j) * G::ASTR + 16 * ct + 4 * q;   // D rows: input columns 16 ct + 4 q + r
+#pragma unroll
+                for (int r = 0; r < 4; r++) pa[r] = pa[r] > 0.0f ? acc[r] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- G3: conv parameter gradients, one partial per wave (= sample pair)
+    {
+        const FeatureTable FT = make_feature_table(q);   // bit position (row + 7 col) of cell 4 m + q; 63 (an always-clear bit) for cell 63
+        f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+#pragma unroll 1
+        for (int k = 0; k < 2; k++) {
+            const int b = 2 * wv + k;
+            const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+            const uint64_t S0 = conv_tap_board(my, op, j);                                               // taps 0..15
+            const uint64_t S1 = j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull);     // taps 16, 17, the bias "tap"
+            const float* ya = act + b * G::ASTR + j * G::HW + q;                                         // A[channel j][cell 4 s + q]
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const uint32_t pos = (FT.t[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+                const float y = 4 * s + q < G::HW ? ya[4 * s] : 0.0f;
+                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, (float)((uint32_t)(S0 >> pos) & 1u), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, (float)((uint32_t)(S1 >> pos) & 1u), a1, 0, 0, 0);
+            }
+        }
+        // D[channel 4 q + r][tap 16 n + j]
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            part[(wv * 16 + 4 * q + r) * 20 + j] = a0[r];
+            if (j < 3) part[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a1[r];
+        }
+    }
+    __syncthreads();
+    // ---- G4: the sixteen partials, added in order
+    if (tid < ConvGeom::CONV_W + G::C) {
+        const int c = tid < ConvGeom::CONV_W ? tid / 18 : tid - ConvGeom::CONV_W;
+        const int t = tid < ConvGeom::CONV_W ? tid - 18 * c : 18;
+        float v = part[c * 20 + t];
+#pragma unroll
+        for (int g = 1; g < 16; g++) v += part[(g * 16 + c) * 20 + t];
+        grads[tid < ConvGeom::CONV_W ? G::P_CW + tid : G::P_CB + c] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- bf16 variant
+// BASELINE configs[4] words the on-node training step "bf16 conv": the same step with every matrix operand rounded to bf16
+// (round-to-nearest-even, v_cvt_pk_bf16_f32) and multiplied on the bf16 matrix cores (v_mfma_f32_16x16x16_bf16: A[i][4 q + e],
+// B[4 q + e][j], e = 0..3, f32 accumulation), master weights, Adam moments, the softmax / KL head and every accumulator in f32.
+// K = 16 per instruction: the conv is 2 MFMAs per cell (18 taps, padded to 32), the head ONE (its k = the 16 channels: a lane's
+// four ReLU outputs are exactly its four k elements), dWh 2 per column tile, dY 1, dWc 4 per sample and tap tile. NOT bit-exact
+// with anything and never used for inference (bf16 cannot hold the 1e-5 bar): tests hold its gradients and an 8-step run to the f32
+// learner within bf16's error. Tap inputs (0 / 1) are exact in bf16; what is rounded: weights, activations, dz, dY.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+SYN_DEV bf16x4 pack_bf16(float a, float b, float c, float d) { return bf16x4{(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d}; }
+
+SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
+                                 const unsigned long long* __restrict__ op_bb, const float* __restrict__ tpi,
+                                 const float* __restrict__ tv, int B, const DevTrainHyper& hp, float* __restrict__ grads,
+                                 float* __restrict__ losses, const int* __restrict__ idx, float* lds, int tid) {
+    using G = ConvMfmaGeom;
+    const int lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    float* act = lds + G::ACT_OFF;
+    float* out = lds + G::OUT_OFF;
+    float* dz = lds + G::DZ_OFF;
+    float* part = lds + G::PART_OFF;
+    uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
+    const float bm = 1.0f / (float)B;
+    if (tid < 2 * G::CHUNK) {
+        const int b = tid >> 1;
+        unsigned long long v = 0ull;
+        if (b < B) {
+            const size_t si = idx ? (size_t)idx[b] : (size_t)b;
+            v = (tid & 1) ? op_bb[si] : my_bb[si];
+        }
+        bb[tid] = v;
+    }
+    if (tid < G::CHUNK * 12) dz[tid] = 0.0f;
+    float tgt[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) tgt[i] = 0.0f;
+    if (tid < 2 * G::CHUNK && (tid >> 1) < B) {
+        const int b = tid >> 1;
+        const size_t si = idx ? (size_t)idx[b] : (size_t)b;
+        if ((tid & 1) == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) tgt[i] = tpi[si * 9 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; i++) tgt[i] = tv[si * 3 + i];
+        }
+    }
+    __syncthreads();
+
+    // ---- F: conv (k = tap 16 h + 4 q + e) + ReLU + head partials (k = channel 4 q + e)
+    {
+        bf16x4 ca[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float t4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int tap = 16 * h + 4 * q + e;
+                t4[e] = tap < 18 ? w[G::P_CW + j * 18 + tap] : 0.0f;
+            }
+            ca[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+        }
+        const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);
+#pragma unroll 1
+        for (int t = 0; t < 2; t++) {
+            const int sample = 16 * t + j;
+            const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
+            uint64_t S[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) S[h][e] = conv_tap_board(my, op, 16 * h + 4 * q + e);   // (taps >= 18: empty boards)
+            f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+            for (int p = wv; p < G::HW; p += 16) {
+                const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
+                f32x4 acc = cbv;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const bf16x4 xb = pack_bf16((float)((uint32_t)(S[h][0] >> pos) & 1u), (float)((uint32_t)(S[h][1] >> pos) & 1u),
+                                                (float)((uint32_t)(S[h][2] >> pos) & 1u), (float)((uint32_t)(S[h][3] >> pos) & 1u));
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ca[h], xb, acc, 0, 0, 0);
+                }
+                float a4[4], h4[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    a4[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+                    act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a4[r];
+                    h4[r] = j < 12 ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+                }
+                hacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16(h4[0], h4[1], h4[2], h4[3]), pack_bf16(a4[0], a4[1], a4[2], a4[3]), hacc, 0, 0, 0);
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) part[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- H (f32, as conv_grad_step_mfma)
+    if (tid < G::CHUNK * 12) {
+        const int b = tid / 12, o = tid - 12 * b;
+        float a = w[G::P_HB + o];
+#pragma unroll
+        for (int g = 0; g < 16; g++) a += part[(g * G::CHUNK + b) * 12 + o];
+        out[tid] = a;
+    }
+    __syncthreads();
+    if (tid < 2 * G::CHUNK) {
+        const int b = tid >> 1, head = tid & 1;
+        const int off = head == 0 ? 0 : 9, n = head == 0 ? 9 : 3;
+        float kl = 0.0f;
+        if (b < B) {
+            const float* x = out + b * 12 + off;
+            const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
+            float xv[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) xv[i] = i < n ? x[i] : 0.0f;
+            float mx = xv[0];
+#pragma unroll
+            for (int i = 1; i < 9; i++) mx = (i < n && xv[i] > mx) ? xv[i] : mx;
+            float se = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < n) se += det_expf(xv[i] - mx);
+            const float lse = mx + det_logf(se);
+            float tsum = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                if (i < n) {
+                    const float logp = xv[i] - lse;
+                    if (tgt[i] > 0.0f) kl += tgt[i] * (det_logf(tgt[i]) - logp);
+                    tsum += tgt[i];
+                }
+            }
+            const float s = weight * bm;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+                if (i < n) dz[b * 12 + off + i] = s * (det_expf(xv[i] - lse) * tsum - tgt[i]);
+        }
+        lds[G::KL_OFF + b * 2 + head] = kl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float pi_acc = 0.0f, v_acc = 0.0f;
+        for (int b = 0; b < B; b++) {
+            pi_acc += lds[G::KL_OFF + b * 2 + 0];
+            v_acc += lds[G::KL_OFF + b * 2 + 1];
+        }
+        losses[0] = bm * pi_acc;
+        losses[1] = bm * v_acc;
+    }
+    // ---- G1: dWh (k = sample 16 h + 4 q + e)
+    {
+        bf16x4 dza[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float t4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) t4[e] = j < 12 ? dz[(16 * h + 4 * q + e) * 12 + j] : 0.0f;
+            dza[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+        }
+#pragma unroll 1
+        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+            const int col = 16 * ct + j;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const float* pa = act + (16 * h + 4 * q) * G::ASTR + col;
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dza[h], pack_bf16(pa[0], pa[G::ASTR], pa[2 * G::ASTR], pa[3 * G::ASTR]), acc, 0, 0, 0);
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + col] = acc[r];
+            }
+        }
+        if (tid >= 1024 - 12) {
+            const int o = tid - (1024 - 12);
+            float a = 0.0f;
+            for (int b = 0; b < B; b++) a += dz[b * 12 + o];
+            grads[G::P_HB + o] = a;
+        }
+    }
+    __syncthreads();
+    // ---- G2: dY (k = output 4 q + e; outputs 12..15: zeros)
+    {
+        bf16x4 dzb[2];
+#pragma unroll
+        for (int bt = 0; bt < 2; bt++) {
+            float t4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) t4[e] = q < 3 ? dz[(16 * bt + j) * 12 + 4 * q + e] : 0.0f;
+            dzb[bt] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+        }
+#pragma unroll 1
+        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+            float t4[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) t4[e] = q < 3 ? w[G::P_HW + (size_t)(4 * q + e) * G::FLAT + 16 * ct + j] : 0.0f;
+            const bf16x4 wa = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+#pragma unroll
+            for (int bt = 0; bt < 2; bt++) {
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wa, dzb[bt], acc, 0, 0, 0);
+                float* pa = act + (16 * bt + j) * G::ASTR + 16 * ct + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; r++) pa[r] = pa[r] > 0.0f ? acc[r] : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- G3: dWc partials (k = cell 16 h + 4 q + e, h = 0..3; cell 63: padding)
+    {
+        f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+#pragma unroll 1
+        for (int k = 0; k < 2; k++) {
+            const int b = 2 * wv + k;
+            const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+            const uint64_t S0 = conv_tap_board(my, op, j);
+            const uint64_t S1 = j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull);
+            const float* ya = act + b * G::ASTR + j * G::HW;
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                float y4[4], x0[4], x1[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int cell = 16 * h + 4 * q + e;                       // per-lane (q), compile-time h, e
+                    const int cc = cell < G::HW ? cell : 0;
+                    const int row = cc / 9, col = cc - 9 * row, pos = row + 7 * col;
+                    y4[e] = cell < G::HW ? ya[cc] : 0.0f;
+                    x0[e] = cell < G::HW ? (float)((uint32_t)(S0 >> pos) & 1u) : 0.0f;
+                    x1[e] = cell < G::HW ? (float)((uint32_t)(S1 >> pos) & 1u) : 0.0f;
+                }
+                const bf16x4 yb = pack_bf16(y4[0], y4[1], y4[2], y4[3]);
+                a0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb, pack_bf16(x0[0], x0[1], x0[2], x0[3]), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb, pack_bf16(x1[0], x1[1], x1[2], x1[3]), a1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            part[(wv * 16 + 4 * q + r) * 20 + j] = a0[r];
+            if (j < 3) part[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a1[r];
+        }
+    }
+    __syncthreads();
+    if (tid < ConvGeom::CONV_W + G::C) {
+        const int c = tid < ConvGeom::CONV_W ? tid / 18 : tid - ConvGeom::CONV_W;
+        const int t = tid < ConvGeom::CONV_W ? tid - 18 * c : 18;
+        float v = part[c * 20 + t];
+#pragma unroll
+        for (int g = 1; g < 16; g++) v += part[(g * 16 + c) * 20 + t];
+        grads[tid < ConvGeom::CONV_W ? G::P_CW + tid : G::P_CB + c] = v;
+    }
+}
+
+// One launch = one minibatch (syn_train_step, the data-parallel gradient half): <<<1, 1024>>>. BF16: the bf16 matrix-core variant.
+template <bool BF16>
+__global__ __launch_bounds__(1024) void train_conv_grad_kernel_mfma(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
+                                                                    const unsigned long long* __restrict__ op_bb,
+                                                                    const float* __restrict__ tpi, const float* __restrict__ tv, int B,
+                                                                    DevTrainHyper hp, float* __restrict__ grads, float* __restrict__ losses,
+                                                                    const int* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (BF16) conv_grad_step_bf16(w, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, lds, threadIdx.x);
+    else conv_grad_step_mfma(w, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, lds, threadIdx.x);
+}
+
+// One launch = every optimiser step of an epoch (syn_train_epoch): the step-ordered batches come from train_gather_kernel, the
+// per-step Adam scalars (bias corrections, in double on the host like libtorch) from the caller. One workgroup: the steps are a
+// dependent chain and a step is a few microseconds of one CU's matrix pipes, so nothing is gained by spreading it.
+struct ConvEpochParams {
+    float *w, *m, *v;
+    const unsigned long long *my_bb, *op_bb;   // [n_steps * batch], step-ordered
+    const float *tpi, *tv;
+    const float *step_size, *inv_sqrt_bc2;     // [n_steps]
+    float* losses;                             // [n_steps][2]
+    float* grads;                              // the last step's gradients stay here (syn_trainer_get_state)
+    int n_steps, batch;
+    DevTrainHyper hp;
+};
+template <bool BF16>
+__global__ __launch_bounds__(1024) void train_conv_epoch_kernel(ConvEpochParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x;
+    const int B = P.batch;
+    for (int s = 0; s < P.n_steps; s++) {
+        const size_t o = (size_t)s * B;
+        if (BF16) conv_grad_step_bf16(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
+        else conv_grad_step_mfma(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
+        // the gradients were written by other threads of this workgroup: make them visible, then Adam (train_kernels.cuh
+        // adam_kernel's expression) over the 12,412 parameters
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const float step_size = P.step_size[s], inv_sqrt_bc2 = P.inv_sqrt_bc2[s];
+        for (int i = tid; i < ConvGeom::NUM_PARAMS; i += 1024) {
+            const float g0 = P.grads[i];
+            const float wi = P.w[i];
+            const float g = P.hp.weight_decay != 0.0f ? __builtin_fmaf(P.hp.weight_decay, wi, g0) : g0;
+            const float mi = __builtin_fmaf(1.0f - P.hp.beta1, g, P.hp.beta1 * P.m[i]);
+            const float vi = __builtin_fmaf((1.0f - P.hp.beta2) * g, g, P.hp.beta2 * P.v[i]);
+            const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.hp.eps;
+            P.m[i] = mi;
+            P.v[i] = vi;
+            P.w[i] = wi - step_size * (mi / denom);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+}
+
+}  // namespace syn

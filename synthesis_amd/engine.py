@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_load_weights_conv",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -114,6 +114,7 @@ def load_library():
                                     [C.c_void_p] * 8
     lib.syn_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.syn_cancel.argtypes = [C.c_void_p]
+    lib.syn_trainer_set_precision.argtypes = [C.c_void_p, C.c_int]
     lib.syn_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     lib.syn_last_launch_shape.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.syn_last_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -382,6 +383,11 @@ class Engine:
         cfg = CTrainConfig(weight_decay, policy_weight, value_weight, beta1, beta2, eps)
         self._check(self._lib.syn_trainer_init_conv(self._h, _p(blob), blob.size, C.byref(cfg)))
         self._trainer_params = CONV_NUM_PARAMS
+
+    def trainer_set_precision(self, precision):
+        """"f32" (default; bit-identical to the oracle) | "bf16" (Connect4ConvNet learner only: bf16 matrix cores, f32 accumulation,
+        f32 master weights and Adam — BASELINE configs[4]'s "bf16 conv")."""
+        self._check(self._lib.syn_trainer_set_precision(self._h, {"f32": 0, "bf16": 1}[precision]))
 
     def train_step(self, my_bb, op_bb, target_pi, target_v, lr):
         my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()

@@ -195,6 +195,61 @@ def test_conv_learner_matches_oracle_and_feeds_selfplay(oracle, cblob, golden_di
     eng.close()
 
 
+def test_conv_learner_bf16_variant_stays_within_bf16_error(oracle, cblob, golden_dir):
+    """BASELINE configs[4] words the training step "bf16 conv": SYN_TRAIN_BF16 rounds every matrix operand of the conv learner to
+    bf16 (bf16 matrix cores, f32 accumulation, f32 master weights / Adam). It is not bit-exact with anything — the bar is bf16's
+    own error against the f32 learner (which is bit-identical to oracle/train.hpp::ConvTrainer): first-step gradients, losses, and
+    the torch float64 goldens after the 8-step run; and the switch is refused for Connect4Net."""
+    import os
+    import synthesis_amd as sa
+    from tests.oracle_lib import default_train_hyper
+
+    g = np.load(os.path.join(golden_dir, "conv_train_torch_goldens.npz"))
+    my, op, tpi, tv, lrs = g["my_bb"], g["op_bb"], g["target_pi"], g["target_v"], g["lrs"]
+    eng = sa.Engine(concurrent_games=256, max_explores=64)
+    eng.load_weights_conv(cblob)
+    hp = default_train_hyper()
+    for B in (32, 7):
+        go, lo = oracle.convtrain_gradients(cblob, hp, my[0][:B], op[0][:B], tpi[0][:B], tv[0][:B])
+        eng.trainer_init_conv(cblob)
+        eng.trainer_set_precision("bf16")
+        l = eng.train_step(my[0][:B], op[0][:B], tpi[0][:B], tv[0][:B], 1e-3)
+        gb = eng.trainer_state()["grads"]
+        assert not np.array_equal(gb, go)                                   # it really is another arithmetic
+        cos = float(np.dot(gb.astype(np.float64), go.astype(np.float64)) / (np.linalg.norm(gb) * np.linalg.norm(go)))
+        assert cos > 0.9995, (B, cos)
+        assert np.abs(gb - go).max() <= 0.02 * np.abs(go).max(), B          # bf16: 8 bits of significand per operand
+        assert np.abs(l - lo).max() <= 5e-3 * max(1.0, np.abs(lo).max()), (l, lo)
+    # the 8 golden steps: bf16 gradients, f32 Adam — stays close to the float64 run (Adam normalises the step to ~lr per parameter)
+    eng.trainer_init_conv(cblob)
+    assert np.array_equal(eng.train_step(my[0], op[0], tpi[0], tv[0], 0.0),  # (f32 again after a re-init: the oracle's losses)
+                          oracle.convtrain_gradients(cblob, hp, my[0], op[0], tpi[0], tv[0])[1])
+    eng.trainer_init_conv(cblob)
+    eng.trainer_set_precision("bf16")
+    ls = np.stack([eng.train_step(my[s], op[s], tpi[s], tv[s], float(lrs[s])) for s in range(8)])
+    st = eng.trainer_state()
+    _, _, _, _, lo = oracle.convtrain_steps(cblob, hp, my, op, tpi, tv, lrs)
+    assert st["step"] == 8 and np.abs(ls - lo).max() <= 2e-2
+    assert np.abs(st["weights"] - g["final_weights_f64"]).max() <= 8 * float(np.max(lrs)) + 1e-6
+    assert np.median(np.abs(st["weights"] - g["final_weights_f64"])) <= 2e-4
+    # and as one device-resident epoch: the persistent kernel's bf16 instantiation gives the queued bf16 steps' bits
+    eng.trainer_init_conv(cblob)
+    eng.trainer_set_precision("bf16")
+    eng.train_set_data(my.reshape(-1), op.reshape(-1), tpi.reshape(-1, 9), tv.reshape(-1, 3))
+    le = eng.train_epoch(np.arange(128, dtype=np.int32), 32, 1e-3)
+    we = eng.trainer_state()["weights"]
+    eng.trainer_init_conv(cblob)
+    eng.trainer_set_precision("bf16")
+    lq = np.stack([eng.train_step(my[s], op[s], tpi[s], tv[s], 1e-3) for s in range(4)])
+    assert np.array_equal(le, lq) and np.array_equal(we, eng.trainer_state()["weights"])
+    # Connect4Net trains in f32 only
+    eng.trainer_init(np.load(os.path.join(golden_dir, "c4net_blob_f32.npy")))
+    with pytest.raises(sa.SynthesisAmdError) as ei:
+        eng.trainer_set_precision("bf16")
+    assert ei.value.code == -5   # SYN_ERR_UNSUPPORTED
+    eng.close()
+
+
 def test_conv_trained_checkpoint_matches_oracle(oracle, golden_dir):
     """A TRAINED conv network (tests/golden/c4conv_trained_f32.npy, produced by examples/train_connect4.py --net conv): sharp priors,
     deep narrow trees, many solved lines — searches and whole games still equal the oracle's."""

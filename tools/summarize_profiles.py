@@ -68,10 +68,10 @@ def traffic(fe, wr):
 
 summary = {
     "command": "python3 bench.py --steps 1 --warmup 1 --skip-counted --no-learner-loop   (the timed launch of each pass)",
-    "trace_command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-4096 --no-policy-cache --no-extras --no-learner-loop",
+    "trace_command": "python3 bench.py --steps 2 --warmup 1 --full-warmup --no-cpu-baseline --no-4096 --no-policy-cache --no-extras --no-learner-loop",
     "bench_config": cfgv, "csrc_sha16": kernel_source_hash(),
     "kernel": ks[0]["Name"] if ks else None, "kernel_calls": int(ks[0]["Calls"]) if ks else None,
-    "kernel_avg_ms_all_launches_incl_quarter_size_warmup": float(ks[0]["AverageNs"]) / 1e6 if ks else None,
+    "kernel_avg_ms": float(ks[0]["AverageNs"]) / 1e6 if ks else None,
     "kernel_max_ms": float(ks[0]["MaxNs"]) / 1e6 if ks and "MaxNs" in ks[0] else None,
     "FETCH_SIZE_kb_per_launch": f.get("FETCH_SIZE"), "WRITE_SIZE_kb_per_launch": w.get("WRITE_SIZE"),
     "traffic_bytes_per_launch": traffic(f, w),

@@ -1,51 +1,38 @@
-"""Microbenchmark of the learner-side kernels: train step latency and replay de-duplication rate.
-Usage: python tools/train_bench.py   (needs a GPU)"""
-import os
-import sys
-import time
-
+#!/usr/bin/env python3
+"""Developer tool: optimiser steps per second of the learners at the reference's batch of 32 (alpha_zero.rs:72-94 step; main.rs:22).
+Connect4Net: persistent epoch kernel (train_epoch.cuh) and queued launches; Connect4ConvNet: persistent one-workgroup epoch kernel
+(train_conv_mfma.cuh) in f32 and bf16, and its queued launches. Run under rocprofv3 --kernel-trace --stats for per-kernel times."""
+import os, sys, time
 import numpy as np
+import torch  # noqa
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import synthesis_amd as sa
+from bench import make_conv_weights, make_weights
 
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-import synthesis_amd as sa  # noqa: E402
-
-blob = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "c4net_blob_f32.npy"))
-eng = sa.Engine(concurrent_games=4096, max_explores=800)
+blob, cblob = make_weights(), make_conv_weights()
+eng = sa.Engine(concurrent_games=4096, max_explores=64)
 eng.load_weights(blob)
 r = eng.selfplay(sa.parity_rollout_config(64), base_seed=1, n_games=8192)
-my = np.concatenate([r["states_bb"][g, : r["plies"][g], 0] for g in range(8192)])
-op = np.concatenate([r["states_bb"][g, : r["plies"][g], 1] for g in range(8192)])
-pi = np.concatenate([r["pis"][g, : r["plies"][g]] for g in range(8192)])
-v = np.concatenate([r["vs"][g, : r["plies"][g]] for g in range(8192)])
-print("states", my.size)
-for rep in range(2):
-    t = time.perf_counter(); d = eng.replay_deduplicate(my, op, pi, v); dt = time.perf_counter() - t
-print(f"dedup: {my.size} -> {d['num'].size} in {dt*1e3:.2f} ms (host buffers, incl. copies) = {my.size/dt/1e6:.1f} M states/s")
-eng.trainer_init(blob)
-for B in (32, 256, 1024):
-    n = 200
-    idx = np.random.default_rng(0).integers(0, d["num"].size, size=(n, B))
-    eng.train_step(d["my_bb"][idx[0]], d["op_bb"][idx[0]], d["pis"][idx[0]], d["vs"][idx[0]], 1e-3)
-    t = time.perf_counter()
-    for i in range(n):
-        eng.train_step(d["my_bb"][idx[i]], d["op_bb"][idx[i]], d["pis"][idx[i]], d["vs"][idx[i]], 1e-3)
-    dt = (time.perf_counter() - t) / n
-    print(f"train_step B={B}: {dt*1e6:.1f} us/step (host batch in, losses out) = {B/dt:.0f} samples/s")
-# device-resident epochs (syn_train_set_data + syn_train_epoch): the path the learning loop uses
-eng.train_set_data(d["my_bb"], d["op_bb"], d["pis"], d["vs"])
-nu = d["num"].size
-perm = np.random.default_rng(1).permutation(nu)
-steps = nu // 32
-eng.train_epoch(perm[: 256 * 32], 32, 1e-3)
-t = time.perf_counter(); eng.train_epoch(perm[: steps * 32], 32, 1e-3); dt = time.perf_counter() - t
-print(f"train_epoch B=32: {steps} steps in {dt*1e3:.1f} ms = {dt/steps*1e6:.2f} us/step = {steps/dt:.0f} steps/s "
-      f"({'VALU kernel' if os.environ.get('SYN_TRAIN_VALU') else 'matrix-core kernel'})")
-
-# the learner of the conv policy/value network (Connect4ConvNet, train_conv.cuh): queued gradient + Adam launches per step
-from bench import make_conv_weights  # noqa: E402
-eng.trainer_init_conv(make_conv_weights())
-eng.train_set_data(d["my_bb"], d["op_bb"], d["pis"], d["vs"])
-eng.train_epoch(perm[: 64 * 32], 32, 1e-3)
-csteps = min(steps, 2000)
-t = time.perf_counter(); eng.train_epoch(perm[: csteps * 32], 32, 1e-3); dt = time.perf_counter() - t
-print(f"train_epoch Connect4ConvNet B=32: {csteps} steps in {dt*1e3:.1f} ms = {dt/csteps*1e6:.2f} us/step = {csteps/dt:.0f} steps/s (VALU kernel)")
+sel = np.arange(63)[None, :] < r["plies"][:, None]
+d = eng.replay_deduplicate(r["states_bb"][..., 0][sel], r["states_bb"][..., 1][sel], r["pis"][sel], r["vs"][sel])
+nu = int(d["num"].size)
+perm = np.random.default_rng(1).permutation(nu).astype(np.int32)
+steps = min(nu // 32, 3000)
+print(f"{nu} unique positions, {steps} steps of 32")
+for name, init, w0, prec in (("Connect4Net", eng.trainer_init, blob, None), ("Connect4ConvNet f32", eng.trainer_init_conv, cblob, "f32"),
+                             ("Connect4ConvNet bf16", eng.trainer_init_conv, cblob, "bf16")):
+    for queued in (False, True):
+        if queued: os.environ["SYN_DEBUG"] = "1"; os.environ["SYN_TRAIN_QUEUED"] = "1"
+        else: os.environ.pop("SYN_TRAIN_QUEUED", None)
+        init(w0)
+        if prec: eng.trainer_set_precision(prec)
+        eng.train_set_data(d["my_bb"], d["op_bb"], d["pis"], d["vs"])
+        n = steps if not queued else min(steps, 500)
+        eng.train_epoch(perm[: 64 * 32], 32, 1e-3)
+        t0 = time.perf_counter()
+        l = eng.train_epoch(perm[: n * 32], 32, 1e-3)
+        dt = time.perf_counter() - t0
+        print(f"{name:22s} {'queued launches' if queued else 'epoch kernel   '}: {n} steps in {dt * 1e3:.1f} ms = {dt / n * 1e6:.2f} us/step = {n / dt:.0f} steps/s   "
+              f"(first / last pi-loss {l[0, 0]:.4f} / {l[-1, 0]:.4f})", flush=True)
+eng.close()
