@@ -254,7 +254,10 @@ typedef struct syn_train_config {
 } syn_train_config;
 
 /* Replaces: P::new(&vs) + Adam::default().build(&vs, lr) (alpha_zero.rs:31-36): parameters (same blob order as
- * syn_load_weights) and zeroed Adam moments on the device. */
+ * syn_load_weights) and zeroed Adam moments on the device. The first call on an engine also runs a ~1 ms self-check of the epoch
+ * kernel's step barrier (eight steps on a synthetic batch through the fast and the device-scope barrier, compared bit for bit; a
+ * mismatch makes this engine use the device-scope barrier) and thereby discards a data set uploaded with syn_train_set_data
+ * before it: upload after initialising. */
 int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg);
 /* The same for Connect4ConvNet (syn_load_weights_conv's network and blob order, 12412 floats): the trainer then runs that
  * network through syn_train_step / syn_train_gradients_device + syn_train_apply_device / syn_train_set_data + syn_train_epoch

@@ -142,6 +142,8 @@ struct syn_engine {
     unsigned* d_tsync = nullptr;  // its arrival counter and status word
     float* d_tsnap = nullptr;     // snapshot of [w][m][v][fwd image][transposed image] taken before an epoch launch (restored if it aborts)
     long long train_step = 0;
+    bool epoch_barrier_checked = false;  // syn_trainer_init's self-check of the epoch kernel's one-XCD barrier has run on this engine
+    bool epoch_device_scope = false;     // ... and it failed (or is running its second half): the epoch kernel uses the device-scope barrier
     long long epoch_fallbacks = 0;  // syn_train_epoch calls whose persistent kernel gave up and ran through the queued launches
     DevTrainHyper train_hp{};
     bool has_trainer = false;
@@ -1392,41 +1394,74 @@ static int alloc_trainer_buffers(syn_engine* h) {
 }
 
 // ------------------------------------------------------------------------------------------------ learner step
+// (re)load the Connect4Net learner's state: parameters, zero moments, both fragment images, step counter
+static int trainer_load_state(syn_engine* h, const float* blob, const std::vector<float>& img, const std::vector<float>& timg) {
+    const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
+    HIP_TRY(h, hipMemcpyAsync(h->d_twimg, img.data(), img.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_ttimg, timg.data(), timg.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tm, 0, bytes, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->d_tv, 0, bytes, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->train_step = 0;
+    return SYN_OK;
+}
+
 int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (!blob || !cfg) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob/cfg is NULL");
     if (n_floats != (size_t)TrainGeom::NUM_PARAMS)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4Net has %d parameters, got %zu", TrainGeom::NUM_PARAMS, n_floats);
     HIP_TRY(h, hipSetDevice(h->device));
-    const size_t bytes = (size_t)TrainGeom::NUM_PARAMS * 4;
     {
         const int rc = alloc_trainer_buffers(h);
         if (rc != SYN_OK) return rc;
     }
-    {
-        // the two fragment-order images the matrix-core learner reads its A operands from (train_mfma.cuh); adam_image_kernel
-        // keeps them in step with the canonical weights afterwards
-        std::vector<float> img, timg((size_t)TrainImg::T_FLOATS, 0.0f);
-        build_weight_image(blob, img);
-        for (int p = 0; p < TrainGeom::NUM_PARAMS; p++) {
-            int fwd, tr;
-            train_image_slots(p, fwd, tr);
-            if (img[(size_t)fwd] != blob[p]) return fail(h, SYN_ERR_HIP, "internal: image slot table disagrees with build_weight_image at %d", p);
-            if (tr >= 0) timg[(size_t)tr] = blob[p];
-        }
-        HIP_TRY(h, hipMemcpyAsync(h->d_twimg, img.data(), img.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(h->d_ttimg, timg.data(), timg.size() * 4, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    // the two fragment-order images the matrix-core learner reads its A operands from (train_mfma.cuh); adam_image_kernel
+    // keeps them in step with the canonical weights afterwards
+    std::vector<float> img, timg((size_t)TrainImg::T_FLOATS, 0.0f);
+    build_weight_image(blob, img);
+    for (int p = 0; p < TrainGeom::NUM_PARAMS; p++) {
+        int fwd, tr;
+        train_image_slots(p, fwd, tr);
+        if (img[(size_t)fwd] != blob[p]) return fail(h, SYN_ERR_HIP, "internal: image slot table disagrees with build_weight_image at %d", p);
+        if (tr >= 0) timg[(size_t)tr] = blob[p];
     }
-    HIP_TRY(h, hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_tm, 0, bytes, h->stream));
-    HIP_TRY(h, hipMemsetAsync(h->d_tv, 0, bytes, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    int rc = trainer_load_state(h, blob, img, timg);
+    if (rc != SYN_OK) return rc;
     h->train_hp = DevTrainHyper{cfg->weight_decay, cfg->policy_weight, cfg->value_weight, cfg->beta1, cfg->beta2, cfg->eps};
-    h->train_step = 0;
     h->has_trainer = true;
     h->trainer_kind = 0;
     h->train_bf16 = 0;
+    // ---- the epoch kernel's one-XCD step barrier rests on observed hardware behaviour (train_epoch.cuh: `buffer_inv sc0` empties
+    //      the vector L1 outside threadgroup-split mode). Once per engine: eight steps on a synthetic batch through that barrier and
+    //      through the device-scope barrier from the same state; any differing bit switches this engine to the device-scope barrier.
+    if (!h->epoch_barrier_checked) {
+        h->epoch_barrier_checked = true;
+        const int n = 64, steps = 8, B = 8;
+        std::vector<uint64_t> my(n), op(n);
+        std::vector<float> tpi((size_t)n * 9, 1.0f / 9.0f), tv((size_t)n * 3, 0.0f);
+        std::vector<int32_t> perm(steps * B);
+        for (int i = 0; i < n; i++) {
+            my[i] = (0x0000040810204081ull * (uint64_t)(i % 7 + 1)) & 0x00003F7EFDFBF7EFull & ~(0x7Full << (7 * (i % 9)));
+            op[i] = (0x7Full << (7 * (i % 9))) & (0x0101010101010101ull * (uint64_t)(i % 5 + 1));
+            op[i] &= ~my[i];
+            tv[(size_t)i * 3 + i % 3] = 1.0f;
+        }
+        for (int i = 0; i < steps * B; i++) perm[i] = (i * 37) % n;
+        std::vector<float> wa((size_t)TrainGeom::NUM_PARAMS), wb((size_t)TrainGeom::NUM_PARAMS);
+        bool ok = true;
+        for (int mode = 0; mode < 2 && ok; mode++) {
+            h->epoch_device_scope = mode == 1;
+            ok = syn_train_set_data(h, my.data(), op.data(), tpi.data(), tv.data(), n) == SYN_OK &&
+                 syn_train_epoch(h, perm.data(), steps, B, 1e-3f, nullptr) == SYN_OK &&
+                 syn_trainer_get_state(h, mode == 0 ? wa.data() : wb.data(), nullptr, nullptr, nullptr, nullptr) == SYN_OK &&
+                 trainer_load_state(h, blob, img, timg) == SYN_OK;
+        }
+        h->epoch_device_scope = !(ok && std::memcmp(wa.data(), wb.data(), wa.size() * 4) == 0);
+        h->train_data_n = 0;   // the synthetic batch replaced whatever syn_train_set_data had uploaded: the caller uploads again (once per engine)
+        if (!ok) return fail(h, SYN_ERR_HIP, "the learner's start-up self-check could not run: %s", h->err.c_str());
+    }
     return SYN_OK;
 }
 
@@ -1479,7 +1514,7 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
         const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
         auto kg = h->train_bf16 ? train_conv_grad_kernel_mfma<true> : train_conv_grad_kernel_mfma<false>;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-        hipLaunchKernelGGL(kg, dim3(1), dim3(1024), clds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
+        hipLaunchKernelGGL(kg, dim3(1), dim3(CONV_TRAIN_THREADS), clds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
                            h->train_hp, d_grads, d_losses ? d_losses : h->d_tloss, d_idx);
         HIP_TRY(h, hipGetLastError());
         return SYN_OK;
@@ -1703,7 +1738,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             ep.prof = prof ? d_prof : nullptr;
             ep.n_steps = (int)n_steps; ep.batch = batch; ep.hp = h->train_hp;
             static const bool device_scope = debug_env("SYN_TRAIN_DEVICE_SCOPE") != nullptr;
-            ep.force_device_scope = device_scope ? 1 : 0;
+            ep.force_device_scope = (device_scope || h->epoch_device_scope) ? 1 : 0;
             const size_t lds = (size_t)TrainGeom::WL_OFF * 4;
             EP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(train_epoch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(train_epoch_kernel, dim3(EP_WGS * EP_XCDS), dim3(EP_THREADS), lds, h->stream, ep);
@@ -1768,7 +1803,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
         auto ke = h->train_bf16 ? train_conv_epoch_kernel<true> : train_conv_epoch_kernel<false>;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-        hipLaunchKernelGGL(ke, dim3(1), dim3(1024), clds, h->stream, ep);
+        hipLaunchKernelGGL(ke, dim3(1), dim3(CONV_TRAIN_THREADS), clds, h->stream, ep);
         HIP_TRY(h, hipGetLastError());
         if (step_losses) HIP_TRY(h, hipMemcpyAsync(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -47,12 +47,14 @@ static_assert(ConvMfmaGeom::LDS_FLOATS * 4 <= 160 * 1024, "one workgroup: 160 KB
 
 // One minibatch (B <= 32 samples; sample b = my_bb[idx ? idx[b] : b]): grads[12412] <- d(loss)/d(param), losses[0..1] <- pi / v
 // loss. Called by all 1024 threads of a workgroup; ends with every gradient written (no trailing barrier).
+template <int NT>
 SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
                                  const unsigned long long* __restrict__ op_bb, const float* __restrict__ tpi,
                                  const float* __restrict__ tv, int B, const DevTrainHyper& hp, float* __restrict__ grads,
                                  float* __restrict__ losses, const int* __restrict__ idx, float* lds, int tid) {
     using G = ConvMfmaGeom;
-    const int lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int lane = tid & 63, rw = tid >> 6, j = lane & 15, q = lane >> 4;
+    constexpr int NWV = NT / 64;   // real waves; the sixteen chains' owners ("virtual waves" wv) are dealt over them
     float* act = lds + G::ACT_OFF;
     float* out = lds + G::OUT_OFF;
     float* dz = lds + G::DZ_OFF;
@@ -88,41 +90,50 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
     __syncthreads();
 
     // ---- F: conv forward + ReLU + head partials
-    {
-        float ca[5];
-#pragma unroll
-        for (int s = 0; s < 5; s++) ca[s] = 4 * s + q < 18 ? w[G::P_CW + j * 18 + 4 * s + q] : 0.0f;   // A[channel j][tap 4 s + q]
-        const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);                         // D rows: channels 4 q + r
-#pragma unroll 1
-        for (int t = 0; t < 2; t++) {
-            const int sample = 16 * t + j;
-            const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
-            uint64_t S[5];
-#pragma unroll
-            for (int s = 0; s < 5; s++) S[s] = conv_tap_board(my, op, 4 * s + q);
-            f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-            for (int p = wv; p < G::HW; p += 16) {
-                const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
-                f32x4 acc = cbv;
-#pragma unroll
-                for (int s = 0; s < 5; s++)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)((uint32_t)(S[s] >> pos) & 1u), acc, 0, 0, 0);
-                float hwv[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) hwv[r] = j < 12 ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
-#pragma unroll
+    for (int wv = rw; wv < 16; wv += NWV) {
+            float ca[5];
+    #pragma unroll
+            for (int s = 0; s < 5; s++) ca[s] = 4 * s + q < 18 ? w[G::P_CW + j * 18 + 4 * s + q] : 0.0f;   // A[channel j][tap 4 s + q]
+            const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);                         // D rows: channels 4 q + r
+            // the head weights of this wave's (up to four) cells: A[output j][channel 4 q + r] per cell, loaded once for both sample tiles
+            float hwv[4][4];
+    #pragma unroll
+            for (int c = 0; c < 4; c++)
+    #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float a = acc[r] > 0.0f ? acc[r] : 0.0f;
-                    act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a;
-                    hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(hwv[r], a, hacc, 0, 0, 0);
+                    const int p = wv + 16 * c;
+                    hwv[c][r] = (j < 12 && p < G::HW) ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+                }
+    #pragma unroll 1
+            for (int t = 0; t < 2; t++) {
+                const int sample = 16 * t + j;
+                const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
+                uint64_t S[5];
+    #pragma unroll
+                for (int s = 0; s < 5; s++) S[s] = conv_tap_board(my, op, 4 * s + q);
+                f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+    #pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int p = wv + 16 * c;
+                    if (p < G::HW) {   // (wave-uniform: only wave 15 has three cells)
+                        const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
+                        f32x4 acc = cbv;
+    #pragma unroll
+                        for (int s = 0; s < 5; s++)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)((uint32_t)(S[s] >> pos) & 1u), acc, 0, 0, 0);
+    #pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float a = acc[r] > 0.0f ? acc[r] : 0.0f;
+                            act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a;
+                            hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(hwv[c][r], a, hacc, 0, 0, 0);
+                        }
+                    }
+                }
+                if (q < 3) {
+    #pragma unroll
+                    for (int r = 0; r < 4; r++) part[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
                 }
             }
-            if (q < 3) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) part[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
-            }
-        }
     }
     __syncthreads();
 
@@ -186,7 +197,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
 #pragma unroll
         for (int s = 0; s < 8; s++) dza[s] = j < 12 ? dz[(4 * s + q) * 12 + j] : 0.0f;
 #pragma unroll 1
-        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+        for (int ct = rw; ct < G::FLAT / 16; ct += NWV) {
             const int col = 16 * ct + j;
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -196,8 +207,8 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
                 for (int r = 0; r < 4; r++) grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + col] = acc[r];
             }
         }
-        if (tid >= 1024 - 12) {   // dbh: plain sums over the samples (threads of the last wave, which has the fewest tiles)
-            const int o = tid - (1024 - 12);
+        if (tid >= NT - 12) {   // dbh: plain sums over the samples (threads of the last wave, which has the fewest tiles)
+            const int o = tid - (NT - 12);
             float a = 0.0f;
             for (int b = 0; b < B; b++) a += dz[b * 12 + o];
             grads[G::P_HB + o] = a;
@@ -212,49 +223,61 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         for (int bt = 0; bt < 2; bt++)
 #pragma unroll
             for (int s = 0; s < 3; s++) dzb[bt][s] = dz[(16 * bt + j) * 12 + 4 * s + q];
+        // column tiles dealt over the real waves, four at a time: all their weight loads first
 #pragma unroll 1
-        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
-            float wa[3];   // A[input column 16 ct + j][output 4 s + q]
+        for (int base = rw; base < G::FLAT / 16; base += 4 * NWV) {
+            float wa[4][3];   // A[input column 16 ct + j][output 4 s + q]
 #pragma unroll
-            for (int s = 0; s < 3; s++) wa[s] = w[G::P_HW + (size_t)(4 * s + q) * G::FLAT + 16 * ct + j];
+            for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int bt = 0; bt < 2; bt++) {
-                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                for (int s = 0; s < 3; s++) {
+                    const int ct = base + NWV * c;
+                    wa[c][s] = ct < G::FLAT / 16 ? w[G::P_HW + (size_t)(4 * s + q) * G::FLAT + 16 * ct + j] : 0.0f;
+                }
 #pragma unroll
-                for (int s = 0; s < 3; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], dzb[bt][s], acc, 0, 0, 0);
-                float* pa = act + (16 * bt + j) * G::ASTR + 16 * ct + 4 * q;   // D rows: input columns 16 ct + 4 q + r
+            for (int c = 0; c < 4; c++) {
+                const int ct = base + NWV * c;
+                if (ct < G::FLAT / 16) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) pa[r] = pa[r] > 0.0f ? acc[r] : 0.0f;
+                    for (int bt = 0; bt < 2; bt++) {
+                        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int s = 0; s < 3; s++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c][s], dzb[bt][s], acc, 0, 0, 0);
+                        float* pa = act + (16 * bt + j) * G::ASTR + 16 * ct + 4 * q;   // D rows: input columns 16 ct + 4 q + r
+#pragma unroll
+                        for (int r = 0; r < 4; r++) pa[r] = pa[r] > 0.0f ? acc[r] : 0.0f;
+                    }
+                }
             }
         }
     }
     __syncthreads();
 
     // ---- G3: conv parameter gradients, one partial per wave (= sample pair)
-    {
-        const FeatureTable FT = make_feature_table(q);   // bit position (row + 7 col) of cell 4 m + q; 63 (an always-clear bit) for cell 63
-        f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
-#pragma unroll 1
-        for (int k = 0; k < 2; k++) {
-            const int b = 2 * wv + k;
-            const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
-            const uint64_t S0 = conv_tap_board(my, op, j);                                               // taps 0..15
-            const uint64_t S1 = j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull);     // taps 16, 17, the bias "tap"
-            const float* ya = act + b * G::ASTR + j * G::HW + q;                                         // A[channel j][cell 4 s + q]
-#pragma unroll
-            for (int s = 0; s < 16; s++) {
-                const uint32_t pos = (FT.t[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-                const float y = 4 * s + q < G::HW ? ya[4 * s] : 0.0f;
-                a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, (float)((uint32_t)(S0 >> pos) & 1u), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, (float)((uint32_t)(S1 >> pos) & 1u), a1, 0, 0, 0);
+    for (int wv = rw; wv < 16; wv += NWV) {
+            const FeatureTable FT = make_feature_table(q);   // bit position (row + 7 col) of cell 4 m + q; 63 (an always-clear bit) for cell 63
+            f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+    #pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                const int b = 2 * wv + k;
+                const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+                const uint64_t S0 = conv_tap_board(my, op, j);                                               // taps 0..15
+                const uint64_t S1 = j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull);     // taps 16, 17, the bias "tap"
+                const float* ya = act + b * G::ASTR + j * G::HW + q;                                         // A[channel j][cell 4 s + q]
+    #pragma unroll
+                for (int s = 0; s < 16; s++) {
+                    const uint32_t pos = (FT.t[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+                    const float y = 4 * s + q < G::HW ? ya[4 * s] : 0.0f;
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, (float)((uint32_t)(S0 >> pos) & 1u), a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(y, (float)((uint32_t)(S1 >> pos) & 1u), a1, 0, 0, 0);
+                }
             }
-        }
-        // D[channel 4 q + r][tap 16 n + j]
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            part[(wv * 16 + 4 * q + r) * 20 + j] = a0[r];
-            if (j < 3) part[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a1[r];
-        }
+            // D[channel 4 q + r][tap 16 n + j]
+    #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                part[(wv * 16 + 4 * q + r) * 20 + j] = a0[r];
+                if (j < 3) part[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a1[r];
+            }
     }
     __syncthreads();
     // ---- G4: the sixteen partials, added in order
@@ -279,12 +302,14 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 SYN_DEV bf16x4 pack_bf16(float a, float b, float c, float d) { return bf16x4{(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d}; }
 
+template <int NT>
 SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
                                  const unsigned long long* __restrict__ op_bb, const float* __restrict__ tpi,
                                  const float* __restrict__ tv, int B, const DevTrainHyper& hp, float* __restrict__ grads,
                                  float* __restrict__ losses, const int* __restrict__ idx, float* lds, int tid) {
     using G = ConvMfmaGeom;
-    const int lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+    const int lane = tid & 63, rw = tid >> 6, j = lane & 15, q = lane >> 4;
+    constexpr int NWV = NT / 64;   // real waves; the sixteen chains' owners ("virtual waves" wv) are dealt over them
     float* act = lds + G::ACT_OFF;
     float* out = lds + G::OUT_OFF;
     float* dz = lds + G::DZ_OFF;
@@ -318,53 +343,64 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
     __syncthreads();
 
     // ---- F: conv (k = tap 16 h + 4 q + e) + ReLU + head partials (k = channel 4 q + e)
-    {
-        bf16x4 ca[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            float t4[4];
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int tap = 16 * h + 4 * q + e;
-                t4[e] = tap < 18 ? w[G::P_CW + j * 18 + tap] : 0.0f;
-            }
-            ca[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
-        }
-        const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);
-#pragma unroll 1
-        for (int t = 0; t < 2; t++) {
-            const int sample = 16 * t + j;
-            const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
-            uint64_t S[2][4];
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) S[h][e] = conv_tap_board(my, op, 16 * h + 4 * q + e);   // (taps >= 18: empty boards)
-            f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
-            for (int p = wv; p < G::HW; p += 16) {
-                const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
-                f32x4 acc = cbv;
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const bf16x4 xb = pack_bf16((float)((uint32_t)(S[h][0] >> pos) & 1u), (float)((uint32_t)(S[h][1] >> pos) & 1u),
-                                                (float)((uint32_t)(S[h][2] >> pos) & 1u), (float)((uint32_t)(S[h][3] >> pos) & 1u));
-                    acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ca[h], xb, acc, 0, 0, 0);
+    for (int wv = rw; wv < 16; wv += NWV) {
+            bf16x4 ca[2];
+    #pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float t4[4];
+    #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int tap = 16 * h + 4 * q + e;
+                    t4[e] = tap < 18 ? w[G::P_CW + j * 18 + tap] : 0.0f;
                 }
-                float a4[4], h4[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    a4[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
-                    act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a4[r];
-                    h4[r] = j < 12 ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+                ca[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+            }
+            const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);
+            bf16x4 hwb[4];   // the head weights of this wave's cells, rounded once for both sample tiles
+    #pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int p = wv + 16 * c;
+                float h4[4];
+    #pragma unroll
+                for (int r = 0; r < 4; r++) h4[r] = (j < 12 && p < G::HW) ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+                hwb[c] = pack_bf16(h4[0], h4[1], h4[2], h4[3]);
+            }
+    #pragma unroll 1
+            for (int t = 0; t < 2; t++) {
+                const int sample = 16 * t + j;
+                const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
+                uint64_t S[2][4];
+    #pragma unroll
+                for (int h = 0; h < 2; h++)
+    #pragma unroll
+                    for (int e = 0; e < 4; e++) S[h][e] = conv_tap_board(my, op, 16 * h + 4 * q + e);   // (taps >= 18: empty boards)
+                f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+    #pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int p = wv + 16 * c;
+                    if (p < G::HW) {
+                        const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
+                        f32x4 acc = cbv;
+    #pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const bf16x4 xb = pack_bf16((float)((uint32_t)(S[h][0] >> pos) & 1u), (float)((uint32_t)(S[h][1] >> pos) & 1u),
+                                                        (float)((uint32_t)(S[h][2] >> pos) & 1u), (float)((uint32_t)(S[h][3] >> pos) & 1u));
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ca[h], xb, acc, 0, 0, 0);
+                        }
+                        float a4[4];
+    #pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            a4[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+                            act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a4[r];
+                        }
+                        hacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hwb[c], pack_bf16(a4[0], a4[1], a4[2], a4[3]), hacc, 0, 0, 0);
+                    }
                 }
-                hacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16(h4[0], h4[1], h4[2], h4[3]), pack_bf16(a4[0], a4[1], a4[2], a4[3]), hacc, 0, 0, 0);
+                if (q < 3) {
+    #pragma unroll
+                    for (int r = 0; r < 4; r++) part[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
+                }
             }
-            if (q < 3) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) part[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
-            }
-        }
     }
     __syncthreads();
     // ---- H (f32, as conv_grad_step_mfma)
@@ -431,7 +467,7 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
             dza[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
         }
 #pragma unroll 1
-        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+        for (int ct = rw; ct < G::FLAT / 16; ct += NWV) {
             const int col = 16 * ct + j;
             f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -444,8 +480,8 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
                 for (int r = 0; r < 4; r++) grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + col] = acc[r];
             }
         }
-        if (tid >= 1024 - 12) {
-            const int o = tid - (1024 - 12);
+        if (tid >= NT - 12) {
+            const int o = tid - (NT - 12);
             float a = 0.0f;
             for (int b = 0; b < B; b++) a += dz[b * 12 + o];
             grads[G::P_HB + o] = a;
@@ -463,7 +499,7 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
             dzb[bt] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
         }
 #pragma unroll 1
-        for (int ct = wv; ct < G::FLAT / 16; ct += 16) {
+        for (int ct = rw; ct < G::FLAT / 16; ct += NWV) {
             float t4[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) t4[e] = q < 3 ? w[G::P_HW + (size_t)(4 * q + e) * G::FLAT + 16 * ct + j] : 0.0f;
@@ -480,37 +516,37 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
     }
     __syncthreads();
     // ---- G3: dWc partials (k = cell 16 h + 4 q + e, h = 0..3; cell 63: padding)
-    {
-        f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
-#pragma unroll 1
-        for (int k = 0; k < 2; k++) {
-            const int b = 2 * wv + k;
-            const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
-            const uint64_t S0 = conv_tap_board(my, op, j);
-            const uint64_t S1 = j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull);
-            const float* ya = act + b * G::ASTR + j * G::HW;
-#pragma unroll
-            for (int h = 0; h < 4; h++) {
-                float y4[4], x0[4], x1[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int cell = 16 * h + 4 * q + e;                       // per-lane (q), compile-time h, e
-                    const int cc = cell < G::HW ? cell : 0;
-                    const int row = cc / 9, col = cc - 9 * row, pos = row + 7 * col;
-                    y4[e] = cell < G::HW ? ya[cc] : 0.0f;
-                    x0[e] = cell < G::HW ? (float)((uint32_t)(S0 >> pos) & 1u) : 0.0f;
-                    x1[e] = cell < G::HW ? (float)((uint32_t)(S1 >> pos) & 1u) : 0.0f;
+    for (int wv = rw; wv < 16; wv += NWV) {
+            f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+    #pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                const int b = 2 * wv + k;
+                const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+                const uint64_t S0 = conv_tap_board(my, op, j);
+                const uint64_t S1 = j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull);
+                const float* ya = act + b * G::ASTR + j * G::HW;
+    #pragma unroll
+                for (int h = 0; h < 4; h++) {
+                    float y4[4], x0[4], x1[4];
+    #pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int cell = 16 * h + 4 * q + e;                       // per-lane (q), compile-time h, e
+                        const int cc = cell < G::HW ? cell : 0;
+                        const int row = cc / 9, col = cc - 9 * row, pos = row + 7 * col;
+                        y4[e] = cell < G::HW ? ya[cc] : 0.0f;
+                        x0[e] = cell < G::HW ? (float)((uint32_t)(S0 >> pos) & 1u) : 0.0f;
+                        x1[e] = cell < G::HW ? (float)((uint32_t)(S1 >> pos) & 1u) : 0.0f;
+                    }
+                    const bf16x4 yb = pack_bf16(y4[0], y4[1], y4[2], y4[3]);
+                    a0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb, pack_bf16(x0[0], x0[1], x0[2], x0[3]), a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb, pack_bf16(x1[0], x1[1], x1[2], x1[3]), a1, 0, 0, 0);
                 }
-                const bf16x4 yb = pack_bf16(y4[0], y4[1], y4[2], y4[3]);
-                a0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb, pack_bf16(x0[0], x0[1], x0[2], x0[3]), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(yb, pack_bf16(x1[0], x1[1], x1[2], x1[3]), a1, 0, 0, 0);
             }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            part[(wv * 16 + 4 * q + r) * 20 + j] = a0[r];
-            if (j < 3) part[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a1[r];
-        }
+    #pragma unroll
+            for (int r = 0; r < 4; r++) {
+                part[(wv * 16 + 4 * q + r) * 20 + j] = a0[r];
+                if (j < 3) part[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a1[r];
+            }
     }
     __syncthreads();
     if (tid < ConvGeom::CONV_W + G::C) {
@@ -523,16 +559,20 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
     }
 }
 
-// One launch = one minibatch (syn_train_step, the data-parallel gradient half): <<<1, 1024>>>. BF16: the bf16 matrix-core variant.
+// The workgroup: 8 waves (2 per SIMD, 256 VGPRs each: the step's prefetched operands do not fit 128), each owning two of the sixteen
+// chains' "virtual waves".
+constexpr int CONV_TRAIN_THREADS = 512;
+
+// One launch = one minibatch (syn_train_step, the data-parallel gradient half): <<<1, 512>>>. BF16: the bf16 matrix-core variant.
 template <bool BF16>
-__global__ __launch_bounds__(1024) void train_conv_grad_kernel_mfma(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
-                                                                    const unsigned long long* __restrict__ op_bb,
-                                                                    const float* __restrict__ tpi, const float* __restrict__ tv, int B,
-                                                                    DevTrainHyper hp, float* __restrict__ grads, float* __restrict__ losses,
-                                                                    const int* __restrict__ idx) {
+__global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_grad_kernel_mfma(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
+                                                                                  const unsigned long long* __restrict__ op_bb,
+                                                                                  const float* __restrict__ tpi, const float* __restrict__ tv, int B,
+                                                                                  DevTrainHyper hp, float* __restrict__ grads,
+                                                                                  float* __restrict__ losses, const int* __restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    if (BF16) conv_grad_step_bf16(w, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, lds, threadIdx.x);
-    else conv_grad_step_mfma(w, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, lds, threadIdx.x);
+    if (BF16) conv_grad_step_bf16<CONV_TRAIN_THREADS>(w, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, lds, threadIdx.x);
+    else conv_grad_step_mfma<CONV_TRAIN_THREADS>(w, my_bb, op_bb, tpi, tv, B, hp, grads, losses, idx, lds, threadIdx.x);
 }
 
 // One launch = every optimiser step of an epoch (syn_train_epoch): the step-ordered batches come from train_gather_kernel, the
@@ -549,34 +589,53 @@ struct ConvEpochParams {
     DevTrainHyper hp;
 };
 template <bool BF16>
-__global__ __launch_bounds__(1024) void train_conv_epoch_kernel(ConvEpochParams P) {
+__global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(ConvEpochParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = CONV_TRAIN_THREADS;
     const int tid = threadIdx.x;
     const int B = P.batch;
     for (int s = 0; s < P.n_steps; s++) {
         const size_t o = (size_t)s * B;
-        if (BF16) conv_grad_step_bf16(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
-        else conv_grad_step_mfma(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
-        // the gradients were written by other threads of this workgroup: make them visible, then Adam (train_kernels.cuh
-        // adam_kernel's expression) over the 12,412 parameters
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (BF16) conv_grad_step_bf16<NT>(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
+        else conv_grad_step_mfma<NT>(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
+        // the gradients were written by other threads of THIS workgroup (one CU, one vector L1): workgroup scope is all the
+        // visibility the step needs — an agent-scope release / acquire here writes back and invalidates the XCD's L2 four times a
+        // step (measured: 41 us per step). Then Adam (adam_kernel's expression) over the 12,412 parameters.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const float step_size = P.step_size[s], inv_sqrt_bc2 = P.inv_sqrt_bc2[s];
-        for (int i = tid; i < ConvGeom::NUM_PARAMS; i += 1024) {
-            const float g0 = P.grads[i];
-            const float wi = P.w[i];
-            const float g = P.hp.weight_decay != 0.0f ? __builtin_fmaf(P.hp.weight_decay, wi, g0) : g0;
-            const float mi = __builtin_fmaf(1.0f - P.hp.beta1, g, P.hp.beta1 * P.m[i]);
-            const float vi = __builtin_fmaf((1.0f - P.hp.beta2) * g, g, P.hp.beta2 * P.v[i]);
-            const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.hp.eps;
-            P.m[i] = mi;
-            P.v[i] = vi;
-            P.w[i] = wi - step_size * (mi / denom);
+        // 25 parameters per thread in two batches: all loads of a batch first, so that their latencies overlap
+        constexpr int PER = 13;
+#pragma unroll 1
+        for (int b0 = 0; b0 < ConvGeom::NUM_PARAMS; b0 += PER * NT) {
+            float g0[PER], wi[PER], mo[PER], vo[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = b0 + tid + NT * k;
+                const bool ok = i < ConvGeom::NUM_PARAMS;
+                g0[k] = ok ? P.grads[i] : 0.0f;
+                wi[k] = ok ? P.w[i] : 0.0f;
+                mo[k] = ok ? P.m[i] : 0.0f;
+                vo[k] = ok ? P.v[i] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = b0 + tid + NT * k;
+                if (i < ConvGeom::NUM_PARAMS) {
+                    const float g = P.hp.weight_decay != 0.0f ? __builtin_fmaf(P.hp.weight_decay, wi[k], g0[k]) : g0[k];
+                    const float mi = __builtin_fmaf(1.0f - P.hp.beta1, g, P.hp.beta1 * mo[k]);
+                    const float vi = __builtin_fmaf((1.0f - P.hp.beta2) * g, g, P.hp.beta2 * vo[k]);
+                    const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.hp.eps;
+                    P.m[i] = mi;
+                    P.v[i] = vi;
+                    P.w[i] = wi[k] - step_size * (mi / denom);
+                }
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
 

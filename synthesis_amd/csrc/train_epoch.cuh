@@ -576,10 +576,14 @@ __global__ __launch_bounds__(EP_THREADS) void train_epoch_kernel(EpochParams P) 
             }
             lds_barrier();
             if (ep_abort) return;  // a workgroup of the launch never arrived (not co-resident): the host reports the failure
-            // acquire: drop this CU's vector L1. sc1 = agent scope: outside threadgroup-split mode the memory model only promises
-            // that an AGENT-scope invalidate empties the L1 (a workgroup-scope one may legally keep lines); the writers' data sits in
-            // the XCD's L2 either way, so the cheap release above stays.
-            if (one_xcd) asm volatile("buffer_inv sc1" ::: "memory");
+            // acquire: drop this CU's vector L1 (sc0 = workgroup scope). ASSUMPTION, documented because the memory model only
+            // promises it for threadgroup-split mode: outside that mode `buffer_inv sc0` still empties the TCP on gfx950. The
+            // agent-scope form (`sc1`) was measured in round 3: it also invalidates the XCD's L2, every fragment of the next step
+            // then comes from memory and the step takes 20.6 us instead of 13.4. What guards the assumption: every build's
+            // tests/test_gpu_training.py::test_epoch_kernel_modes_agree compares this mode bit for bit with the device-scope
+            // barrier and with the queued launches, and syn_trainer_init runs the same comparison on the box it is called on
+            // (epoch_barrier_selfcheck): a mismatch switches the engine to the device-scope barrier.
+            if (one_xcd) asm volatile("buffer_inv sc0" ::: "memory");
             else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             EP_STAMP();  // step barrier
         }
