@@ -24,6 +24,7 @@
 // 72 + 32 + 24 + 64 MFMAs per wave and step. Measured in DESIGN.md §6.4.
 #pragma once
 #include "train_conv.cuh"
+#include "train_epoch.cuh"
 
 namespace syn {
 
@@ -56,7 +57,6 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
     const int lane = tid & 63, rw = tid >> 6, j = lane & 15, q = lane >> 4;
     constexpr int NWV = NT / 64;   // real waves; the sixteen chains' owners ("virtual waves" wv) are dealt over them
     float* act = lds + G::ACT_OFF;
-    float* out = lds + G::OUT_OFF;
     float* dz = lds + G::DZ_OFF;
     float* part = lds + G::PART_OFF;
     uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
@@ -72,21 +72,15 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         }
         bb[tid] = v;
     }
-    if (tid < G::CHUNK * 12) dz[tid] = 0.0f;
-    float tgt[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) tgt[i] = 0.0f;
-    if (tid < 2 * G::CHUNK && (tid >> 1) < B) {
-        const int b = tid >> 1;
-        const size_t si = idx ? (size_t)idx[b] : (size_t)b;
-        if ((tid & 1) == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) tgt[i] = tpi[si * 9 + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; i++) tgt[i] = tv[si * 3 + i];
-        }
+    // heads: 16 lanes per sample, one output entry per lane (0..8 policy, 9..11 outcome); its target and the target's logarithm
+    static_assert(NT == 16 * G::CHUNK, "the heads phase maps thread -> (sample tid >> 4, entry tid & 15)");
+    const int hb = tid >> 4, jx = tid & 15;
+    float tgt = 0.0f;
+    if (hb < B && jx < 12) {
+        const size_t si = idx ? (size_t)idx[hb] : (size_t)hb;
+        tgt = jx < 9 ? tpi[si * 9 + jx] : tv[si * 3 + (jx - 9)];
     }
+    const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;
     __syncthreads();
 
     // ---- F: conv forward + ReLU + head partials
@@ -138,47 +132,35 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
     __syncthreads();
 
     // ---- H: the 12 outputs (bias + the sixteen partials in order), then log_softmax + kl_div and their gradient
-    if (tid < G::CHUNK * 12) {
-        const int b = tid / 12, o = tid - 12 * b;
-        float a = w[G::P_HB + o];
+    {
+        // this lane's output: bias + the sixteen partials in order; then log_softmax + kl_div and their gradient with the row's
+        // values exchanged as DPP row broadcasts (train_epoch.cuh ep_row_gather / ep_row_sum: sums sequential in entry order)
+        const bool pol = jx < 9;
+        const bool live = jx < 12 && hb < B;
+        float xo = 0.0f;
+        if (jx < 12) {
+            xo = w[G::P_HB + jx];
 #pragma unroll
-        for (int g = 0; g < 16; g++) a += part[(g * G::CHUNK + b) * 12 + o];
-        out[tid] = a;
-    }
-    __syncthreads();
-    if (tid < 2 * G::CHUNK) {
-        const int b = tid >> 1, head = tid & 1;
-        const int off = head == 0 ? 0 : 9, n = head == 0 ? 9 : 3;
-        float kl = 0.0f;
-        if (b < B) {
-            const float* x = out + b * 12 + off;
-            const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
-            float xv[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) xv[i] = i < n ? x[i] : 0.0f;
-            float mx = xv[0];
-#pragma unroll
-            for (int i = 1; i < 9; i++) mx = (i < n && xv[i] > mx) ? xv[i] : mx;
-            float se = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 9; i++)
-                if (i < n) se += det_expf(xv[i] - mx);
-            const float lse = mx + det_logf(se);
-            float tsum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                if (i < n) {
-                    const float logp = xv[i] - lse;
-                    if (tgt[i] > 0.0f) kl += tgt[i] * (det_logf(tgt[i]) - logp);
-                    tsum += tgt[i];
-                }
-            }
-            const float s = weight * bm;
-#pragma unroll
-            for (int i = 0; i < 9; i++)
-                if (i < n) dz[b * 12 + off + i] = s * (det_expf(xv[i] - lse) * tsum - tgt[i]);
+            for (int g = 0; g < 16; g++) xo += part[(g * G::CHUNK + hb) * 12 + jx];
         }
-        lds[G::KL_OFF + b * 2 + head] = kl;
+        xo = live ? xo : 0.0f;
+        float xs[12];
+        ep_row_gather(xo, xs);
+        float mxp = xs[0], mxv = xs[9];
+#pragma unroll
+        for (int t = 1; t < 9; t++) mxp = xs[t] > mxp ? xs[t] : mxp;
+#pragma unroll
+        for (int t = 10; t < 12; t++) mxv = xs[t] > mxv ? xs[t] : mxv;
+        const float mx = pol ? mxp : mxv;
+        const float e = live ? det_expf(xo - mx) : 0.0f;
+        const float se = ep_row_sum(e, pol), tsum = ep_row_sum(tgt, pol);
+        const float lse = mx + det_logf(live ? se : 1.0f);
+        const float logp = xo - lse;
+        const float term = (live && tgt > 0.0f) ? tgt * (ltgt - logp) : 0.0f;
+        const float kl = ep_row_sum(term, pol);
+        const float sc = (pol ? hp.policy_weight : hp.value_weight) * bm;
+        if (jx < 12) dz[hb * 12 + jx] = live ? sc * (det_expf(xo - lse) * tsum - tgt) : 0.0f;   // rows >= B: zeros
+        if (jx == 0 || jx == 9) lds[G::KL_OFF + hb * 2 + (pol ? 0 : 1)] = hb < B ? kl : 0.0f;
     }
     __syncthreads();
     if (tid == 0) {
@@ -311,7 +293,6 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
     const int lane = tid & 63, rw = tid >> 6, j = lane & 15, q = lane >> 4;
     constexpr int NWV = NT / 64;   // real waves; the sixteen chains' owners ("virtual waves" wv) are dealt over them
     float* act = lds + G::ACT_OFF;
-    float* out = lds + G::OUT_OFF;
     float* dz = lds + G::DZ_OFF;
     float* part = lds + G::PART_OFF;
     uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
@@ -325,21 +306,15 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
         }
         bb[tid] = v;
     }
-    if (tid < G::CHUNK * 12) dz[tid] = 0.0f;
-    float tgt[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) tgt[i] = 0.0f;
-    if (tid < 2 * G::CHUNK && (tid >> 1) < B) {
-        const int b = tid >> 1;
-        const size_t si = idx ? (size_t)idx[b] : (size_t)b;
-        if ((tid & 1) == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) tgt[i] = tpi[si * 9 + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 3; i++) tgt[i] = tv[si * 3 + i];
-        }
+    // heads: 16 lanes per sample, one output entry per lane (0..8 policy, 9..11 outcome); its target and the target's logarithm
+    static_assert(NT == 16 * G::CHUNK, "the heads phase maps thread -> (sample tid >> 4, entry tid & 15)");
+    const int hb = tid >> 4, jx = tid & 15;
+    float tgt = 0.0f;
+    if (hb < B && jx < 12) {
+        const size_t si = idx ? (size_t)idx[hb] : (size_t)hb;
+        tgt = jx < 9 ? tpi[si * 9 + jx] : tv[si * 3 + (jx - 9)];
     }
+    const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;
     __syncthreads();
 
     // ---- F: conv (k = tap 16 h + 4 q + e) + ReLU + head partials (k = channel 4 q + e)
@@ -404,47 +379,35 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
     }
     __syncthreads();
     // ---- H (f32, as conv_grad_step_mfma)
-    if (tid < G::CHUNK * 12) {
-        const int b = tid / 12, o = tid - 12 * b;
-        float a = w[G::P_HB + o];
+    {
+        // this lane's output: bias + the sixteen partials in order; then log_softmax + kl_div and their gradient with the row's
+        // values exchanged as DPP row broadcasts (train_epoch.cuh ep_row_gather / ep_row_sum: sums sequential in entry order)
+        const bool pol = jx < 9;
+        const bool live = jx < 12 && hb < B;
+        float xo = 0.0f;
+        if (jx < 12) {
+            xo = w[G::P_HB + jx];
 #pragma unroll
-        for (int g = 0; g < 16; g++) a += part[(g * G::CHUNK + b) * 12 + o];
-        out[tid] = a;
-    }
-    __syncthreads();
-    if (tid < 2 * G::CHUNK) {
-        const int b = tid >> 1, head = tid & 1;
-        const int off = head == 0 ? 0 : 9, n = head == 0 ? 9 : 3;
-        float kl = 0.0f;
-        if (b < B) {
-            const float* x = out + b * 12 + off;
-            const float weight = head == 0 ? hp.policy_weight : hp.value_weight;
-            float xv[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) xv[i] = i < n ? x[i] : 0.0f;
-            float mx = xv[0];
-#pragma unroll
-            for (int i = 1; i < 9; i++) mx = (i < n && xv[i] > mx) ? xv[i] : mx;
-            float se = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 9; i++)
-                if (i < n) se += det_expf(xv[i] - mx);
-            const float lse = mx + det_logf(se);
-            float tsum = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 9; i++) {
-                if (i < n) {
-                    const float logp = xv[i] - lse;
-                    if (tgt[i] > 0.0f) kl += tgt[i] * (det_logf(tgt[i]) - logp);
-                    tsum += tgt[i];
-                }
-            }
-            const float s = weight * bm;
-#pragma unroll
-            for (int i = 0; i < 9; i++)
-                if (i < n) dz[b * 12 + off + i] = s * (det_expf(xv[i] - lse) * tsum - tgt[i]);
+            for (int g = 0; g < 16; g++) xo += part[(g * G::CHUNK + hb) * 12 + jx];
         }
-        lds[G::KL_OFF + b * 2 + head] = kl;
+        xo = live ? xo : 0.0f;
+        float xs[12];
+        ep_row_gather(xo, xs);
+        float mxp = xs[0], mxv = xs[9];
+#pragma unroll
+        for (int t = 1; t < 9; t++) mxp = xs[t] > mxp ? xs[t] : mxp;
+#pragma unroll
+        for (int t = 10; t < 12; t++) mxv = xs[t] > mxv ? xs[t] : mxv;
+        const float mx = pol ? mxp : mxv;
+        const float e = live ? det_expf(xo - mx) : 0.0f;
+        const float se = ep_row_sum(e, pol), tsum = ep_row_sum(tgt, pol);
+        const float lse = mx + det_logf(live ? se : 1.0f);
+        const float logp = xo - lse;
+        const float term = (live && tgt > 0.0f) ? tgt * (ltgt - logp) : 0.0f;
+        const float kl = ep_row_sum(term, pol);
+        const float sc = (pol ? hp.policy_weight : hp.value_weight) * bm;
+        if (jx < 12) dz[hb * 12 + jx] = live ? sc * (det_expf(xo - lse) * tsum - tgt) : 0.0f;   // rows >= B: zeros
+        if (jx == 0 || jx == 9) lds[G::KL_OFF + hb * 2 + (pol ? 0 : 1)] = hb < B ? kl : 0.0f;
     }
     __syncthreads();
     if (tid == 0) {
