@@ -96,7 +96,8 @@ struct MCTS {
     MCTSConfig cfg;
     MCTSCounters* ctr = nullptr;
     uint64_t noise_seed = 0;          // this tree's stream for Fpu::Func Normal draws / the Dirichlet sample (noise.hpp)
-    mutable uint32_t fpu_draws = 0;   // Normal draws taken so far (exploit_value is const in the reference too)
+    mutable uint32_t fpu_scans = 0;   // select_best_child calls of this tree that took at least one Normal draw (noise.hpp)
+    mutable bool fpu_scan_used = false;   // ... the one in progress did (exploit_value is const in the reference too)
 
     // mcts.rs:123-137
     // `storage`: an empty vector whose capacity is reused (the reference allocates a fresh Vec::with_capacity per
@@ -262,6 +263,7 @@ struct MCTS {
         bool have = false;
         float best_value = 0.0f;
         if (ctr) { ctr->select_levels++; ctr->children_scanned += parent.num_children; }
+        fpu_scan_used = false;
         for (uint32_t child_id = parent.first_child; child_id < parent.last_child(); child_id++) {
             const Node<G>& child = nodes[child_id];
             float q = exploit_value(parent, child);
@@ -273,6 +275,7 @@ struct MCTS {
                 have = true;
             }
         }
+        if (fpu_scan_used) fpu_scans++;
         return best_child;
     }
 
@@ -287,7 +290,8 @@ struct MCTS {
                 case FPU_PARENT_Q: return parent.q();
                 default:
                     if (cfg.fpu_fn) return cfg.fpu_fn();
-                    return noise_fpu_normal(noise_seed, fpu_draws++, cfg.fpu_value, cfg.fpu_std);
+                    fpu_scan_used = true;
+                    return noise_fpu_normal(noise_seed, fpu_scans, (uint32_t)(&child - &nodes[parent.first_child]), cfg.fpu_value, cfg.fpu_std);
             }
         } else {
             return -child.q();

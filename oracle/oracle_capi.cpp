@@ -85,6 +85,11 @@ int orc_conv2d_forward(int CIN, int COUT, int K, int RP, int CP, int S, int H_IN
 }
 void orc_relu(float* x, int n) { relu_inplace(x, n); }
 void orc_tanh(float* x, int n) { tanh_inplace(x, n); }
+// Fpu::Func draws of n_scans consecutive scans of one tree, nine child slots each (oracle/noise.hpp): out[scan][slot]
+void orc_noise_fpu_normals(uint64_t tree_seed, int n_scans, float mean, float std_dev, float* out) {
+    for (int s = 0; s < n_scans; s++)
+        for (int i = 0; i < 9; i++) out[(size_t)s * 9 + i] = noise_fpu_normal(tree_seed, (uint32_t)s, (uint32_t)i, mean, std_dev);
+}
 void orc_softmax_slimnn(const float* x, float* y, int n) { softmax_slimnn(x, y, n); }
 void orc_softmax_stable(const float* x, float* y, int n) { softmax_stable(x, y, n); }
 void orc_det_expf(const float* x, float* y, int n) {

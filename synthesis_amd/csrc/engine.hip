@@ -1800,6 +1800,10 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         ep.step_size = d_sc; ep.inv_sqrt_bc2 = d_sc + n_steps;
         ep.losses = d_losses; ep.grads = h->d_tgrad;
         ep.n_steps = (int)n_steps; ep.batch = batch; ep.hp = h->train_hp;
+        unsigned long long* d_cprof = reinterpret_cast<unsigned long long*>(sc + perm_bytes + loss_bytes + batch_bytes + loss_bytes);
+        const bool cprof = debug_env("SYN_TRAIN_PROFILE") != nullptr && n_steps > 2 && !h->train_bf16;
+        if (cprof) HIP_TRY(h, hipMemsetAsync(d_cprof, 0, 128, h->stream));
+        ep.prof = cprof ? d_cprof : nullptr;
         const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
         auto ke = h->train_bf16 ? train_conv_epoch_kernel<true> : train_conv_epoch_kernel<false>;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
@@ -1807,6 +1811,12 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         HIP_TRY(h, hipGetLastError());
         if (step_losses) HIP_TRY(h, hipMemcpyAsync(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (cprof) {
+            unsigned long long t[16] = {0};
+            HIP_TRY(h, hipMemcpy(t, d_cprof, sizeof(t), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[syn train profile] conv epoch kernel, step 2, cycles: stage %llu | F %llu | H %llu | losses+G1 %llu | G2 %llu | G3 %llu | G4 %llu | Adam %llu | total %llu\n",
+                    t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6], t[15] - t[7], t[15] - t[0]);
+        }
         h->train_step += (long long)n_steps;
         return SYN_OK;
     }

@@ -156,9 +156,14 @@ SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
     return b;
 }
 
-// Out of line: the draws sit on the slow (runtime-switched) configuration path, nine call sites per level of the descent
-__device__ __attribute__((noinline)) float lane_fpu_draw(uint64_t tree_seed, uint32_t j, float mean, float std) {
-    return noise_fpu_normal(tree_seed, j, mean, std);
+// Out of line: the draws sit on the slow (runtime-switched) configuration path; one call per level of the descent
+struct FpuScan { float q[9]; };
+__device__ __attribute__((noinline)) FpuScan lane_fpu_scan(uint64_t tree_seed, uint32_t scan, uint32_t need, float mean, float std, float q_default) {
+    FpuScan r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.q[i] = q_default;
+    noise_fpu_scan(tree_seed, scan, need, mean, std, r.q);
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------- phase A
@@ -236,13 +241,19 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
 #pragma unroll
     for (uint32_t i = 0; i < 9; i++) qf[i] = q_fpu;
     if (cfg.fpu_normal()) {
-        uint32_t draws = T.fpu_draws;
+        // T.fpu_draws counts this tree's scans that took a draw (noise.cuh)
+        uint32_t need = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 9; i++) {
             const uint32_t nf = d[3 * i + 2];
-            if (i < nc && !nf_solved(nf) && nf_blk(nf) == 0u) qf[i] = lane_fpu_draw(noise_seed, draws++, cfg.fpu_value(), cfg_.fpu_std);
+            need |= (i < nc && !nf_solved(nf) && nf_blk(nf) == 0u) ? (1u << i) : 0u;
         }
-        T.fpu_draws = draws;
+        if (__ballot(need != 0u) != 0ull) {
+            const FpuScan fs = lane_fpu_scan(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, q_fpu);
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) qf[i] = ((need >> i) & 1u) ? fs.q[i] : qf[i];
+            T.fpu_draws += need != 0u ? 1u : 0u;
+        }
     }
     float vv[9];
     if (cfg.puct()) {

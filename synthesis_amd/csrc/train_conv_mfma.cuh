@@ -52,7 +52,10 @@ template <int NT>
 SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned long long* __restrict__ my_bb,
                                  const unsigned long long* __restrict__ op_bb, const float* __restrict__ tpi,
                                  const float* __restrict__ tv, int B, const DevTrainHyper& hp, float* __restrict__ grads,
-                                 float* __restrict__ losses, const int* __restrict__ idx, float* lds, int tid) {
+                                 float* __restrict__ losses, const int* __restrict__ idx, float* lds, int tid, unsigned long long* prof = nullptr) {
+    int pk = 0;   // SYN_TRAIN_PROFILE: cycle stamps of thread 0 after every barrier (stage, F, H, G1, G2, G3)
+#define CONV_STAMP() do { if (prof && tid == 0) prof[pk++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+    CONV_STAMP();
     using G = ConvMfmaGeom;
     const int lane = tid & 63, rw = tid >> 6, j = lane & 15, q = lane >> 4;
     constexpr int NWV = NT / 64;   // real waves; the sixteen chains' owners ("virtual waves" wv) are dealt over them
@@ -82,6 +85,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
     }
     const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;
     __syncthreads();
+    CONV_STAMP();
 
     // ---- F: conv forward + ReLU + head partials
     for (int wv = rw; wv < 16; wv += NWV) {
@@ -130,6 +134,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
             }
     }
     __syncthreads();
+    CONV_STAMP();
 
     // ---- H: the 12 outputs (bias + the sixteen partials in order), then log_softmax + kl_div and their gradient
     {
@@ -163,6 +168,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         if (jx == 0 || jx == 9) lds[G::KL_OFF + hb * 2 + (pol ? 0 : 1)] = hb < B ? kl : 0.0f;
     }
     __syncthreads();
+    CONV_STAMP();
     if (tid == 0) {
         float pi_acc = 0.0f, v_acc = 0.0f;
         for (int b = 0; b < B; b++) {
@@ -197,6 +203,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         }
     }
     __syncthreads();
+    CONV_STAMP();
 
     // ---- G2: activation gradients through the ReLU, in place
     {
@@ -234,6 +241,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         }
     }
     __syncthreads();
+    CONV_STAMP();
 
     // ---- G3: conv parameter gradients, one partial per wave (= sample pair)
     for (int wv = rw; wv < 16; wv += NWV) {
@@ -262,6 +270,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
             }
     }
     __syncthreads();
+    CONV_STAMP();
     // ---- G4: the sixteen partials, added in order
     if (tid < ConvGeom::CONV_W + G::C) {
         const int c = tid < ConvGeom::CONV_W ? tid / 18 : tid - ConvGeom::CONV_W;
@@ -271,6 +280,8 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         for (int g = 1; g < 16; g++) v += part[(g * 16 + c) * 20 + t];
         grads[tid < ConvGeom::CONV_W ? G::P_CW + tid : G::P_CB + c] = v;
     }
+    CONV_STAMP();
+#undef CONV_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------- bf16 variant
@@ -550,6 +561,7 @@ struct ConvEpochParams {
     float* grads;                              // the last step's gradients stay here (syn_trainer_get_state)
     int n_steps, batch;
     DevTrainHyper hp;
+    unsigned long long* prof;                  // SYN_TRAIN_PROFILE: stamps of step 2 (f32 variant), else null
 };
 template <bool BF16>
 __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(ConvEpochParams P) {
@@ -560,7 +572,8 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(Co
     for (int s = 0; s < P.n_steps; s++) {
         const size_t o = (size_t)s * B;
         if (BF16) conv_grad_step_bf16<NT>(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
-        else conv_grad_step_mfma<NT>(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid);
+        else conv_grad_step_mfma<NT>(P.w, P.my_bb + o, P.op_bb + o, P.tpi + o * 9, P.tv + o * 3, B, P.hp, P.grads, P.losses + 2 * s, nullptr, lds, tid,
+                                     (P.prof && s == 2) ? P.prof : nullptr);
         // the gradients were written by other threads of THIS workgroup (one CU, one vector L1): workgroup scope is all the
         // visibility the step needs — an agent-scope release / acquire here writes back and invalidates the XCD's L2 four times a
         // step (measured: 41 us per step). Then Adam (adam_kernel's expression) over the 12,412 parameters.
@@ -599,6 +612,7 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(Co
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (P.prof && s == 2 && tid == 0) P.prof[15] = (unsigned long long)__builtin_readcyclecounter();   // end of the step incl. Adam
     }
 }
 

@@ -150,6 +150,12 @@ class Oracle:
         self.lib.orc_det_logf(_p(x), _p(y), int(x.size))
         return y
 
+    def noise_fpu_normals(self, tree_seed, n_scans, mean=0.0, std=1.0):
+        """Fpu::Func draws [scan][child slot] of one tree (oracle/noise.hpp noise_fpu_normal)"""
+        out = np.zeros((int(n_scans), 9), np.float32)
+        self.lib.orc_noise_fpu_normals(C.c_uint64(int(tree_seed)), int(n_scans), C.c_float(mean), C.c_float(std), _p(out))
+        return out
+
     def tanh(self, x):
         y = np.ascontiguousarray(x, np.float32).ravel().copy()
         self.lib.orc_tanh(_p(y), int(y.size))

@@ -484,6 +484,28 @@ def test_oracle_dirichlet_noise_and_normal_fpu_properties(oracle, golden_dir):
     assert (a["child_N"][0] >= 1).all() and a["child_N"][0].sum() == 200
 
 
+def test_oracle_fpu_normal_stream_statistics(oracle):
+    """Fpu::Func(|| Normal(mean, std)) as the device and the oracle draw it (oracle/noise.hpp: a draw is a pure function of (tree,
+    scan, child slot); first 64 bits from the tree's scan stream, the ziggurat's rare continuation from a generator of the draw's
+    own): rand_distr's StandardNormal restated — moments and tail mass of 900,000 draws are a standard normal's, slots and scans and
+    trees are uncorrelated, and the call is reproducible."""
+    z = oracle.noise_fpu_normals(0x1234ABCD, 100000)
+    assert np.array_equal(z, oracle.noise_fpu_normals(0x1234ABCD, 100000))
+    x = z.astype(np.float64).ravel()
+    n = x.size
+    assert abs(x.mean()) < 4 / np.sqrt(n) and abs(x.var() - 1.0) < 6 * np.sqrt(2.0 / n)
+    assert abs(((x - x.mean()) ** 4).mean() / x.var() ** 2 - 3.0) < 0.03               # kurtosis
+    assert abs((np.abs(x) > 1.959964).mean() - 0.05) < 0.002 and abs((np.abs(x) > 3.0).mean() - 0.0027) < 4e-4
+    assert 4.0 < np.abs(x).max() < 6.5                                                 # the ziggurat's tail is reached
+    c = np.corrcoef(z.astype(np.float64).T)                                            # child slots of the same scans
+    assert np.abs(c - np.eye(9)).max() < 0.02
+    assert abs(np.corrcoef(x[:-9], x[9:])[0, 1]) < 0.01                                # consecutive scans
+    other = oracle.noise_fpu_normals(0x1234ABCE, 100000).astype(np.float64).ravel()    # another tree
+    assert abs(np.corrcoef(x, other)[0, 1]) < 0.01 and not np.array_equal(x[:9], other[:9])
+    w = oracle.noise_fpu_normals(7, 2000, mean=1.0, std=0.1).astype(np.float64)
+    assert abs(w.mean() - 1.0) < 0.004 and abs(w.std() - 0.1) < 0.004                  # Normal(1.0, 0.1), main.rs:43-47
+
+
 def test_oracle_tanh_and_slimnn_softmax(oracle):
     """slimnn Tanh (activations.rs:39-44: x.tanh()) through the deterministic det_tanhf: within 2 ulp-ish of float64 tanh
     everywhere, odd, saturating; Softmax::apply_1d (activations.rs:46-63): exp / sum WITHOUT max subtraction."""
