@@ -41,8 +41,10 @@ def per_launch(name, pick, largest=True):
 
 # the un-instrumented (COUNT = false) self-play launches: the parity configuration takes the FAST instantiation, the reference's
 # Fpu::Func configuration the general one (template arguments <MODE, COUNT, FAST, ...>)
-timed = lambda n: "selfplay_kernel" in n and "<0, false, true" in n
-timed_general = lambda n: "selfplay_kernel" in n and "<0, false, false" in n
+import re  # noqa: E402
+timed = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (true|1),", n) is not None
+# the reference's Fpu::Func configuration: its own instantiation (family 2) since round 3's last build, the general one (0) before
+timed_general = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (false|0|2),", n) is not None
 line = None
 for l in open(f"{out}/{tag}_bench_lines_under_profiler.jsonl"):
     line = json.loads(l)
