@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--dump-weights", default="", help="write the final weights of every rank to <prefix>.rank<r>.npy")
     ap.add_argument("--net", default="mlp", choices=["mlp", "conv"], help="mlp = the reference's Connect4Net; conv = Connect4ConvNet "
                     "(north_star's Conv2d over the bitplanes + Linear heads)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"], help="arithmetic of the conv learner's gradient step: bf16 = bf16 "
+                    "matrix cores with f32 accumulation, master weights and Adam (BASELINE configs[4]: \"bf16 conv\"; --net conv only)")
     ap.add_argument("--data-parallel", action="store_true", help="gradient all-reduce per optimiser step on every rank instead of "
                     "the learner on rank 0 + one weight broadcast per iteration")
     args = ap.parse_args()
@@ -93,12 +95,15 @@ def main():
     if args.data_parallel:
         (eng.load_weights_conv if conv else eng.load_weights)(blob)
         learner = DataParallelLearner(eng, blob, dist=dist, device=local_rank, net=args.net, **hyper)
+        if args.precision != "f32":
+            eng.trainer_set_precision(args.precision)
         # replay buffer: positions as bitboards + targets + the game each step came from
         R = dict(my=np.zeros(0, np.uint64), op=np.zeros(0, np.uint64), pi=np.zeros((0, 9), np.float32),
                  v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
         games_played = 0
     else:
-        loop = LearningLoop(eng, args.net, blob, dist=dist, device=local_rank, lr_schedule=lr_schedule, seed=args.seed, **hyper)
+        loop = LearningLoop(eng, args.net, blob, dist=dist, device=local_rank, lr_schedule=lr_schedule, seed=args.seed,
+                            precision=args.precision, **hyper)
     log = []
     eval_eng = None
     for it in range(args.iterations):

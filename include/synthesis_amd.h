@@ -297,7 +297,9 @@ int syn_trainer_publish_weights(syn_engine* h);
  * gradient of the LAST step is what syn_trainer_get_state reports). That kernel needs its 16 workgroups resident together; the
  * learner's state is snapshotted before the launch, and if the workgroups never become co-resident (another kernel holds the CUs:
  * it gives up after ~10 s) the snapshot is restored and the epoch runs through the queued per-step launches instead — same bits,
- * the call still returns SYN_OK. Larger batches and the Connect4ConvNet learner with batch > 32 queue two launches per step. */
+ * the call still returns SYN_OK. Larger batches queue two launches per step. The Connect4ConvNet learner (syn_trainer_init_conv;
+ * minibatches of at most 32) runs an epoch as ONE launch of a single persistent workgroup (csrc/train_conv_mfma.cuh: no
+ * co-residency requirement), in f32 or — after syn_trainer_set_precision(SYN_TRAIN_BF16) — on the bf16 matrix cores. */
 int syn_train_set_data(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
                        const float* target_v, size_t n);
 int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batch, float lr, float* step_losses);

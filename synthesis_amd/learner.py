@@ -43,10 +43,11 @@ class LearningLoop:
     engine       this rank's sa.Engine (self-play; on rank 0 also the learner and the de-duplication)
     net          "mlp" (Connect4Net, study-connect4/src/policies.rs:14-59) | "conv" (Connect4ConvNet)
     blob         initial parameters — identical on every rank (P::new(&vs), alpha_zero.rs:31)
+    precision    "f32" | "bf16" (Connect4ConvNet's learner only: syn_trainer_set_precision)
     dist         torch.distributed (initialised) or None for one rank
     """
 
-    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, **hyper):
+    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, precision="f32", **hyper):
         import torch
 
         self._torch = torch
@@ -68,6 +69,8 @@ class LearningLoop:
         self._wbuf = torch.zeros(self.n_params, dtype=torch.float32, device=torch.device(f"cuda:{device}") if on_gpu else "cpu")
         if self.rank == 0:
             (engine.trainer_init_conv if net == "conv" else engine.trainer_init)(blob, **hyper)
+            if precision != "f32":
+                engine.trainer_set_precision(precision)   # "bf16": the conv learner's bf16 matrix-core variant (BASELINE configs[4])
         # replay buffer (rank 0): positions as bitboards + targets + the game each step came from (data.rs:107-158)
         self.R = dict(my=np.zeros(0, np.uint64), op=np.zeros(0, np.uint64), pi=np.zeros((0, 9), np.float32),
                       v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
