@@ -436,6 +436,13 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
             nw = want_slots > h->num_cus * 512 ? 16 : (want_slots > h->num_cus * 256 ? 8 : 4);
         }
+        // The runtime-switched (general) instantiations need 300-450 more registers than the 128 of a 16-wave workgroup and are
+        // bound by their own scratch traffic there (PMC: 8.8x the algorithmic bytes; Fpu::ParentQ 29.5k games/s against 42.4k,
+        // Fpu::Func 15.9k against 31.2k): they run 8 waves of 256 registers on at most 512 trees per CU, whatever the capacity.
+        if (!fast && nw > 8 && debug_env("SYN_LANES") == nullptr) {
+            nw = 8;
+            if (want_slots > h->num_cus * 512) want_slots = h->num_cus * 512;
+        }
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
             // (slots are rounded up to whole workgroups; the pool was allocated for a multiple of 1024 slabs)

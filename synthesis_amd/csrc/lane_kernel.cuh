@@ -156,15 +156,42 @@ SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
     return b;
 }
 
-// Out of line: the draws sit on the slow (runtime-switched) configuration path; one call per level of the descent
-struct FpuScan { float q[9]; };
+// Out of line: the draws sit on the slow (runtime-switched) configuration path. lane_fpu_scan is a leaf function written to stay
+// inside the caller-saved registers (no prologue saves, no scratch); the rare continuation of a draw (1.2 %) is its own cold call.
+struct FpuScan { float q[9]; uint32_t fail; };
 __device__ __attribute__((noinline)) FpuScan lane_fpu_scan(uint64_t tree_seed, uint32_t scan, uint32_t need, float mean, float std, float q_default) {
     FpuScan r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.q[i] = q_default;
-    noise_fpu_scan(tree_seed, scan, need, mean, std, r.q);
+    r.fail = noise_fpu_scan(tree_seed, scan, need, mean, std, r.q);
     return r;
 }
+__device__ __attribute__((noinline, cold)) float lane_fpu_redo(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std) {
+    return noise_fpu_redo(tree_seed, scan, slot, mean, std);
+}
+// All nine scores of one select_best_child scan under Fpu::Func: slots outside `need` get q_default
+SYN_DEV void lane_fpu_draws(uint64_t tree_seed, uint32_t scan, uint32_t need, float mean, float std, float q_default, float (&qf)[9]) {
+    const FpuScan fs = lane_fpu_scan(tree_seed, scan, need, mean, std, q_default);
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) qf[i] = fs.q[i];
+    uint32_t fail = fs.fail;
+    while (__ballot(fail != 0u) != 0ull) {
+        if (fail != 0u) {
+            const uint32_t slot = (uint32_t)__ffs((int)fail) - 1u;
+            fail &= fail - 1u;
+            const float z = lane_fpu_redo(tree_seed, scan, slot, mean, std);
+#pragma unroll
+            for (uint32_t i = 0; i < 9; i++) qf[i] = slot == i ? z : qf[i];
+        }
+    }
+}
+
+// Fpu::Func in the one-tree-per-lane descent loop: a lane whose node needs draws waits (`wait`, with the slots in `need`) until no
+// lane of the wave can take a level without them; then ONE scan serves all waiting lanes (lane_select_expand). A draw is a function
+// of (tree, scan index, slot) only, so when it is computed does not matter.
+struct FpuHold {
+    bool wait;
+};
 
 // ---------------------------------------------------------------------------------------------- phase A
 // The node a descent stands on: its record and own block (0 = none), solution, q slot, N and position.
@@ -216,9 +243,11 @@ SYN_DEV void lane_begin_explore(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
 // One level of the descent (mcts.rs:310-341: select_best_child + the step into the chosen child) = one cache line.
 // lm = legal columns of the cursor's position (updated as the descent drops stones: a column leaves the mask when its seventh
 // stone lands); the children of a node are its legal columns in ascending order.
-template <bool COUNT, bool FAST>
+// DEFER (lane_select_expand): with `scan_now` false a lane that needs draws only records that in H and returns; the caller's
+// next call with scan_now true (wave-uniform) takes the draws and the level.
+template <bool COUNT, bool FAST, bool DEFER = false>
 SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint32_t& lm, uint4* pl, uint32_t* ctr,
-                                uint64_t noise_seed) {
+                                uint64_t noise_seed, FpuHold* H = nullptr, bool scan_now = true) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     const uint32_t nc = (uint32_t)__popc(lm);
@@ -230,7 +259,6 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
         const uint4 t = line[1 + j];
         d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
     }
-    pl[PATH_PLANE + C.level * 64] = hdr;  // (the entry's PM_HAS_W flag was set when the descent arrived here)
     const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(C.qt);  // parent.q() = -(stored q)
     const float visits = cfg.puct() ? sqrtf(C.pN) : sqrtf(cfg.cc() * det_logf(C.pN));
     // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
@@ -248,13 +276,17 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
             const uint32_t nf = d[3 * i + 2];
             need |= (i < nc && !nf_solved(nf) && nf_blk(nf) == 0u) ? (1u << i) : 0u;
         }
-        if (__ballot(need != 0u) != 0ull) {
-            const FpuScan fs = lane_fpu_scan(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, q_fpu);
-#pragma unroll
-            for (uint32_t i = 0; i < 9; i++) qf[i] = ((need >> i) & 1u) ? fs.q[i] : qf[i];
+        if (DEFER && !scan_now) {
+            if (need != 0u) {
+                H->wait = true;
+                return;
+            }
+        } else if (__ballot(need != 0u) != 0ull) {
+            lane_fpu_draws(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, q_fpu, qf);
             T.fpu_draws += need != 0u ? 1u : 0u;
         }
     }
+    pl[PATH_PLANE + C.level * 64] = hdr;  // (the entry's PM_HAS_W flag was set when the descent arrived here)
     float vv[9];
     if (cfg.puct()) {
         // explore_value = ((c * P) * sqrt(N_parent)) / (1 + n) (mcts.rs:361-372), two children per instruction.
@@ -434,6 +466,24 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     bool hit_solved = false, at_leaf = pending;
     // legal columns of the current position: computed once per round and updated as the descent drops stones
     uint32_t lm = legal_mask_of(C.my | C.op);
+    if (!FAST && cfg_.fpu == 2) {
+        // Fpu::Func: levels that need no draws first, then one scan for every lane that waits for draws (FpuHold)
+        FpuHold H;
+        H.wait = false;
+        for (;;) {
+            if (desc && !H.wait) {
+                if (C.nsolved) { hit_solved = true; desc = false; at_leaf = true; }
+                else if (C.blk == 0u) { desc = false; at_leaf = true; }
+            }
+            if (__popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
+            const bool scan_now = __ballot(desc && !H.wait) == 0ull;
+            if (scan_now && __ballot(desc) == 0ull) break;
+            if (desc && H.wait == scan_now) {
+                H.wait = false;
+                lane_descend_level<COUNT, FAST, true>(cfg_, T, C, lm, pl, ctr, noise_seed, &H, scan_now);
+            }
+        }
+    } else
     for (;;) {
         if (desc) {
             if (C.nsolved) { hit_solved = true; desc = false; at_leaf = true; }

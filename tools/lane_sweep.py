@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool: throughput of the lane-per-tree / producer-consumer kernels. Args: conc:nw[:games[:policy_cache_log2]] ...
 (nw = waves per workgroup of the lane kernel, 0 = the engine's own choice, negative = producer/consumer kernel with -nw
-virtual waves per tree wave). A first argument "conv" runs Connect4ConvNet (convnet.cuh) instead of Connect4Net; "eval" appended
+virtual waves per tree wave, 208 / 212 = the two-trees-per-lane kernel with 8 / 12 waves). A first argument "reference" runs the
+reference's own self-play configuration (trained checkpoint + Fpu::Func(Normal(1.0, 0.1)); give a policy_cache_log2 too). A first argument "conv" runs Connect4ConvNet (convnet.cuh) instead of Connect4Net; "eval" appended
 measures the stand-alone batched Policy::eval of the chosen network on 4M positions as well."""
 import os
 os.environ["SYN_DEBUG"] = "1"  # developer knobs (SYN_LANES, SYN_PROFILE, ...) are honoured only with SYN_DEBUG=1
@@ -15,6 +16,10 @@ from bench import make_conv_weights, make_weights
 argv = sys.argv[1:]
 conv = bool(argv) and argv[0] == "conv"
 if conv: argv = argv[1:]
+reference = bool(argv) and argv[0] == "reference"
+if reference: argv = ["trained"] + argv[1:]
+parentq = bool(argv) and argv[0] == "parentq"   # a non-parity configuration without draws (general kernel instantiation): Fpu::ParentQ
+if parentq: argv = ["trained"] + argv[1:]
 trained = bool(argv) and argv[0] == "trained"   # the trained Connect4Net checkpoint (deep narrow trees) instead of the fixed-seed init
 if trained: argv = argv[1:]
 do_eval = bool(argv) and argv[-1] == "eval"
@@ -22,13 +27,15 @@ if do_eval: argv = argv[:-1]
 blob = make_conv_weights() if conv else make_weights()
 if trained: blob = np.load(os.path.join(ROOT, 'tests', 'golden', 'c4net_trained_f32.npy'))
 combos = [tuple(map(int, a.split(":"))) for a in argv] or [(65536, 16), (131072, 16), (262144, 16)]
-cfg = sa.parity_rollout_config(800)
+cfg = sa.parity_rollout_config(800, mcts_cfg=sa.reference_selfplay_mcts_config()) if reference else sa.parity_rollout_config(800)
+if parentq: cfg = sa.parity_rollout_config(800, mcts_cfg=sa.MCTSConfig(fpu=sa.Fpu.ParentQ))
 for c in combos:
     conc, nw = c[0], c[1]
     n = c[2] if len(c) > 2 else 2 * conc
     clog = c[3] if len(c) > 3 else 0
-    os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None)
-    if nw > 0: os.environ["SYN_LANES"] = str(nw); os.environ["SYN_PC"] = "0"
+    os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None); os.environ.pop("SYN_LANES2", None)
+    if nw in (208, 212): os.environ["SYN_LANES2"] = str(nw - 200)
+    elif nw > 0: os.environ["SYN_LANES"] = str(nw); os.environ["SYN_PC"] = "0"
     elif nw < 0: os.environ["SYN_PC"] = str(-nw)
     eng = sa.Engine(concurrent_games=conc, max_explores=800, policy_cache_log2=clog)
     (eng.load_weights_conv if conv else eng.load_weights)(blob)
