@@ -540,7 +540,7 @@ def main():
             steady = (gps - gx) / max(1e-9, t_step - dt2)    # games/s of the tail-free three quarters of a step
             out["launch_tail"] = {"games_per_s_at_quarter_games_per_step": gx / dt2, "steady_state_games_per_s": steady,
                                   "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
-        if world == 1 and not args.no_4096 and fits("at_4096_concurrent_games", 6):
+        if world == 1 and not args.no_4096 and fits("at_4096_concurrent_games", 15):
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration
             e2 = sa.Engine(concurrent_games=4096, max_explores=args.explores, device=local_rank)
@@ -551,6 +551,30 @@ def main():
             dt = time.perf_counter() - t1
             out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
                                                "games": 16384, "plies_per_game": float(r2["plies"].mean())}
+            # configs[1] as worded — host trees in lock step, one batched Policy::eval launch per round
+            # (include/synthesis_amd_lockstep.hpp behind syn_mcts_search_lockstep) — beside the fused search on the same 4,096 roots
+            # (mid-game positions of the self-play run above): the form a caller with another Game impl would use
+            try:
+                r2s = e2.selfplay(cfg, base_seed=3, n_games=4096)
+                ply = np.minimum(r2s["plies"] - 1, 8)
+                roots = r2s["states_bb"][np.arange(4096), ply]
+                e2.mcts_search(cfg.mcts_cfg, roots[:, 0], roots[:, 1], 16)
+                t1 = time.perf_counter()
+                fs = e2.mcts_search(cfg.mcts_cfg, roots[:, 0], roots[:, 1], args.explores)
+                dt_f = time.perf_counter() - t1
+                e2.mcts_search_lockstep(cfg.mcts_cfg, roots[:64, 0], roots[:64, 1], 16)
+                t1 = time.perf_counter()
+                ls = e2.mcts_search_lockstep(cfg.mcts_cfg, roots[:, 0], roots[:, 1], args.explores)
+                dt_l = time.perf_counter() - t1
+                st = ls["stats"]
+                out["at_4096_concurrent_games"]["lockstep_host_trees"] = {
+                    "roots": 4096, "explores": args.explores, "searches_per_s": 4096 / dt_l, "leaf_evals_per_s": st["positions_evaluated"] / dt_l,
+                    "policy_eval_launches": st["rounds"], "seconds": dt_l, "seconds_in_policy_eval": st["seconds_policy"],
+                    "host_threads": "hardware concurrency (at most 32)",
+                    "identical_to_fused_search": bool(all(np.array_equal(ls[k], fs[k]) for k in ("child_N", "child_W", "best_action", "num_nodes"))),
+                    "fused_search_on_the_same_roots": {"searches_per_s": 4096 / dt_f, "seconds": dt_f}}
+            except Exception as ex:  # noqa: BLE001
+                out["at_4096_concurrent_games"]["lockstep_host_trees"] = {"error": str(ex)[:200]}
             e2.close()
         if extras and fits("learner", 10):
             # the step after the path: optimiser steps per second of the learner at the reference's batch of 32, on

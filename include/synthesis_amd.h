@@ -182,6 +182,24 @@ int syn_mcts_search(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* m
 int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t seed, const uint64_t* my_bb,
                             const uint64_t* op_bb, int n, int explores, int action_selection, syn_search_result* results);
 
+/* Replaces: the same reference call as syn_mcts_search — MCTS::with_capacity + explore_n for n roots (mcts.rs:123-147) — in the
+ * reference's own division of labour (BASELINE.json configs[1] as worded: concurrent games, batched leaf inference): the trees
+ * live on the HOST (include/synthesis_amd_lockstep.hpp: MCTS<G, P, N> restated over any Game, Policy::eval taken out of visit()),
+ * all n searches advance in lock step, and every round's leaves go through ONE syn_policy_eval_batch launch. This is the driver a
+ * caller with a different Game impl instantiates; for Connect4 the fused syn_mcts_search is the fast path and this entry point
+ * exists to hold the driver to it: results are identical, field for field. host_threads: threads for the tree phases (0 = the
+ * host's hardware concurrency, at most 32). cfg: SYN_FPU_NORMAL and SYN_NOISE_DIRICHLET return SYN_ERR_UNSUPPORTED (their
+ * draws are defined on the device path's per-tree streams). stats may be NULL. */
+typedef struct syn_lockstep_stats {
+    uint64_t rounds;               /* syn_policy_eval_batch launches */
+    uint64_t positions_evaluated;  /* leaves over all rounds */
+    double seconds_total;
+    double seconds_policy;         /* of which inside syn_policy_eval_batch (copies + kernel) */
+} syn_lockstep_stats;
+int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
+                             int explores, int action_selection, int host_threads, syn_search_result* results,
+                             syn_lockstep_stats* stats);
+
 /* ---- evaluator baseline ---------------------------------------------------------------------------------------- */
 
 /* One root of the evaluator's baseline tree after the search (evaluator.rs:233-243 Node fields of the root's children,

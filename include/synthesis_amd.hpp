@@ -155,21 +155,19 @@ public:
     bool operator==(const Connect4& o) const { return my_ == o.my_ && op_ == o.op_; }
 
 private:
+    // connect4.rs:70-83: four shift-AND chains (up-left diagonal >> 6, up-right >> 8, horizontal >> 7, vertical >> 1), each masked
+    // to the cells a line of that direction can start on
     static bool four_in_a_row(uint64_t bb) {
-        for (int col = 0; col < WIDTH; col++)
-            for (int row = 0; row < HEIGHT; row++) {
-                static const int dirs[4][2] = {{0, 1}, {1, 0}, {1, 1}, {1, -1}};  // (dcol, drow)
-                for (auto& d : dirs) {
-                    int n = 0;
-                    for (; n < 4; n++) {
-                        const int c = col + n * d[0], r = row + n * d[1];
-                        if (c < 0 || c >= WIDTH || r < 0 || r >= HEIGHT || !((bb >> (r + HEIGHT * c)) & 1ull)) break;
-                    }
-                    if (n == 4) return true;
-                }
-            }
-        return false;
+        constexpr uint64_t ROW0 = 0x0040810204081ull;                    // bit 7c, columns 0..6 (a line's first of four columns)
+        constexpr uint64_t ROWS_0_3 = ROW0 * 0xFull, ROWS_3_6 = ROW0 * 0x78ull;
+        constexpr uint64_t ALL_COLS_ROWS_0_3 = ROWS_0_3 | (0xFull << 49) | (0xFull << 56);
+        const uint64_t d1 = bb & (bb >> 6) & (bb >> 12) & (bb >> 18) & (ROWS_3_6 & COLS_0_5);
+        const uint64_t d2 = bb & (bb >> 8) & (bb >> 16) & (bb >> 24) & (ROWS_0_3 & COLS_0_5);
+        const uint64_t h = bb & (bb >> 7) & (bb >> 14) & (bb >> 21) & COLS_0_5;
+        const uint64_t v = bb & (bb >> 1) & (bb >> 2) & (bb >> 3) & ALL_COLS_ROWS_0_3;
+        return (d1 | d2 | h | v) != 0;
     }
+    static constexpr uint64_t COLS_0_5 = (1ull << 42) - 1;
     bool full() const { return (my_ | op_) == ((1ull << 63) - 1); }
     uint64_t my_ = 0, op_ = 0;
     PlayerId player_ = Red;

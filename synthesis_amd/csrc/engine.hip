@@ -162,6 +162,9 @@ static int fail(syn_engine* h, int code, const char* fmt, ...) {
     return code;
 }
 
+// for the library's host-only translation units (lockstep_capi.cpp)
+extern "C" int syn_internal_fail(syn_engine* h, int code, const char* msg) { return fail(h, code, "%s", msg); }
+
 #define HIP_TRY(h, call)                                                                          \
     do {                                                                                          \
         hipError_t e_ = (call);                                                                   \

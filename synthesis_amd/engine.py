@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_load_weights_conv",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -106,6 +106,8 @@ def load_library():
     lib.syn_activation_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.syn_mcts_search.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p]
+    lib.syn_mcts_search_lockstep.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                             C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.syn_mcts_search_rollout.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int,
                                             C.c_int, C.c_int, C.c_void_p]
     lib.syn_frozen_search_rollout.argtypes = [C.c_void_p, C.POINTER(CMctsConfig), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -278,6 +280,13 @@ class Engine:
                                                    int(explores), int(action_selection), C.cast(res, C.c_void_p))
         if rc != -7:    # SYN_ERR_CANCELLED (Engine.cancel from another thread): searched roots are valid, the others all zero
             self._check(rc)
+        out = self._search_records(res, n)
+        if rc == -7:
+            out["cancelled"] = True
+        return out
+
+    @staticmethod
+    def _search_records(res, n):
         raw = np.frombuffer(res, dtype=np.uint8).reshape(max(n, 1), C.sizeof(CSearchResult))[:n]
         dt = np.dtype([("child_N", np.float32, (9,)), ("child_W", np.float32, (9, 3)), ("child_P", np.float32, (9,)),
                        ("child_sol", np.int32, (9, 3)), ("root_N", np.float32), ("root_W", np.float32, (3,)),
@@ -287,8 +296,28 @@ class Engine:
         rec = raw.copy().view(dt).reshape(n)
         out = {k: rec[k].copy() for k in dt.names}
         out["root_stat"] = np.concatenate([out.pop("root_N")[:, None], out.pop("root_W")], axis=1)
-        if rc == -7:
-            out["cancelled"] = True
+        return out
+
+    def mcts_search_lockstep(self, cfg: MCTSConfig, my_bb, op_bb, explores, action_selection=1, host_threads=0):
+        """The same search with the trees on the host and only Policy::eval on the GPU (include/synthesis_amd_lockstep.hpp behind
+        syn_mcts_search_lockstep): all roots advance in lock step, one syn_policy_eval_batch launch per round. Returns mcts_search's
+        dict plus "stats" (rounds, positions_evaluated, seconds_total, seconds_policy)."""
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        n = int(my.size)
+        res = (CSearchResult * max(n, 1))()
+
+        class CStats(C.Structure):
+            _fields_ = [("rounds", C.c_uint64), ("positions_evaluated", C.c_uint64), ("seconds_total", C.c_double),
+                        ("seconds_policy", C.c_double)]
+        st = CStats()
+        c = cfg.to_c()
+        rc = self._lib.syn_mcts_search_lockstep(self._h, C.byref(c), _p(my), _p(op), n, int(explores), int(action_selection),
+                                                int(host_threads), C.cast(res, C.c_void_p), C.cast(C.byref(st), C.c_void_p))
+        self._check(rc)
+        out = self._search_records(res, n)
+        out["stats"] = {"rounds": int(st.rounds), "positions_evaluated": int(st.positions_evaluated),
+                        "seconds_total": float(st.seconds_total), "seconds_policy": float(st.seconds_policy)}
         return out
 
     # ---- the evaluator's baseline: FrozenMCTS::exploit over RolloutPolicy on n roots (evaluator.rs:308-319)

@@ -1,0 +1,129 @@
+// Test harness (CPU): include/synthesis_amd_lockstep.hpp driven without a GPU. The batch policy is the ORACLE's Connect4Net
+// (liboracle.so, test infrastructure) — so every tree must come out identical to oracle/mcts.hpp's sequential MCTS over the same
+// network — and a second, unrelated Game (a three-action subtraction game) checks that the driver is generic over Game<N>.
+//   lockstep_harness c4 <blob.f32> <roots.u64> <explores> <variant> <threads> <out.bin>
+//   lockstep_harness nim
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+
+#include "synthesis_amd_lockstep.hpp"
+
+extern "C" void orc_c4net_eval(const float* blob, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits, float* value,
+                               int mode);
+
+using namespace synthesis;
+
+struct OraclePolicy : BatchPolicy<Connect4, 9> {
+    const float* blob;
+    size_t calls = 0, positions = 0;
+    void eval_batch(const std::vector<const Connect4*>& games, float* logits, float* value) override {
+        std::vector<uint64_t> my(games.size()), op(games.size());
+        for (size_t i = 0; i < games.size(); i++) { my[i] = games[i]->my_bb(); op[i] = games[i]->op_bb(); }
+        orc_c4net_eval(blob, my.data(), op.data(), (int)games.size(), logits, value, /* ACC_FMA */ 1);
+        calls++;
+        positions += games.size();
+    }
+};
+
+// Take 1, 2 or 3 stones; whoever takes the last stone wins. Game<3>.
+struct Nim {
+    enum PlayerId { First = 0, Second = 1 };
+    int stones = 0;
+    PlayerId to_move = First;
+    bool last_taken = false;
+    PlayerId player() const { return to_move; }
+    bool is_over() const { return stones == 0; }
+    float reward(PlayerId p) const { return stones != 0 ? 0.0f : (p == to_move ? -1.0f : 1.0f); }  // the side to move has lost
+    std::vector<int> iter_actions() const {
+        std::vector<int> a;
+        for (int k = 0; k < 3; k++)
+            if (k + 1 <= stones) a.push_back(k);
+        return a;
+    }
+    bool step(int action) {
+        stones -= action + 1;
+        to_move = to_move == First ? Second : First;
+        return is_over();
+    }
+};
+
+struct UniformPolicy : BatchPolicy<Nim, 3> {
+    void eval_batch(const std::vector<const Nim*>& games, float* logits, float* value) override {
+        for (size_t i = 0; i < games.size(); i++) {
+            for (int k = 0; k < 3; k++) logits[i * 3 + k] = 0.0f;
+            value[i * 3 + 0] = value[i * 3 + 1] = value[i * 3 + 2] = 1.0f / 3.0f;
+        }
+    }
+};
+
+int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "nim") {
+        UniformPolicy policy;
+        MCTSConfig cfg;
+        std::vector<Nim> roots;
+        for (int s = 1; s <= 14; s++) {
+            Nim g;
+            g.stones = s;
+            roots.push_back(g);
+        }
+        const auto trees = lockstep_search<Nim, 3>(policy, cfg, roots, 600, 1);
+        for (size_t i = 0; i < trees.size(); i++) {
+            const auto& r = trees[i].root();
+            std::printf("nim %d %d %d %u %d\n", roots[i].stones, r.solution.some ? 1 : 0, (int)r.solution.outcome.kind,
+                        r.solution.outcome.turns, trees[i].best_action(ActionSelection::NumVisits));
+        }
+        return 0;
+    }
+    if (argc != 8 || std::string(argv[1]) != "c4") return 2;
+    std::ifstream bf(argv[2], std::ios::binary);
+    std::vector<float> blob((size_t)30492);
+    bf.read(reinterpret_cast<char*>(blob.data()), (std::streamsize)(blob.size() * 4));
+    std::ifstream rf(argv[3], std::ios::binary | std::ios::ate);
+    const size_t n = (size_t)rf.tellg() / 16;
+    rf.seekg(0);
+    std::vector<uint64_t> bb(2 * n);
+    rf.read(reinterpret_cast<char*>(bb.data()), (std::streamsize)(bb.size() * 8));
+    const int explores = std::atoi(argv[4]), variant = std::atoi(argv[5]), threads = std::atoi(argv[6]);
+    MCTSConfig cfg;  // variant 0: the parity configuration
+    if (variant == 1) { cfg.exploration = Exploration::Uct; cfg.c = 1.4f; cfg.fpu = Fpu::ParentQ; }
+    if (variant == 2) { cfg.root_policy_noise = PolicyNoise::Equal; cfg.noise_weight = 0.25f; cfg.auto_extend = false; cfg.select_solved_nodes = false; }
+    if (variant == 3) { cfg.solve = false; cfg.fpu_value = 0.5f; }
+    if (variant == 4) { cfg.correct_values_on_solve = false; cfg.c = 1.5f; }
+    std::vector<Connect4> roots;
+    for (size_t i = 0; i < n; i++) roots.push_back(Connect4::from_bitboards(bb[i], bb[n + i]));
+    OraclePolicy policy;
+    policy.blob = blob.data();
+    size_t rounds = 0, evals = 0;
+    const auto trees = lockstep_search<Connect4, 9>(policy, cfg, roots, explores, threads, &rounds, &evals);
+    std::vector<syn_search_result> out(n);
+    for (size_t i = 0; i < n; i++) {
+        const auto& t = trees[i];
+        syn_search_result r{};
+        for (auto c = t.children_begin(); c != t.children_end(); ++c) {
+            const int a = c->action;
+            r.child_N[a] = c->num_visits;
+            for (int k = 0; k < 3; k++) r.child_W[a][k] = c->outcome_probs[k];
+            r.child_P[a] = c->action_prob;
+            r.child_sol[a][0] = c->solution.some;
+            r.child_sol[a][1] = c->solution.some ? (int)c->solution.outcome.kind : 0;
+            r.child_sol[a][2] = c->solution.some ? (int)c->solution.outcome.turns : 0;
+        }
+        r.root_N = t.root().num_visits;
+        for (int k = 0; k < 3; k++) r.root_W[k] = t.root().outcome_probs[k];
+        r.root_sol[0] = t.root().solution.some;
+        r.root_sol[1] = t.root().solution.some ? (int)t.root().solution.outcome.kind : 0;
+        r.root_sol[2] = t.root().solution.some ? (int)t.root().solution.outcome.turns : 0;
+        r.num_nodes = (uint32_t)t.num_nodes();
+        r.best_action = t.best_action(ActionSelection::NumVisits);
+        const auto pi = t.target_policy();
+        for (int k = 0; k < 9; k++) r.target_pi[k] = pi[(size_t)k];
+        const auto q = t.target_q();
+        for (int k = 0; k < 3; k++) r.target_q[k] = q[(size_t)k];
+        out[i] = r;
+    }
+    std::ofstream of(argv[7], std::ios::binary);
+    of.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * sizeof(syn_search_result)));
+    std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policy.calls);
+    return 0;
+}
