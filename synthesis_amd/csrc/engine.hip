@@ -145,6 +145,10 @@ struct syn_engine {
     bool epoch_barrier_checked = false;  // syn_trainer_init's self-check of the epoch kernel's one-XCD barrier has run on this engine
     bool epoch_device_scope = false;     // ... and it failed (or is running its second half): the epoch kernel uses the device-scope barrier
     long long epoch_fallbacks = 0;  // syn_train_epoch calls whose persistent kernel gave up and ran through the queued launches
+    float* d_cxbuf = nullptr;       // Connect4ConvNet learner on four workgroups: the exchange buffer (train_conv_mfma.cuh ConvMwGeom)
+    bool conv_mw_checked = false;   // syn_trainer_init_conv's self-check of that kernel against the one-workgroup kernel has run
+    bool conv_mw_disabled = false;  // ... and it failed: this engine keeps the one-workgroup epoch kernel
+    int conv_mw_force = -1;         // self-check only: 0 = one workgroup, 1 = four
     DevTrainHyper train_hp{};
     bool has_trainer = false;
     int trainer_kind = 0;  // 0 = Connect4Net (train_mfma.cuh / train_epoch.cuh), 1 = Connect4ConvNet (train_conv_mfma.cuh)
@@ -691,6 +695,7 @@ int syn_engine_destroy(syn_engine* h) {
     hipFree(h->d_timg2);
     hipFree(h->d_tsync);
     hipFree(h->d_tsnap);
+    hipFree(h->d_cxbuf);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->stream) hipStreamDestroy(h->stream);
@@ -1388,6 +1393,7 @@ static int alloc_trainer_buffers(syn_engine* h) {
         {reinterpret_cast<void**>(&h->d_tloss), 64},      {reinterpret_cast<void**>(&h->d_twimg), img},
         {reinterpret_cast<void**>(&h->d_ttimg), timg},    {reinterpret_cast<void**>(&h->d_timg2), img + timg},
         {reinterpret_cast<void**>(&h->d_tsync), 256},     {reinterpret_cast<void**>(&h->d_tsnap), 3 * bytes + img + timg},
+        {reinterpret_cast<void**>(&h->d_cxbuf), (size_t)ConvMwGeom::FLOATS * 4},
     };
     for (auto& w : want) {
         hipError_t e = hipMalloc(w.p, w.n);
@@ -1498,6 +1504,42 @@ int syn_trainer_init_conv(syn_engine* h, const float* blob, size_t n_floats, con
     h->has_trainer = true;
     h->trainer_kind = 1;
     h->train_bf16 = 0;
+    // ---- the four-workgroup epoch kernel exchanges its intermediates through L2 behind the one-XCD barrier of train_epoch.cuh (observed
+    //      hardware behaviour, see there). Once per engine: eight steps on a synthetic batch through it and through the one-workgroup
+    //      kernel from the same state; any differing bit (or a launch that cannot run) keeps this engine on the one-workgroup kernel.
+    if (!h->conv_mw_checked) {
+        h->conv_mw_checked = true;
+        const int n = 64, steps = 8, B = 8;
+        std::vector<uint64_t> my(n), op(n);
+        std::vector<float> tpi((size_t)n * 9, 1.0f / 9.0f), tv((size_t)n * 3, 0.0f);
+        std::vector<int32_t> perm(steps * B);
+        for (int i = 0; i < n; i++) {
+            my[i] = (0x0000040810204081ull * (uint64_t)(i % 7 + 1)) & 0x00003F7EFDFBF7EFull & ~(0x7Full << (7 * (i % 9)));
+            op[i] = (0x7Full << (7 * (i % 9))) & (0x0101010101010101ull * (uint64_t)(i % 5 + 1));
+            op[i] &= ~my[i];
+            tv[(size_t)i * 3 + i % 3] = 1.0f;
+        }
+        for (int i = 0; i < steps * B; i++) perm[i] = (i * 37) % n;
+        std::vector<float> wa((size_t)ConvGeom::NUM_PARAMS), wb((size_t)ConvGeom::NUM_PARAMS);
+        const long long fallbacks0 = h->epoch_fallbacks;
+        bool ok = true;
+        for (int mode = 0; mode < 2 && ok; mode++) {
+            h->conv_mw_force = mode;   // 0: one workgroup, 1: four
+            ok = syn_train_set_data(h, my.data(), op.data(), tpi.data(), tv.data(), n) == SYN_OK &&
+                 syn_train_epoch(h, perm.data(), steps, B, 1e-3f, nullptr) == SYN_OK &&
+                 syn_trainer_get_state(h, mode == 0 ? wa.data() : wb.data(), nullptr, nullptr, nullptr, nullptr) == SYN_OK;
+            // back to the caller's state
+            ok = ok && hipMemcpyAsync(h->d_tw, blob, bytes, hipMemcpyHostToDevice, h->stream) == hipSuccess &&
+                 hipMemsetAsync(h->d_tm, 0, cap_bytes, h->stream) == hipSuccess && hipMemsetAsync(h->d_tv, 0, cap_bytes, h->stream) == hipSuccess &&
+                 hipMemsetAsync(h->d_tgrad, 0, cap_bytes, h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+            h->train_step = 0;
+        }
+        h->conv_mw_force = -1;
+        h->conv_mw_disabled = !(ok && h->epoch_fallbacks == fallbacks0 && std::memcmp(wa.data(), wb.data(), wa.size() * 4) == 0);
+        h->epoch_fallbacks = fallbacks0;
+        h->train_data_n = 0;   // the synthetic batch replaced whatever syn_train_set_data had uploaded: the caller uploads again (once per engine)
+        if (!ok) return fail(h, SYN_ERR_HIP, "the conv learner's start-up self-check could not run: %s", h->err.c_str());
+    }
     return SYN_OK;
 }
 
@@ -1815,6 +1857,55 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         if (cprof) HIP_TRY(h, hipMemsetAsync(d_cprof, 0, 128, h->stream));
         ep.prof = cprof ? d_cprof : nullptr;
         const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
+        // f32: the step spread over four workgroups of one XCD (train_conv_epoch_kernel_mw: same chains, same bits). They must be
+        // resident together: the learner is snapshotted first, and a launch that gives up (or SYN_DEBUG=1 SYN_TRAIN_CONV_MW=0, or a
+        // failed start-up self-check) runs the one-workgroup kernel below instead.
+        static const bool mw_off = [] { const char* e = debug_env("SYN_TRAIN_CONV_MW"); return e && std::atoi(e) == 0; }();
+        const bool want_mw = h->conv_mw_force >= 0 ? h->conv_mw_force == 1 : (!mw_off && !h->conv_mw_disabled);
+        if (!h->train_bf16 && want_mw) {
+            const size_t pb = (size_t)ConvGeom::NUM_PARAMS * 4;
+            unsigned char* sn = reinterpret_cast<unsigned char*>(h->d_tsnap);
+            HIP_TRY(h, hipMemcpyAsync(sn, h->d_tw, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sn + pb, h->d_tm, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(sn + 2 * pb, h->d_tv, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemsetAsync(h->d_tsync, 0, 256, h->stream));
+            if (cprof) HIP_TRY(h, hipMemsetAsync(d_cprof, 0, 512, h->stream));
+            ConvMwParams mp{};
+            mp.e = ep;
+            mp.xbuf = h->d_cxbuf;
+            mp.sync = h->d_tsync;
+            static const bool device_scope = debug_env("SYN_TRAIN_DEVICE_SCOPE") != nullptr;
+            mp.force_device_scope = device_scope ? 1 : 0;
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_conv_epoch_kernel_mw),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
+            hipLaunchKernelGGL(train_conv_epoch_kernel_mw, dim3(CONV_MW_WGS * CONV_MW_XCDS), dim3(CONV_TRAIN_THREADS), clds, h->stream, mp);
+            HIP_TRY(h, hipGetLastError());
+            unsigned status[4] = {0u, 0u, 0u, 0u};
+            HIP_TRY(h, hipMemcpyAsync(status, h->d_tsync, 16, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            const bool aborted = status[1] != 0u || debug_env("SYN_TRAIN_FORCE_ABORT") != nullptr;
+            if (!aborted) {
+                if (step_losses) HIP_TRY(h, hipMemcpy(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost));
+                if (cprof) {
+                    unsigned long long t[16 * CONV_MW_WGS] = {0};
+                    HIP_TRY(h, hipMemcpy(t, d_cprof, sizeof(t), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[syn train profile] conv epoch kernel on %d workgroups (%s), step 2, cycles: stage | F | barrier | H | G1 | G2 | barrier | G3 | barrier | Adam | barrier\n",
+                            CONV_MW_WGS, status[3] ? "one XCD" : "device-scope barrier");
+                    for (int g = 0; g < CONV_MW_WGS; g++) {
+                        fprintf(stderr, "  wg %d (start %+lld):", g, (long long)(t[16 * g] - t[0]));
+                        for (int i = 1; i < 12; i++) fprintf(stderr, " %llu", t[16 * g + i] - t[16 * g + i - 1]);
+                        fprintf(stderr, " | total %llu\n", t[16 * g + 11] - t[16 * g]);
+                    }
+                }
+                h->train_step += (long long)n_steps;
+                return SYN_OK;
+            }
+            HIP_TRY(h, hipMemcpyAsync(h->d_tw, sn, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_tm, sn + pb, pb, hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(h->d_tv, sn + 2 * pb, pb, hipMemcpyDeviceToDevice, h->stream));
+            h->epoch_fallbacks++;
+            if (cprof) HIP_TRY(h, hipMemsetAsync(d_cprof, 0, 128, h->stream));
+        }
         auto ke = h->train_bf16 ? train_conv_epoch_kernel<true> : train_conv_epoch_kernel<false>;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(ke), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
         hipLaunchKernelGGL(ke, dim3(1), dim3(CONV_TRAIN_THREADS), clds, h->stream, ep);

@@ -616,4 +616,359 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(Co
     }
 }
 
+// ---------------------------------------------------------------------------------------------- the epoch on four workgroups
+// One CU cannot take a step below ~15 us (384 f32 MFMAs per wave and step, two waves per SIMD, + Adam on the same FP32 datapath);
+// the persistent one-workgroup kernel above runs at 29 us. This kernel spreads a step over CONV_MW_WGS workgroups of one XCD, the
+// way train_epoch.cuh does for Connect4Net, WITHOUT changing a single chain: every f32 result is produced by the same instruction
+// sequence on the same operands as in conv_grad_step_mfma, only by another workgroup. Workgroup g owns
+//   F, G1, G2   the board cells p = o, o + 16, o + 32, o + 48 of the chain owners o = 4 g .. 4 g + 3 (G1 / G2 take their 16-column
+//               tiles as "the 16 channels of one cell": a column's chain never leaves its column, so any tiling gives the same bits),
+//   G3          the sample pairs 4 g .. 4 g + 3 (the two tap tiles of a pair on two waves),
+//   Adam        every fourth block of 512 parameters (the conv parameters' gradient = the sixteen partials added in order, G4),
+// and H (the 12 outputs, losses, dz) is computed by every workgroup. What crosses workgroups goes through a 170 KB exchange buffer in
+// L2: the head partials (F -> H), dY (G2 -> G3), the conv-gradient partials (G3 -> Adam), and grads / w themselves; four
+// barriers per step (after F, G2, G3, Adam), the barrier of train_epoch.cuh (one XCD: stores acknowledged by L2 + `buffer_inv sc0`;
+// otherwise device-scope release / acquire).
+constexpr int CONV_MW_WGS = 4, CONV_MW_XCDS = 8;
+struct ConvMwGeom {
+    static constexpr int XPART = 0;                                  // [16 owners][32 samples][12]
+    static constexpr int XDY = XPART + 16 * 32 * 12;                 // [32 samples][1008]
+    static constexpr int XCONV = XDY + 32 * ConvGeom::FLAT;          // [16 pairs][16 channels][20]
+    static constexpr int FLOATS = XCONV + 16 * 16 * 20;
+};
+struct ConvMwParams {
+    ConvEpochParams e;
+    float* xbuf;          // ConvMwGeom::FLOATS
+    unsigned* sync;       // [0] arrivals, [1] abort flag, [2] start-up arrivals, [3] one-XCD mode (out), [8..] XCC ids
+    int force_device_scope;
+};
+
+__global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw(ConvMwParams P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    using G = ConvMfmaGeom;
+    using X = ConvMwGeom;
+    constexpr int NT = CONV_TRAIN_THREADS, NWG = CONV_MW_WGS;
+    if (blockIdx.x % CONV_MW_XCDS != 0) return;
+    const int g = blockIdx.x / CONV_MW_XCDS;
+    const int tid0 = threadIdx.x;
+    const int B = P.e.batch;
+    const float bm = 1.0f / (float)B;
+    __shared__ unsigned mw_abort, mw_fast;
+    float* act = lds + G::ACT_OFF;
+    float* dz = lds + G::DZ_OFF;
+    uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
+    float* xpart = P.xbuf + X::XPART;
+    float* xdy = P.xbuf + X::XDY;
+    float* xconv = P.xbuf + X::XCONV;
+    const float* w = P.e.w;   // (rewritten by Adam every step: no __restrict__, and the barriers are compiler barriers too)
+
+    // ---- where did the workgroups land? (train_epoch.cuh)
+    if (tid0 == 0) {
+        mw_abort = 0u;
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) + 1u;  // HW_REG_XCC_ID[3:0]
+        __hip_atomic_store(P.sync + 8 + g, xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(P.sync + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(P.sync + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)NWG) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) {
+                __hip_atomic_store(P.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mw_abort = 1u;
+                break;
+            }
+        }
+        bool same = true;
+        for (int i = 0; i < NWG; i++) same = same && __hip_atomic_load(P.sync + 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc;
+        mw_fast = (same && !P.force_device_scope) ? 1u : 0u;
+        if (g == 0) P.sync[3] = mw_fast;
+    }
+    __syncthreads();
+    if (mw_abort) return;
+    const bool one_xcd = mw_fast != 0u;
+    unsigned barriers = 0;
+    // release what this workgroup stored, arrive, wait for all NWG, acquire. Returns false when a workgroup never arrived.
+    auto xbarrier = [&]() -> bool {
+        if (one_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        barriers++;
+        if (tid0 == 0) {
+            __hip_atomic_fetch_add(P.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)NWG * barriers;
+            unsigned spins = 0;
+            for (;;) {
+                const unsigned have = one_xcd ? __hip_atomic_load(P.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : __hip_atomic_load(P.sync, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (have >= want) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 24) || __hip_atomic_load(P.sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(P.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mw_abort = 1u;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (mw_abort) return false;
+        if (one_xcd) asm volatile("buffer_inv sc0" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return true;
+    };
+
+    int pk = 0;
+#define MW_STAMP() do { if (P.e.prof && tid0 == 0 && s == 2) P.e.prof[g * 16 + pk++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
+    for (int s = 0; s < P.e.n_steps; s++) {
+        // per-iteration opaque copies of the thread coordinates: without them the compiler hoists every step-invariant address and
+        // operand out of the step loop and keeps hundreds of values in scratch for the whole epoch (train_epoch.cuh, same remedy)
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, rw = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
+        const size_t so = (size_t)s * B;
+        const unsigned long long* my_bb = P.e.my_bb + so;
+        const unsigned long long* op_bb = P.e.op_bb + so;
+        const float* tpi = P.e.tpi + so * 9;
+        const float* tv = P.e.tv + so * 3;
+        MW_STAMP();
+        // ---- stage: boards of all samples, this thread's head entry (sample tid >> 4, entry tid & 15) and its target
+        if (tid < 2 * G::CHUNK) {
+            const int b = tid >> 1;
+            unsigned long long v = 0ull;
+            if (b < B) v = (tid & 1) ? op_bb[b] : my_bb[b];
+            bb[tid] = v;
+        }
+        const int hb = tid >> 4, jx = tid & 15;
+        float tgt = 0.0f;
+        if (hb < B && jx < 12) tgt = jx < 9 ? tpi[(size_t)hb * 9 + jx] : tv[(size_t)hb * 3 + (jx - 9)];
+        const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;
+        __syncthreads();
+        MW_STAMP();
+
+        // ---- F: chain owner wv = 4 g + (wave >> 1), sample tile t = wave & 1 (conv_grad_step_mfma's F for that (owner, tile))
+        {
+            const int wv = 4 * g + (rw >> 1), t = rw & 1;
+            float ca[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) ca[k] = 4 * k + q < 18 ? w[G::P_CW + j * 18 + 4 * k + q] : 0.0f;
+            const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);
+            float hwv[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int p = wv + 16 * c;
+                    hwv[c][r] = (j < 12 && p < G::HW) ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+                }
+            const int sample = 16 * t + j;
+            const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
+            uint64_t S[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) S[k] = conv_tap_board(my, op, 4 * k + q);
+            f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int p = wv + 16 * c;
+                if (p < G::HW) {
+                    const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
+                    f32x4 acc = cbv;
+#pragma unroll
+                    for (int k = 0; k < 5; k++)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[k], (float)((uint32_t)(S[k] >> pos) & 1u), acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float a = acc[r] > 0.0f ? acc[r] : 0.0f;
+                        act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a;
+                        hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(hwv[c][r], a, hacc, 0, 0, 0);
+                    }
+                }
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) xpart[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
+            }
+        }
+        MW_STAMP();
+        if (!xbarrier()) return;
+        MW_STAMP();
+
+        // ---- H (every workgroup): bias + the sixteen partials in order, log_softmax + kl_div, dz
+        {
+            const bool pol = jx < 9;
+            const bool live = jx < 12 && hb < B;
+            float xo = 0.0f;
+            if (jx < 12) {
+                float pv[16];
+#pragma unroll
+                for (int o = 0; o < 16; o++) pv[o] = xpart[(o * G::CHUNK + hb) * 12 + jx];
+                xo = w[G::P_HB + jx];
+#pragma unroll
+                for (int o = 0; o < 16; o++) xo += pv[o];
+            }
+            xo = live ? xo : 0.0f;
+            float xs[12];
+            ep_row_gather(xo, xs);
+            float mxp = xs[0], mxv = xs[9];
+#pragma unroll
+            for (int t = 1; t < 9; t++) mxp = xs[t] > mxp ? xs[t] : mxp;
+#pragma unroll
+            for (int t = 10; t < 12; t++) mxv = xs[t] > mxv ? xs[t] : mxv;
+            const float mx = pol ? mxp : mxv;
+            const float e = live ? det_expf(xo - mx) : 0.0f;
+            const float se = ep_row_sum(e, pol), tsum = ep_row_sum(tgt, pol);
+            const float lse = mx + det_logf(live ? se : 1.0f);
+            const float logp = xo - lse;
+            const float term = (live && tgt > 0.0f) ? tgt * (ltgt - logp) : 0.0f;
+            const float kl = ep_row_sum(term, pol);
+            const float sc = (pol ? P.e.hp.policy_weight : P.e.hp.value_weight) * bm;
+            if (jx < 12) dz[hb * 12 + jx] = live ? sc * (det_expf(xo - lse) * tsum - tgt) : 0.0f;
+            if (jx == 0 || jx == 9) lds[G::KL_OFF + hb * 2 + (pol ? 0 : 1)] = hb < B ? kl : 0.0f;
+        }
+        __syncthreads();
+        MW_STAMP();
+        if (g == 0 && tid == 0) {
+            float pi_acc = 0.0f, v_acc = 0.0f;
+            for (int b = 0; b < B; b++) {
+                pi_acc += lds[G::KL_OFF + b * 2 + 0];
+                v_acc += lds[G::KL_OFF + b * 2 + 1];
+            }
+            P.e.losses[2 * s] = bm * pi_acc;
+            P.e.losses[2 * s + 1] = bm * v_acc;
+        }
+
+        // ---- G1 + G2 on this workgroup's cells: cell index ci = wave + 8 k -> owner 4 g + (ci & 3), p = owner + 16 (ci >> 2)
+        {
+            float dza[8];   // A[output j][sample 4 s + q]
+#pragma unroll
+            for (int k = 0; k < 8; k++) dza[k] = j < 12 ? dz[(4 * k + q) * 12 + j] : 0.0f;
+            float dzb[2][3];   // B[output 4 s + q][sample 16 bt + j]
+#pragma unroll
+            for (int bt = 0; bt < 2; bt++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) dzb[bt][k] = dz[(16 * bt + j) * 12 + 4 * k + q];
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int ci = rw + 8 * kk;
+                const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
+                if (p < G::HW) {   // (wave-uniform)
+                    // G1: dWh[output][channel j of cell p] = chain over the samples
+                    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dza[k], act[(4 * k + q) * G::ASTR + j * G::HW + p], acc, 0, 0, 0);
+                    if (q < 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) P.e.grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + j * G::HW + p] = acc[r];
+                    }
+                }
+            }
+            if (g == 0 && tid >= NT - 12) {   // dbh: plain sums over the samples
+                const int o = tid - (NT - 12);
+                float a = 0.0f;
+                for (int b = 0; b < B; b++) a += dz[b * 12 + o];
+                P.e.grads[G::P_HB + o] = a;
+            }
+            MW_STAMP();   // (G2 leaves act alone here: dY goes to the exchange buffer, G3 reads it from there)
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                const int ci = rw + 8 * kk;
+                const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
+                if (p < G::HW) {
+                    float wa[3];   // A[channel j of cell p][output 4 s + q]
+#pragma unroll
+                    for (int k = 0; k < 3; k++) wa[k] = w[G::P_HW + (size_t)(4 * k + q) * G::FLAT + j * G::HW + p];
+#pragma unroll
+                    for (int bt = 0; bt < 2; bt++) {
+                        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int k = 0; k < 3; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k], dzb[bt][k], acc, 0, 0, 0);
+                        // D rows: channels 4 q + r of cell p; column: sample 16 bt + j
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int col = (4 * q + r) * G::HW + p;
+                            const float dy = act[(16 * bt + j) * G::ASTR + col] > 0.0f ? acc[r] : 0.0f;
+                            xdy[(16 * bt + j) * G::FLAT + col] = dy;
+                        }
+                    }
+                }
+            }
+        }
+        MW_STAMP();
+        if (!xbarrier()) return;
+        MW_STAMP();
+
+        // ---- G3: sample pair wv = 4 g + (wave >> 1); wave & 1 = tap tile (0: taps 0..15, 1: taps 16, 17 and the bias "tap")
+        {
+            const int wv = 4 * g + (rw >> 1), half = rw & 1;
+            const FeatureTable FT = make_feature_table(q);
+            f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                const int b = 2 * wv + k;
+                const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+                const uint64_t Sx = half == 0 ? conv_tap_board(my, op, j)
+                                              : (j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull));
+                const float* ya = xdy + b * G::FLAT + j * G::HW + q;   // A[channel j][cell 4 s + q]
+                float y[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) y[i] = 4 * i + q < G::HW ? ya[4 * i] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t pos = (FT.t[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], (float)((uint32_t)(Sx >> pos) & 1u), a, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (half == 0) xconv[(wv * 16 + 4 * q + r) * 20 + j] = a[r];
+                else if (j < 3) xconv[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a[r];
+            }
+        }
+        MW_STAMP();
+        if (!xbarrier()) return;
+        MW_STAMP();
+
+        // ---- Adam (adam_kernel's expression): parameter block (g + NWG k) of NT; the conv parameters' gradient = G4's ordered sum
+        {
+            const float step_size = P.e.step_size[s], inv_sqrt_bc2 = P.e.inv_sqrt_bc2[s];
+            constexpr int PER = (ConvGeom::NUM_PARAMS + NT * NWG - 1) / (NT * NWG);
+            float g0[PER], wi[PER], mo[PER], vo[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = tid + NT * (g + NWG * k);
+                const bool ok = i < ConvGeom::NUM_PARAMS;
+                if (k == 0 && g == 0 && i < ConvGeom::CONV_W + G::C) {   // (block 0 = workgroup 0, k = 0)
+                    const int c = i < ConvGeom::CONV_W ? i / 18 : i - ConvGeom::CONV_W;
+                    const int t = i < ConvGeom::CONV_W ? i - 18 * c : 18;
+                    float v = xconv[c * 20 + t];
+#pragma unroll
+                    for (int o = 1; o < 16; o++) v += xconv[(o * 16 + c) * 20 + t];
+                    g0[k] = v;
+                    P.e.grads[i] = v;
+                } else {
+                    g0[k] = ok ? P.e.grads[i] : 0.0f;
+                }
+                wi[k] = ok ? P.e.w[i] : 0.0f;
+                mo[k] = ok ? P.e.m[i] : 0.0f;
+                vo[k] = ok ? P.e.v[i] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = tid + NT * (g + NWG * k);
+                if (i < ConvGeom::NUM_PARAMS) {
+                    const float gr = P.e.hp.weight_decay != 0.0f ? __builtin_fmaf(P.e.hp.weight_decay, wi[k], g0[k]) : g0[k];
+                    const float mi = __builtin_fmaf(1.0f - P.e.hp.beta1, gr, P.e.hp.beta1 * mo[k]);
+                    const float vi = __builtin_fmaf((1.0f - P.e.hp.beta2) * gr, gr, P.e.hp.beta2 * vo[k]);
+                    const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.e.hp.eps;
+                    P.e.m[i] = mi;
+                    P.e.v[i] = vi;
+                    P.e.w[i] = wi[k] - step_size * (mi / denom);
+                }
+            }
+        }
+        MW_STAMP();
+        if (!xbarrier()) return;
+        MW_STAMP();
+    }
+#undef MW_STAMP
+}
+
 }  // namespace syn

@@ -195,6 +195,59 @@ def test_conv_learner_matches_oracle_and_feeds_selfplay(oracle, cblob, golden_di
     eng.close()
 
 
+def test_conv_epoch_kernel_modes_agree(tmp_path, oracle, cblob, golden_dir):
+    """The ways a conv epoch can run — the step spread over four workgroups of one XCD (L2-coherent barrier), the same kernel with
+    the device-scope barrier, the one-workgroup kernel, and a four-workgroup launch that is thrown away and redone by the
+    one-workgroup kernel — leave bit-identical weights, moments, gradients and losses, equal to the oracle's, for full and ragged
+    minibatches. The modes are debug knobs, hence one child process each."""
+    import os
+    import subprocess
+    import sys
+    from tests.oracle_lib import default_train_hyper
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bpath = str(tmp_path / "cblob.npy")
+    np.save(bpath, cblob)
+    script = (
+        "import sys, os, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import synthesis_amd as sa\n"
+        f"g = np.load(os.path.join({golden_dir!r}, 'conv_train_torch_goldens.npz')); blob = np.load({bpath!r})\n"
+        "my = g['my_bb'].reshape(-1); op = g['op_bb'].reshape(-1); tpi = g['target_pi'].reshape(-1, 9); tv = g['target_v'].reshape(-1, 3)\n"
+        "eng = sa.Engine(concurrent_games=64, max_explores=16); eng.load_weights_conv(blob); eng.trainer_init_conv(blob)\n"
+        "eng.train_set_data(my, op, tpi, tv)\n"
+        "perm = np.random.default_rng(5).integers(0, my.size, size=9 * 32).astype(np.int32)\n"
+        "l1 = eng.train_epoch(perm, 32, 1e-3); l2 = eng.train_epoch(perm[: 6 * 31], 31, 5e-4); l3 = eng.train_epoch(perm[: 7 * 5], 5, 2e-3)\n"
+        "st = eng.trainer_state()\n"
+        "np.savez(sys.argv[1], w=st['weights'], m=st['m'], v=st['v'], g=st['grads'], l=np.concatenate([l1, l2, l3]), perm=perm)\n")
+    outs = {}
+    for name, knobs in (("four_wgs", {}), ("four_wgs_device_scope", {"SYN_DEBUG": "1", "SYN_TRAIN_DEVICE_SCOPE": "1"}),
+                        ("one_wg", {"SYN_DEBUG": "1", "SYN_TRAIN_CONV_MW": "0"}),
+                        ("thrown_away", {"SYN_DEBUG": "1", "SYN_TRAIN_FORCE_ABORT": "1"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SYN_")}
+        env.update(knobs)
+        path = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", script, path], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        outs[name] = np.load(path)
+    for name in ("four_wgs_device_scope", "one_wg", "thrown_away"):
+        for k in ("w", "m", "v", "g", "l"):
+            assert np.array_equal(outs["four_wgs"][k].view(np.uint32), outs[name][k].view(np.uint32)), (name, k)
+    # ... and the oracle's
+    g = np.load(os.path.join(golden_dir, "conv_train_torch_goldens.npz"))
+    my = g["my_bb"].reshape(-1); op = g["op_bb"].reshape(-1); tpi = g["target_pi"].reshape(-1, 9); tv = g["target_v"].reshape(-1, 3)
+    perm = outs["four_wgs"]["perm"]
+    hp = default_train_hyper()
+    w, m, v, step = cblob, None, None, 0
+    losses = []
+    for B, n, lr in ((32, 9, 1e-3), (31, 6, 5e-4), (5, 7, 2e-3)):
+        idx = perm[: n * B].reshape(n, B)
+        w, m, v, step, lo = oracle.convtrain_steps(w, hp, my[idx], op[idx], tpi[idx], tv[idx], [lr] * n, m=m, v=v, step=step)
+        losses.append(lo)
+    assert np.array_equal(outs["four_wgs"]["l"], np.concatenate(losses))
+    assert np.array_equal(outs["four_wgs"]["w"], w) and np.array_equal(outs["four_wgs"]["m"], m) and np.array_equal(outs["four_wgs"]["v"], v)
+
+
 def test_conv_learner_bf16_variant_stays_within_bf16_error(oracle, cblob, golden_dir):
     """BASELINE configs[4] words the training step "bf16 conv": SYN_TRAIN_BF16 rounds every matrix operand of the conv learner to
     bf16 (bf16 matrix cores, f32 accumulation, f32 master weights / Adam). It is not bit-exact with anything — the bar is bf16's
