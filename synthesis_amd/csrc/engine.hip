@@ -1889,7 +1889,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
                 if (cprof) {
                     unsigned long long t[16 * CONV_MW_WGS] = {0};
                     HIP_TRY(h, hipMemcpy(t, d_cprof, sizeof(t), hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[syn train profile] conv epoch kernel on %d workgroups (%s), step 2, cycles: stage | F | barrier | H | G1 | G2 | barrier | G3 | barrier | Adam | barrier\n",
+                    fprintf(stderr, "[syn train profile] conv epoch kernel on %d workgroups (%s), step 2, cycles: stage | F | barrier | H | G1 | G2 | barrier | G3 | Adam (own head weights) | barrier | G4 + Adam (shared)\n",
                             CONV_MW_WGS, status[3] ? "one XCD" : "device-scope barrier");
                     for (int g = 0; g < CONV_MW_WGS; g++) {
                         fprintf(stderr, "  wg %d (start %+lld):", g, (long long)(t[16 * g] - t[0]));

@@ -46,6 +46,18 @@ struct ConvMfmaGeom {
 static_assert(16 * 16 * 20 <= ConvMfmaGeom::PART_FLOATS, "conv-gradient partials fit the head-partial region");
 static_assert(ConvMfmaGeom::LDS_FLOATS * 4 <= 160 * 1024, "one workgroup: 160 KB of LDS");
 
+// sum over b < B of x[b * stride], added in sample order (the oracle's order) — all 32 values are requested first so that their LDS
+// latencies overlap instead of forming a chain of 32 dependent round trips (rows >= B are not added: x + 0 could flip a -0)
+SYN_DEV float conv_ordered_sum32(const float* x, int stride, int B) {
+    float v[ConvMfmaGeom::CHUNK];
+#pragma unroll
+    for (int b = 0; b < ConvMfmaGeom::CHUNK; b++) v[b] = x[b * stride];
+    float a = 0.0f;
+#pragma unroll
+    for (int b = 0; b < ConvMfmaGeom::CHUNK; b++) a = b < B ? a + v[b] : a;
+    return a;
+}
+
 // One minibatch (B <= 32 samples; sample b = my_bb[idx ? idx[b] : b]): grads[12412] <- d(loss)/d(param), losses[0..1] <- pi / v
 // loss. Called by all 1024 threads of a workgroup; ends with every gradient written (no trailing barrier).
 template <int NT>
@@ -169,15 +181,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
     }
     __syncthreads();
     CONV_STAMP();
-    if (tid == 0) {
-        float pi_acc = 0.0f, v_acc = 0.0f;
-        for (int b = 0; b < B; b++) {
-            pi_acc += lds[G::KL_OFF + b * 2 + 0];
-            v_acc += lds[G::KL_OFF + b * 2 + 1];
-        }
-        losses[0] = bm * pi_acc;
-        losses[1] = bm * v_acc;
-    }
+    if (tid < 2) losses[tid] = bm * conv_ordered_sum32(lds + G::KL_OFF + tid, 2, B);
 
     // ---- G1: head parameter gradients
     {
@@ -197,9 +201,7 @@ SYN_DEV void conv_grad_step_mfma(const float* __restrict__ w, const unsigned lon
         }
         if (tid >= NT - 12) {   // dbh: plain sums over the samples (threads of the last wave, which has the fewest tiles)
             const int o = tid - (NT - 12);
-            float a = 0.0f;
-            for (int b = 0; b < B; b++) a += dz[b * 12 + o];
-            grads[G::P_HB + o] = a;
+            grads[G::P_HB + o] = conv_ordered_sum32(dz + o, 12, B);
         }
     }
     __syncthreads();
@@ -421,15 +423,7 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
         if (jx == 0 || jx == 9) lds[G::KL_OFF + hb * 2 + (pol ? 0 : 1)] = hb < B ? kl : 0.0f;
     }
     __syncthreads();
-    if (tid == 0) {
-        float pi_acc = 0.0f, v_acc = 0.0f;
-        for (int b = 0; b < B; b++) {
-            pi_acc += lds[G::KL_OFF + b * 2 + 0];
-            v_acc += lds[G::KL_OFF + b * 2 + 1];
-        }
-        losses[0] = bm * pi_acc;
-        losses[1] = bm * v_acc;
-    }
+    if (tid < 2) losses[tid] = bm * conv_ordered_sum32(lds + G::KL_OFF + tid, 2, B);
     // ---- G1: dWh (k = sample 16 h + 4 q + e)
     {
         bf16x4 dza[2];
@@ -456,9 +450,7 @@ SYN_DEV void conv_grad_step_bf16(const float* __restrict__ w, const unsigned lon
         }
         if (tid >= NT - 12) {
             const int o = tid - (NT - 12);
-            float a = 0.0f;
-            for (int b = 0; b < B; b++) a += dz[b * 12 + o];
-            grads[G::P_HB + o] = a;
+            grads[G::P_HB + o] = conv_ordered_sum32(dz + o, 12, B);
         }
     }
     __syncthreads();
@@ -623,19 +615,25 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(Co
 // sequence on the same operands as in conv_grad_step_mfma, only by another workgroup. Workgroup g owns
 //   F, G1, G2   the board cells p = o, o + 16, o + 32, o + 48 of the chain owners o = 4 g .. 4 g + 3 (G1 / G2 take their 16-column
 //               tiles as "the 16 channels of one cell": a column's chain never leaves its column, so any tiling gives the same bits),
-//   G3          the sample pairs 4 g .. 4 g + 3 (the two tap tiles of a pair on two waves),
-//   Adam        every fourth block of 512 parameters (the conv parameters' gradient = the sixteen partials added in order, G4),
-// and H (the 12 outputs, losses, dz) is computed by every workgroup. What crosses workgroups goes through a 170 KB exchange buffer in
-// L2: the head partials (F -> H), dY (G2 -> G3), the conv-gradient partials (G3 -> Adam), and grads / w themselves; four
-// barriers per step (after F, G2, G3, Adam), the barrier of train_epoch.cuh (one XCD: stores acknowledged by L2 + `buffer_inv sc0`;
-// otherwise device-scope release / acquire).
+//               and with them the head weights of those cells: their gradients, their Adam update and their only reader are here;
+//   G3          the sample pairs 4 g .. 4 g + 3 (the two tap tiles of a pair on two waves);
+// H (the 12 outputs, losses, dz, dbh) is computed by every workgroup, and so is the Adam update of the 316 parameters every workgroup
+// reads (conv weights and biases, head biases): each keeps its own copy of them and of their moments in LDS for the whole epoch
+// (identical bits everywhere; workgroup 0 writes them back at the end). What crosses workgroups goes through a 170 KB exchange
+// buffer in L2 — the head partials (F -> H), dY (G2 -> G3), the conv-gradient partials (G3 -> G4 + Adam) — behind three barriers per
+// step, the barrier of train_epoch.cuh (one XCD: stores acknowledged by L2 + `buffer_inv sc0`; otherwise device-scope release /
+// acquire).
 constexpr int CONV_MW_WGS = 4, CONV_MW_XCDS = 8;
 struct ConvMwGeom {
     static constexpr int XPART = 0;                                  // [16 owners][32 samples][12]
     static constexpr int XDY = XPART + 16 * 32 * 12;                 // [32 samples][1008]
     static constexpr int XCONV = XDY + 32 * ConvGeom::FLAT;          // [16 pairs][16 channels][20]
     static constexpr int FLOATS = XCONV + 16 * 16 * 20;
+    // the shared parameters' private copies, in the (otherwise unused) head-partial region of LDS: index si = parameter index for the
+    // conv weights / biases (0..303), 304 + o for head bias o; [w][m][v] of SMALL_STRIDE floats each
+    static constexpr int SMALL = ConvGeom::CONV_W + ConvGeom::C + 12, SMALL_STRIDE = 320;
 };
+static_assert(3 * ConvMwGeom::SMALL_STRIDE <= ConvMfmaGeom::PART_FLOATS, "the shared parameters fit the head-partial region");
 struct ConvMwParams {
     ConvEpochParams e;
     float* xbuf;          // ConvMwGeom::FLOATS
@@ -657,10 +655,13 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
     float* act = lds + G::ACT_OFF;
     float* dz = lds + G::DZ_OFF;
     uint64_t* bb = reinterpret_cast<uint64_t*>(lds + G::BB_OFF);
+    float* sw = lds + G::PART_OFF;               // shared parameters: weights, moments
+    float* sm = sw + X::SMALL_STRIDE;
+    float* sv = sm + X::SMALL_STRIDE;
     float* xpart = P.xbuf + X::XPART;
     float* xdy = P.xbuf + X::XDY;
     float* xconv = P.xbuf + X::XCONV;
-    const float* w = P.e.w;   // (rewritten by Adam every step: no __restrict__, and the barriers are compiler barriers too)
+    const float* w = P.e.w;   // (the head weights are rewritten by Adam every step: no __restrict__; the barriers are compiler barriers too)
 
     // ---- where did the workgroups land? (train_epoch.cuh)
     if (tid0 == 0) {
@@ -681,6 +682,13 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         for (int i = 0; i < NWG; i++) same = same && __hip_atomic_load(P.sync + 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc;
         mw_fast = (same && !P.force_device_scope) ? 1u : 0u;
         if (g == 0) P.sync[3] = mw_fast;
+    }
+    // the shared parameters and their moments: this workgroup's copies
+    if (tid0 < X::SMALL) {
+        const int i = tid0 < ConvGeom::CONV_W + G::C ? tid0 : G::P_HB + (tid0 - (ConvGeom::CONV_W + G::C));
+        sw[tid0] = P.e.w[i];
+        sm[tid0] = P.e.m[i];
+        sv[tid0] = P.e.v[i];
     }
     __syncthreads();
     if (mw_abort) return;
@@ -715,31 +723,43 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         return true;
     };
 
+    // the batch of step 0 (later batches are requested one step ahead, before the step's last barrier)
+    unsigned long long board_next = 0ull;   // thread tid < 64: board word tid (sample tid >> 1, mine / theirs)
+    float tgt_next = 0.0f;                  // this thread's head entry (sample tid >> 4, entry tid & 15)
+    auto request_batch = [&](int s, int tid) {
+        const size_t so = (size_t)s * B;
+        board_next = 0ull;
+        if (tid < 2 * G::CHUNK && (tid >> 1) < B) board_next = (tid & 1) ? P.e.op_bb[so + (tid >> 1)] : P.e.my_bb[so + (tid >> 1)];
+        const int hb = tid >> 4, jx = tid & 15;
+        tgt_next = 0.0f;
+        if (hb < B && jx < 12) tgt_next = jx < 9 ? P.e.tpi[(so + hb) * 9 + jx] : P.e.tv[(so + hb) * 3 + (jx - 9)];
+    };
+    request_batch(0, tid0);
+
     int pk = 0;
 #define MW_STAMP() do { if (P.e.prof && tid0 == 0 && s == 2) P.e.prof[g * 16 + pk++] = (unsigned long long)__builtin_readcyclecounter(); } while (0)
     for (int s = 0; s < P.e.n_steps; s++) {
-        // per-iteration opaque copies of the thread coordinates: without them the compiler hoists every step-invariant address and
-        // operand out of the step loop and keeps hundreds of values in scratch for the whole epoch (train_epoch.cuh, same remedy)
+        // per-iteration opaque copy of the thread index: without it the compiler hoists every step-invariant address and operand
+        // out of the step loop and keeps hundreds of values in scratch for the whole epoch (train_epoch.cuh, same remedy)
         int tid = tid0;
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, rw = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, q = lane >> 4;
-        const size_t so = (size_t)s * B;
-        const unsigned long long* my_bb = P.e.my_bb + so;
-        const unsigned long long* op_bb = P.e.op_bb + so;
-        const float* tpi = P.e.tpi + so * 9;
-        const float* tv = P.e.tv + so * 3;
         MW_STAMP();
-        // ---- stage: boards of all samples, this thread's head entry (sample tid >> 4, entry tid & 15) and its target
-        if (tid < 2 * G::CHUNK) {
-            const int b = tid >> 1;
-            unsigned long long v = 0ull;
-            if (b < B) v = (tid & 1) ? op_bb[b] : my_bb[b];
-            bb[tid] = v;
-        }
+        // ---- stage: boards of all samples, this thread's head entry and its target
+        if (tid < 2 * G::CHUNK) bb[tid] = board_next;
         const int hb = tid >> 4, jx = tid & 15;
-        float tgt = 0.0f;
-        if (hb < B && jx < 12) tgt = jx < 9 ? tpi[(size_t)hb * 9 + jx] : tv[(size_t)hb * 3 + (jx - 9)];
+        const float tgt = tgt_next;
         const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;
+        // this workgroup's two cells per wave (G1 / G2): cell index ci = wave + 8 k -> owner 4 g + (ci & 3), p = owner + 16 (ci >> 2);
+        // G2's head-weight operands are requested here, a phase and a barrier ahead of their use
+        float wa[2][3];   // A[channel j of cell p][output 4 s + q]
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int ci = rw + 8 * kk;
+            const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
+#pragma unroll
+            for (int k = 0; k < 3; k++) wa[kk][k] = p < G::HW ? w[G::P_HW + (size_t)(4 * k + q) * G::FLAT + j * G::HW + p] : 0.0f;
+        }
         __syncthreads();
         MW_STAMP();
 
@@ -748,8 +768,8 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
             const int wv = 4 * g + (rw >> 1), t = rw & 1;
             float ca[5];
 #pragma unroll
-            for (int k = 0; k < 5; k++) ca[k] = 4 * k + q < 18 ? w[G::P_CW + j * 18 + 4 * k + q] : 0.0f;
-            const f32x4 cbv = *reinterpret_cast<const f32x4*>(w + G::P_CB + 4 * q);
+            for (int k = 0; k < 5; k++) ca[k] = 4 * k + q < 18 ? sw[G::P_CW + j * 18 + 4 * k + q] : 0.0f;
+            const f32x4 cbv = *reinterpret_cast<const f32x4*>(sw + G::P_CB + 4 * q);
             float hwv[4][4];
 #pragma unroll
             for (int c = 0; c < 4; c++)
@@ -799,7 +819,7 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                 float pv[16];
 #pragma unroll
                 for (int o = 0; o < 16; o++) pv[o] = xpart[(o * G::CHUNK + hb) * 12 + jx];
-                xo = w[G::P_HB + jx];
+                xo = sw[ConvGeom::CONV_W + G::C + jx];
 #pragma unroll
                 for (int o = 0; o < 16; o++) xo += pv[o];
             }
@@ -824,17 +844,10 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         }
         __syncthreads();
         MW_STAMP();
-        if (g == 0 && tid == 0) {
-            float pi_acc = 0.0f, v_acc = 0.0f;
-            for (int b = 0; b < B; b++) {
-                pi_acc += lds[G::KL_OFF + b * 2 + 0];
-                v_acc += lds[G::KL_OFF + b * 2 + 1];
-            }
-            P.e.losses[2 * s] = bm * pi_acc;
-            P.e.losses[2 * s + 1] = bm * v_acc;
-        }
+        if (g == 0 && tid < 2) P.e.losses[2 * s + tid] = bm * conv_ordered_sum32(lds + G::KL_OFF + tid, 2, B);
 
-        // ---- G1 + G2 on this workgroup's cells: cell index ci = wave + 8 k -> owner 4 g + (ci & 3), p = owner + 16 (ci >> 2)
+        // ---- G1 + G2 on this workgroup's cells
+        float dbh = 0.0f;   // threads NT - 12 ..: dbh[o], plain sum over the samples (every workgroup: it feeds its own copy's Adam)
         {
             float dza[8];   // A[output j][sample 4 s + q]
 #pragma unroll
@@ -860,26 +873,18 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                     }
                 }
             }
-            if (g == 0 && tid >= NT - 12) {   // dbh: plain sums over the samples
-                const int o = tid - (NT - 12);
-                float a = 0.0f;
-                for (int b = 0; b < B; b++) a += dz[b * 12 + o];
-                P.e.grads[G::P_HB + o] = a;
-            }
+            if (tid >= NT - 12) dbh = conv_ordered_sum32(dz + (tid - (NT - 12)), 12, B);
             MW_STAMP();   // (G2 leaves act alone here: dY goes to the exchange buffer, G3 reads it from there)
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 const int ci = rw + 8 * kk;
                 const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
                 if (p < G::HW) {
-                    float wa[3];   // A[channel j of cell p][output 4 s + q]
-#pragma unroll
-                    for (int k = 0; k < 3; k++) wa[k] = w[G::P_HW + (size_t)(4 * k + q) * G::FLAT + j * G::HW + p];
 #pragma unroll
                     for (int bt = 0; bt < 2; bt++) {
                         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                        for (int k = 0; k < 3; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[k], dzb[bt][k], acc, 0, 0, 0);
+                        for (int k = 0; k < 3; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kk][k], dzb[bt][k], acc, 0, 0, 0);
                         // D rows: channels 4 q + r of cell p; column: sample 16 bt + j
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -899,21 +904,25 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         {
             const int wv = 4 * g + (rw >> 1), half = rw & 1;
             const FeatureTable FT = make_feature_table(q);
+            // both samples' dY operands first (32 loads from the exchange buffer in flight together)
+            float y[2][16];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float* ya = xdy + (2 * wv + k) * G::FLAT + j * G::HW + q;   // A[channel j][cell 4 s + q]
+#pragma unroll
+                for (int i = 0; i < 16; i++) y[k][i] = 4 * i + q < G::HW ? ya[4 * i] : 0.0f;
+            }
             f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 1
+#pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int b = 2 * wv + k;
                 const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
                 const uint64_t Sx = half == 0 ? conv_tap_board(my, op, j)
                                               : (j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull));
-                const float* ya = xdy + b * G::FLAT + j * G::HW + q;   // A[channel j][cell 4 s + q]
-                float y[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) y[i] = 4 * i + q < G::HW ? ya[4 * i] : 0.0f;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const uint32_t pos = (FT.t[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(y[i], (float)((uint32_t)(Sx >> pos) & 1u), a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(y[k][i], (float)((uint32_t)(Sx >> pos) & 1u), a, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -923,52 +932,89 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
             }
         }
         MW_STAMP();
-        if (!xbarrier()) return;
-        MW_STAMP();
-
-        // ---- Adam (adam_kernel's expression): parameter block (g + NWG k) of NT; the conv parameters' gradient = G4's ordered sum
+        const float step_size = P.e.step_size[s], inv_sqrt_bc2 = P.e.inv_sqrt_bc2[s];
+        if (s + 1 < P.e.n_steps) request_batch(s + 1, tid);
+        // ---- Adam (adam_kernel's expression) of this workgroup's head weights: entry e = tid + NT k -> output e / 256, channel
+        //      (e & 255) / 16, cell index e & 15; their gradients were written by this workgroup's G1, before the last barrier
         {
-            const float step_size = P.e.step_size[s], inv_sqrt_bc2 = P.e.inv_sqrt_bc2[s];
-            constexpr int PER = (ConvGeom::NUM_PARAMS + NT * NWG - 1) / (NT * NWG);
+            constexpr int PER = 12 * 256 / NT;
+            int pi[PER];
             float g0[PER], wi[PER], mo[PER], vo[PER];
 #pragma unroll
             for (int k = 0; k < PER; k++) {
-                const int i = tid + NT * (g + NWG * k);
-                const bool ok = i < ConvGeom::NUM_PARAMS;
-                if (k == 0 && g == 0 && i < ConvGeom::CONV_W + G::C) {   // (block 0 = workgroup 0, k = 0)
-                    const int c = i < ConvGeom::CONV_W ? i / 18 : i - ConvGeom::CONV_W;
-                    const int t = i < ConvGeom::CONV_W ? i - 18 * c : 18;
-                    float v = xconv[c * 20 + t];
-#pragma unroll
-                    for (int o = 1; o < 16; o++) v += xconv[(o * 16 + c) * 20 + t];
-                    g0[k] = v;
-                    P.e.grads[i] = v;
-                } else {
-                    g0[k] = ok ? P.e.grads[i] : 0.0f;
-                }
-                wi[k] = ok ? P.e.w[i] : 0.0f;
-                mo[k] = ok ? P.e.m[i] : 0.0f;
-                vo[k] = ok ? P.e.v[i] : 0.0f;
+                const int e = tid + NT * k, ci = e & 15;
+                const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
+                pi[k] = p < G::HW ? G::P_HW + (e >> 8) * G::FLAT + ((e & 255) >> 4) * G::HW + p : -1;
+                const bool ok = pi[k] >= 0;
+                g0[k] = ok ? P.e.grads[pi[k]] : 0.0f;
+                wi[k] = ok ? P.e.w[pi[k]] : 0.0f;
+                mo[k] = ok ? P.e.m[pi[k]] : 0.0f;
+                vo[k] = ok ? P.e.v[pi[k]] : 0.0f;
             }
 #pragma unroll
             for (int k = 0; k < PER; k++) {
-                const int i = tid + NT * (g + NWG * k);
-                if (i < ConvGeom::NUM_PARAMS) {
+                if (pi[k] >= 0) {
                     const float gr = P.e.hp.weight_decay != 0.0f ? __builtin_fmaf(P.e.hp.weight_decay, wi[k], g0[k]) : g0[k];
                     const float mi = __builtin_fmaf(1.0f - P.e.hp.beta1, gr, P.e.hp.beta1 * mo[k]);
                     const float vi = __builtin_fmaf((1.0f - P.e.hp.beta2) * gr, gr, P.e.hp.beta2 * vo[k]);
                     const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.e.hp.eps;
-                    P.e.m[i] = mi;
-                    P.e.v[i] = vi;
-                    P.e.w[i] = wi[k] - step_size * (mi / denom);
+                    P.e.m[pi[k]] = mi;
+                    P.e.v[pi[k]] = vi;
+                    P.e.w[pi[k]] = wi[k] - step_size * (mi / denom);
                 }
             }
         }
         MW_STAMP();
         if (!xbarrier()) return;
         MW_STAMP();
+        // ---- G4 + Adam of the shared parameters, on this workgroup's own copy: conv weights / biases (gradient = the sixteen partials
+        //      added in order), head biases (dbh from above)
+        {
+            const bool is_conv = tid < ConvGeom::CONV_W + G::C, is_hb = tid >= NT - 12;
+            if (is_conv || is_hb) {
+                float gsum;
+                int si, gi;
+                if (is_conv) {
+                    const int c = tid < ConvGeom::CONV_W ? tid / 18 : tid - ConvGeom::CONV_W;
+                    const int t = tid < ConvGeom::CONV_W ? tid - 18 * c : 18;
+                    float pv[16];
+#pragma unroll
+                    for (int o = 0; o < 16; o++) pv[o] = xconv[(o * 16 + c) * 20 + t];
+                    gsum = pv[0];
+#pragma unroll
+                    for (int o = 1; o < 16; o++) gsum += pv[o];
+                    si = tid;
+                    gi = tid;
+                } else {
+                    gsum = dbh;
+                    si = ConvGeom::CONV_W + G::C + (tid - (NT - 12));
+                    gi = G::P_HB + (tid - (NT - 12));
+                }
+                if (g == 0) P.e.grads[gi] = gsum;
+                const float wo = sw[si];
+                const float gr = P.e.hp.weight_decay != 0.0f ? __builtin_fmaf(P.e.hp.weight_decay, wo, gsum) : gsum;
+                const float mi = __builtin_fmaf(1.0f - P.e.hp.beta1, gr, P.e.hp.beta1 * sm[si]);
+                const float vi = __builtin_fmaf((1.0f - P.e.hp.beta2) * gr, gr, P.e.hp.beta2 * sv[si]);
+                const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.e.hp.eps;
+                sm[si] = mi;
+                sv[si] = vi;
+                sw[si] = wo - step_size * (mi / denom);
+            }
+        }
+        // this workgroup's head-weight stores must be visible to its own F / G2 loads of the next step (one CU, one vector L1:
+        // workgroup scope), and the shared copies in LDS to everybody
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        MW_STAMP();
     }
 #undef MW_STAMP
+    if (g == 0 && tid0 < X::SMALL) {
+        const int i = tid0 < ConvGeom::CONV_W + G::C ? tid0 : G::P_HB + (tid0 - (ConvGeom::CONV_W + G::C));
+        P.e.w[i] = sw[tid0];
+        P.e.m[i] = sm[tid0];
+        P.e.v[i] = sv[tid0];
+    }
 }
 
 }  // namespace syn
