@@ -1876,9 +1876,10 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             mp.sync = h->d_tsync;
             static const bool device_scope = debug_env("SYN_TRAIN_DEVICE_SCOPE") != nullptr;
             mp.force_device_scope = device_scope ? 1 : 0;
+            const size_t mlds = (size_t)ConvMwGeom::LDS_FLOATS * 4;
             HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_conv_epoch_kernel_mw),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-            hipLaunchKernelGGL(train_conv_epoch_kernel_mw, dim3(CONV_MW_WGS * CONV_MW_XCDS), dim3(CONV_TRAIN_THREADS), clds, h->stream, mp);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(train_conv_epoch_kernel_mw, dim3(CONV_MW_WGS * CONV_MW_XCDS), dim3(CONV_TRAIN_THREADS), mlds, h->stream, mp);
             HIP_TRY(h, hipGetLastError());
             unsigned status[4] = {0u, 0u, 0u, 0u};
             HIP_TRY(h, hipMemcpyAsync(status, h->d_tsync, 16, hipMemcpyDeviceToHost, h->stream));
@@ -1889,12 +1890,12 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
                 if (cprof) {
                     unsigned long long t[16 * CONV_MW_WGS] = {0};
                     HIP_TRY(h, hipMemcpy(t, d_cprof, sizeof(t), hipMemcpyDeviceToHost));
-                    fprintf(stderr, "[syn train profile] conv epoch kernel on %d workgroups (%s), step 2, cycles: stage | F | barrier | H | G1 | G2 | barrier | G3 | Adam (own head weights) | barrier | G4 + Adam (shared)\n",
+                    fprintf(stderr, "[syn train profile] conv epoch kernel on %d workgroups (%s), step 2, cycles: stage | F | barrier | H | G1 | G2 | Adam (own head weights, inside the barrier) | rest of the barrier | dY in | G3 | barrier | G4 + Adam (shared)\n",
                             CONV_MW_WGS, status[3] ? "one XCD" : "device-scope barrier");
                     for (int g = 0; g < CONV_MW_WGS; g++) {
                         fprintf(stderr, "  wg %d (start %+lld):", g, (long long)(t[16 * g] - t[0]));
-                        for (int i = 1; i < 12; i++) fprintf(stderr, " %llu", t[16 * g + i] - t[16 * g + i - 1]);
-                        fprintf(stderr, " | total %llu\n", t[16 * g + 11] - t[16 * g]);
+                        for (int i = 1; i < 13; i++) fprintf(stderr, " %llu", t[16 * g + i] - t[16 * g + i - 1]);
+                        fprintf(stderr, " | total %llu\n", t[16 * g + 12] - t[16 * g]);
                     }
                 }
                 h->train_step += (long long)n_steps;

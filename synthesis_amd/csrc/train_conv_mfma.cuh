@@ -626,14 +626,21 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel(Co
 constexpr int CONV_MW_WGS = 4, CONV_MW_XCDS = 8;
 struct ConvMwGeom {
     static constexpr int XPART = 0;                                  // [16 owners][32 samples][12]
-    static constexpr int XDY = XPART + 16 * 32 * 12;                 // [32 samples][1008]
-    static constexpr int XCONV = XDY + 32 * ConvGeom::FLAT;          // [16 pairs][16 channels][20]
+    static constexpr int XDY = XPART + 16 * 32 * 12;                 // [32 samples][4 workgroups][16 channels][16 cell indices]
+    static constexpr int XCONV = XDY + 32 * 1024;                    // [16 pairs][16 channels][20]
     static constexpr int FLOATS = XCONV + 16 * 16 * 20;
     // the shared parameters' private copies, in the (otherwise unused) head-partial region of LDS: index si = parameter index for the
     // conv weights / biases (0..303), 304 + o for head bias o; [w][m][v] of SMALL_STRIDE floats each
     static constexpr int SMALL = ConvGeom::CONV_W + ConvGeom::C + 12, SMALL_STRIDE = 320;
+    // this workgroup's head weights and their gradients, entry e = output * 256 + channel * 16 + cell index (cell index ci -> owner
+    // 4 g + (ci & 3), cell p = owner + 16 (ci >> 2)): F / G2 read their operands here, G1 leaves the gradients here, Adam keeps the
+    // weights and moments of its six entries per thread in registers for the whole epoch
+    // (LDS strides OWN_SO per output and OWN_SC per channel chosen so that F's, G1's and G2's fragment accesses are at most 3-way
+    // bank conflicts; the natural 256 / 16 make every one of them a 16- to 64-way conflict)
+    static constexpr int OWN = 12 * 256, OWN_SO = 279, OWN_SC = 17;
+    static constexpr int LDS_FLOATS = ConvMfmaGeom::PART_OFF + 3 * SMALL_STRIDE + 2 * 12 * OWN_SO;
 };
-static_assert(3 * ConvMwGeom::SMALL_STRIDE <= ConvMfmaGeom::PART_FLOATS, "the shared parameters fit the head-partial region");
+static_assert(ConvMwGeom::LDS_FLOATS * 4 + 64 <= 160 * 1024, "one workgroup: 160 KB of LDS");
 struct ConvMwParams {
     ConvEpochParams e;
     float* xbuf;          // ConvMwGeom::FLOATS
@@ -658,10 +665,11 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
     float* sw = lds + G::PART_OFF;               // shared parameters: weights, moments
     float* sm = sw + X::SMALL_STRIDE;
     float* sv = sm + X::SMALL_STRIDE;
+    float* whead = sv + X::SMALL_STRIDE;         // this workgroup's head weights [12][16][16]
+    float* ghead = whead + 12 * X::OWN_SO;       // ... and their gradients
     float* xpart = P.xbuf + X::XPART;
     float* xdy = P.xbuf + X::XDY;
     float* xconv = P.xbuf + X::XCONV;
-    const float* w = P.e.w;   // (the head weights are rewritten by Adam every step: no __restrict__; the barriers are compiler barriers too)
 
     // ---- where did the workgroups land? (train_epoch.cuh)
     if (tid0 == 0) {
@@ -690,18 +698,35 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         sm[tid0] = P.e.m[i];
         sv[tid0] = P.e.v[i];
     }
+    // this thread's six head-weight entries (e = tid + NT k) with their moments: registers for the whole epoch, weights also in LDS
+    constexpr int OWN_PER = X::OWN / NT;
+    int own_pi[OWN_PER];
+    float own_w[OWN_PER], own_m[OWN_PER], own_v[OWN_PER];
+#pragma unroll
+    for (int k = 0; k < OWN_PER; k++) {
+        const int e = tid0 + NT * k, ci = e & 15;
+        const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
+        own_pi[k] = p < G::HW ? G::P_HW + (e >> 8) * G::FLAT + ((e & 255) >> 4) * G::HW + p : -1;
+        own_w[k] = own_pi[k] >= 0 ? P.e.w[own_pi[k]] : 0.0f;
+        own_m[k] = own_pi[k] >= 0 ? P.e.m[own_pi[k]] : 0.0f;
+        own_v[k] = own_pi[k] >= 0 ? P.e.v[own_pi[k]] : 0.0f;
+        whead[(e >> 8) * X::OWN_SO + ((e & 255) >> 4) * X::OWN_SC + ci] = own_w[k];
+    }
     __syncthreads();
     if (mw_abort) return;
     const bool one_xcd = mw_fast != 0u;
     unsigned barriers = 0;
-    // release what this workgroup stored, arrive, wait for all NWG, acquire. Returns false when a workgroup never arrived.
-    auto xbarrier = [&]() -> bool {
+    // split-phase barrier: xarrive() releases what this workgroup stored and arrives; xwait() waits for all NWG arrivals and acquires
+    // (false when a workgroup never arrived). Work that needs nothing from the other workgroups goes in between.
+    auto xarrive = [&]() {
         if (one_xcd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         barriers++;
+        if (tid0 == 0) __hip_atomic_fetch_add(P.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto xwait = [&]() -> bool {
         if (tid0 == 0) {
-            __hip_atomic_fetch_add(P.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = (unsigned)NWG * barriers;
             unsigned spins = 0;
             for (;;) {
@@ -721,6 +746,10 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         if (one_xcd) asm volatile("buffer_inv sc0" ::: "memory");
         else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         return true;
+    };
+    auto xbarrier = [&]() -> bool {
+        xarrive();
+        return xwait();
     };
 
     // the batch of step 0 (later batches are requested one step ahead, before the step's last barrier)
@@ -758,7 +787,7 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
             const int ci = rw + 8 * kk;
             const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
 #pragma unroll
-            for (int k = 0; k < 3; k++) wa[kk][k] = p < G::HW ? w[G::P_HW + (size_t)(4 * k + q) * G::FLAT + j * G::HW + p] : 0.0f;
+            for (int k = 0; k < 3; k++) wa[kk][k] = p < G::HW ? whead[(4 * k + q) * X::OWN_SO + j * X::OWN_SC + ci] : 0.0f;
         }
         __syncthreads();
         MW_STAMP();
@@ -776,7 +805,7 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int p = wv + 16 * c;
-                    hwv[c][r] = (j < 12 && p < G::HW) ? w[G::P_HW + (size_t)j * G::FLAT + (4 * q + r) * G::HW + p] : 0.0f;
+                    hwv[c][r] = (j < 12 && p < G::HW) ? whead[j * X::OWN_SO + (4 * q + r) * X::OWN_SC + (rw >> 1) + 4 * c] : 0.0f;
                 }
             const int sample = 16 * t + j;
             const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
@@ -823,6 +852,10 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
 #pragma unroll
                 for (int o = 0; o < 16; o++) xo += pv[o];
             }
+            // the next step's batch: a cold read from memory, and loads return in order — issued here, behind the partials' loads and
+            // in front of the longest stretch without global loads (the rest of H, G1, G2), it costs nothing; issued in front of a
+            // barrier's arrival it added its latency to the barrier (measured: 10k instead of 3.4k cycles)
+            if (s + 1 < P.e.n_steps) request_batch(s + 1, tid);
             xo = live ? xo : 0.0f;
             float xs[12];
             ep_row_gather(xo, xs);
@@ -844,7 +877,8 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         }
         __syncthreads();
         MW_STAMP();
-        if (g == 0 && tid < 2) P.e.losses[2 * s + tid] = bm * conv_ordered_sum32(lds + G::KL_OFF + tid, 2, B);
+        // (losses: by the wave whose second cell slot is empty — cell 63 does not exist)
+        if (g == NWG - 1 && tid >= NT - 64 && tid < NT - 62) P.e.losses[2 * s + (tid - (NT - 64))] = bm * conv_ordered_sum32(lds + G::KL_OFF + (tid - (NT - 64)), 2, B);
 
         // ---- G1 + G2 on this workgroup's cells
         float dbh = 0.0f;   // threads NT - 12 ..: dbh[o], plain sum over the samples (every workgroup: it feeds its own copy's Adam)
@@ -869,12 +903,16 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dza[k], act[(4 * k + q) * G::ASTR + j * G::HW + p], acc, 0, 0, 0);
                     if (q < 3) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) P.e.grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + j * G::HW + p] = acc[r];
+                        for (int r = 0; r < 4; r++) {
+                            ghead[(4 * q + r) * X::OWN_SO + j * X::OWN_SC + ci] = acc[r];
+                            // (the caller reads the last step's gradients: syn_trainer_get_state)
+                            if (s + 1 == P.e.n_steps) P.e.grads[G::P_HW + (size_t)(4 * q + r) * G::FLAT + j * G::HW + p] = acc[r];
+                        }
                     }
                 }
             }
             if (tid >= NT - 12) dbh = conv_ordered_sum32(dz + (tid - (NT - 12)), 12, B);
-            MW_STAMP();   // (G2 leaves act alone here: dY goes to the exchange buffer, G3 reads it from there)
+            MW_STAMP();   // (G2 overwrites this wave's own cells' columns of act, which only this wave's G1 read)
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 const int ci = rw + 8 * kk;
@@ -888,27 +926,81 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                         // D rows: channels 4 q + r of cell p; column: sample 16 bt + j
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
-                            const int col = (4 * q + r) * G::HW + p;
-                            const float dy = act[(16 * bt + j) * G::ASTR + col] > 0.0f ? acc[r] : 0.0f;
-                            xdy[(16 * bt + j) * G::FLAT + col] = dy;
+                            float* pa = act + (16 * bt + j) * G::ASTR + (4 * q + r) * G::HW + p;
+                            *pa = *pa > 0.0f ? acc[r] : 0.0f;
                         }
                     }
                 }
             }
+            // dY of this workgroup's cells -> exchange buffer, [sample][workgroup][channel][cell index]: a thread moves the four
+            // cells 4 g + 16 c .. + 3 of one (sample, channel) as one 16-byte store, a wave 1 KB of consecutive addresses (the
+            // per-element stores of the fragments' owners are 64 different lines per instruction: measured 2x the whole phase)
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int it = tid + NT * k, b = it >> 6, ch = (it >> 2) & 15, c = it & 3;
+                const int p0 = 4 * g + 16 * c;
+                const float* pa = act + b * G::ASTR + ch * G::HW + p0;
+                f32x4 v4;
+                v4[0] = pa[0]; v4[1] = pa[1]; v4[2] = pa[2];
+                v4[3] = p0 + 3 < G::HW ? pa[3] : 0.0f;
+                *reinterpret_cast<f32x4*>(xdy + b * 1024 + g * 256 + ch * 16 + 4 * c) = v4;
+            }
         }
         MW_STAMP();
-        if (!xbarrier()) return;
+        xarrive();   // (dY published; the barrier's latency is covered by the Adam update of this workgroup's head weights)
+        const float step_size = P.e.step_size[s], inv_sqrt_bc2 = P.e.inv_sqrt_bc2[s];
+        // ---- Adam (adam_kernel's expression) of this workgroup's head weights: gradients from G1 (LDS), weights and moments in registers
+        {
+#pragma unroll
+            for (int k = 0; k < OWN_PER; k++) {
+                if (own_pi[k] >= 0) {
+                    const int e = tid + NT * k, la = (e >> 8) * X::OWN_SO + ((e & 255) >> 4) * X::OWN_SC + (e & 15);
+                    const float g0 = ghead[la];
+                    const float gr = P.e.hp.weight_decay != 0.0f ? __builtin_fmaf(P.e.hp.weight_decay, own_w[k], g0) : g0;
+                    const float mi = __builtin_fmaf(1.0f - P.e.hp.beta1, gr, P.e.hp.beta1 * own_m[k]);
+                    const float vi = __builtin_fmaf((1.0f - P.e.hp.beta2) * gr, gr, P.e.hp.beta2 * own_v[k]);
+                    const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.e.hp.eps;
+                    own_m[k] = mi;
+                    own_v[k] = vi;
+                    own_w[k] = own_w[k] - step_size * (mi / denom);
+                    whead[la] = own_w[k];   // (G2 took its operands before the arrival above; F of the next step reads these)
+                }
+            }
+        }
+        MW_STAMP();
+        if (!xwait()) return;
         MW_STAMP();
 
+        // ---- dY of this workgroup's eight samples (pairs 4 g .. 4 g + 3), all cells, from the exchange buffer into their rows of act:
+        //      16-byte loads, 1 KB of consecutive addresses per wave instruction, all in flight together (G3 reading its operands
+        //      straight from the buffer — 4 bytes per lane, 16 of every 64 — took 4k cycles longer and another 5k in the barrier behind it)
+        {
+            f32x4 v4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int it = tid + NT * k;
+                v4[k] = *reinterpret_cast<const f32x4*>(xdy + (8 * g + (it >> 8)) * 1024 + (it & 255) * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int it = tid + NT * k, rest = it & 255;
+                const int p0 = 4 * (rest >> 6) + 16 * (rest & 3);   // block (= writer) rest >> 6, channel (rest >> 2) & 15, cell group rest & 3
+                float* pa = act + (8 * g + (it >> 8)) * G::ASTR + ((rest >> 2) & 15) * G::HW + p0;
+                pa[0] = v4[k][0]; pa[1] = v4[k][1]; pa[2] = v4[k][2];
+                if (p0 + 3 < G::HW) pa[3] = v4[k][3];
+            }
+        }
+        __syncthreads();
+        MW_STAMP();
         // ---- G3: sample pair wv = 4 g + (wave >> 1); wave & 1 = tap tile (0: taps 0..15, 1: taps 16, 17 and the bias "tap")
         {
             const int wv = 4 * g + (rw >> 1), half = rw & 1;
             const FeatureTable FT = make_feature_table(q);
-            // both samples' dY operands first (32 loads from the exchange buffer in flight together)
             float y[2][16];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const float* ya = xdy + (2 * wv + k) * G::FLAT + j * G::HW + q;   // A[channel j][cell 4 s + q]
+                const float* ya = act + (2 * wv + k) * G::ASTR + j * G::HW + q;   // A[channel j][cell 4 i + q]
 #pragma unroll
                 for (int i = 0; i < 16; i++) y[k][i] = 4 * i + q < G::HW ? ya[4 * i] : 0.0f;
             }
@@ -929,39 +1021,6 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
             for (int r = 0; r < 4; r++) {
                 if (half == 0) xconv[(wv * 16 + 4 * q + r) * 20 + j] = a[r];
                 else if (j < 3) xconv[(wv * 16 + 4 * q + r) * 20 + 16 + j] = a[r];
-            }
-        }
-        MW_STAMP();
-        const float step_size = P.e.step_size[s], inv_sqrt_bc2 = P.e.inv_sqrt_bc2[s];
-        if (s + 1 < P.e.n_steps) request_batch(s + 1, tid);
-        // ---- Adam (adam_kernel's expression) of this workgroup's head weights: entry e = tid + NT k -> output e / 256, channel
-        //      (e & 255) / 16, cell index e & 15; their gradients were written by this workgroup's G1, before the last barrier
-        {
-            constexpr int PER = 12 * 256 / NT;
-            int pi[PER];
-            float g0[PER], wi[PER], mo[PER], vo[PER];
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                const int e = tid + NT * k, ci = e & 15;
-                const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
-                pi[k] = p < G::HW ? G::P_HW + (e >> 8) * G::FLAT + ((e & 255) >> 4) * G::HW + p : -1;
-                const bool ok = pi[k] >= 0;
-                g0[k] = ok ? P.e.grads[pi[k]] : 0.0f;
-                wi[k] = ok ? P.e.w[pi[k]] : 0.0f;
-                mo[k] = ok ? P.e.m[pi[k]] : 0.0f;
-                vo[k] = ok ? P.e.v[pi[k]] : 0.0f;
-            }
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                if (pi[k] >= 0) {
-                    const float gr = P.e.hp.weight_decay != 0.0f ? __builtin_fmaf(P.e.hp.weight_decay, wi[k], g0[k]) : g0[k];
-                    const float mi = __builtin_fmaf(1.0f - P.e.hp.beta1, gr, P.e.hp.beta1 * mo[k]);
-                    const float vi = __builtin_fmaf((1.0f - P.e.hp.beta2) * gr, gr, P.e.hp.beta2 * vo[k]);
-                    const float denom = sqrtf(vi) * inv_sqrt_bc2 + P.e.hp.eps;
-                    P.e.m[pi[k]] = mi;
-                    P.e.v[pi[k]] = vi;
-                    P.e.w[pi[k]] = wi[k] - step_size * (mi / denom);
-                }
             }
         }
         MW_STAMP();
@@ -1001,14 +1060,18 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                 sw[si] = wo - step_size * (mi / denom);
             }
         }
-        // this workgroup's head-weight stores must be visible to its own F / G2 loads of the next step (one CU, one vector L1:
-        // workgroup scope), and the shared copies in LDS to everybody
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        __syncthreads();   // the shared copies (and, since the last barrier, the head weights) in LDS are the next step's
         MW_STAMP();
     }
 #undef MW_STAMP
+#pragma unroll
+    for (int k = 0; k < OWN_PER; k++) {
+        if (own_pi[k] >= 0) {
+            P.e.w[own_pi[k]] = own_w[k];
+            P.e.m[own_pi[k]] = own_m[k];
+            P.e.v[own_pi[k]] = own_v[k];
+        }
+    }
     if (g == 0 && tid0 < X::SMALL) {
         const int i = tid0 < ConvGeom::CONV_W + G::C ? tid0 : G::P_HB + (tid0 - (ConvGeom::CONV_W + G::C));
         P.e.w[i] = sw[tid0];
