@@ -1853,16 +1853,16 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         ep.losses = d_losses; ep.grads = h->d_tgrad;
         ep.n_steps = (int)n_steps; ep.batch = batch; ep.hp = h->train_hp;
         unsigned long long* d_cprof = reinterpret_cast<unsigned long long*>(sc + perm_bytes + loss_bytes + batch_bytes + loss_bytes);
-        const bool cprof = debug_env("SYN_TRAIN_PROFILE") != nullptr && n_steps > 2 && !h->train_bf16;
+        const bool cprof = debug_env("SYN_TRAIN_PROFILE") != nullptr && n_steps > 2;
         if (cprof) HIP_TRY(h, hipMemsetAsync(d_cprof, 0, 128, h->stream));
         ep.prof = cprof ? d_cprof : nullptr;
         const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
-        // f32: the step spread over four workgroups of one XCD (train_conv_epoch_kernel_mw: same chains, same bits). They must be
+        // the step spread over four workgroups of one XCD (train_conv_epoch_kernel_mw: same chains, same bits, f32 and bf16). They must be
         // resident together: the learner is snapshotted first, and a launch that gives up (or SYN_DEBUG=1 SYN_TRAIN_CONV_MW=0, or a
         // failed start-up self-check) runs the one-workgroup kernel below instead.
         static const bool mw_off = [] { const char* e = debug_env("SYN_TRAIN_CONV_MW"); return e && std::atoi(e) == 0; }();
         const bool want_mw = h->conv_mw_force >= 0 ? h->conv_mw_force == 1 : (!mw_off && !h->conv_mw_disabled);
-        if (!h->train_bf16 && want_mw) {
+        if (want_mw) {
             const size_t pb = (size_t)ConvGeom::NUM_PARAMS * 4;
             unsigned char* sn = reinterpret_cast<unsigned char*>(h->d_tsnap);
             HIP_TRY(h, hipMemcpyAsync(sn, h->d_tw, pb, hipMemcpyDeviceToDevice, h->stream));
@@ -1877,9 +1877,9 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
             static const bool device_scope = debug_env("SYN_TRAIN_DEVICE_SCOPE") != nullptr;
             mp.force_device_scope = device_scope ? 1 : 0;
             const size_t mlds = (size_t)ConvMwGeom::LDS_FLOATS * 4;
-            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(train_conv_epoch_kernel_mw),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
-            hipLaunchKernelGGL(train_conv_epoch_kernel_mw, dim3(CONV_MW_WGS * CONV_MW_XCDS), dim3(CONV_TRAIN_THREADS), mlds, h->stream, mp);
+            auto km = h->train_bf16 ? train_conv_epoch_kernel_mw<true> : train_conv_epoch_kernel_mw<false>;
+            HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(km), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlds));
+            hipLaunchKernelGGL(km, dim3(CONV_MW_WGS * CONV_MW_XCDS), dim3(CONV_TRAIN_THREADS), mlds, h->stream, mp);
             HIP_TRY(h, hipGetLastError());
             unsigned status[4] = {0u, 0u, 0u, 0u};
             HIP_TRY(h, hipMemcpyAsync(status, h->d_tsync, 16, hipMemcpyDeviceToHost, h->stream));
@@ -1913,7 +1913,7 @@ int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batc
         HIP_TRY(h, hipGetLastError());
         if (step_losses) HIP_TRY(h, hipMemcpyAsync(step_losses, d_losses, n_steps * 8, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (cprof) {
+        if (cprof && !h->train_bf16) {
             unsigned long long t[16] = {0};
             HIP_TRY(h, hipMemcpy(t, d_cprof, sizeof(t), hipMemcpyDeviceToHost));
             fprintf(stderr, "[syn train profile] conv epoch kernel, step 2, cycles: stage %llu | F %llu | H %llu | losses+G1 %llu | G2 %llu | G3 %llu | G4 %llu | Adam %llu | total %llu\n",

@@ -648,6 +648,7 @@ struct ConvMwParams {
     int force_device_scope;
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw(ConvMwParams P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     using G = ConvMfmaGeom;
@@ -781,19 +782,27 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         const float ltgt = tgt > 0.0f ? det_logf(tgt) : 0.0f;
         // this workgroup's two cells per wave (G1 / G2): cell index ci = wave + 8 k -> owner 4 g + (ci & 3), p = owner + 16 (ci >> 2);
         // G2's head-weight operands are requested here, a phase and a barrier ahead of their use
-        float wa[2][3];   // A[channel j of cell p][output 4 s + q]
+        float wa[2][3];   // f32: A[channel j of cell p][output 4 s + q]
+        bf16x4 wab[2];    // bf16: A[channel j of cell p][output 4 q + e] (outputs 12..15: zeros)
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             const int ci = rw + 8 * kk;
             const int p = 4 * g + (ci & 3) + 16 * (ci >> 2);
+            if (BF16) {
+                float t4[4];
 #pragma unroll
-            for (int k = 0; k < 3; k++) wa[kk][k] = p < G::HW ? whead[(4 * k + q) * X::OWN_SO + j * X::OWN_SC + ci] : 0.0f;
+                for (int e = 0; e < 4; e++) t4[e] = (q < 3 && p < G::HW) ? whead[(4 * q + e) * X::OWN_SO + j * X::OWN_SC + ci] : 0.0f;
+                wab[kk] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; k++) wa[kk][k] = p < G::HW ? whead[(4 * k + q) * X::OWN_SO + j * X::OWN_SC + ci] : 0.0f;
+            }
         }
         __syncthreads();
         MW_STAMP();
 
-        // ---- F: chain owner wv = 4 g + (wave >> 1), sample tile t = wave & 1 (conv_grad_step_mfma's F for that (owner, tile))
-        {
+        // ---- F: chain owner wv = 4 g + (wave >> 1), sample tile t = wave & 1 (conv_grad_step_mfma's / _bf16's F for that (owner, tile))
+        if (!BF16) {
             const int wv = 4 * g + (rw >> 1), t = rw & 1;
             float ca[5];
 #pragma unroll
@@ -828,6 +837,62 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                         act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a;
                         hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(hwv[c][r], a, hacc, 0, 0, 0);
                     }
+                }
+            }
+            if (q < 3) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) xpart[(wv * G::CHUNK + sample) * 12 + 4 * q + r] = hacc[r];
+            }
+        } else {
+            const int wv = 4 * g + (rw >> 1), t = rw & 1;
+            bf16x4 ca[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float t4[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int tap = 16 * h + 4 * q + e;
+                    t4[e] = tap < 18 ? sw[G::P_CW + j * 18 + tap] : 0.0f;
+                }
+                ca[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+            }
+            const f32x4 cbv = *reinterpret_cast<const f32x4*>(sw + G::P_CB + 4 * q);
+            bf16x4 hwb[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int p = wv + 16 * c;
+                float h4[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) h4[r] = (j < 12 && p < G::HW) ? whead[j * X::OWN_SO + (4 * q + r) * X::OWN_SC + (rw >> 1) + 4 * c] : 0.0f;
+                hwb[c] = pack_bf16(h4[0], h4[1], h4[2], h4[3]);
+            }
+            const int sample = 16 * t + j;
+            const uint64_t my = bb[2 * sample], op = bb[2 * sample + 1];
+            uint64_t S[2][4];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) S[h][e] = conv_tap_board(my, op, 16 * h + 4 * q + e);   // (taps >= 18: empty boards)
+            f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int p = wv + 16 * c;
+                if (p < G::HW) {
+                    const int row = p / 9, col = p - 9 * row, pos = row + 7 * col;
+                    f32x4 acc = cbv;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const bf16x4 xb = pack_bf16((float)((uint32_t)(S[h][0] >> pos) & 1u), (float)((uint32_t)(S[h][1] >> pos) & 1u),
+                                                    (float)((uint32_t)(S[h][2] >> pos) & 1u), (float)((uint32_t)(S[h][3] >> pos) & 1u));
+                        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ca[h], xb, acc, 0, 0, 0);
+                    }
+                    float a4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        a4[r] = acc[r] > 0.0f ? acc[r] : 0.0f;
+                        act[sample * G::ASTR + (4 * q + r) * G::HW + p] = a4[r];
+                    }
+                    hacc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(hwb[c], pack_bf16(a4[0], a4[1], a4[2], a4[3]), hacc, 0, 0, 0);
                 }
             }
             if (q < 3) {
@@ -883,14 +948,30 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         // ---- G1 + G2 on this workgroup's cells
         float dbh = 0.0f;   // threads NT - 12 ..: dbh[o], plain sum over the samples (every workgroup: it feeds its own copy's Adam)
         {
-            float dza[8];   // A[output j][sample 4 s + q]
+            float dza[8];      // f32: A[output j][sample 4 s + q]
+            float dzb[2][3];   // f32: B[output 4 s + q][sample 16 bt + j]
+            bf16x4 dzab[2];    // bf16: A[output j][sample 16 h + 4 q + e]
+            bf16x4 dzbb[2];    // bf16: B[output 4 q + e][sample 16 bt + j] (outputs 12..15: zeros)
+            if (BF16) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) dza[k] = j < 12 ? dz[(4 * k + q) * 12 + j] : 0.0f;
-            float dzb[2][3];   // B[output 4 s + q][sample 16 bt + j]
+                for (int h = 0; h < 2; h++) {
+                    float t4[4], u4[4];
 #pragma unroll
-            for (int bt = 0; bt < 2; bt++)
+                    for (int e = 0; e < 4; e++) {
+                        t4[e] = j < 12 ? dz[(16 * h + 4 * q + e) * 12 + j] : 0.0f;
+                        u4[e] = q < 3 ? dz[(16 * h + j) * 12 + 4 * q + e] : 0.0f;
+                    }
+                    dzab[h] = pack_bf16(t4[0], t4[1], t4[2], t4[3]);
+                    dzbb[h] = pack_bf16(u4[0], u4[1], u4[2], u4[3]);
+                }
+            } else {
 #pragma unroll
-                for (int k = 0; k < 3; k++) dzb[bt][k] = dz[(16 * bt + j) * 12 + 4 * k + q];
+                for (int k = 0; k < 8; k++) dza[k] = j < 12 ? dz[(4 * k + q) * 12 + j] : 0.0f;
+#pragma unroll
+                for (int bt = 0; bt < 2; bt++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) dzb[bt][k] = dz[(16 * bt + j) * 12 + 4 * k + q];
+            }
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 const int ci = rw + 8 * kk;
@@ -898,9 +979,17 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
                 if (p < G::HW) {   // (wave-uniform)
                     // G1: dWh[output][channel j of cell p] = chain over the samples
                     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (BF16) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dza[k], act[(4 * k + q) * G::ASTR + j * G::HW + p], acc, 0, 0, 0);
+                        for (int h = 0; h < 2; h++) {
+                            const float* pa = act + (16 * h + 4 * q) * G::ASTR + j * G::HW + p;
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(dzab[h], pack_bf16(pa[0], pa[G::ASTR], pa[2 * G::ASTR], pa[3 * G::ASTR]), acc, 0, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dza[k], act[(4 * k + q) * G::ASTR + j * G::HW + p], acc, 0, 0, 0);
+                    }
                     if (q < 3) {
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -921,8 +1010,12 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
 #pragma unroll
                     for (int bt = 0; bt < 2; bt++) {
                         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (BF16) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wab[kk], dzbb[bt], acc, 0, 0, 0);
+                        } else {
 #pragma unroll
-                        for (int k = 0; k < 3; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kk][k], dzb[bt][k], acc, 0, 0, 0);
+                            for (int k = 0; k < 3; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[kk][k], dzb[bt][k], acc, 0, 0, 0);
+                        }
                         // D rows: channels 4 q + r of cell p; column: sample 16 bt + j
 #pragma unroll
                         for (int r = 0; r < 4; r++) {
@@ -996,25 +1089,49 @@ __global__ __launch_bounds__(CONV_TRAIN_THREADS) void train_conv_epoch_kernel_mw
         // ---- G3: sample pair wv = 4 g + (wave >> 1); wave & 1 = tap tile (0: taps 0..15, 1: taps 16, 17 and the bias "tap")
         {
             const int wv = 4 * g + (rw >> 1), half = rw & 1;
-            const FeatureTable FT = make_feature_table(q);
-            float y[2][16];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const float* ya = act + (2 * wv + k) * G::ASTR + j * G::HW + q;   // A[channel j][cell 4 i + q]
-#pragma unroll
-                for (int i = 0; i < 16; i++) y[k][i] = 4 * i + q < G::HW ? ya[4 * i] : 0.0f;
-            }
             f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (!BF16) {
+                const FeatureTable FT = make_feature_table(q);
+                float y[2][16];
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                const int b = 2 * wv + k;
-                const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
-                const uint64_t Sx = half == 0 ? conv_tap_board(my, op, j)
-                                              : (j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull));
+                for (int k = 0; k < 2; k++) {
+                    const float* ya = act + (2 * wv + k) * G::ASTR + j * G::HW + q;   // A[channel j][cell 4 i + q]
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t pos = (FT.t[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                    a = __builtin_amdgcn_mfma_f32_16x16x4f32(y[k][i], (float)((uint32_t)(Sx >> pos) & 1u), a, 0, 0, 0);
+                    for (int i = 0; i < 16; i++) y[k][i] = 4 * i + q < G::HW ? ya[4 * i] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int b = 2 * wv + k;
+                    const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+                    const uint64_t Sx = half == 0 ? conv_tap_board(my, op, j)
+                                                  : (j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull));
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t pos = (FT.t[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(y[k][i], (float)((uint32_t)(Sx >> pos) & 1u), a, 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const int b = 2 * wv + k;
+                    const uint64_t my = bb[2 * b], op = bb[2 * b + 1];
+                    const uint64_t Sx = half == 0 ? conv_tap_board(my, op, j)
+                                                  : (j < 2 ? conv_tap_board(my, op, 16 + j) : (j == 2 ? c4::FULL : 0ull));
+                    const float* ya = act + b * G::ASTR + j * G::HW;
+#pragma unroll
+                    for (int h = 0; h < 4; h++) {   // k = cell 16 h + 4 q + e; cell 63: padding
+                        float y4[4], x4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int cell = 16 * h + 4 * q + e;
+                            const int cc = cell < G::HW ? cell : 0;
+                            const int row = cc / 9, col = cc - 9 * row, pos = row + 7 * col;
+                            y4[e] = cell < G::HW ? ya[cc] : 0.0f;
+                            x4[e] = cell < G::HW ? (float)((uint32_t)(Sx >> pos) & 1u) : 0.0f;
+                        }
+                        a = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16(y4[0], y4[1], y4[2], y4[3]), pack_bf16(x4[0], x4[1], x4[2], x4[3]), a, 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll

@@ -215,6 +215,7 @@ def test_conv_epoch_kernel_modes_agree(tmp_path, oracle, cblob, golden_dir):
         f"g = np.load(os.path.join({golden_dir!r}, 'conv_train_torch_goldens.npz')); blob = np.load({bpath!r})\n"
         "my = g['my_bb'].reshape(-1); op = g['op_bb'].reshape(-1); tpi = g['target_pi'].reshape(-1, 9); tv = g['target_v'].reshape(-1, 3)\n"
         "eng = sa.Engine(concurrent_games=64, max_explores=16); eng.load_weights_conv(blob); eng.trainer_init_conv(blob)\n"
+        "if len(sys.argv) > 2: eng.trainer_set_precision(sys.argv[2])\n"
         "eng.train_set_data(my, op, tpi, tv)\n"
         "perm = np.random.default_rng(5).integers(0, my.size, size=9 * 32).astype(np.int32)\n"
         "l1 = eng.train_epoch(perm, 32, 1e-3); l2 = eng.train_epoch(perm[: 6 * 31], 31, 5e-4); l3 = eng.train_epoch(perm[: 7 * 5], 5, 2e-3)\n"
@@ -233,6 +234,18 @@ def test_conv_epoch_kernel_modes_agree(tmp_path, oracle, cblob, golden_dir):
     for name in ("four_wgs_device_scope", "one_wg", "thrown_away"):
         for k in ("w", "m", "v", "g", "l"):
             assert np.array_equal(outs["four_wgs"][k].view(np.uint32), outs[name][k].view(np.uint32)), (name, k)
+    # the bf16 variant: four workgroups and one leave the same bits as well (same operands, same instruction per chain element)
+    bouts = {}
+    for name, knobs in (("four_wgs", {}), ("one_wg", {"SYN_DEBUG": "1", "SYN_TRAIN_CONV_MW": "0"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SYN_")}
+        env.update(knobs)
+        path = str(tmp_path / ("bf16_" + name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", script, path, "bf16"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        bouts[name] = np.load(path)
+    for k in ("w", "m", "v", "g", "l"):
+        assert np.array_equal(bouts["four_wgs"][k].view(np.uint32), bouts["one_wg"][k].view(np.uint32)), ("bf16", k)
+    assert not np.array_equal(bouts["four_wgs"]["w"], outs["four_wgs"]["w"])   # (and it IS the other arithmetic)
     # ... and the oracle's
     g = np.load(os.path.join(golden_dir, "conv_train_torch_goldens.npz"))
     my = g["my_bb"].reshape(-1); op = g["op_bb"].reshape(-1); tpi = g["target_pi"].reshape(-1, 9); tv = g["target_v"].reshape(-1, 3)
