@@ -281,7 +281,9 @@ int syn_trainer_init(syn_engine* h, const float* blob, size_t n_floats, const sy
  * network through syn_train_step / syn_train_gradients_device + syn_train_apply_device / syn_train_set_data + syn_train_epoch
  * (minibatches of at most 32 positions, else SYN_ERR_UNSUPPORTED), syn_trainer_get_state copies 12412 floats per array, and
  * syn_trainer_publish_weights makes the trained conv network the engine's policy. f32, the arithmetic order of
- * oracle/train.hpp::ConvTrainer (checked against torch float64 goldens); an engine trains one network at a time. */
+ * oracle/train.hpp::ConvTrainer (checked against torch float64 goldens); an engine trains one network at a time. Like
+ * syn_trainer_init, the first call on an engine runs a self-check (eight steps on a synthetic batch through the four-workgroup
+ * epoch kernel and through the one-workgroup kernel, compared bit for bit) and thereby discards a data set uploaded before it. */
 int syn_trainer_init_conv(syn_engine* h, const float* blob, size_t n_floats, const syn_train_config* cfg);
 /* Replaces: one iteration of the minibatch loop alpha_zero.rs:76-92 (forward, log_softmax, kl_div(Sum)/batch for both
  * heads, loss, backward_step). States are given as bitboards; losses[2] = {pi_loss, v_loss} (may be NULL). */
@@ -316,8 +318,11 @@ int syn_trainer_publish_weights(syn_engine* h);
  * learner's state is snapshotted before the launch, and if the workgroups never become co-resident (another kernel holds the CUs:
  * it gives up after ~10 s) the snapshot is restored and the epoch runs through the queued per-step launches instead — same bits,
  * the call still returns SYN_OK. Larger batches queue two launches per step. The Connect4ConvNet learner (syn_trainer_init_conv;
- * minibatches of at most 32) runs an epoch as ONE launch of a single persistent workgroup (csrc/train_conv_mfma.cuh: no
- * co-residency requirement), in f32 or — after syn_trainer_set_precision(SYN_TRAIN_BF16) — on the bf16 matrix cores. */
+ * minibatches of at most 32) runs an epoch as ONE persistent launch as well (csrc/train_conv_mfma.cuh), in f32 or — after
+ * syn_trainer_set_precision(SYN_TRAIN_BF16) — on the bf16 matrix cores: four workgroups of one XCD share every step (same
+ * chains, same bits as one workgroup), with the same snapshot; if they never become co-resident, or if the start-up self-check of
+ * syn_trainer_init_conv found this engine's four-workgroup kernel disagreeing with the one-workgroup kernel, the epoch is one
+ * launch of a single persistent workgroup instead (no co-residency requirement, 2.3x slower). */
 int syn_train_set_data(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,
                        const float* target_v, size_t n);
 int syn_train_epoch(syn_engine* h, const int32_t* perm, size_t n_steps, int batch, float lr, float* step_losses);

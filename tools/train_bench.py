@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: optimiser steps per second of the learners at the reference's batch of 32 (alpha_zero.rs:72-94 step; main.rs:22).
-Connect4Net: persistent epoch kernel (train_epoch.cuh) and queued launches; Connect4ConvNet: persistent one-workgroup epoch kernel
-(train_conv_mfma.cuh) in f32 and bf16, and its queued launches. Run under rocprofv3 --kernel-trace --stats for per-kernel times."""
+Connect4Net: persistent epoch kernel (train_epoch.cuh); Connect4ConvNet: persistent four-workgroup epoch kernel (train_conv_mfma.cuh;
+SYN_DEBUG=1 SYN_TRAIN_CONV_MW=0: the one-workgroup kernel) in f32 and bf16. SYN_DEBUG=1 SYN_TRAIN_PROFILE=1 prints the phase stamps. Run under rocprofv3 --kernel-trace --stats for per-kernel times."""
 import os, sys, time
 import numpy as np
 import torch  # noqa
@@ -22,7 +22,7 @@ steps = min(nu // 32, 3000)
 print(f"{nu} unique positions, {steps} steps of 32")
 for name, init, w0, prec in (("Connect4Net", eng.trainer_init, blob, None), ("Connect4ConvNet f32", eng.trainer_init_conv, cblob, "f32"),
                              ("Connect4ConvNet bf16", eng.trainer_init_conv, cblob, "bf16")):
-    for queued in (False, True):
+    for queued in (False,):   # (SYN_TRAIN_QUEUED is read once per process: run the tool with it set to time the queued launches)
         if queued: os.environ["SYN_DEBUG"] = "1"; os.environ["SYN_TRAIN_QUEUED"] = "1"
         else: os.environ.pop("SYN_TRAIN_QUEUED", None)
         init(w0)
