@@ -23,7 +23,11 @@
 // streams of the device path and are not offered here: Error(SYN_ERR_UNSUPPORTED).
 #pragma once
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "synthesis_amd.hpp"
@@ -95,22 +99,96 @@ inline float det_logf(float x) {
     return std::fmaf(fe, 0.693359375f, r);
 }
 
-// fn(i) for i in [0, n) on up to `threads` host threads (contiguous chunks; trees are independent)
-template <class F>
-void parallel_for(size_t n, int threads, F&& fn) {
-    if (threads <= 1 || n < 64) {
-        for (size_t i = 0; i < n; i++) fn(i);
-        return;
+// A fixed set of host threads that run fn(i) for i in [0, n), contiguous chunks (trees are independent). One pool lives for a whole
+// search: its two phases per round would otherwise start and join `threads` threads 2 x (explores + 1) times.
+class WorkerPool {
+public:
+    explicit WorkerPool(int threads) : nthreads_((size_t)(threads < 1 ? 1 : threads)) {
+        for (size_t k = 1; k < nthreads_; k++) workers_.emplace_back([this, k] { loop(k); });
     }
-    const size_t t = std::min<size_t>((size_t)threads, n);
-    std::vector<std::thread> pool;
-    pool.reserve(t);
-    for (size_t k = 0; k < t; k++)
-        pool.emplace_back([&, k] {
-            for (size_t i = n * k / t; i < n * (k + 1) / t; i++) fn(i);
-        });
-    for (auto& th : pool) th.join();
-}
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+            generation_++;
+        }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+
+    template <class F>
+    void run(size_t n, F&& fn) {
+        if (nthreads_ <= 1 || n < 64) {
+            for (size_t i = 0; i < n; i++) fn(i);
+            return;
+        }
+        std::function<void(size_t)> f = std::ref(fn);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            job_ = &f;
+            n_ = n;
+            pending_ = nthreads_ - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        std::exception_ptr mine = nullptr;
+        try {
+            chunk(0, f, n);
+        } catch (...) {
+            mine = std::current_exception();   // (the workers still hold a pointer to f: wait for them before unwinding)
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        if (mine && !error_) error_ = mine;
+        job_ = nullptr;
+        if (error_) {
+            std::exception_ptr e = error_;
+            error_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+
+private:
+    void chunk(size_t k, const std::function<void(size_t)>& f, size_t n) const {
+        for (size_t i = n * k / nthreads_; i < n * (k + 1) / nthreads_; i++) f(i);
+    }
+    void loop(size_t k) {
+        size_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* f;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+                if (stop_) return;
+                f = job_;
+                n = n_;
+            }
+            try {
+                chunk(k, *f, n);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!error_) error_ = std::current_exception();
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                pending_--;
+            }
+            done_.notify_one();
+        }
+    }
+    const size_t nthreads_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)>* job_ = nullptr;
+    size_t n_ = 0, pending_ = 0, generation_ = 0;
+    bool stop_ = false;
+    std::exception_ptr error_ = nullptr;
+};
 }  // namespace detail
 
 // ---- game.rs:9-62 ---------------------------------------------------------------------------------------------------------
@@ -440,8 +518,9 @@ std::vector<LockstepTree<G, N>> lockstep_search(BatchPolicy<G, N>& policy, const
     size_t rounds = 0, evals = 0;
     std::vector<uint32_t> live(trees.size());
     for (size_t i = 0; i < trees.size(); i++) live[i] = (uint32_t)i;
+    detail::WorkerPool pool(threads);
     while (!live.empty()) {
-        detail::parallel_for(live.size(), threads, [&](size_t k) { want[live[k]] = trees[live[k]].advance(); });
+        pool.run(live.size(), [&](size_t k) { want[live[k]] = trees[live[k]].advance(); });
         batch.clear();
         owner.clear();
         for (uint32_t t : live)
@@ -455,8 +534,7 @@ std::vector<LockstepTree<G, N>> lockstep_search(BatchPolicy<G, N>& policy, const
         policy.eval_batch(batch, logits.data(), value.data());
         rounds++;
         evals += batch.size();
-        detail::parallel_for(owner.size(), threads,
-                             [&](size_t k) { trees[owner[k]].supply(&logits[k * (size_t)N], &value[k * 3]); });
+        pool.run(owner.size(), [&](size_t k) { trees[owner[k]].supply(&logits[k * (size_t)N], &value[k * 3]); });
         live = owner;  // a tree that returned nullptr is finished
     }
     if (rounds_out) *rounds_out = rounds;
