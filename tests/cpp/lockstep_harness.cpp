@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <stdexcept>
 
 #include "synthesis_amd_lockstep.hpp"
 
@@ -57,7 +58,42 @@ struct UniformPolicy : BatchPolicy<Nim, 3> {
     }
 };
 
+// the same game, but a position with exactly seven stones cannot be constructed: step() throws (a worker thread of the pool)
+struct ThrowingNim : Nim {
+    bool step(int action) {
+        if (stones - (action + 1) == 7) throw std::runtime_error("seven stones");
+        return Nim::step(action);
+    }
+};
+struct UniformThrowingPolicy : BatchPolicy<ThrowingNim, 3> {
+    void eval_batch(const std::vector<const ThrowingNim*>& games, float* logits, float* value) override {
+        for (size_t i = 0; i < games.size(); i++) {
+            for (int k = 0; k < 3; k++) logits[i * 3 + k] = 0.0f;
+            value[i * 3 + 0] = value[i * 3 + 1] = value[i * 3 + 2] = 1.0f / 3.0f;
+        }
+    }
+};
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "nimthrow") {
+        // 256 trees on 4 threads; the roots with 8..10 stones reach the forbidden position in their first expansion
+        UniformThrowingPolicy policy;
+        std::vector<ThrowingNim> roots(256);
+        for (size_t i = 0; i < roots.size(); i++) roots[i].stones = 3 + (int)(i % 9);
+        try {
+            lockstep_search<ThrowingNim, 3>(policy, MCTSConfig{}, roots, 50, 4);
+            std::printf("no exception\n");
+            return 1;
+        } catch (const std::runtime_error& e) {
+            std::printf("caught %s\n", e.what());
+        }
+        // and the pool is gone with the failed search: a second search on the same thread count works
+        std::vector<ThrowingNim> ok(128);
+        for (auto& g : ok) g.stones = 5;
+        const auto trees = lockstep_search<ThrowingNim, 3>(policy, MCTSConfig{}, ok, 50, 4);
+        std::printf("second search %zu trees, root solved %d\n", trees.size(), trees[0].root().solution.some ? 1 : 0);
+        return 0;
+    }
     if (argc >= 2 && std::string(argv[1]) == "nim") {
         UniformPolicy policy;
         MCTSConfig cfg;

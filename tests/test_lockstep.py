@@ -86,6 +86,15 @@ def test_lockstep_driver_is_generic_over_the_game(harness):
             assert kind == 2 and best == stones % 4 - 1 and turns == 2 * (stones // 4) + 1
 
 
+def test_lockstep_pool_hands_a_worker_threads_exception_to_the_caller(harness):
+    """Game::step throwing on a pool thread: the search ends with that exception on the calling thread (no terminate, no hang), and
+    the next search starts its own pool."""
+    exe, _, _ = harness
+    p = subprocess.run([exe, "nimthrow"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.splitlines() == ["caught seven stones", "second search 128 trees, root solved 1"]
+
+
 @pytest.mark.gpu
 def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
     import synthesis_amd as sa
