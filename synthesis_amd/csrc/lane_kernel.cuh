@@ -158,12 +158,25 @@ SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
 
 // Out of line: the draws sit on the slow (runtime-switched) configuration path. lane_fpu_scan is a leaf function written to stay
 // inside the caller-saved registers (no prologue saves, no scratch); the rare continuation of a draw (1.2 %) is its own cold call.
-struct FpuScan { float q[9]; uint32_t fail; };
+struct FpuScan { float q[9]; uint32_t fail; uint32_t first_lo, first_hi; /* the first bits of the lowest failing slot */ };
 __device__ __attribute__((noinline)) FpuScan lane_fpu_scan(uint64_t tree_seed, uint32_t scan, uint32_t need, float mean, float std, float q_default) {
     FpuScan r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.q[i] = q_default;
-    r.fail = noise_fpu_scan(tree_seed, scan, need, mean, std, r.q);
+    uint64_t first = 0ull;
+    r.fail = noise_fpu_scan(tree_seed, scan, need, mean, std, r.q, first);
+    r.first_lo = (uint32_t)first;
+    r.first_hi = (uint32_t)(first >> 32);
+    return r;
+}
+// the common continuations in registers (noise_fpu_redo_fast)
+struct FpuRedo { float z; uint32_t done; };
+__device__ __attribute__((noinline)) FpuRedo lane_fpu_redo_fast(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std,
+                                                                bool have_first, uint32_t first_lo, uint32_t first_hi) {
+    FpuRedo r;
+    bool done;
+    r.z = noise_fpu_redo_fast(tree_seed, scan, slot, mean, std, have_first, (uint64_t)first_lo | ((uint64_t)first_hi << 32), done);
+    r.done = done ? 1u : 0u;
     return r;
 }
 __device__ __attribute__((noinline, cold)) float lane_fpu_redo(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std) {
@@ -175,11 +188,17 @@ SYN_DEV void lane_fpu_draws(uint64_t tree_seed, uint32_t scan, uint32_t need, fl
 #pragma unroll
     for (uint32_t i = 0; i < 9; i++) qf[i] = fs.q[i];
     uint32_t fail = fs.fail;
+    bool have_first = true;   // (the scan handed out the first bits of the lowest failing slot: the first pass of this loop)
     while (__ballot(fail != 0u) != 0ull) {
         if (fail != 0u) {
             const uint32_t slot = (uint32_t)__ffs((int)fail) - 1u;
             fail &= fail - 1u;
-            const float z = lane_fpu_redo(tree_seed, scan, slot, mean, std);
+            const FpuRedo fr = lane_fpu_redo_fast(tree_seed, scan, slot, mean, std, have_first, fs.first_lo, fs.first_hi);
+            have_first = false;
+            float z = fr.z;
+            if (__ballot(fr.done == 0u) != 0ull) {   // a tail or two failures in a row (0.6 % of the continuations): the generic sampler
+                if (fr.done == 0u) z = lane_fpu_redo(tree_seed, scan, slot, mean, std);
+            }
 #pragma unroll
             for (uint32_t i = 0; i < 9; i++) qf[i] = slot == i ? z : qf[i];
         }
