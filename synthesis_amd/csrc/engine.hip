@@ -28,6 +28,7 @@
 #include "layer_kernels.cuh"
 #include "train_conv.cuh"
 #include "train_conv_mfma.cuh"
+#include "lane_instances.h"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -63,6 +64,12 @@ SYN_LANES2(MODE_SEARCH, false)
 SYN_LANES2(MODE_SELFPLAY, false)
 SYN_LANES2(MODE_SELFPLAY, true)
 #undef SYN_LANES2
+// ... and the Connect4Net / RolloutPolicy lane-per-tree kernels in engine_lanes_fast.hip and engine_lanes_gen.hip
+#define SYN_X(MODE, COUNT, FAST, NW, PROF, POLICY) \
+    extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF, POLICY>(EngineParams);
+SYN_LANES_FAST_LIST(SYN_X)
+SYN_LANES_GEN_LIST(SYN_X)
+#undef SYN_X
 }  // namespace syn
 
 static_assert(sizeof(DevSearchResult) == sizeof(syn_search_result), "search result layout must match the C ABI");
@@ -1266,23 +1273,38 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
                             "tree waves=%.0f: per visit: wait=%.0f C=%.0f A+submit=%.0f cycles, explores finished=%.2f, visits per wave=%.0f\n",
                     pgrid, nm, 100.0 * mb / (mb + mw + 1e-9), mb / (mt + 1e-9), mt / (nm + 1e-9), ntw, tw / (tr + 1e-9), tc / (tr + 1e-9),
                     ta / (tr + 1e-9), tf / (tr + 1e-9), tr / (ntw + 1e-9));
-        } else if (pgrid < 0) {  // lane kernel: per wave [A, B, C, move, rounds, tiles, active lanes, evals]
+        } else if (pgrid < 0) {  // lane kernel: per wave [A, B, C, move, rounds, tiles, active lanes, evals, then the LP_* fields]
             int nwv = -pgrid * (pnt / 64);
-            std::vector<unsigned long long> hp((size_t)nwv * 10);
+            constexpr int F = LP_FIELDS;
+            std::vector<unsigned long long> hp((size_t)nwv * F);
             HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
             unsigned long long* d_prof_keep = d_prof;
-            double s[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            double s[F];
+            for (int j = 0; j < F; j++) s[j] = 0;
             for (int w = 0; w < nwv; w++)
-                for (int j = 0; j < 10; j++) s[j] += (double)hp[(size_t)w * 10 + j];
+                for (int j = 0; j < F; j++) s[j] += (double)hp[(size_t)w * F + j];
             fprintf(stderr, "[syn profile lanes] grid=%d nt=%d waves=%d rounds/wave=%.0f | cycles per round: A=%.0f B=%.0f C: children=%.0f "
                             "solver walk=%.0f sweep=%.0f move=%.0f total=%.0f | per round: tiles=%.3f explores finished=%.2f evals=%.2f "
                             "(%.2f per tile) | cycles per finished explore=%.0f\n",
                     -pgrid, pnt, nwv, s[4] / nwv, s[0] / s[4], s[1] / s[4], s[6] / s[4], s[7] / s[4], s[2] / s[4], s[3] / s[4],
                     (s[0] + s[1] + s[2] + s[3] + s[6] + s[7]) / s[4], s[5] / s[4], s[8] / s[4], s[9] / s[4], s[9] / s[5],
                     (s[0] + s[1] + s[2] + s[3] + s[6] + s[7]) / s[8]);
+            const double R = s[4];  // rounds (all waves)
+            fprintf(stderr, "[syn profile lanes, inside the phases; cycles per round and wave] A: %.2f iterations (%.1f lanes each), line wait %.0f "
+                            "(%.0f per iteration), level arithmetic %.0f (%.0f per iteration), arrive %.0f | B: tiles %.0f (%.0f per tile), "
+                            "scatter %.0f | C children: softmaxes %.0f, records %.0f (%.1f lanes) | solver walk: %.2f iterations (%.1f lanes each), "
+                            "line wait %.0f (%.0f per iteration) | sweep: %.2f steps, %.1f lane-levels per step, log wait %.0f (%.0f per step), "
+                            "arithmetic + stores %.0f (%.0f per step) | end of search: %.3f calls per round, %.1f lanes per call\n",
+                    s[LP_A_ITERS] / R, s[LP_A_LANES] / (s[LP_A_ITERS] + 1e-9), s[LP_A_WAIT] / R, s[LP_A_WAIT] / (s[LP_A_ITERS] + 1e-9),
+                    s[LP_A_ALU] / R, s[LP_A_ALU] / (s[LP_A_ITERS] + 1e-9), s[LP_A_ARRIVE] / R, s[LP_B_TILE] / R,
+                    s[LP_B_TILE] / (s[5] + 1e-9), s[LP_B_SCATTER] / R, s[LP_C_SOFT] / R, (s[LP_C_WRITE] - s[LP_C_SOFT]) / R,
+                    s[LP_C_LANES] / R, s[LP_W_ITERS] / R, s[LP_W_LANES] / (s[LP_W_ITERS] + 1e-9), s[LP_W_WAIT] / R,
+                    s[LP_W_WAIT] / (s[LP_W_ITERS] + 1e-9), s[LP_S_STEPS] / R, s[LP_S_LANES] / (s[LP_S_STEPS] + 1e-9), s[LP_S_WAIT] / R,
+                    s[LP_S_WAIT] / (s[LP_S_STEPS] + 1e-9), s[LP_S_ALU] / R, s[LP_S_ALU] / (s[LP_S_STEPS] + 1e-9), s[LP_M_CALLS] / R,
+                    s[LP_M_LANES] / (s[LP_M_CALLS] + 1e-9));
             {
                 std::vector<unsigned long long> tlv(4 * 16 * 3);
-                (void)hipMemcpy(tlv.data(), d_prof_keep + 40000, tlv.size() * 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(tlv.data(), d_prof_keep + PROF_TIMELINE_OFF, tlv.size() * 8, hipMemcpyDeviceToHost);
                 unsigned long long t0 = ~0ull;
                 for (auto v : tlv) if (v && v < t0) t0 = v;
                 for (int w = 0; w < pnt / 256; w++) {

@@ -1,0 +1,25 @@
+// synthesis_amd — which instantiations of selfplay_kernel_lanes (lane_kernel.cuh) for Connect4Net (POLICY 0) and RolloutPolicy
+// (POLICY 1) the library ships, as X-macro lists: engine.hip declares them `extern template`, engine_lanes_fast.hip (the compile-
+// time-folded parity configuration family) and engine_lanes_gen.hip (the runtime-switched one) define them. Separate translation
+// units only so that `make -j` builds them beside engine.hip.
+//   X(MODE, COUNT, FAST, NW, PROF, POLICY)
+#pragma once
+#define SYN_LANES_FAST_LIST(X)                                                                                   \
+    X(MODE_SELFPLAY, false, true, 4, false, 0) X(MODE_SELFPLAY, false, true, 8, false, 0)                        \
+    X(MODE_SELFPLAY, false, true, 12, false, 0) X(MODE_SELFPLAY, false, true, 16, false, 0)                      \
+    X(MODE_SELFPLAY, false, true, 4, true, 0) X(MODE_SELFPLAY, false, true, 8, true, 0)                          \
+    X(MODE_SELFPLAY, false, true, 12, true, 0) X(MODE_SELFPLAY, false, true, 16, true, 0)                        \
+    X(MODE_SELFPLAY, true, true, 4, false, 0) X(MODE_SELFPLAY, true, true, 8, false, 0)                          \
+    X(MODE_SELFPLAY, true, true, 12, false, 0) X(MODE_SELFPLAY, true, true, 16, false, 0)                        \
+    X(MODE_SEARCH, false, true, 4, false, 0) X(MODE_SEARCH, false, true, 8, false, 0)                            \
+    X(MODE_SEARCH, false, true, 12, false, 0) X(MODE_SEARCH, false, true, 16, false, 0)
+#define SYN_LANES_GEN_LIST(X)                                                                                    \
+    X(MODE_SELFPLAY, false, false, 4, false, 0) X(MODE_SELFPLAY, false, false, 8, false, 0)                      \
+    X(MODE_SELFPLAY, false, false, 12, false, 0) X(MODE_SELFPLAY, false, false, 16, false, 0)                    \
+    X(MODE_SELFPLAY, false, false, 4, true, 0) X(MODE_SELFPLAY, false, false, 8, true, 0)                        \
+    X(MODE_SELFPLAY, false, false, 12, true, 0) X(MODE_SELFPLAY, false, false, 16, true, 0)                      \
+    X(MODE_SELFPLAY, true, false, 4, false, 0) X(MODE_SELFPLAY, true, false, 8, false, 0)                        \
+    X(MODE_SELFPLAY, true, false, 12, false, 0) X(MODE_SELFPLAY, true, false, 16, false, 0)                      \
+    X(MODE_SEARCH, false, false, 4, false, 0) X(MODE_SEARCH, false, false, 8, false, 0)                          \
+    X(MODE_SEARCH, false, false, 12, false, 0) X(MODE_SEARCH, false, false, 16, false, 0)                        \
+    X(MODE_SEARCH, false, false, 8, false, 1)

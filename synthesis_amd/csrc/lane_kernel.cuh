@@ -126,6 +126,30 @@ struct LaneLeaf {             // phase A -> phase C (valid for lanes with at_lea
     float p0, p1, p2;
 };
 
+// Diagnostic build only (SYN_DEBUG=1 SYN_PROFILE=1, template parameter PROF): cycle stamps INSIDE the phases. "wait" = from the
+// issue of a step's loads to their arrival (an explicit s_waitcnt vmcnt(0) that the production build does not have), "alu" = the
+// rest of the step (arithmetic, stores, control flow). The stamps sit inside divergent code, so the first active lane adds the
+// (wave-uniform) interval to this wave's row of P.prof with one no-return atomic. nullptr everywhere else: it all compiles away.
+enum { LP_A_WAIT = 10, LP_A_ALU, LP_A_ITERS, LP_A_LANES, LP_A_ARRIVE, LP_W_WAIT, LP_W_ALU, LP_W_ITERS, LP_W_LANES, LP_S_WAIT, LP_S_ALU,
+       LP_S_STEPS, LP_S_LANES, LP_C_SOFT, LP_C_WRITE, LP_C_LANES, LP_B_GATHER, LP_B_TILE, LP_B_SCATTER, LP_M_CALLS, LP_M_LANES, LP_FIELDS };
+struct LaneProf { unsigned long long* row; };
+constexpr size_t PROF_TIMELINE_OFF = (size_t)4096 * LP_FIELDS;  // behind the rows of up to 4096 waves
+SYN_DEV unsigned long long lp_now() { return (unsigned long long)__builtin_readcyclecounter(); }
+SYN_DEV void lp_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+SYN_DEV void lp_add(const LaneProf* lp, int field, unsigned long long v) {
+    const unsigned long long ex = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) atomicAdd(lp->row + field, v);
+}
+// one interval + how many lanes shared it
+SYN_DEV void lp_step(const LaneProf* lp, int f_time, int f_count, int f_lanes, unsigned long long dt) {
+    const unsigned long long ex = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
+        atomicAdd(lp->row + f_time, dt);
+        if (f_count >= 0) atomicAdd(lp->row + f_count, 1ull);
+        if (f_lanes >= 0) atomicAdd(lp->row + f_lanes, (unsigned long long)__popcll(ex));
+    }
+}
+
 template <int MODE>
 SYN_DEV void lane_start_job(const EngineParams& P, LaneTree& T) {
     int j = atomicAdd(P.job_next, 1);
@@ -266,11 +290,12 @@ SYN_DEV void lane_begin_explore(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
 // next call with scan_now true (wave-uniform) takes the draws and the level.
 template <bool COUNT, bool FAST, bool DEFER = false>
 SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint32_t& lm, uint4* pl, uint32_t* ctr,
-                                uint64_t noise_seed, FpuHold* H = nullptr, bool scan_now = true) {
+                                uint64_t noise_seed, FpuHold* H = nullptr, bool scan_now = true, LaneProf* lp = nullptr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     const uint32_t nc = (uint32_t)__popc(lm);
     const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, C.blk));
+    const unsigned long long lp_t0 = lp ? lp_now() : 0ull;
     const uint4 hdr = line[0];  // the node's own sums: logged for backprop (same line, no extra transaction)
     uint32_t d[28];
 #pragma unroll
@@ -278,6 +303,8 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
         const uint4 t = line[1 + j];
         d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
     }
+    unsigned long long lp_t1 = 0ull;
+    if (lp) { lp_wait_vm(); lp_t1 = lp_now(); lp_add(lp, LP_A_WAIT, lp_t1 - lp_t0); }
     const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(C.qt);  // parent.q() = -(stored q)
     const float visits = cfg.puct() ? sqrtf(C.pN) : sqrtf(cfg.cc() * det_logf(C.pN));
     // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
@@ -380,6 +407,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
     pl[C.level * 64] = make_uint4(C.rec, f32_bits(C.pN),
                                   pm_make(C.blk, (uint32_t)__popc(lm), C.nsolved, C.kind) |
                                       ((!C.nsolved && C.blk != 0u) ? PM_HAS_W : 0u), C.qt);
+    if (lp) lp_step(lp, LP_A_ALU, LP_A_ITERS, LP_A_LANES, lp_now() - lp_t1);
 }
 
 // The descent stands on a leaf: a solved node (explore() returns its outcome) or an unexpanded one, which visit()
@@ -459,7 +487,7 @@ SYN_DEV void lane_arrive(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, Lan
 template <bool COUNT, bool FAST, bool ROOT_IN_T = false>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
                                 uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride,
-                                uint64_t noise_seed = 0) {
+                                uint64_t noise_seed = 0, LaneProf* lp = nullptr) {
     const bool pending = active && Wk.pending;
     X.at_leaf = false;
     X.was_pending = pending;
@@ -499,7 +527,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
             if (scan_now && __ballot(desc) == 0ull) break;
             if (desc && H.wait == scan_now) {
                 H.wait = false;
-                lane_descend_level<COUNT, FAST, true>(cfg_, T, C, lm, pl, ctr, noise_seed, &H, scan_now);
+                lane_descend_level<COUNT, FAST, true>(cfg_, T, C, lm, pl, ctr, noise_seed, &H, scan_now, lp);
             }
         }
     } else
@@ -509,10 +537,12 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
             else if (C.blk == 0u) { desc = false; at_leaf = true; }
         }
         if (__ballot(desc) == 0ull || __popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
-        if (desc) lane_descend_level<COUNT, FAST>(cfg_, T, C, lm, pl, ctr, noise_seed);
+        if (desc) lane_descend_level<COUNT, FAST>(cfg_, T, C, lm, pl, ctr, noise_seed, nullptr, true, lp);
     }
 
+    const unsigned long long lp_ta = lp ? lp_now() : 0ull;
     if (at_leaf && !pending) lane_arrive<COUNT, FAST>(cfg_, T, C, X, hit_solved, pl, bcap, ctr, error);
+    if (lp) lp_add(lp, LP_A_ARRIVE, lp_now() - lp_ta);
     X.at_leaf = at_leaf;
     Wk.descending = desc;
     Wk.rec = C.rec;
@@ -686,7 +716,8 @@ template <bool COUNT, bool FAST>
 // `leaf_flag`: header word 3 of the node expanded in this pass (lane_create_children), 0 otherwise; every other visited node
 // keeps the word it has (a node that was never backpropagated into has no header yet: 0).
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
-                           bool active, const uint4* pl, uint32_t* ctr, uint32_t leaf_flag, unsigned long long* t_mid = nullptr) {
+                           bool active, const uint4* pl, uint32_t* ctr, uint32_t leaf_flag, unsigned long long* t_mid = nullptr,
+                           LaneProf* lp = nullptr) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     if (COUNT && active) {
@@ -711,6 +742,11 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
             }
             const uint4 pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
+            if (lp) {
+                const unsigned long long t0_ = lp_now();
+                lp_wait_vm();
+                lp_step(lp, LP_W_WAIT, LP_W_ITERS, LP_W_LANES, lp_now() - t0_);
+            }
             // a node that was never backpropagated into has nothing in its header yet
             float W0 = N == 0.0f ? 0.0f : bits_f32(hdr.x), W1 = N == 0.0f ? 0.0f : bits_f32(hdr.y),
                   W2 = N == 0.0f ? 0.0f : bits_f32(hdr.z);
@@ -777,12 +813,23 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
     for (int base = wave_max_i32(L); base >= 0; base -= 4) {
         uint4 pe[4];
         float4 a[4];
+        const unsigned long long lp_t0 = lp ? lp_now() : 0ull;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int Lj = base - j;
             pe[j] = pl[(Lj < 0 ? 0 : Lj) * 64];
             // the node's sums as the descent logged them (coalesced row of the second plane)
             a[j] = *reinterpret_cast<const float4*>(pl + PATH_PLANE + (Lj < 0 ? 0 : Lj) * 64);
+        }
+        unsigned long long lp_t1 = 0ull;
+        if (lp) {
+            lp_wait_vm();
+            lp_t1 = lp_now();
+            unsigned long long nl = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) nl += (unsigned long long)__popcll(__ballot(base - j >= 0 && base - j <= L));
+            lp_add(lp, LP_S_WAIT, lp_t1 - lp_t0);
+            lp_add(lp, LP_S_LANES, nl);
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -814,6 +861,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 }
             }
         }
+        if (lp) lp_step(lp, LP_S_ALU, LP_S_STEPS, -1, lp_now() - lp_t1);
     }
 }
 
@@ -1307,16 +1355,19 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         const uint64_t stream = P.base_seed + (MODE == MODE_SELFPLAY ? P.first_game : 0ull) + (uint64_t)(uint32_t)T.job;
         return noise_tree_seed(stream, MODE == MODE_SELFPLAY ? (pk[4 * NT] & 0xFFu) : 0u);
     };
+    LaneProf lp_store;
+    lp_store.row = (PROF && P.prof) ? P.prof + ((size_t)blockIdx.x * NW + wave) * LP_FIELDS : nullptr;
+    LaneProf* const lp = (PROF && P.prof) ? &lp_store : nullptr;
     for (;;) {
         const bool active = T.job >= 0;
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT, lane_noise_seed());
+        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT, lane_noise_seed(), lp);
         SYN_LAP(pA)
         // PROF: timeline of the three waves of SIMD 0 of workgroup 0 (rounds 2000..2015): [A end = B start, B end, C end]
         const bool tl = PROF && P.prof && blockIdx.x == 0 && (wave & 3) == 0 && pRounds >= 2000 && pRounds < 2016;
-        if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 0] = SYN_STAMP();
+        if (tl && lane == 0) P.prof[PROF_TIMELINE_OFF + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 0] = SYN_STAMP();
         // ---- phase B: the lanes that need the network, compacted into tiles of 16 positions. While other lanes are still
         // descending only whole tiles are evaluated: requests beyond `thresh` stay pending and go first next round.
         const bool want_nn = X.at_leaf && X.needs_eval;  // this lane's expanded leaf needs Policy::eval
@@ -1358,6 +1409,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 #pragma unroll 1
         for (int j = 0; j * 16 < n_need; j++) {
             if (PROF) pTiles++;
+            const unsigned long long lp_b0 = lp ? lp_now() : 0ull;
             // everything a tile needs is re-derived here instead of living in registers across the whole matrix phase:
             // the two derived boards (10 VALU) and the lane's feature shift table (one 16-byte LDS read)
             const int src = (int)idxw[16 * j + (lane & 15)];  // (slots past the last request read lane 0: finite input)
@@ -1378,6 +1430,8 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             }
             // (raw outputs: the softmax over the three outcome logits runs per tree lane in phase C, lane_softmaxes)
+            const unsigned long long lp_b1 = lp ? lp_now() : 0ull;
+            if (lp) lp_add(lp, LP_B_TILE, lp_b1 - lp_b0);
             const int q = lane >> 4;
             if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 16 + q * 4) = o;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1395,9 +1449,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lp) lp_add(lp, LP_B_SCATTER, lp_now() - lp_b1);
         }
 
-        if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 1] = SYN_STAMP();
+        if (tl && lane == 0) P.prof[PROF_TIMELINE_OFF + ((wave >> 2) * 16 + (pRounds - 2000)) * 3 + 1] = SYN_STAMP();
         SYN_LAP(pB)
         if (PROF) { pRounds++; pLanes += (unsigned long long)__popcll(__ballot(fin)); pEvals += (unsigned long long)n_need; }
 
@@ -1408,7 +1463,9 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             // the leaf's two softmaxes (RolloutPolicy delivers outcome probabilities already), then — with the probabilities —
             // the PolicyWithCache entry of a position the network has just evaluated
             float pr[9];
+            const unsigned long long lp_c0 = lp ? lp_now() : 0ull;
             lane_softmaxes(X.legal_mask, lg, pr, POLICY != 1 && need, v0, v1, v2);
+            if (lp) lp_step(lp, LP_C_SOFT, -1, LP_C_LANES, lp_now() - lp_c0);
             if (POLICY != 1 && P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
@@ -1416,10 +1473,11 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                                          (!FAST && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
                                          P.mcts.noise_alpha, lane_noise_seed(),
                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
+            if (lp) lp_add(lp, LP_C_WRITE, lp_now() - lp_c0);
         }
         SYN_LAP(pC1)
         unsigned long long tmid = 0;
-        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, PROF ? &tmid : nullptr);
+        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, PROF ? &tmid : nullptr, lp);
         if (PROF) { pC2 += tmid - pT; pT = tmid; }
         SYN_LAP(pC)
         if (fin) {
@@ -1429,6 +1487,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 // a private copy of the arguments goes to the callee and the slab pointer is re-derived afterwards, so
                 // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
                 EngineParams Pc = P;
+                if (lp) lp_step(lp, LP_M_CALLS, -1, LP_M_LANES, 1ull);
                 SYN_UNPARK();
                 if (MODE == MODE_SELFPLAY) T = lane_move_step_call<COUNT>(Pc, T, ctr);
                 else T = lane_search_finish_call(Pc, T);
@@ -1436,7 +1495,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 SYN_PARK();
             }
         }
-        if (tl && lane == 0) P.prof[40000 + ((wave >> 2) * 16 + (pRounds - 1 - 2000)) * 3 + 2] = SYN_STAMP();
+        if (tl && lane == 0) P.prof[PROF_TIMELINE_OFF + ((wave >> 2) * 16 + (pRounds - 1 - 2000)) * 3 + 2] = SYN_STAMP();
         SYN_LAP(pM)
     }
 #undef SYN_STAMP
@@ -1445,7 +1504,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 #undef SYN_UNPARK
     if (PROF) {
         if (P.prof && lane == 0) {
-            unsigned long long* o = P.prof + ((size_t)blockIdx.x * NW + wave) * 10;
+            unsigned long long* o = P.prof + ((size_t)blockIdx.x * NW + wave) * LP_FIELDS;
             o[0] = pA; o[1] = pB; o[2] = pC; o[3] = pM; o[4] = pRounds; o[5] = pTiles; o[6] = pC1; o[7] = pC2; o[8] = pLanes; o[9] = pEvals;
         }
     }

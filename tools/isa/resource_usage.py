@@ -54,7 +54,7 @@ def loop_scratch(body):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         with ThreadPoolExecutor(3) as ex:
-            res = list(ex.map(lambda n: compile_tu(n, tmp), ["engine", "engine_conv", "engine_lanes2"]))
+            res = list(ex.map(lambda n: compile_tu(n, tmp), ["engine", "engine_conv", "engine_lanes2", "engine_lanes_fast", "engine_lanes_gen"]))
         rows = []
         for path, err in res:
             if not os.path.exists(path):
