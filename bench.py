@@ -573,6 +573,18 @@ def main():
                     "host_threads": "hardware concurrency (at most 32)",
                     "identical_to_fused_search": bool(all(np.array_equal(ls[k], fs[k]) for k in ("child_N", "child_W", "best_action", "num_nodes"))),
                     "fused_search_on_the_same_roots": {"searches_per_s": 4096 / dt_f, "seconds": dt_f}}
+                if fits("lockstep_selfplay", 40):
+                    # ... and whole games in that form (syn_selfplay_run_lockstep = run_n_games over the host trees): 4,096 concurrent
+                    # games, one batched Policy::eval launch per round; held to the fused kernel's games on the same seeds
+                    t1 = time.perf_counter()
+                    lg = e2.selfplay_lockstep(cfg, base_seed=3, n_games=4096)
+                    dt_g = time.perf_counter() - t1
+                    sg = lg["stats"]
+                    out["at_4096_concurrent_games"]["lockstep_host_trees"].update({
+                        "games": 4096, "games_per_s": 4096 / dt_g, "selfplay_seconds": dt_g,
+                        "selfplay_seconds_in_policy_eval": sg["seconds_policy"], "selfplay_policy_eval_launches": sg["rounds"],
+                        "selfplay_leaf_evals_per_s": sg["positions_evaluated"] / dt_g,
+                        "games_identical_to_fused_selfplay": bool(all(np.array_equal(lg[k], r2s[k]) for k in ("plies", "final_kind", "actions", "root_nodes")))})
             except Exception as ex:  # noqa: BLE001
                 out["at_4096_concurrent_games"]["lockstep_host_trees"] = {"error": str(ex)[:200]}
             e2.close()

@@ -199,6 +199,15 @@ typedef struct syn_lockstep_stats {
 int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
                              int explores, int action_selection, int host_threads, syn_search_result* results,
                              syn_lockstep_stats* stats);
+/* Replaces: run_n_games (alpha_zero.rs:181-209) in the same division of labour — BASELINE.json configs[1] as worded: n_games
+ * concurrent games, every game's MCTS on the HOST (one tree per move, alpha_zero.rs:240-244), the leaves of all games through one
+ * syn_policy_eval_batch launch per round, run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) on
+ * the host with game g's own StdRng::seed_from_u64(base_seed + g) (include/synthesis_amd_lockstep.hpp::lockstep_selfplay).
+ * Arguments and outputs are syn_selfplay_run's; the games are identical to that call's, move for move and float for float.
+ * host_threads as above; SYN_FPU_NORMAL / SYN_NOISE_DIRICHLET: SYN_ERR_UNSUPPORTED; stats may be NULL. */
+int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game, int n_games,
+                              int host_threads, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
+                              uint32_t* root_nodes, uint8_t* final_kind, syn_lockstep_stats* stats);
 
 /* ---- evaluator baseline ---------------------------------------------------------------------------------------- */
 

@@ -15,10 +15,12 @@
 //                                           229-269 (root noise: None / Equal), 273-306 (best_action, solution)
 //   synthesis::BatchPolicy<G, N>            policies/traits.rs:4-6 for a batch
 //   synthesis::lockstep_search              `MCTS::with_capacity(explores + 1, ..) + explore_n(explores)` for many roots
+//   synthesis::lockstep_selfplay            run_n_games (alpha_zero.rs:181-209) over such trees: run_game / sample_action /
+//                                           fill_state_info / store_rewards (alpha_zero.rs:229-338), one StdRng per game
 //   synthesis::HipBatchPolicy               BatchPolicy<Connect4, 9> over syn_policy_eval_batch
 //
 // Numerics: the f32 expression order of mcts.rs, exp / ln through the same deterministic restatements the device and the oracle
-// use (det_expf / det_logf below). Compile with -ffp-contract=off for bit parity with syn_mcts_search (tests/test_gpu_lockstep.py
+// use (det_expf / det_logf below). Compile with -ffp-contract=off for bit parity with syn_mcts_search (tests/test_lockstep.py
 // holds this driver to the oracle and to the device search). Fpu::Normal and PolicyNoise::Dirichlet need the per-tree random
 // streams of the device path and are not offered here: Error(SYN_ERR_UNSUPPORTED).
 #pragma once
@@ -98,6 +100,77 @@ inline float det_logf(float x) {
     const float r = f + y;
     return std::fmaf(fe, 0.693359375f, r);
 }
+
+// rand 0.8.3 `StdRng` as far as run_game draws from it (alpha_zero.rs:189,281,286-287): ChaCha with 12 rounds keyed by rand_core
+// 0.6's `seed_from_u64` (a PCG32 stream fills the 32-byte key), 64-bit block counter, stream 0, words handed out in order;
+// `gen_range(0..n as u8)` = UniformInt<u8>::sample_single (32-bit widening multiply with a rejection zone);
+// `WeightedIndex::<f32>::new(w).sample()` = one f32 in [0, total) from the top 23 bits of one word, partition point of the
+// cumulative weights. Same stream as csrc/device_common.cuh::StdRng (checked word for word in tests/test_lockstep.py).
+class StdRng {
+public:
+    explicit StdRng(uint64_t seed) {
+        uint64_t state = seed;
+        for (int i = 0; i < 8; i++) {
+            state = state * 6364136223846793005ull + 11634580027462260723ull;
+            const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+            const uint32_t rot = (uint32_t)(state >> 59);
+            key_[i] = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        }
+    }
+    uint32_t next_u32() {
+        if (pos_ == 16) refill();
+        return buf_[pos_++];
+    }
+    uint64_t words_drawn() const { return drawn_blocks_ * 16 - (uint64_t)(16 - pos_); }
+    uint32_t gen_range_u8(uint32_t n) {
+        const uint32_t zone = 0xFFFFFFFFu - (0xFFFFFFFFu - n + 1u) % n;
+        for (;;) {
+            const uint64_t m = (uint64_t)next_u32() * (uint64_t)n;
+            if ((uint32_t)m <= zone) return (uint32_t)(m >> 32);
+        }
+    }
+    template <size_t N>
+    int weighted_index(const std::array<float, N>& w) {
+        float cum[N > 1 ? N - 1 : 1];
+        float total = w[0];
+        for (size_t c = 1; c < N; c++) {
+            cum[c - 1] = total;
+            total += w[c];
+        }
+        const float unit = bits_f32((next_u32() >> 9) | 0x3F800000u) - 1.0f;   // [0, 1)
+        const float chosen = unit * total + 0.0f;                            // Uniform::new(0, total).sample
+        int idx = 0;
+        for (size_t c = 0; c + 1 < N; c++)
+            if (cum[c] <= chosen) idx = (int)c + 1;
+        return idx;
+    }
+
+private:
+    static uint32_t rotl(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+    void refill() {
+        const uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key_[0], key_[1], key_[2], key_[3],
+                                 key_[4], key_[5], key_[6], key_[7], (uint32_t)drawn_blocks_, (uint32_t)(drawn_blocks_ >> 32), 0u, 0u};
+        uint32_t x[16];
+        for (int k = 0; k < 16; k++) x[k] = in[k];
+        auto quarter = [&x](int a, int b, int c, int d) {
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+            x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);
+            x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+        };
+        for (int r = 0; r < 6; r++) {
+            quarter(0, 4, 8, 12); quarter(1, 5, 9, 13); quarter(2, 6, 10, 14); quarter(3, 7, 11, 15);
+            quarter(0, 5, 10, 15); quarter(1, 6, 11, 12); quarter(2, 7, 8, 13); quarter(3, 4, 9, 14);
+        }
+        for (int k = 0; k < 16; k++) buf_[k] = x[k] + in[k];
+        drawn_blocks_++;
+        pos_ = 0;
+    }
+    uint32_t key_[8];
+    uint32_t buf_[16];
+    uint64_t drawn_blocks_ = 0;
+    int pos_ = 16;
+};
 
 // A fixed set of host threads that run fn(i) for i in [0, n), contiguous chunks (trees are independent). One pool lives for a whole
 // search: its two phases per round would otherwise start and join `threads` threads 2 x (explores + 1) times.
@@ -257,6 +330,19 @@ public:
         Node root;
         root.game = game;
         nodes_.push_back(root);
+    }
+
+    // The next move's tree in the same storage (run_game builds a fresh MCTS per move, alpha_zero.rs:240-241): the node arena keeps
+    // its capacity, so a game allocates once.
+    void reset(const G& game) {
+        nodes_.clear();
+        Node root;
+        root.game = game;
+        nodes_.push_back(root);
+        done_ = 0;
+        constructed_ = false;
+        pending_ = 0;
+        pending_any_solved_ = false;
     }
 
     // Runs this tree until it stands on a leaf whose position the policy has to evaluate — returns that position; supply() must be
@@ -540,6 +626,147 @@ std::vector<LockstepTree<G, N>> lockstep_search(BatchPolicy<G, N>& policy, const
     if (rounds_out) *rounds_out = rounds;
     if (evals_out) *evals_out = evals;
     return trees;
+}
+
+// ---- run_n_games over host trees (alpha_zero.rs:181-338) --------------------------------------------------------------------
+// What ReplayBuffer::add stores for one game (data.rs:151-158) plus the bookkeeping syn_selfplay_run reports.
+template <class G, int N>
+struct LockstepGameRecord {
+    std::vector<G> states;
+    std::vector<std::array<float, N>> pis;
+    std::vector<std::array<float, 3>> vs;       // after store_rewards
+    std::vector<uint8_t> actions;
+    std::vector<uint32_t> root_nodes;            // nodes.len() of each move's tree
+    Outcome final_outcome;                       // for the side to move in the final position (alpha_zero.rs:258)
+};
+
+// `num_games` games [first_game, first_game + num_games), all in flight at once: every game searches its current position on its own
+// host tree, the leaves of all games go through one eval_batch per round, a game whose search is over plays its move
+// (sample_action on its own StdRng::seed_from_u64(seed + game index): the per-game seeding of syn_selfplay_run),
+// starts the next move's tree and keeps going until it, too, stands on a leaf. Identical, game for game and float for float, to
+// syn_selfplay_run on the same policy (tests/test_lockstep.py).
+template <class G, int N>
+std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& policy, const RolloutConfig& cfg, size_t num_games,
+                                                        uint64_t seed, uint64_t first_game = 0, int threads = 0,
+                                                        size_t* rounds_out = nullptr, size_t* evals_out = nullptr) {
+    if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    struct StateInfo { int turn; float t; std::array<float, 3> q, z; };   // alpha_zero.rs:211-227
+    struct Play {
+        G game;
+        detail::StdRng rng;
+        LockstepTree<G, N> tree;
+        int num_turns = 0;
+        bool over = false;
+        std::vector<StateInfo> infos;
+        Play(const MCTSConfig& m, int explores, uint64_t s) : game(), rng(s), tree(m, G(), explores) {}
+    };
+    std::vector<LockstepGameRecord<G, N>> out(num_games);
+    std::vector<Play> plays;
+    plays.reserve(num_games);
+    for (size_t g = 0; g < num_games; g++) plays.emplace_back(cfg.mcts_cfg, cfg.num_explores, seed + first_game + (uint64_t)g);
+
+    // the part of run_game's loop body behind explore_n (alpha_zero.rs:246-264), then the game's end (266-267)
+    auto play_move = [&cfg](Play& p, LockstepGameRecord<G, N>& rec) {
+        const std::array<float, N> search_policy = p.tree.target_policy();
+        rec.states.push_back(p.game);
+        rec.pis.push_back(search_policy);
+        rec.vs.push_back({0.0f, 0.0f, 0.0f});
+        rec.root_nodes.push_back((uint32_t)p.tree.num_nodes());
+        p.infos.push_back(StateInfo{p.num_turns + 1, 0.0f, p.tree.target_q(), {0.0f, 0.0f, 0.0f}});
+        // sample_action (alpha_zero.rs:270-294)
+        const int best = p.tree.best_action(cfg.action);
+        const Solution best_solution = p.tree.solution(best);
+        int action;
+        if (p.num_turns < cfg.random_actions_until) {
+            const std::vector<int> legal = p.game.iter_actions();
+            action = legal[p.rng.gen_range_u8((uint32_t)legal.size())];
+        } else if (p.num_turns < cfg.sample_actions_until && (!best_solution.some || !cfg.stop_games_when_solved)) {
+            action = p.rng.weighted_index(search_policy);
+        } else {
+            action = best;
+        }
+        rec.actions.push_back((uint8_t)action);
+        Solution solution = p.tree.solution(action);
+        const bool is_over = p.game.step(action);
+        if (is_over) {
+            solution.some = true;
+            solution.outcome = Outcome::from_reward(p.game.reward(p.game.player()));
+        } else if (!cfg.stop_games_when_solved) {
+            solution.some = false;
+        }
+        p.num_turns++;
+        if (!solution.some) return;
+        p.over = true;
+        rec.final_outcome = solution.outcome;
+        // fill_state_info (alpha_zero.rs:296-307)
+        const int num_turns = (int)p.infos.size();
+        Outcome outcome = solution.outcome.reversed();
+        for (int i = num_turns - 1; i >= 0; i--) {
+            p.infos[(size_t)i].z[outcome.kind] = 1.0f;
+            p.infos[(size_t)i].t = (float)p.infos[(size_t)i].turn / (float)num_turns;
+            outcome = outcome.reversed();
+        }
+        // store_rewards (alpha_zero.rs:309-338)
+        for (int i = 0; i < num_turns; i++) {
+            const StateInfo& st = p.infos[(size_t)i];
+            std::array<float, 3> v{};
+            switch (cfg.value_target) {
+                case ValueTarget::Q: v = st.q; break;
+                case ValueTarget::Z: v = st.z; break;
+                case ValueTarget::QZaverage:
+                    for (int k = 0; k < 3; k++) v[k] = st.q[k] * cfg.value_target_p + st.z[k] * (1.0f - cfg.value_target_p);
+                    break;
+                case ValueTarget::QtoZ: {
+                    const float pp = (1.0f - st.t) * cfg.value_target_from + st.t * cfg.value_target_to;
+                    for (int k = 0; k < 3; k++) v[k] = st.q[k] * (1.0f - pp) + st.z[k] * pp;
+                    break;
+                }
+            }
+            rec.vs[(size_t)i] = v;
+        }
+    };
+    // a game runs until it stands on a leaf (returned) or has ended (nullptr)
+    auto advance_game = [&](size_t g) -> const G* {
+        Play& p = plays[g];
+        for (;;) {
+            if (const G* leaf = p.tree.advance()) return leaf;
+            play_move(p, out[g]);
+            if (p.over) return nullptr;
+            p.tree.reset(p.game);
+        }
+    };
+
+    std::vector<const G*> want(num_games, nullptr);
+    std::vector<const G*> batch;
+    std::vector<uint32_t> owner, live(num_games);
+    std::vector<float> logits, value;
+    size_t rounds = 0, evals = 0;
+    for (size_t g = 0; g < num_games; g++) {
+        live[g] = (uint32_t)g;
+        plays[g].tree.reset(plays[g].game);
+    }
+    detail::WorkerPool pool(threads);
+    while (!live.empty()) {
+        pool.run(live.size(), [&](size_t k) { want[live[k]] = advance_game(live[k]); });
+        batch.clear();
+        owner.clear();
+        for (uint32_t g : live)
+            if (want[g]) {
+                batch.push_back(want[g]);
+                owner.push_back(g);
+            }
+        if (batch.empty()) break;
+        logits.resize(batch.size() * (size_t)N);
+        value.resize(batch.size() * 3);
+        policy.eval_batch(batch, logits.data(), value.data());
+        rounds++;
+        evals += batch.size();
+        pool.run(owner.size(), [&](size_t k) { plays[owner[k]].tree.supply(&logits[k * (size_t)N], &value[k * 3]); });
+        live = owner;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    if (evals_out) *evals_out = evals;
+    return out;
 }
 
 // BatchPolicy<Connect4, 9> on the GPU: one syn_policy_eval_batch call per round

@@ -475,6 +475,8 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             if (const char* ev = debug_env("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
             if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
             PL.lane_thresh &= ~15;  // whole tiles
+            PL.debug_stub = 0;
+            if (PROF) { if (const char* ev = debug_env("SYN_ABLATE")) PL.debug_stub = std::atoi(ev); }
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \
@@ -1294,14 +1296,17 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
                             "(%.0f per iteration), level arithmetic %.0f (%.0f per iteration), arrive %.0f | B: tiles %.0f (%.0f per tile), "
                             "scatter %.0f | C children: softmaxes %.0f, records %.0f (%.1f lanes) | solver walk: %.2f iterations (%.1f lanes each), "
                             "line wait %.0f (%.0f per iteration) | sweep: %.2f steps, %.1f lane-levels per step, log wait %.0f (%.0f per step), "
-                            "arithmetic + stores %.0f (%.0f per step) | end of search: %.3f calls per round, %.1f lanes per call\n",
+                            "arithmetic + stores %.0f (%.0f per step) | end of search: %.3f calls per round, %.1f lanes per call, cycles per call %.0f = "
+                            "root line + generator %.0f, targets %.0f, sample %.0f, step %.0f, game end / reset %.0f\n",
                     s[LP_A_ITERS] / R, s[LP_A_LANES] / (s[LP_A_ITERS] + 1e-9), s[LP_A_WAIT] / R, s[LP_A_WAIT] / (s[LP_A_ITERS] + 1e-9),
                     s[LP_A_ALU] / R, s[LP_A_ALU] / (s[LP_A_ITERS] + 1e-9), s[LP_A_ARRIVE] / R, s[LP_B_TILE] / R,
                     s[LP_B_TILE] / (s[5] + 1e-9), s[LP_B_SCATTER] / R, s[LP_C_SOFT] / R, (s[LP_C_WRITE] - s[LP_C_SOFT]) / R,
                     s[LP_C_LANES] / R, s[LP_W_ITERS] / R, s[LP_W_LANES] / (s[LP_W_ITERS] + 1e-9), s[LP_W_WAIT] / R,
                     s[LP_W_WAIT] / (s[LP_W_ITERS] + 1e-9), s[LP_S_STEPS] / R, s[LP_S_LANES] / (s[LP_S_STEPS] + 1e-9), s[LP_S_WAIT] / R,
                     s[LP_S_WAIT] / (s[LP_S_STEPS] + 1e-9), s[LP_S_ALU] / R, s[LP_S_ALU] / (s[LP_S_STEPS] + 1e-9), s[LP_M_CALLS] / R,
-                    s[LP_M_LANES] / (s[LP_M_CALLS] + 1e-9));
+                    s[LP_M_LANES] / (s[LP_M_CALLS] + 1e-9), s[LP_M_TOTAL] / (s[LP_M_CALLS] + 1e-9), s[LP_M_T1] / (s[LP_M_CALLS] + 1e-9),
+                    s[LP_M_T2] / (s[LP_M_CALLS] + 1e-9), s[LP_M_T3] / (s[LP_M_CALLS] + 1e-9), s[LP_M_T4] / (s[LP_M_CALLS] + 1e-9),
+                    s[LP_M_T5] / (s[LP_M_CALLS] + 1e-9));
             {
                 std::vector<unsigned long long> tlv(4 * 16 * 3);
                 (void)hipMemcpy(tlv.data(), d_prof_keep + PROF_TIMELINE_OFF, tlv.size() * 8, hipMemcpyDeviceToHost);

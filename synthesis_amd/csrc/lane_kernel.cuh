@@ -131,17 +131,26 @@ struct LaneLeaf {             // phase A -> phase C (valid for lanes with at_lea
 // rest of the step (arithmetic, stores, control flow). The stamps sit inside divergent code, so the first active lane adds the
 // (wave-uniform) interval to this wave's row of P.prof with one no-return atomic. nullptr everywhere else: it all compiles away.
 enum { LP_A_WAIT = 10, LP_A_ALU, LP_A_ITERS, LP_A_LANES, LP_A_ARRIVE, LP_W_WAIT, LP_W_ALU, LP_W_ITERS, LP_W_LANES, LP_S_WAIT, LP_S_ALU,
-       LP_S_STEPS, LP_S_LANES, LP_C_SOFT, LP_C_WRITE, LP_C_LANES, LP_B_GATHER, LP_B_TILE, LP_B_SCATTER, LP_M_CALLS, LP_M_LANES, LP_FIELDS };
-struct LaneProf { unsigned long long* row; };
+       LP_S_STEPS, LP_S_LANES, LP_C_SOFT, LP_C_WRITE, LP_C_LANES, LP_B_GATHER, LP_B_TILE, LP_B_SCATTER, LP_M_CALLS, LP_M_LANES, LP_M_TOTAL, LP_M_T1, LP_M_T2, LP_M_T3, LP_M_T4, LP_M_T5, LP_FIELDS };
+// `ablate` (SYN_DEBUG=1 SYN_PROFILE=1 SYN_ABLATE=<mask>): additive sensitivity runs — a component is executed TWICE (same addresses,
+// same values: results unchanged) and the launch's slowdown is that component's marginal cost in the real, contended kernel; the
+// stamps are off in such a run. 1 child-record stores, 2 backprop sweep stores, 4 path-log stores of the descent, 8 the descent's
+// line loads, 16 every network tile, 32 the leaf softmaxes, 64 the solver walk's line loads.
+enum { ABL_CHILD_ST = 1, ABL_SWEEP_ST = 2, ABL_LOG_ST = 4, ABL_LINE_LD = 8, ABL_TILE = 16, ABL_SOFTMAX = 32, ABL_WALK_LD = 64 };
+struct LaneProf { unsigned long long* row; int ablate; };
+SYN_DEV bool lp_abl(const LaneProf* lp, int bit) { return lp != nullptr && (lp->ablate & bit) != 0; }
+SYN_DEV void lp_fence() { asm volatile("" ::: "memory"); }
 constexpr size_t PROF_TIMELINE_OFF = (size_t)4096 * LP_FIELDS;  // behind the rows of up to 4096 waves
 SYN_DEV unsigned long long lp_now() { return (unsigned long long)__builtin_readcyclecounter(); }
-SYN_DEV void lp_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+SYN_DEV void lp_wait_vm(const LaneProf* lp) { if (lp->ablate == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 SYN_DEV void lp_add(const LaneProf* lp, int field, unsigned long long v) {
+    if (lp->ablate != 0) return;
     const unsigned long long ex = __ballot(1);
     if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) atomicAdd(lp->row + field, v);
 }
 // one interval + how many lanes shared it
 SYN_DEV void lp_step(const LaneProf* lp, int f_time, int f_count, int f_lanes, unsigned long long dt) {
+    if (lp->ablate != 0) return;
     const unsigned long long ex = __ballot(1);
     if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) {
         atomicAdd(lp->row + f_time, dt);
@@ -303,8 +312,18 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
         const uint4 t = line[1 + j];
         d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
     }
+    if (lp_abl(lp, ABL_LINE_LD)) {
+        lp_fence();
+        uint32_t sink = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint4 t = line[j];
+            sink ^= t.x ^ t.y ^ t.z ^ t.w;
+        }
+        asm volatile("" ::"v"(sink));
+    }
     unsigned long long lp_t1 = 0ull;
-    if (lp) { lp_wait_vm(); lp_t1 = lp_now(); lp_add(lp, LP_A_WAIT, lp_t1 - lp_t0); }
+    if (lp) { lp_wait_vm(lp); lp_t1 = lp_now(); lp_add(lp, LP_A_WAIT, lp_t1 - lp_t0); }
     const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(C.qt);  // parent.q() = -(stored q)
     const float visits = cfg.puct() ? sqrtf(C.pN) : sqrtf(cfg.cc() * det_logf(C.pN));
     // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
@@ -333,6 +352,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
         }
     }
     pl[PATH_PLANE + C.level * 64] = hdr;  // (the entry's PM_HAS_W flag was set when the descent arrived here)
+    if (lp_abl(lp, ABL_LOG_ST)) { lp_fence(); pl[PATH_PLANE + C.level * 64] = hdr; lp_fence(); }
     float vv[9];
     if (cfg.puct()) {
         // explore_value = ((c * P) * sqrt(N_parent)) / (1 + n) (mcts.rs:361-372), two children per instruction.
@@ -407,6 +427,13 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
     pl[C.level * 64] = make_uint4(C.rec, f32_bits(C.pN),
                                   pm_make(C.blk, (uint32_t)__popc(lm), C.nsolved, C.kind) |
                                       ((!C.nsolved && C.blk != 0u) ? PM_HAS_W : 0u), C.qt);
+    if (lp_abl(lp, ABL_LOG_ST)) {
+        lp_fence();
+        pl[C.level * 64] = make_uint4(C.rec, f32_bits(C.pN),
+                                      pm_make(C.blk, (uint32_t)__popc(lm), C.nsolved, C.kind) |
+                                          ((!C.nsolved && C.blk != 0u) ? PM_HAS_W : 0u), C.qt);
+        lp_fence();
+    }
     if (lp) lp_step(lp, LP_A_ALU, LP_A_ITERS, LP_A_LANES, lp_now() - lp_t1);
 }
 
@@ -635,7 +662,7 @@ SYN_DEV void lane_softmaxes(uint32_t lmask, const float (&lg)[9], float (&pr)[9]
 // 1 = PolicyNoise::Equal{weight}, 2 = PolicyNoise::Dirichlet{alpha, weight} sampled from the tree's stream (noise.cuh).
 SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lmask, uint64_t leaf_my, uint64_t leaf_op,
                                  const float (&pr)[9], int noise_kind, float noise_weight, float noise_alpha, uint64_t noise_seed,
-                                 float y_unvisited, uint32_t& hdr_flag) {
+                                 float y_unvisited, uint32_t& hdr_flag, bool store_twice = false) {
     const uint32_t nc = (uint32_t)__popc(lmask);
     const float noise = 1.0f / (float)nc;
     float dir[9];
@@ -671,6 +698,11 @@ SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lma
         if (legal) {
             flag = flag || !(p == 0.0f || (p >= PRIOR_SAFE_MIN && p <= 2.0f));
             *reinterpret_cast<lu3*>(rec0 + idx * 12u) = lu3{over ? 0u : f32_bits(y_unvisited), f32_bits(p), nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u)};
+            if (store_twice) {
+                lp_fence();
+                *reinterpret_cast<lu3*>(rec0 + idx * 12u) = lu3{over ? 0u : f32_bits(y_unvisited), f32_bits(p), nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u)};
+                lp_fence();
+            }
             any_solved = any_solved || over;
             idx++;
         }
@@ -742,9 +774,19 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
             }
             const uint4 pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
+            if (lp_abl(lp, ABL_WALK_LD)) {
+                lp_fence();
+                uint32_t sink = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint4 t = line[j];
+                    sink ^= t.x ^ t.y ^ t.z ^ t.w;
+                }
+                asm volatile("" ::"v"(sink));
+            }
             if (lp) {
                 const unsigned long long t0_ = lp_now();
-                lp_wait_vm();
+                lp_wait_vm(lp);
                 lp_step(lp, LP_W_WAIT, LP_W_ITERS, LP_W_LANES, lp_now() - t0_);
             }
             // a node that was never backpropagated into has nothing in its header yet
@@ -823,7 +865,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
         }
         unsigned long long lp_t1 = 0ull;
         if (lp) {
-            lp_wait_vm();
+            lp_wait_vm(lp);
             lp_t1 = lp_now();
             unsigned long long nl = 0;
 #pragma unroll
@@ -859,6 +901,16 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                     if (!pm_solved(meta)) *reinterpret_cast<float*>(r) = -((W2 - W0) / N);
                     *reinterpret_cast<unsigned short*>(r + 8) = (unsigned short)((uint32_t)N | (pm_solved(meta) ? 0x8000u : 0u));
                 }
+                if (lp_abl(lp, ABL_SWEEP_ST)) {
+                    lp_fence();
+                    *reinterpret_cast<float4*>(blk_ptr(slab, pm_blk(meta))) = make_float4(W0, W1, W2, bits_f32(w3));
+                    if (rec != REC_ROOT) {
+                        unsigned char* r = rec_ptr(slab, rec);
+                        if (!pm_solved(meta)) *reinterpret_cast<float*>(r) = -((W2 - W0) / N);
+                        *reinterpret_cast<unsigned short*>(r + 8) = (unsigned short)((uint32_t)N | (pm_solved(meta) ? 0x8000u : 0u));
+                    }
+                    lp_fence();
+                }
             }
         }
         if (lp) lp_step(lp, LP_S_ALU, LP_S_STEPS, -1, lp_now() - lp_t1);
@@ -866,35 +918,52 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
 }
 
 // ---------------------------------------------------------------------------------------------- end of a search
+// The root's block read ONCE — one memory round trip for everything the end of a search needs (the code below used to fetch every
+// child record two or three times, each behind its own wait: ~25 dependent round trips per move, executed by one or two lanes of
+// the wave while the other 62 stand by): the root's own sums and the nine child records in slot order (slot i = the i-th legal
+// column in ascending order; entries past `nc` are unspecified).
 struct LaneRoot {
     uint32_t nc, lmask;
     float rootN;
+    float4 hdr;
+    uint32_t d[28];
 };
 SYN_DEV LaneRoot lane_root(const LaneTree& T) {
     LaneRoot R;
     R.rootN = (float)T.iter;
     R.lmask = T.next_block > 1u ? legal_mask_of(T.root_my | T.root_op) : 0u;  // the root's children: its legal columns
     R.nc = (uint32_t)__popc(R.lmask);
+    const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(T.slab, 1));     // (block 1 exists in every slab)
+    R.hdr = *reinterpret_cast<const float4*>(line);
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        const uint4 t = line[1 + j];
+        R.d[4 * j] = t.x; R.d[4 * j + 1] = t.y; R.d[4 * j + 2] = t.z; R.d[4 * j + 3] = t.w;
+    }
     return R;
 }
+// column of slot k
+SYN_DEV int lane_slot_column(uint32_t lmask, uint32_t k) {
+    uint32_t m = lmask;
+    for (uint32_t i = 0; i < k; i++) m &= m - 1u;
+    return __ffs((int)m) - 1;
+}
 
-// MCTS::target_policy numerators (mcts.rs:174-211) per column (0 for non-children) and their sum in child order
+// MCTS::target_policy numerators (mcts.rs:174-211) per child slot (0 past the last child) and their sum in child order
 SYN_DEV float lane_policy_weights(const LaneTree& T, const LaneRoot& R, float (&wts)[9]) {
     const bool first_visit = R.rootN == 1.0f;
     const bool root_win = T.root_solved && (T.root_sol & 3u) == 2u;
     float total = 0.0f;
-    uint32_t idx = 0;
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        wts[c] = 0.0f;
-        if ((R.lmask >> c) & 1u) {
-            const uint32_t nf = ld_rec(T.slab, 16u + idx)[2];
+    for (uint32_t i = 0; i < 9; i++) {
+        wts[i] = 0.0f;
+        if (i < R.nc) {
+            const uint32_t nf = R.d[3 * i + 2];
             float v;
             if (first_visit) v = root_win ? ((nf_solved(nf) && nf_kind(nf) == 0u) ? 1.0f : 0.0f) : 1.0f;
             else v = nf_N(nf);
-            wts[c] = v;
+            wts[i] = v;
             total += v;
-            idx++;
         }
     }
     return total;
@@ -907,28 +976,28 @@ SYN_DEV void lane_target_q(const LaneTree& T, const LaneRoot& R, float& q0, floa
         q1 = k == 1u ? 1.0f : 0.0f;
         q2 = k == 2u ? 1.0f : 0.0f;
     } else {
-        const float4 a = *reinterpret_cast<const float4*>(blk_ptr(T.slab, 1));
-        q0 = a.x / R.rootN;
-        q1 = a.y / R.rootN;
-        q2 = a.z / R.rootN;
+        q0 = R.hdr.x / R.rootN;
+        q1 = R.hdr.y / R.rootN;
+        q2 = R.hdr.z / R.rootN;
     }
 }
 
 // MCTS::best_action (mcts.rs:273-294); also returns the record word (N | solved | block | kind) of the chosen child
-SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_selection, uint32_t& best_nf) {
+SYN_DEV int lane_best_action(const LaneRoot& R, int action_selection, uint32_t& best_nf) {
     int best = -1;
     float b0 = 0.0f, b1 = 0.0f;
     best_nf = 0;
-    uint32_t idx = 0;
+    uint32_t m = R.lmask;
 #pragma unroll
-    for (int c = 0; c < 9; c++) {
-        if ((R.lmask >> c) & 1u) {
-            const lu3 r = ld_rec(T.slab, 16u + idx);
-            const uint32_t nf = r[2];
+    for (uint32_t i = 0; i < 9; i++) {
+        if (i < R.nc) {
+            const int c = __ffs((int)m) - 1;
+            m &= m - 1u;
+            const uint32_t nf = R.d[3 * i + 2];
             float k0, k1;
             if (nf_solved(nf)) {
                 const uint32_t kind = nf_kind(nf);
-                const float t = (float)r[0];
+                const float t = (float)R.d[3 * i];
                 if (kind == 2u) { k0 = 0.0f; k1 = t; }
                 else if (kind == 1u) { k0 = 2.0f; k1 = -t; }
                 else { k0 = 3.0f; k1 = -t; }
@@ -936,55 +1005,74 @@ SYN_DEV int lane_best_action(const LaneTree& T, const LaneRoot& R, int action_se
                 k0 = 1.0f;
                 // -child.q(): the stored q, except for a never-visited child where the reference divides 0 by 0
                 const float cN = nf_N(nf);
-                const float nq = cN == 0.0f ? -((0.0f - 0.0f) / cN) : bits_f32(r[0]);
+                const float nq = cN == 0.0f ? -((0.0f - 0.0f) / cN) : bits_f32(R.d[3 * i]);
                 k1 = action_selection == 0 ? nq : cN;
             }
             const bool gt = best < 0 || (k0 > b0) || (k0 == b0 && k1 > b1);
             if (gt) { best = c; b0 = k0; b1 = k1; best_nf = nf; }
-            idx++;
         }
     }
     return best;
 }
 
-SYN_DEV uint32_t lane_child_nf(const LaneTree& T, const LaneRoot& R, int action, bool& is_child) {
+SYN_DEV uint32_t lane_child_nf(const LaneRoot& R, int action, bool& is_child) {
     is_child = ((R.lmask >> action) & 1u) != 0u;
-    const uint32_t idx = (uint32_t)__popc(R.lmask & ((1u << action) - 1u));
-    return is_child ? ld_rec(T.slab, 16u + idx)[2] : 0u;
+    const uint32_t slot = (uint32_t)__popc(R.lmask & ((1u << action) - 1u));
+    uint32_t nf = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) nf = slot == i ? R.d[3 * i + 2] : nf;
+    return is_child ? nf : 0u;
 }
 
 // run_game's per-move tail (alpha_zero.rs:243-264) + game end (fill_state_info / store_rewards, 296-338)
 template <bool COUNT>
-SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
+SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr, const LaneProf* lp = nullptr) {
     const DevRolloutCfg& rc = P.roll;
+    unsigned long long lp_t = lp ? lp_now() : 0ull;
+#define SYN_MLAP(f) if (lp) { lp_wait_vm(lp); const unsigned long long n_ = lp_now(); lp_add(lp, f, n_ - lp_t); lp_t = n_; }
     const bool want_random = T.turn < rc.random_until;
     const bool maybe_sample = !want_random && T.turn < rc.sample_until;
+    const LaneRoot R = lane_root(T);   // (its loads are in flight while the generator below runs)
     uint32_t rnd = 0;
     if (want_random || maybe_sample) {
         StdRng rng;
         rng.seed_from_u64(P.base_seed + P.first_game + (unsigned long long)T.job);
         rnd = rng.word(T.rng_index);
     }
-    const LaneRoot R = lane_root(T);
-    float pi[9];
-    const float wtotal = lane_policy_weights(T, R, pi);
+    SYN_MLAP(LP_M_T1)
+    float ps[9];   // target policy per child slot
+    const float wtotal = lane_policy_weights(T, R, ps);
 #pragma unroll
-    for (int c = 0; c < 9; c++) pi[c] = pi[c] / wtotal;
+    for (int i = 0; i < 9; i++) ps[i] = ps[i] / wtotal;
+    const float pz = 0.0f / wtotal;   // what the reference's division leaves in a non-child column
     float q0, q1, q2;
     lane_target_q(T, R, q0, q1, q2);
     const size_t pos = (size_t)T.job * 63 + (size_t)T.turn;
     P.states_bb[pos * 2 + 0] = T.root_my;
     P.states_bb[pos * 2 + 1] = T.root_op;
     P.root_nodes[pos] = T.num_nodes;
+    // pi by column: every column first, then the children over it (two stores of one lane to one address stay in order)
 #pragma unroll
-    for (int c = 0; c < 9; c++) P.pis[pos * 9 + c] = pi[c];
+    for (int c = 0; c < 9; c++) P.pis[pos * 9 + c] = pz;
+    {
+        uint32_t m = R.lmask;
+#pragma unroll
+        for (uint32_t i = 0; i < 9; i++) {
+            if (i < R.nc) {
+                const int c = __ffs((int)m) - 1;
+                m &= m - 1u;
+                P.pis[pos * 9 + c] = ps[i];
+            }
+        }
+    }
     P.vs[pos * 3 + 0] = q0;
     P.vs[pos * 3 + 1] = q1;
     P.vs[pos * 3 + 2] = q2;
 
+    SYN_MLAP(LP_M_T2)
     // sample_action (alpha_zero.rs:270-294)
     uint32_t best_nf;
-    const int best = lane_best_action(T, R, rc.action, best_nf);
+    const int best = lane_best_action(R, rc.action, best_nf);
     int action;
     if (want_random) {
         const uint32_t n = (uint32_t)__popc(R.lmask);
@@ -997,32 +1085,33 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
             mm = (uint64_t)rng.word(T.rng_index) * (uint64_t)n;
             T.rng_index += 1;
         }
-        const uint32_t r = (uint32_t)(mm >> 32);
-        uint32_t m = R.lmask;
-        for (uint32_t i = 0; i < r; i++) m &= m - 1u;
-        action = __ffs((int)m) - 1;
+        action = lane_slot_column(R.lmask, (uint32_t)(mm >> 32));
     } else if (maybe_sample && (!nf_solved(best_nf) || !rc.stop_when_solved)) {
-        float total = pi[0];
+        // WeightedIndex over the nine columns: a column that is no child weighs 0 and never changes a cumulative sum, so the
+        // partition point among the columns is the column of the partition point among the child slots
         const float chosen_unit = bits_f32((rnd >> 9) | 0x3F800000u) - 1.0f;
+        float total = ps[0];
         float cum[8];
 #pragma unroll
-        for (int c = 1; c < 9; c++) {
-            cum[c - 1] = total;
-            total += pi[c];
+        for (int i = 1; i < 9; i++) {
+            cum[i - 1] = total;
+            total += (uint32_t)i < R.nc ? ps[i] : 0.0f;
         }
         const float chosen = chosen_unit * total + 0.0f;
         T.rng_index += 1;
-        int idx = 0;
+        uint32_t slot = 0;
 #pragma unroll
-        for (int c = 0; c < 8; c++) idx = cum[c] <= chosen ? c + 1 : idx;
-        action = idx;
+        for (uint32_t i = 0; i < 8; i++) slot = (i + 1u < R.nc && cum[i] <= chosen) ? i + 1u : slot;
+        // (with the last column no child its cumulative weight is the total, which `chosen` stays below)
+        action = lane_slot_column(R.lmask, slot);
     } else {
         action = best;
     }
     P.actions[pos] = (unsigned char)action;
+    SYN_MLAP(LP_M_T3)
 
     bool a_child;
-    const uint32_t a_nf = lane_child_nf(T, R, action, a_child);
+    const uint32_t a_nf = lane_child_nf(R, action, a_child);
     bool sol_some = a_child && nf_solved(a_nf);
     uint32_t sol_kind = nf_kind(a_nf);
 
@@ -1040,6 +1129,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     }
     T.turn += 1;
     if (COUNT) ctr[CTR_MOVES]++;
+    SYN_MLAP(LP_M_T4)
 
     if (!sol_some) {
         T.root_my = nmy;
@@ -1055,6 +1145,8 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
 
     const int n = T.turn;
     const uint32_t last_kind = sol_kind == 1u ? 1u : 2u - sol_kind;
+    // store_rewards: ValueTarget::Q keeps the q already stored move by move (alpha_zero.rs:319): nothing to rewrite
+    if (rc.value_target != 1)
     for (int i = 0; i < n; i++) {
         const bool flip = ((n - 1 - i) & 1) != 0;
         const uint32_t zk = (flip && last_kind != 1u) ? 2u - last_kind : last_kind;
@@ -1063,8 +1155,7 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
         float* v = P.vs + ((size_t)T.job * 63 + (size_t)i) * 3;
         const float a0 = v[0], a1 = v[1], a2 = v[2];
         float o0, o1, o2;
-        if (rc.value_target == 1) { o0 = a0; o1 = a1; o2 = a2; }
-        else if (rc.value_target == 0) { o0 = z0; o1 = z1; o2 = z2; }
+        if (rc.value_target == 0) { o0 = z0; o1 = z1; o2 = z2; }
         else if (rc.value_target == 2) {
             const float p = rc.vt_p;
             o0 = a0 * p + z0 * (1.0f - p);
@@ -1083,42 +1174,52 @@ SYN_DEV void lane_move_step(const EngineParams& P, LaneTree& T, uint32_t* ctr) {
     atomicAdd(P.job_next + 1, 1);  // games finished so far (syn_progress)
     if (COUNT) ctr[CTR_GAMES]++;
     lane_start_job<MODE_SELFPLAY>(P, T);
+    SYN_MLAP(LP_M_T5)
+#undef SYN_MLAP
 }
 
 SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
     const LaneRoot R = lane_root(T);
-    float pi[9];
-    const float wtotal = lane_policy_weights(T, R, pi);
+    float ps[9];
+    const float wtotal = lane_policy_weights(T, R, ps);
     float q0, q1, q2;
     lane_target_q(T, R, q0, q1, q2);
     uint32_t bnf;
-    const int best = lane_best_action(T, R, P.action_selection, bnf);
+    const int best = lane_best_action(R, P.action_selection, bnf);
     DevSearchResult* out = P.results + T.job;
-    uint32_t idx = 0;
+    // every column as "no child" first, then the children over their columns
+    const float pz = 0.0f / wtotal;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
-        const bool ch = ((R.lmask >> c) & 1u) != 0u;
-        lu3 r = lu3{0u, 0u, 0u};
-        float4 ca = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ch) {
-            r = ld_rec(T.slab, 16u + idx);
-            if (nf_N(r[2]) != 0.0f) ca = *reinterpret_cast<const float4*>(blk_ptr(T.slab, nf_blk(r[2])));
-            idx++;
-        }
-        out->child_N[c] = nf_N(r[2]);
-        out->child_W[c][0] = ca.x;
-        out->child_W[c][1] = ca.y;
-        out->child_W[c][2] = ca.z;
-        out->child_P[c] = ch ? bits_f32(r[1]) : 0.0f;
-        const bool some = ch && nf_solved(r[2]);
-        out->child_sol[c][0] = some ? 1 : 0;
-        out->child_sol[c][1] = some ? (int)nf_kind(r[2]) : 0;
-        out->child_sol[c][2] = some ? (int)r[0] : 0;
-        out->target_pi[c] = pi[c] / wtotal;
+        out->child_N[c] = 0.0f;
+        out->child_W[c][0] = 0.0f; out->child_W[c][1] = 0.0f; out->child_W[c][2] = 0.0f;
+        out->child_P[c] = 0.0f;
+        out->child_sol[c][0] = 0; out->child_sol[c][1] = 0; out->child_sol[c][2] = 0;
+        out->target_pi[c] = pz;
     }
-    const float4 ra = *reinterpret_cast<const float4*>(blk_ptr(T.slab, 1));
+    uint32_t m = R.lmask;
+#pragma unroll
+    for (uint32_t i = 0; i < 9; i++) {
+        if (i < R.nc) {
+            const int c = __ffs((int)m) - 1;
+            m &= m - 1u;
+            const uint32_t r0 = R.d[3 * i], r1 = R.d[3 * i + 1], nf = R.d[3 * i + 2];
+            float4 ca = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nf_N(nf) != 0.0f) ca = *reinterpret_cast<const float4*>(blk_ptr(T.slab, nf_blk(nf)));
+            out->child_N[c] = nf_N(nf);
+            out->child_W[c][0] = ca.x;
+            out->child_W[c][1] = ca.y;
+            out->child_W[c][2] = ca.z;
+            out->child_P[c] = bits_f32(r1);
+            const bool some = nf_solved(nf);
+            out->child_sol[c][0] = some ? 1 : 0;
+            out->child_sol[c][1] = some ? (int)nf_kind(nf) : 0;
+            out->child_sol[c][2] = some ? (int)r0 : 0;
+            out->target_pi[c] = ps[i] / wtotal;
+        }
+    }
     out->root_N = R.rootN;
-    out->root_W[0] = ra.x; out->root_W[1] = ra.y; out->root_W[2] = ra.z;
+    out->root_W[0] = R.hdr.x; out->root_W[1] = R.hdr.y; out->root_W[2] = R.hdr.z;
     out->root_sol[0] = T.root_solved ? 1 : 0;
     out->root_sol[1] = T.root_solved ? (int)(T.root_sol & 3u) : 0;
     out->root_sol[2] = T.root_solved ? (int)(T.root_sol >> 2) : 0;
@@ -1132,6 +1233,11 @@ SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
 template <bool COUNT>
 __device__ __attribute__((noinline)) LaneTree lane_move_step_call(const EngineParams& P, LaneTree t, uint32_t* ctr) {
     lane_move_step<COUNT>(P, t, ctr);
+    return t;
+}
+// (diagnostic build: the same with stamps between its parts)
+__device__ __attribute__((noinline)) LaneTree lane_move_step_call_prof(const EngineParams& P, LaneTree t, const LaneProf* lp) {
+    lane_move_step<false>(P, t, nullptr, lp);
     return t;
 }
 __device__ __attribute__((noinline)) LaneTree lane_search_finish_call(const EngineParams& P, LaneTree t) {
@@ -1357,6 +1463,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     };
     LaneProf lp_store;
     lp_store.row = (PROF && P.prof) ? P.prof + ((size_t)blockIdx.x * NW + wave) * LP_FIELDS : nullptr;
+    lp_store.ablate = PROF ? P.debug_stub : 0;
     LaneProf* const lp = (PROF && P.prof) ? &lp_store : nullptr;
     for (;;) {
         const bool active = T.job >= 0;
@@ -1427,6 +1534,12 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 FeatureTable FT;
                 FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
                 const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
+                if (lp_abl(lp, ABL_TILE)) {
+                    uint64_t thi2 = thi, tlo2 = tlo;
+                    asm volatile("" : "+v"(thi2), "+v"(tlo2));
+                    const f32x4 o2 = mlp_tile16_pipe(wimg, bimg, lane, FT, thi2, tlo2);
+                    asm volatile("" ::"v"(o2));
+                }
                 o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
             }
             // (raw outputs: the softmax over the three outcome logits runs per tree lane in phase C, lane_softmaxes)
@@ -1464,6 +1577,15 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             // the PolicyWithCache entry of a position the network has just evaluated
             float pr[9];
             const unsigned long long lp_c0 = lp ? lp_now() : 0ull;
+            if (lp_abl(lp, ABL_SOFTMAX)) {
+                float pr2[9], w0 = v0, w1 = v1, w2 = v2, lg2[9];
+#pragma unroll
+                for (int c = 0; c < 9; c++) { lg2[c] = lg[c]; asm volatile("" : "+v"(lg2[c])); }
+                lane_softmaxes(X.legal_mask, lg2, pr2, POLICY != 1 && need, w0, w1, w2);
+#pragma unroll
+                for (int c = 0; c < 9; c++) asm volatile("" ::"v"(pr2[c]));
+                asm volatile("" ::"v"(w0), "v"(w1), "v"(w2));
+            }
             lane_softmaxes(X.legal_mask, lg, pr, POLICY != 1 && need, v0, v1, v2);
             if (lp) lp_step(lp, LP_C_SOFT, -1, LP_C_LANES, lp_now() - lp_c0);
             if (POLICY != 1 && P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
@@ -1472,7 +1594,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             solved = lane_write_children(T.slab, Wk.blk, X.legal_mask, Wk.my, Wk.op, pr,
                                          (!FAST && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
                                          P.mcts.noise_alpha, lane_noise_seed(),
-                                         cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
+                                         cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag, lp_abl(lp, ABL_CHILD_ST));
             if (lp) lp_add(lp, LP_C_WRITE, lp_now() - lp_c0);
         }
         SYN_LAP(pC1)
@@ -1488,9 +1610,14 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
                 EngineParams Pc = P;
                 if (lp) lp_step(lp, LP_M_CALLS, -1, LP_M_LANES, 1ull);
+                const unsigned long long lp_m0 = lp ? lp_now() : 0ull;
                 SYN_UNPARK();
-                if (MODE == MODE_SELFPLAY) T = lane_move_step_call<COUNT>(Pc, T, ctr);
+                if (MODE == MODE_SELFPLAY) {
+                    if (PROF && lp) T = lane_move_step_call_prof(Pc, T, lp);
+                    else T = lane_move_step_call<COUNT>(Pc, T, ctr);
+                }
                 else T = lane_search_finish_call(Pc, T);
+                if (lp) lp_add(lp, LP_M_TOTAL, lp_now() - lp_m0);
                 T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;
                 SYN_PARK();
             }

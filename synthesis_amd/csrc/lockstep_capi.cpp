@@ -22,6 +22,94 @@ struct TimedPolicy : synthesis::BatchPolicy<synthesis::Connect4, 9> {
 };
 }  // namespace
 
+namespace {
+// syn_mcts_config -> MCTSConfig for the host trees; 0 or the error code left in syn_last_error
+int host_mcts_config(syn_engine* h, const syn_mcts_config* cfg, const char* who, synthesis::MCTSConfig& m) {
+    using namespace synthesis;
+    if (cfg->exploration != SYN_EXPLORATION_UCT && cfg->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration");
+    if (cfg->fpu == SYN_FPU_NORMAL || cfg->root_policy_noise == SYN_NOISE_DIRICHLET) {
+        const std::string msg = std::string(who) + ": SYN_FPU_NORMAL / SYN_NOISE_DIRICHLET draw from the device path's per-tree streams";
+        return syn_internal_fail(h, SYN_ERR_UNSUPPORTED, msg.c_str());
+    }
+    if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q) return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu");
+    if (cfg->root_policy_noise != SYN_NOISE_NONE && cfg->root_policy_noise != SYN_NOISE_EQUAL)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown root policy noise");
+    m.exploration = (Exploration)cfg->exploration;
+    m.c = cfg->c;
+    m.solve = cfg->solve != 0;
+    m.correct_values_on_solve = cfg->correct_values_on_solve != 0;
+    m.select_solved_nodes = cfg->select_solved_nodes != 0;
+    m.auto_extend = cfg->auto_extend != 0;
+    m.fpu = (Fpu)cfg->fpu;
+    m.fpu_value = cfg->fpu_value;
+    m.root_policy_noise = (PolicyNoise)cfg->root_policy_noise;
+    m.noise_alpha = cfg->noise_alpha;
+    m.noise_weight = cfg->noise_weight;
+    m.fpu_std = cfg->fpu_std;
+    return SYN_OK;
+}
+}  // namespace
+
+extern "C" int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game,
+                                         int n_games, int host_threads, int32_t* plies, uint64_t* states_bb, float* pis, float* vs,
+                                         uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind, syn_lockstep_stats* stats) {
+    using namespace synthesis;
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!cfg || n_games < 0) return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_selfplay_run_lockstep");
+    if (cfg->value_target < SYN_VALUE_Z || cfg->value_target > SYN_VALUE_Q_TO_Z)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown value target");
+    if (cfg->action != SYN_ACTION_Q && cfg->action != SYN_ACTION_NUM_VISITS)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection");
+    if (cfg->num_explores < 0 || cfg->random_actions_until < 0 || cfg->sample_actions_until < 0)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "num_explores / random_actions_until / sample_actions_until must be >= 0");
+    RolloutConfig rc;
+    const int cr = host_mcts_config(h, &cfg->mcts_cfg, "syn_selfplay_run_lockstep", rc.mcts_cfg);
+    if (cr != SYN_OK) return cr;
+    rc.num_explores = cfg->num_explores;
+    rc.random_actions_until = cfg->random_actions_until;
+    rc.sample_actions_until = cfg->sample_actions_until;
+    rc.stop_games_when_solved = cfg->stop_games_when_solved != 0;
+    rc.value_target = (ValueTarget)cfg->value_target;
+    rc.value_target_p = cfg->value_target_p;
+    rc.value_target_from = cfg->value_target_from;
+    rc.value_target_to = cfg->value_target_to;
+    rc.action = (ActionSelection)cfg->action;
+    try {
+        TimedPolicy policy(h);
+        size_t rounds = 0, evals = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        const auto games = lockstep_selfplay<Connect4, 9>(policy, rc, (size_t)n_games, base_seed, first_game, host_threads, &rounds, &evals);
+        const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        constexpr size_t T = Connect4::MAX_TURNS;
+        for (size_t g = 0; g < games.size(); g++) {
+            const auto& r = games[g];
+            const size_t n = r.states.size();
+            if (plies) plies[g] = (int32_t)n;
+            if (final_kind) final_kind[g] = (uint8_t)r.final_outcome.kind;
+            for (size_t k = 0; k < n; k++) {
+                const size_t p = g * T + k;
+                if (states_bb) { states_bb[p * 2] = r.states[k].my_bb(); states_bb[p * 2 + 1] = r.states[k].op_bb(); }
+                if (pis) for (int c = 0; c < 9; c++) pis[p * 9 + (size_t)c] = r.pis[k][(size_t)c];
+                if (vs) for (int c = 0; c < 3; c++) vs[p * 3 + (size_t)c] = r.vs[k][(size_t)c];
+                if (actions) actions[p] = r.actions[k];
+                if (root_nodes) root_nodes[p] = r.root_nodes[k];
+            }
+        }
+        if (stats) {
+            stats->rounds = rounds;
+            stats->positions_evaluated = evals;
+            stats->seconds_total = total;
+            stats->seconds_policy = policy.seconds;
+        }
+    } catch (const Error& e) {
+        return e.code;
+    } catch (const std::exception& e) {
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, e.what());
+    }
+    return SYN_OK;
+}
+
 extern "C" int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb,
                                         int n, int explores, int action_selection, int host_threads,
                                         syn_search_result* results, syn_lockstep_stats* stats) {

@@ -120,9 +120,18 @@ SYN_DEV void mlp_layer(const float* __restrict__ wimg, const float* __restrict__
     }
 }
 
+// slimnn's ReLU, x.max(0.0) (activations.rs:32-37; NaN -> 0, -0 -> +0), as ONE instruction: the median of (x, 0, +inf). fmaxf costs
+// two — the compiler canonicalises its operand first (a signalling NaN must come out quiet), which a value straight out of an
+// fma chain never needs.
+// (+inf comes from a scalar register the optimiser cannot see through: with the literal it rewrites the median as that same fmaxf.)
+SYN_DEV float relu1(float x) {
+    float inf = __builtin_inff();
+    asm("" : "+s"(inf));
+    return __builtin_amdgcn_fmed3f(x, 0.0f, inf);
+}
 SYN_DEV f32x4 relu4_(f32x4 v) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.0f);  // x.max(0.0): NaN -> 0
+    for (int r = 0; r < 4; r++) v[r] = relu1(v[r]);
     return v;
 }
 
@@ -131,7 +140,7 @@ SYN_DEV void relu_inplace(f32x4 (&acc)[NOB]) {
 #pragma unroll
     for (int ob = 0; ob < NOB; ob++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[ob][r] = __builtin_fmaxf(acc[ob][r], 0.0f);  // x.max(0.0): NaN -> 0
+        for (int r = 0; r < 4; r++) acc[ob][r] = relu1(acc[ob][r]);
 }
 
 // Evaluates the network for the 16 positions of this wave's tile. Lane l = (j = l&15, q = l>>4) must pass the
@@ -400,7 +409,7 @@ SYN_DEV void mlp_split_load_weights(const float* __restrict__ g_img, int mw, int
 
 SYN_DEV f32x4 relu4(f32x4 v) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) v[r] = __builtin_fmaxf(v[r], 0.0f);
+    for (int r = 0; r < 4; r++) v[r] = relu1(v[r]);
     return v;
 }
 

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_load_weights_conv",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
-    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
+    "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_selfplay_run_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
@@ -114,6 +114,8 @@ def load_library():
                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.syn_selfplay_run.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int] + \
                                     [C.c_void_p] * 8
+    lib.syn_selfplay_run_lockstep.argtypes = [C.c_void_p, C.POINTER(CRolloutConfig), C.c_uint64, C.c_uint64, C.c_int, C.c_int] + \
+                                             [C.c_void_p] * 8
     lib.syn_progress.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.syn_cancel.argtypes = [C.c_void_p]
     lib.syn_trainer_set_precision.argtypes = [C.c_void_p, C.c_int]
@@ -319,6 +321,28 @@ class Engine:
         out["stats"] = {"rounds": int(st.rounds), "positions_evaluated": int(st.positions_evaluated),
                         "seconds_total": float(st.seconds_total), "seconds_policy": float(st.seconds_policy)}
         return out
+
+    def selfplay_lockstep(self, cfg: RolloutConfig, base_seed, n_games, first_game=0, host_threads=0):
+        """run_n_games with every game's trees on the host and only Policy::eval on the GPU (syn_selfplay_run_lockstep; BASELINE
+        configs[1] as worded). Returns selfplay()'s arrays plus "stats"; the games equal selfplay()'s."""
+        n = int(n_games)
+        r = dict(plies=np.zeros(n, np.int32), states_bb=np.zeros((n, 63, 2), np.uint64), pis=np.zeros((n, 63, 9), np.float32),
+                 vs=np.zeros((n, 63, 3), np.float32), actions=np.zeros((n, 63), np.uint8), root_nodes=np.zeros((n, 63), np.uint32),
+                 final_kind=np.zeros(n, np.uint8))
+
+        class CStats(C.Structure):
+            _fields_ = [("rounds", C.c_uint64), ("positions_evaluated", C.c_uint64), ("seconds_total", C.c_double),
+                        ("seconds_policy", C.c_double)]
+        st = CStats()
+        c = cfg.to_c()
+        rc = self._lib.syn_selfplay_run_lockstep(
+            self._h, C.byref(c), int(base_seed), int(first_game), n, int(host_threads), _p(r["plies"]),
+            _p(r["states_bb"]), _p(r["pis"]), _p(r["vs"]), _p(r["actions"]), _p(r["root_nodes"]), _p(r["final_kind"]),
+            C.cast(C.byref(st), C.c_void_p))
+        self._check(rc)
+        r["stats"] = {"rounds": int(st.rounds), "positions_evaluated": int(st.positions_evaluated),
+                      "seconds_total": float(st.seconds_total), "seconds_policy": float(st.seconds_policy)}
+        return r
 
     # ---- the evaluator's baseline: FrozenMCTS::exploit over RolloutPolicy on n roots (evaluator.rs:308-319)
     FROZEN_DTYPE = np.dtype([("child_N", np.float32, (9,)), ("child_cum", np.float32, (9,)), ("child_P", np.float32, (9,)),

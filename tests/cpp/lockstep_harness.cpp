@@ -3,6 +3,8 @@
 // network — and a second, unrelated Game (a three-action subtraction game) checks that the driver is generic over Game<N>.
 //   lockstep_harness c4 <blob.f32> <roots.u64> <explores> <variant> <threads> <out.bin>
 //   lockstep_harness nim
+//   lockstep_harness selfplay <blob.f32> <games> <explores> <variant> <threads> <seed> <first_game> <out.bin>
+//   lockstep_harness rng <seed> <words>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -109,6 +111,53 @@ int main(int argc, char** argv) {
             std::printf("nim %d %d %d %u %d\n", roots[i].stones, r.solution.some ? 1 : 0, (int)r.solution.outcome.kind,
                         r.solution.outcome.turns, trees[i].best_action(ActionSelection::NumVisits));
         }
+        return 0;
+    }
+    if (argc == 4 && std::string(argv[1]) == "rng") {   // the first <words> outputs of StdRng::seed_from_u64(seed)
+        detail::StdRng rng(std::strtoull(argv[2], nullptr, 10));
+        for (int i = 0; i < std::atoi(argv[3]); i++) std::printf("%u\n", rng.next_u32());
+        return 0;
+    }
+    if (argc == 10 && std::string(argv[1]) == "selfplay") {
+        // run_n_games over host trees with the oracle's network: every game must equal oracle/selfplay.hpp's sequential run_game
+        std::ifstream bf(argv[2], std::ios::binary);
+        std::vector<float> blob((size_t)30492);
+        bf.read(reinterpret_cast<char*>(blob.data()), (std::streamsize)(blob.size() * 4));
+        const size_t games = (size_t)std::atoi(argv[3]);
+        const int variant = std::atoi(argv[5]);
+        RolloutConfig rc;   // variant 0: the parity rollout configuration
+        rc.num_explores = std::atoi(argv[4]);
+        if (variant == 1) { rc.value_target = ValueTarget::Z; rc.stop_games_when_solved = true; rc.action = ActionSelection::Q; }
+        if (variant == 2) { rc.value_target = ValueTarget::QZaverage; rc.value_target_p = 0.25f; rc.random_actions_until = 3; rc.sample_actions_until = 10;
+                            rc.mcts_cfg.exploration = Exploration::Uct; rc.mcts_cfg.c = 1.4f; rc.mcts_cfg.fpu = Fpu::ParentQ; }
+        if (variant == 3) { rc.value_target = ValueTarget::QtoZ; rc.value_target_from = 0.1f; rc.value_target_to = 0.9f;
+                            rc.mcts_cfg.root_policy_noise = PolicyNoise::Equal; rc.mcts_cfg.noise_weight = 0.25f; }
+        OraclePolicy policy;
+        policy.blob = blob.data();
+        size_t rounds = 0, evals = 0;
+        const auto recs = lockstep_selfplay<Connect4, 9>(policy, rc, games, std::strtoull(argv[7], nullptr, 10),
+                                                         std::strtoull(argv[8], nullptr, 10), std::atoi(argv[6]), &rounds, &evals);
+        // out.bin: per game [plies i32][final_kind i32] then 63 x {my u64, op u64, pi f32[9], v f32[3], action u32, root_nodes u32}
+        std::ofstream of(argv[9], std::ios::binary);
+        for (const auto& r : recs) {
+            const int32_t head[2] = {(int32_t)r.states.size(), (int32_t)r.final_outcome.kind};
+            of.write(reinterpret_cast<const char*>(head), 8);
+            for (size_t k = 0; k < 63; k++) {
+                uint64_t bb[2] = {0, 0};
+                float f[12] = {0};
+                uint32_t u[2] = {0, 0};
+                if (k < r.states.size()) {
+                    bb[0] = r.states[k].my_bb(); bb[1] = r.states[k].op_bb();
+                    for (int c = 0; c < 9; c++) f[c] = r.pis[k][(size_t)c];
+                    for (int c = 0; c < 3; c++) f[9 + c] = r.vs[k][(size_t)c];
+                    u[0] = r.actions[k]; u[1] = r.root_nodes[k];
+                }
+                of.write(reinterpret_cast<const char*>(bb), 16);
+                of.write(reinterpret_cast<const char*>(f), 48);
+                of.write(reinterpret_cast<const char*>(u), 8);
+            }
+        }
+        std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policy.calls);
         return 0;
     }
     if (argc != 8 || std::string(argv[1]) != "c4") return 2;

@@ -69,6 +69,68 @@ def test_lockstep_trees_equal_the_sequential_oracle(harness, oracle, golden_dir)
         assert calls == rounds <= explores + 1 and evals <= len(my) * (explores + 1)
 
 
+SELFPLAY_DTYPE = np.dtype([("bb", np.uint64, (2,)), ("pi", np.float32, (9,)), ("v", np.float32, (3,)), ("action", np.uint32),
+                           ("root_nodes", np.uint32)])
+GAME_DTYPE = np.dtype([("plies", np.int32), ("final_kind", np.int32), ("pos", SELFPLAY_DTYPE, (63,))])
+# the harness's rollout variants as oracle rollout configurations (tests/oracle_lib.py::parity_rollout_config keywords)
+SELFPLAY_VARIANTS = {
+    0: dict(),
+    1: dict(value_target=0, stop_games_when_solved=1, action=0),
+    2: dict(value_target=2, vt_p=0.25, random_actions_until=3, sample_actions_until=10, mcts=dict(exploration=0, c=1.4, fpu=1)),
+    3: dict(value_target=3, vt_from=0.1, vt_to=0.9, mcts=dict(noise=1, noise_weight=0.25)),
+}
+
+
+def assert_games_equal(got, ref, what):
+    """plies, final outcome and every recorded position (state, pi, v, action, nodes.len()) of every game, bit for bit"""
+    np.testing.assert_array_equal(got["plies"], ref["plies"], err_msg=what + ": plies")
+    np.testing.assert_array_equal(got["final_kind"], ref["final_kind"], err_msg=what + ": final_kind")
+    for g in range(len(ref["plies"])):
+        n = int(ref["plies"][g])
+        for k in ("states_bb", "actions", "root_nodes"):
+            np.testing.assert_array_equal(got[k][g, :n], ref[k][g, :n], err_msg=f"{what}: game {g} {k}")
+        for k in ("pis", "vs"):
+            np.testing.assert_array_equal(got[k][g, :n].view(np.uint32), ref[k][g, :n].view(np.uint32), err_msg=f"{what}: game {g} {k}")
+
+
+def test_lockstep_stdrng_is_the_oracles_stream(harness, oracle):
+    """The host StdRng of the lock-step self-play driver (ChaCha12 keyed by seed_from_u64) against the oracle's, word for word
+    across several blocks, and against rand's own value-stability constant through it."""
+    exe, _, _ = harness
+    for seed in (0, 1, 20211003, 2 ** 63 + 12345):
+        p = subprocess.run([exe, "rng", str(seed), "70"], capture_output=True, text=True, timeout=60)
+        assert p.returncode == 0
+        got = np.array([int(x) for x in p.stdout.split()], np.uint32)
+        ref = oracle.stdrng_u32(seed, 70)
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_lockstep_selfplay_equals_the_sequential_oracle(harness, oracle, golden_dir):
+    """run_n_games over host trees (lockstep_selfplay): every game — states, targets after store_rewards, actions, tree sizes —
+    equals oracle/selfplay.hpp's sequential run_game with the same per-game seeding, for every ValueTarget, both action
+    selections, stop_games_when_solved, Uct / ParentQ and the equalising root noise."""
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    exe, blobf, d = harness
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    for variant, games, explores, threads, seed, first in ((0, 12, 60, 3, 7, 0), (1, 8, 50, 1, 99, 5), (2, 8, 40, 2, 3, 0), (3, 8, 40, 4, 11, 2)):
+        out = str(d / f"sp{variant}.bin")
+        p = subprocess.run([exe, "selfplay", blobf, str(games), str(explores), str(variant), str(threads), str(seed), str(first), out],
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout + p.stderr
+        rec = np.fromfile(out, GAME_DTYPE)
+        assert rec.shape == (games,)
+        got = dict(plies=rec["plies"], final_kind=rec["final_kind"].astype(np.uint8), states_bb=rec["pos"]["bb"], pis=rec["pos"]["pi"],
+                   vs=rec["pos"]["v"], actions=rec["pos"]["action"].astype(np.uint8), root_nodes=rec["pos"]["root_nodes"])
+        kw = dict(SELFPLAY_VARIANTS[variant])
+        mcts = kw.pop("mcts", {})
+        ref = oracle.c4_selfplay(parity_rollout_config(explores, mcts=parity_mcts_config(**mcts), **kw), blob, seed, games, first_game=first,
+                                 nn_mode=oracle.ACC_FMA)
+        assert_games_equal(got, ref, f"lockstep self-play variant {variant}")
+        rounds, evals, calls = [int(x) for x in p.stdout.split()[1::2]]
+        assert calls == rounds and evals <= int(ref["plies"].sum()) * (explores + 1)
+
+
 def test_lockstep_driver_is_generic_over_the_game(harness):
     """A three-action subtraction game (take 1-3 stones, the last stone wins) under the same driver with a uniform policy: the
     solver proves every root (a multiple of four loses, anything else wins by moving to one) and best_action plays the proof."""
@@ -117,5 +179,29 @@ def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
     # the draws of Fpu::Func / Dirichlet live on the device path only
     with pytest.raises(sa.SynthesisAmdError) as e:
         eng.mcts_search_lockstep(sa.reference_selfplay_mcts_config(), my[:4], op[:4], 8)
+    assert e.value.code == -5
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_lockstep_selfplay_on_the_gpu_equals_the_fused_selfplay(oracle, golden_dir):
+    """BASELINE configs[1] as worded — 4,096 concurrent games, host-side MCTS, batched HIP inference — against the fused kernel's
+    games (syn_selfplay_run) game for game, and a sample of them against the oracle."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_rollout_config
+
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    eng = sa.Engine(concurrent_games=4096, max_explores=64)
+    eng.load_weights(blob)
+    cfg = sa.parity_rollout_config(48)
+    got = eng.selfplay_lockstep(cfg, 77, 4096, first_game=3)
+    stats = got.pop("stats")
+    fused = eng.selfplay(cfg, 77, 4096, first_game=3)
+    assert_games_equal(got, fused, "lockstep self-play vs fused")
+    ref = oracle.c4_selfplay(parity_rollout_config(48), blob, 77, 64, first_game=3, nn_mode=oracle.ACC_FMA)
+    assert_games_equal({k: v[:64] for k, v in got.items()}, ref, "lockstep self-play vs oracle")
+    assert stats["rounds"] >= 49 and stats["positions_evaluated"] <= int(got["plies"].sum()) * 49
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.selfplay_lockstep(sa.parity_rollout_config(8, mcts_cfg=sa.reference_selfplay_mcts_config()), 1, 4)
     assert e.value.code == -5
     eng.close()
