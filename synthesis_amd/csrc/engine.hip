@@ -69,6 +69,7 @@ SYN_LANES2(MODE_SELFPLAY, true)
     extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF, POLICY>(EngineParams);
 SYN_LANES_FAST_LIST(SYN_X)
 SYN_LANES_GEN_LIST(SYN_X)
+SYN_LANES_REF_LIST(SYN_X)
 #undef SYN_X
 }  // namespace syn
 
@@ -453,9 +454,18 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         // The runtime-switched (general) instantiations need 300-450 more registers than the 128 of a 16-wave workgroup and are
         // bound by their own scratch traffic there (PMC: 8.8x the algorithmic bytes; Fpu::ParentQ 29.5k games/s against 42.4k,
         // Fpu::Func 15.9k against 31.2k): they run 8 waves of 256 registers on at most 512 trees per CU, whatever the capacity.
-        if (!fast && nw > 8 && debug_env("SYN_LANES") == nullptr) {
+        if (!fast && cfg_family(P.mcts) != 2 && nw > 8 && debug_env("SYN_LANES") == nullptr) {
             nw = 8;
             if (want_slots > h->num_cus * 512) want_slots = h->num_cus * 512;
+        }
+        // Tree-bound regimes — PolicyWithCache on (most leaf evaluations are table hits) or the reference's own Fpu::Func
+        // configuration — run 12 waves of 168 registers (17 spilled) on at most 768 trees per CU rather than 16 x 128 (55 spilled):
+        // measured 90.5k against 84.8k games/s with the cache, 61.2k against 55.8k with the trained checkpoint and the cache,
+        // 51.2k against 47.7k for the reference configuration; without the cache the two shapes are equal (70.6k / 71.2k).
+        if (!conv && nw == 16 && (P.cache != nullptr || cfg_family(P.mcts) == 2) && (fast || cfg_family(P.mcts) == 2) &&
+            debug_env("SYN_LANES") == nullptr) {
+            nw = 12;
+            if (want_slots > h->num_cus * 768) want_slots = h->num_cus * 768;
         }
         if ((nw == 4 || nw == 8 || nw == 12 || nw == 16) && h->cap <= LANE_MAX_CAP) {
             int lgrid = (want_slots + 64 * nw - 1) / (64 * nw);
@@ -485,6 +495,14 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                       \
     }
+#define SYN_LAUNCH_LR(NW)                                                                                          \
+    {                                                                                                              \
+        auto k = selfplay_kernel_lanes<MODE, COUNT, 2, NW, PROF && MODE == MODE_SELFPLAY && !COUNT, 0>;                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneLds<NW>::BYTES);   \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                      \
+    }
 #define SYN_LAUNCH_LC(NW, FAST)                                                                                    \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, false, 2>;                                           \
@@ -493,6 +511,12 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                      \
     }
+            // the reference's own self-play configuration (Fpu::Func folded at compile time: mcts.cuh cfg_family) has instantiations of
+            // its own at 8 and 16 waves
+            const bool ref_family = !conv && (!PROF || (MODE == MODE_SELFPLAY && !COUNT)) && cfg_family(P.mcts) == 2 && (nw == 8 || nw == 12 || nw == 16);
+            if (ref_family) {
+                if (nw == 8) SYN_LAUNCH_LR(8) else if (nw == 12) SYN_LAUNCH_LR(12) else SYN_LAUNCH_LR(16)
+            } else
             if (conv) {
                 if (nw == 4) { if (fast) SYN_LAUNCH_LC(4, true) else SYN_LAUNCH_LC(4, false) }
                 else if (nw == 8) { if (fast) SYN_LAUNCH_LC(8, true) else SYN_LAUNCH_LC(8, false) }
@@ -504,6 +528,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             else { if (fast) SYN_LAUNCH_L(16, true) else SYN_LAUNCH_L(16, false) }
 #undef SYN_LAUNCH_L
 #undef SYN_LAUNCH_LC
+#undef SYN_LAUNCH_LR
             h->last_shape = 4; h->last_grid = lgrid; h->last_threads = 64 * nw;
             if (out_grid) *out_grid = -lgrid;  // negative: lane kernel (profile layout differs)
             if (out_nt) *out_nt = 64 * nw;

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
             if (T.iter > n_explores || T.root_solved) {
                 // a private copy of the arguments goes to the callee and the slab pointer is re-derived afterwards, so
                 // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
-                EngineParams Pc = P;
+                const KernargPtr Pc = lane_kernarg();
                 SYN_UNPARK(pk);
                 if (MODE == MODE_SELFPLAY) T = lane_move_step_call<COUNT>(Pc, T, ctr);
                 else T = lane_search_finish_call(Pc, T);

@@ -2,7 +2,8 @@
 // (POLICY 1) the library ships, as X-macro lists: engine.hip declares them `extern template`, engine_lanes_fast.hip (the compile-
 // time-folded parity configuration family) and engine_lanes_gen.hip (the runtime-switched one) define them. Separate translation
 // units only so that `make -j` builds them beside engine.hip.
-//   X(MODE, COUNT, FAST, NW, PROF, POLICY)
+//   X(MODE, COUNT, FAST, NW, PROF, POLICY)      FAST: 0 runtime-switched, 1 parity family, 2 the reference's self-play configuration
+//                                                (mcts.cuh CfgView; engine_lanes_ref.hip holds the third list)
 #pragma once
 #define SYN_LANES_FAST_LIST(X)                                                                                   \
     X(MODE_SELFPLAY, false, true, 4, false, 0) X(MODE_SELFPLAY, false, true, 8, false, 0)                        \
@@ -23,3 +24,10 @@
     X(MODE_SEARCH, false, false, 4, false, 0) X(MODE_SEARCH, false, false, 8, false, 0)                          \
     X(MODE_SEARCH, false, false, 12, false, 0) X(MODE_SEARCH, false, false, 16, false, 0)                        \
     X(MODE_SEARCH, false, false, 8, false, 1)
+#define SYN_LANES_REF_LIST(X)                                                                                    \
+    X(MODE_SELFPLAY, false, 2, 8, false, 0) X(MODE_SELFPLAY, false, 2, 16, false, 0)                             \
+    X(MODE_SELFPLAY, true, 2, 8, false, 0) X(MODE_SELFPLAY, true, 2, 16, false, 0)                               \
+    X(MODE_SEARCH, false, 2, 8, false, 0) X(MODE_SEARCH, false, 2, 16, false, 0)                                 \
+    X(MODE_SELFPLAY, false, 2, 8, true, 0) X(MODE_SELFPLAY, false, 2, 16, true, 0)                               \
+    X(MODE_SELFPLAY, false, 2, 12, false, 0) X(MODE_SELFPLAY, true, 2, 12, false, 0) X(MODE_SEARCH, false, 2, 12, false, 0) \
+    X(MODE_SELFPLAY, false, 2, 12, true, 0)

@@ -189,55 +189,6 @@ SYN_DEV uint32_t lane_alloc_block(LaneTree& T, uint32_t bcap, int* error) {
     return b;
 }
 
-// Out of line: the draws sit on the slow (runtime-switched) configuration path. lane_fpu_scan is a leaf function written to stay
-// inside the caller-saved registers (no prologue saves, no scratch); the rare continuation of a draw (1.2 %) is its own cold call.
-struct FpuScan { float q[9]; uint32_t fail; uint32_t first_lo, first_hi; /* the first bits of the lowest failing slot */ };
-__device__ __attribute__((noinline)) FpuScan lane_fpu_scan(uint64_t tree_seed, uint32_t scan, uint32_t need, float mean, float std, float q_default) {
-    FpuScan r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) r.q[i] = q_default;
-    uint64_t first = 0ull;
-    r.fail = noise_fpu_scan(tree_seed, scan, need, mean, std, r.q, first);
-    r.first_lo = (uint32_t)first;
-    r.first_hi = (uint32_t)(first >> 32);
-    return r;
-}
-// the common continuations in registers (noise_fpu_redo_fast)
-struct FpuRedo { float z; uint32_t done; };
-__device__ __attribute__((noinline)) FpuRedo lane_fpu_redo_fast(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std,
-                                                                bool have_first, uint32_t first_lo, uint32_t first_hi) {
-    FpuRedo r;
-    bool done;
-    r.z = noise_fpu_redo_fast(tree_seed, scan, slot, mean, std, have_first, (uint64_t)first_lo | ((uint64_t)first_hi << 32), done);
-    r.done = done ? 1u : 0u;
-    return r;
-}
-__device__ __attribute__((noinline, cold)) float lane_fpu_redo(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std) {
-    return noise_fpu_redo(tree_seed, scan, slot, mean, std);
-}
-// All nine scores of one select_best_child scan under Fpu::Func: slots outside `need` get q_default
-SYN_DEV void lane_fpu_draws(uint64_t tree_seed, uint32_t scan, uint32_t need, float mean, float std, float q_default, float (&qf)[9]) {
-    const FpuScan fs = lane_fpu_scan(tree_seed, scan, need, mean, std, q_default);
-#pragma unroll
-    for (uint32_t i = 0; i < 9; i++) qf[i] = fs.q[i];
-    uint32_t fail = fs.fail;
-    bool have_first = true;   // (the scan handed out the first bits of the lowest failing slot: the first pass of this loop)
-    while (__ballot(fail != 0u) != 0ull) {
-        if (fail != 0u) {
-            const uint32_t slot = (uint32_t)__ffs((int)fail) - 1u;
-            fail &= fail - 1u;
-            const FpuRedo fr = lane_fpu_redo_fast(tree_seed, scan, slot, mean, std, have_first, fs.first_lo, fs.first_hi);
-            have_first = false;
-            float z = fr.z;
-            if (__ballot(fr.done == 0u) != 0ull) {   // a tail or two failures in a row (0.6 % of the continuations): the generic sampler
-                if (fr.done == 0u) z = lane_fpu_redo(tree_seed, scan, slot, mean, std);
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < 9; i++) qf[i] = slot == i ? z : qf[i];
-        }
-    }
-}
-
 // Fpu::Func in the one-tree-per-lane descent loop: a lane whose node needs draws waits (`wait`, with the slots in `need`) until no
 // lane of the wave can take a level without them; then ONE scan serves all waiting lanes (lane_select_expand). A draw is a function
 // of (tree, scan index, slot) only, so when it is computed does not matter.
@@ -257,7 +208,7 @@ struct LaneCursor {
 
 // explore() starts at the root (mcts.rs:310-312). pl = this lane's column of the wave's path buffer: level L lives at
 // pl[L * 64]. ROOT_IN_T: the root position is live in T.root_my / T.root_op (pc_kernel.cuh) instead of parked in LDS at pk[].
-template <bool COUNT, bool FAST, bool ROOT_IN_T>
+template <bool COUNT, int FAST, bool ROOT_IN_T>
 SYN_DEV void lane_begin_explore(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint4* pl, uint32_t* ctr, const uint32_t* pk,
                                 int pk_stride) {
     const CfgView<FAST> cfg{cfg_};
@@ -297,7 +248,7 @@ SYN_DEV void lane_begin_explore(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
 // stone lands); the children of a node are its legal columns in ascending order.
 // DEFER (lane_select_expand): with `scan_now` false a lane that needs draws only records that in H and returns; the caller's
 // next call with scan_now true (wave-uniform) takes the draws and the level.
-template <bool COUNT, bool FAST, bool DEFER = false>
+template <bool COUNT, int FAST, bool DEFER = false>
 SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint32_t& lm, uint4* pl, uint32_t* ctr,
                                 uint64_t noise_seed, FpuHold* H = nullptr, bool scan_now = true, LaneProf* lp = nullptr) {
     const CfgView<FAST> cfg{cfg_};
@@ -347,7 +298,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
                 return;
             }
         } else if (__ballot(need != 0u) != 0ull) {
-            lane_fpu_draws(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, q_fpu, qf);
+            noise_fpu_scan(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, qf);
             T.fpu_draws += need != 0u ? 1u : 0u;
         }
     }
@@ -427,6 +378,10 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
     pl[C.level * 64] = make_uint4(C.rec, f32_bits(C.pN),
                                   pm_make(C.blk, (uint32_t)__popc(lm), C.nsolved, C.kind) |
                                       ((!C.nsolved && C.blk != 0u) ? PM_HAS_W : 0u), C.qt);
+    // Fpu::Func, deferred scans: a node with N visits has at most N - 1 expanded children, so a child entered with N <= its number
+    // of children is certain to score an unexpanded child — it waits for the wave's next scan right away instead of finding that
+    // out with a wasted pass over its line (a child whose unexpanded children are all terminal waits for nothing: harmless)
+    if (DEFER && cfg.fpu_normal() && H != nullptr && !C.nsolved && C.blk != 0u && C.pN <= (float)__popc(lm)) H->wait = true;
     if (lp_abl(lp, ABL_LOG_ST)) {
         lp_fence();
         pl[C.level * 64] = make_uint4(C.rec, f32_bits(C.pN),
@@ -440,7 +395,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
 // The descent stands on a leaf: a solved node (explore() returns its outcome) or an unexpanded one, which visit()
 // (mcts.rs:374-406) gives its block; the children's records are written in phase C together with their priors. Only an
 // auto-extended single child is written here (prior 1.0, no policy call). Sets X.{p0,p1,p2,solved,needs_eval,legal_mask}.
-template <bool COUNT, bool FAST>
+template <bool COUNT, int FAST>
 SYN_DEV void lane_arrive(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, LaneLeaf& X, bool hit_solved, uint4* pl,
                          uint32_t bcap, uint32_t* ctr, int* error) {
     const CfgView<FAST> cfg{cfg_};
@@ -511,7 +466,7 @@ SYN_DEV void lane_arrive(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, Lan
 }
 
 // Phase A of a round of the one-tree-per-lane kernels: start an explore, descend, stop on a leaf.
-template <bool COUNT, bool FAST, bool ROOT_IN_T = false>
+template <bool COUNT, int FAST, bool ROOT_IN_T = false>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
                                 uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride,
                                 uint64_t noise_seed = 0, LaneProf* lp = nullptr) {
@@ -540,7 +495,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     bool hit_solved = false, at_leaf = pending;
     // legal columns of the current position: computed once per round and updated as the descent drops stones
     uint32_t lm = legal_mask_of(C.my | C.op);
-    if (!FAST && cfg_.fpu == 2) {
+    if (CfgView<FAST>{cfg_}.fpu_normal()) {
         // Fpu::Func: levels that need no draws first, then one scan for every lane that waits for draws (FpuHold)
         FpuHold H;
         H.wait = false;
@@ -744,7 +699,7 @@ SYN_DEV int wave_max_i32(int v) {
 //            (win/lose swapped once per level climbed) and one visit, so the levels are independent; the node's sums
 //            come from the path log's second plane (the descent read them with the line it needed anyway), so four
 //            levels cost ONE round trip of coalesced rows and no random line read — only the dirtied lines remain.
-template <bool COUNT, bool FAST>
+template <bool COUNT, int FAST>
 // `leaf_flag`: header word 3 of the node expanded in this pass (lane_create_children), 0 otherwise; every other visited node
 // keeps the word it has (a node that was never backpropagated into has no header yet: 0).
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
@@ -1229,18 +1184,32 @@ SYN_DEV void lane_search_finish(const EngineParams& P, LaneTree& T) {
     lane_start_job<MODE_SEARCH>(P, T);
 }
 
-// cold path out of line, state by value (see engine_kernels.cuh: TreeGame)
+// Cold path out of line, the tree's state by value. The callee reads the launch parameters where they already are — the kernel
+// argument segment (every lane-per-tree kernel takes EngineParams as its only argument, at offset 0) — through scalar loads. (It
+// used to receive a reference to a private copy of the 300-byte struct: twenty dependent scratch load -> wait -> store pairs in
+// front of every call, on top of the caller-saved registers; a reference to the kernel's own parameter would have demoted the hot
+// loop's pointers to the generic address space.)
+typedef const __attribute__((address_space(4))) void* KernargPtr;
+SYN_DEV KernargPtr lane_kernarg() { return (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr(); }
+SYN_DEV EngineParams lane_params_from_kernarg(KernargPtr k) {
+    EngineParams P;
+    __builtin_memcpy(&P, k, sizeof(EngineParams));   // (only the fields the callee uses survive: scalar loads)
+    return P;
+}
 template <bool COUNT>
-__device__ __attribute__((noinline)) LaneTree lane_move_step_call(const EngineParams& P, LaneTree t, uint32_t* ctr) {
+__device__ __attribute__((noinline)) LaneTree lane_move_step_call(KernargPtr k, LaneTree t, uint32_t* ctr) {
+    const EngineParams P = lane_params_from_kernarg(k);
     lane_move_step<COUNT>(P, t, ctr);
     return t;
 }
 // (diagnostic build: the same with stamps between its parts)
-__device__ __attribute__((noinline)) LaneTree lane_move_step_call_prof(const EngineParams& P, LaneTree t, const LaneProf* lp) {
+__device__ __attribute__((noinline)) LaneTree lane_move_step_call_prof(KernargPtr k, LaneTree t, const LaneProf* lp) {
+    const EngineParams P = lane_params_from_kernarg(k);
     lane_move_step<false>(P, t, nullptr, lp);
     return t;
 }
-__device__ __attribute__((noinline)) LaneTree lane_search_finish_call(const EngineParams& P, LaneTree t) {
+__device__ __attribute__((noinline)) LaneTree lane_search_finish_call(KernargPtr k, LaneTree t) {
+    const EngineParams P = lane_params_from_kernarg(k);
     lane_search_finish(P, t);
     return t;
 }
@@ -1386,7 +1355,7 @@ SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
 
 // POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (policies/rollout.rs; searches only),
 //         2 = Connect4ConvNet on the matrix cores (convnet.cuh: its image takes the first 66 KB of the Connect4Net image's LDS)
-template <int MODE, bool COUNT, bool FAST, int NW, bool PROF = false, int POLICY = 0>
+template <int MODE, bool COUNT, int FAST, int NW, bool PROF = false, int POLICY = 0>
 __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 64 * NW;
@@ -1457,7 +1426,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     // seed of this lane's current tree for Fpu::Func / Dirichlet draws (noise.cuh): stream = seed + game (or root) index,
     // turn from the parked game state; only the runtime-switched configurations evaluate it
     auto lane_noise_seed = [&]() -> uint64_t {
-        if (FAST || (P.mcts.fpu != 2 && P.mcts.noise != 2)) return 0ull;
+        if (FAST == 1 || (FAST == 0 && P.mcts.fpu != 2 && P.mcts.noise != 2)) return 0ull;
         const uint64_t stream = P.base_seed + (MODE == MODE_SELFPLAY ? P.first_game : 0ull) + (uint64_t)(uint32_t)T.job;
         return noise_tree_seed(stream, MODE == MODE_SELFPLAY ? (pk[4 * NT] & 0xFFu) : 0u);
     };
@@ -1592,7 +1561,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
             solved = lane_write_children(T.slab, Wk.blk, X.legal_mask, Wk.my, Wk.op, pr,
-                                         (!FAST && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
+                                         (FAST == 0 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
                                          P.mcts.noise_alpha, lane_noise_seed(),
                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag, lp_abl(lp, ABL_CHILD_ST));
             if (lp) lp_add(lp, LP_C_WRITE, lp_now() - lp_c0);
@@ -1606,9 +1575,9 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             T.iter += 1;
             // explore_n (mcts.rs:139-147): the root visit, then up to n explores unless the root is solved
             if (T.iter > n_explores || T.root_solved) {
-                // a private copy of the arguments goes to the callee and the slab pointer is re-derived afterwards, so
-                // the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
-                EngineParams Pc = P;
+                // the callee reads the launch parameters from the kernel argument segment; the slab pointer is re-derived
+                // afterwards, so the hot loop's pointers never round-trip through memory (they would come back generic: flat_load)
+                const KernargPtr Pc = lane_kernarg();
                 if (lp) lp_step(lp, LP_M_CALLS, -1, LP_M_LANES, 1ull);
                 const unsigned long long lp_m0 = lp ? lp_now() : 0ull;
                 SYN_UNPARK();

@@ -49,12 +49,15 @@ struct DevRolloutCfg {
 // Compile-time view of the MCTS config. FAST = the reference's own configuration family (PolynomialUct, Fpu::Const,
 // solver + value correction + select_solved_nodes + auto_extend, study-connect4/src/main.rs:37-66): every switch folds
 // away and only `c` and `fpu_value` stay runtime. The generic view serves every other combination with the same code.
-template <bool FAST>
+// FAST (an int since round 4): 0 = every switch at run time; 1 = the parity configuration family above; 2 = the reference's OWN
+// self-play configuration (study-connect4/src/main.rs:37-49): the same switches with Fpu::Func(|| Normal(mean, std)) instead of
+// the constant — its draws (noise.cuh) exist in the lane-per-tree kernels only.
+template <int FAST>
 struct CfgView {
     const DevMctsCfg& c;
     SYN_DEV bool puct() const { return FAST ? true : c.exploration == 1; }
-    SYN_DEV bool fpu_const() const { return FAST ? true : c.fpu == 0; }
-    SYN_DEV bool fpu_normal() const { return FAST ? false : c.fpu == 2; }
+    SYN_DEV bool fpu_const() const { return FAST == 1 ? true : (FAST == 2 ? false : c.fpu == 0); }
+    SYN_DEV bool fpu_normal() const { return FAST == 2 ? true : (FAST == 1 ? false : c.fpu == 2); }
     SYN_DEV bool select_solved() const { return FAST ? true : c.select_solved != 0; }
     SYN_DEV bool solve() const { return FAST ? true : c.solve != 0; }
     SYN_DEV bool correct_values() const { return FAST ? true : c.correct_values != 0; }
@@ -64,6 +67,11 @@ struct CfgView {
 };
 inline bool cfg_is_fast(const DevMctsCfg& c) {
     return c.exploration == 1 && c.fpu == 0 && c.select_solved && c.solve && c.correct_values && c.auto_extend && c.noise == 0;
+}
+// the compile-time family of a configuration (CfgView): 1 parity, 2 the reference's self-play configuration, 0 anything else
+inline int cfg_family(const DevMctsCfg& c) {
+    const bool folded = c.exploration == 1 && c.select_solved && c.solve && c.correct_values && c.auto_extend && c.noise == 0;
+    return folded ? (c.fpu == 0 ? 1 : (c.fpu == 2 ? 2 : 0)) : 0;
 }
 
 struct DevCounters {  // index order = syn_counters

@@ -322,7 +322,7 @@ __global__ __launch_bounds__(PcGeom::NT, 1) void selfplay_kernel_pc(EngineParams
                 if (PROF) pFin++;
                 // explore_n (mcts.rs:139-147): the root visit, then up to n explores unless the root is solved
                 if (T.iter > n_explores || T.root_solved) {
-                    EngineParams Pc = P;
+                    const KernargPtr Pc = lane_kernarg();
                     if (MODE == MODE_SELFPLAY) T = lane_move_step_call<COUNT>(Pc, T, ctr);
                     else T = lane_search_finish_call(Pc, T);
                     T.slab = reinterpret_cast<unsigned char*>(P.stat) + slot * (size_t)P.cap * 32u;

@@ -150,6 +150,13 @@ class Oracle:
         self.lib.orc_det_logf(_p(x), _p(y), int(x.size))
         return y
 
+    def std_normal_from_bits(self, k):
+        """oracle/noise.hpp det_std_normal: the standard normal the Fpu::Func draw makes of 23 random bits"""
+        k = np.ascontiguousarray(k, np.uint32)
+        out = np.zeros(k.size, np.float32)
+        self.lib.orc_std_normal_from_bits(_p(k), int(k.size), _p(out))
+        return out
+
     def noise_fpu_normals(self, tree_seed, n_scans, mean=0.0, std=1.0):
         """Fpu::Func draws [scan][child slot] of one tree (oracle/noise.hpp noise_fpu_normal)"""
         out = np.zeros((int(n_scans), 9), np.float32)
