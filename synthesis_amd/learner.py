@@ -77,6 +77,36 @@ class LearningLoop:
         self.games_played = 0
         self.iterations_done = 0
 
+    # one replay position on the wire: my_bb, op_bb (u64), gid (i64), pi[9], v[3] (f32) = 72 bytes, no pickling
+    _POS = np.dtype([("my", "<u8"), ("op", "<u8"), ("gid", "<i8"), ("pi", "<f4", (9,)), ("v", "<f4", (3,))])
+
+    def _gather_positions(self, new):
+        """The ranks' new positions to the learner's rank (in rank order = game order) as ONE fixed-layout tensor gather: the
+        counts travel first (one all_gather of an int64 per rank), then every rank contributes a buffer of the largest count —
+        device buffers under RCCL, host buffers under gloo. (The round-3 form pickled a dict of arrays per rank: rank 0 unpickled
+        8 x 18 MB per iteration.)"""
+        t = self._torch
+        n = int(new["my"].size)
+        on_gpu = self._wbuf.is_cuda
+        dev = self._wbuf.device
+        cnt = t.tensor([n], dtype=t.int64, device=dev)
+        counts = [t.zeros(1, dtype=t.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(counts, cnt)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        rec = np.zeros(cap, self._POS)
+        for k in ("my", "op", "gid", "pi", "v"):
+            rec[k][:n] = new[k]
+        mine = t.from_numpy(rec.view(np.uint8).reshape(-1))
+        if on_gpu:
+            mine = mine.to(dev)
+        parts = [t.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(mine, parts, dst=0)
+        if self.rank != 0:
+            return new
+        out = [p_.cpu().numpy().view(self._POS)[:c] for p_, c in zip(parts, counts)]
+        return {k: np.concatenate([o[k] for o in out]) for k in ("my", "op", "pi", "v", "gid")}
+
     def iteration(self, cfg, games_per_train, games_to_keep, epochs, batch_size):
         """One pass of the loop body (alpha_zero.rs:42-100). Returns this rank's record of it (rank 0's has the learner's numbers)."""
         it = self.iterations_done
@@ -92,11 +122,7 @@ class LearningLoop:
                    gid=(first + np.arange(count))[:, None].repeat(63, 1)[mask])
         t1 = time.perf_counter()
         if self.dist is not None:
-            # the new positions go to the learner's rank only (in rank order = game order): ~18 MB per 8,192 games
-            parts = [None] * self.world if self.rank == 0 else None
-            self.dist.gather_object(new, parts, dst=0)
-            if self.rank == 0:
-                new = {k: np.concatenate([p_[k] for p_ in parts]) for k in new}
+            new = self._gather_positions(new)
         t_gather = time.perf_counter() - t1
         self.games_played += games_per_train
         lr = _lr_at(self.lr_schedule, it)

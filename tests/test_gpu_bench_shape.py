@@ -78,6 +78,35 @@ def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, 
     assert np.array_equal(got["root_nodes"][idx, last], ref["root_nodes"][idx, last])
 
 
+def test_reference_configuration_leg_matches_oracle_at_its_bench_shape(oracle, golden_dir, monkeypatch):
+    """bench.py's `reference_selfplay_config` leg as it is timed: the trained checkpoint, PolicyWithCache with 2^28 entries, the
+    reference's own mcts_cfg (study-connect4/src/main.rs:37-49: Fpu::Func(|| Normal(1.0, 0.1)), alpha_zero.rs:197-198 for the cache),
+    a 262,144-slot engine, 800 explores, the engine's own launch selection (the compile-time family-2 instantiation at 12 waves) —
+    sampled games of the first wave, of the pool's last slots and of the refill equal the oracle's game for game, draws included."""
+    import synthesis_amd as sa
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+    from tests.test_gpu_parity import assert_selfplay_equal
+
+    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_LANES2", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE", "SYN_PC"):
+        monkeypatch.delenv(k, raising=False)
+    weights = np.load(os.path.join(golden_dir, "c4net_trained_f32.npy"))
+    conc, seed = 262144, 4242
+    n_games = conc + 8192
+    cfg = sa.parity_rollout_config(800, mcts_cfg=sa.reference_selfplay_mcts_config())
+    eng = sa.Engine(concurrent_games=conc, max_explores=800, device=0, policy_cache_log2=28)
+    eng.load_weights(weights)
+    got = eng.selfplay(cfg, base_seed=seed, n_games=n_games)
+    assert eng.last_launch_shape() == (4, 256, 768), "the launch shape this configuration takes by default"
+    hits, misses = eng.last_cache_stats()
+    eng.close()
+    assert hits > 0.5 * (hits + misses)
+    ocfg = parity_rollout_config(800, mcts=parity_mcts_config(fpu=2, fpu_value=1.0, fpu_std=0.1))
+    for first in (0, 100000 + 3, 196608 - 4, conc - 8, conc, n_games - 8):
+        ref = oracle.c4_selfplay(ocfg, weights, seed, 8, first_game=first, threads=8, nn_mode=oracle.ACC_FMA)
+        sub = {k: got[k][first:first + 8] for k in ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind")}
+        assert_selfplay_equal(sub, ref, f"reference configuration at its bench shape, games {first}..{first + 7}")
+
+
 def test_policy_cache_at_bench_scale_changes_no_game(blob):
     """PolicyWithCache at the bench's own size: 262,144 concurrent games hammering one lock-free table (2^24 entries: heavily
     contended, torn and overwritten entries must read as misses) play exactly the games of the uncached run."""
@@ -93,7 +122,7 @@ def test_policy_cache_at_bench_scale_changes_no_game(blob):
     cached.load_weights(blob)
     b = cached.selfplay(cfg, base_seed=99, n_games=n, outputs=False)
     hits, misses = cached.last_cache_stats()
-    assert cached.last_launch_shape() == (4, 256, 1024)
+    assert cached.last_launch_shape() == (4, 256, 768)   # with the cache on: 12 waves, 768 of the 1,024 slots per CU
     cached.close()
     assert np.array_equal(a["plies"], b["plies"])
     assert hits > 0.2 * (hits + misses)
