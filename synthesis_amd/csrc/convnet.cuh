@@ -115,21 +115,29 @@ SYN_DEV f32x4 conv_tile16(const float* __restrict__ img, int lane, uint64_t my, 
             lo[s] = (uint32_t)v;
             hi[s] = (uint32_t)(v >> 32);
         }
-#pragma unroll
-        for (int c = 0; c < 9; c++) {
-            const int p = r * 9 + c;
+        // Software-pipelined over the row's nine cells: the five conv MFMAs of cell c + 1 are issued BEFORE the ReLU and the four
+        // head MFMAs of cell c, so the ReLU never reads an accumulator whose chain has just been issued (the compiler filled that
+        // dependency with ~20 wait states of s_nop per cell when the cells ran one after the other) and the two chains — conv of the
+        // next cell, heads of this one — interleave on the matrix pipe. Same instructions on the same operands: same bits.
+        auto conv_cell = [&](int c) {
             f32x4 acc = cb;
 #pragma unroll
             for (int s = 0; s < 5; s++) {
                 const uint32_t bit = 7 * c < 32 ? __builtin_amdgcn_ubfe(lo[s], 7 * c, 1) : __builtin_amdgcn_ubfe(hi[s], 7 * c - 32, 1);
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[s], (float)bit, acc, 0, 0, 0);
             }
-            const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + p * 256);
+            return acc;
+        };
+        f32x4 acc = conv_cell(0);
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const float a = acc[k] > 0.0f ? acc[k] : 0.0f;
-                hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[k], a, hacc, 0, 0, 0);
-            }
+        for (int c = 0; c < 9; c++) {
+            const int p = r * 9 + c;
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(hw + p * 256);
+            f32x4 nxt = acc;
+            if (c < 8) nxt = conv_cell(c + 1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) hacc = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[k], relu1(acc[k]), hacc, 0, 0, 0);
+            acc = nxt;
         }
     }
     return hacc;

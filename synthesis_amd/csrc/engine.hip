@@ -314,6 +314,9 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     {                                                                                                              \
         auto k = selfplay_kernel<MODE, COUNT, WPS, FAST, PROF>;                                                    \
         size_t lds = WPS == 1 ? EngineLds::BYTES_WPS1 : EngineLds::BYTES_WPS2;                                     \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+        if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, h->stream, P);                                           \
     }
     // Kernel choice by trees per CU: <= 16 -> one 16-tree workgroup per CU, weights in registers (latency-optimal);

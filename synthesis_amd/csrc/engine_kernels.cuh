@@ -394,7 +394,9 @@ struct EngineLds {
     static constexpr size_t FLAG_OFF = OUT_OFF + TPW * 64;
     static constexpr size_t W345_OFF = FLAG_OFF + 16;
     static constexpr size_t W345_FLOATS = MlpGeom::W_FLOATS - MlpGeom::W_OFF[2];  // layers 3-5: 9,984 floats
-    static constexpr size_t BYTES_WPS1 = W345_OFF;                                // all weights in registers
+    static constexpr int HOT_NODES = 256;                                         // records per tree kept in LDS (WPS = 1 only)
+    static constexpr size_t HOT_OFF = W345_OFF;                                   // 16 trees x 256 records x 32 B = 128 KB
+    static constexpr size_t BYTES_WPS1 = HOT_OFF + (size_t)TPW * HOT_NODES * 32;  // all weights in registers
     static constexpr size_t BYTES_WPS2 = W345_OFF + W345_FLOATS * 4;              // + 39,936 B
 };
 
@@ -440,6 +442,12 @@ __global__ __launch_bounds__(256, WPS) void selfplay_kernel(EngineParams P) {
     const size_t slot = (size_t)blockIdx.x * EngineLds::TPW + (size_t)t;
     T.stat.base = P.stat + 2 * slot * P.cap;
     T.edge.base = P.edge + 2 * slot * P.cap;
+    // WPS = 1 (<= 16 trees per CU: every explore is a dependent chain A -> B -> C on four waves): the first 256 records of each tree
+    // in LDS — the root's children and grandchildren are always among them — so the top two levels of a descent and of a backprop
+    // cost LDS accesses instead of memory round trips
+    T.stat.hot = WPS == 1 ? reinterpret_cast<float4*>(smem_raw + EngineLds::HOT_OFF) + (size_t)t * EngineLds::HOT_NODES * 2 : nullptr;
+    T.edge.hot = reinterpret_cast<uint4*>(T.stat.hot);
+    T.stat.k = T.edge.k = WPS == 1 ? (uint32_t)EngineLds::HOT_NODES : 0u;
     GameCtx G;
     start_job<MODE>(P, T, G, gl);
     __syncthreads();
@@ -592,6 +600,7 @@ __global__ __launch_bounds__(256 * NQ) void selfplay_kernel_quads(EngineParams P
     const size_t slot = ((size_t)blockIdx.x * NQ + quad) * 16 + (size_t)t;
     T.stat.base = P.stat + 2 * slot * P.cap;
     T.edge.base = P.edge + 2 * slot * P.cap;
+    T.stat.hot = nullptr; T.edge.hot = nullptr; T.stat.k = T.edge.k = 0u;
     GameCtx G;
     start_job<MODE>(P, T, G, gl);
     __syncthreads();  // weights staged; the only workgroup-wide barrier of the kernel

@@ -117,13 +117,22 @@ SYN_DEV uint32_t outcome_key_reversed(uint32_t meta) {
 // A node is one 32-byte record {stat (16 B), edge (16 B)}; stat[i] / edge[i] are views on record i. Interleaving the
 // two halves keeps a sibling scan (<= 9 consecutive nodes) inside one contiguous 288-byte span instead of two 144-byte
 // spans in different arrays: fewer cache lines and DRAM pages per level for the same two 16-byte loads per lane.
+// The first `k` records of a tree (the nodes created first: the root, its children, the grandchildren — the top of the tree, read by
+// every descent and written by every backprop) may live in a second place, `hot`: the latency-bound 16-trees-per-CU kernel keeps them
+// in LDS (engine_kernels.cuh selfplay_kernel<WPS = 1>), where a level of the descent costs an LDS access instead of a memory round
+// trip. k = 0 (every other kernel): the select folds away and the accesses stay plain global loads / stores. A tree never outlives
+// its search, so the two places need no write-back.
 struct StatView {
     float4* base;
-    SYN_DEV float4& operator[](uint32_t i) const { return base[2u * i]; }
+    float4* hot;
+    uint32_t k;
+    SYN_DEV float4& operator[](uint32_t i) const { return (i < k ? hot : base)[2u * i]; }
 };
 struct EdgeView {
     uint4* base;
-    SYN_DEV uint4& operator[](uint32_t i) const { return base[2u * i + 1u]; }
+    uint4* hot;
+    uint32_t k;
+    SYN_DEV uint4& operator[](uint32_t i) const { return (i < k ? hot : base)[2u * i + 1u]; }
 };
 
 struct TreeCtx {
