@@ -198,10 +198,11 @@ def main():
     ap.add_argument("--skip-counted", action="store_true", help="profiling passes: only the warm-up and timed launches, a reduced line")
     ap.add_argument("--no-learner-loop", action="store_true", help="skip the two iterations of the N-rank learning loop (learner_loop)")
     ap.add_argument("--no-policy-cache", action="store_true", help="skip the extra PolicyWithCache measurement")
-    ap.add_argument("--only-policy-cache", action="store_true",
-                    help="run nothing but the PolicyWithCache + reference-config legs (the command tools/collect_profiles.sh profiles for their rooflines)")
+    ap.add_argument("--only-policy-cache", "--only-extra-legs", dest="only_policy_cache", action="store_true",
+                    help="run nothing but the extra self-play legs (PolicyWithCache, reference configuration, trained network, conv network) "
+                         "at their bench size: the command tools/collect_profiles.sh profiles for their rooflines")
     ap.add_argument("--no-extras", action="store_true", help="skip the trained-weights / replay-output / reference-config / conv / tail / learner legs")
-    ap.add_argument("--time-budget-s", type=float, default=870.0, help="wall-clock budget of the whole run: the extra legs (never the timed "
+    ap.add_argument("--time-budget-s", type=float, default=1500.0, help="wall-clock budget of the whole run: the extra legs (never the timed "
                     "steps, the roofline or the CPU baseline) are skipped, least important first, once they would overrun it")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (dry run: every rank "
                                                            "on GPU 0, used to exercise the N>1 path on a 1-GPU box)")
@@ -276,13 +277,7 @@ def main():
             if w3 is None or cfg3 is None:
                 continue
             e3.load_weights(w3)   # (a new network empties the table)
-            if name == "reference_selfplay_config":
-                # Fpu::Func draws a Normal per unexpanded child and scan (one ChaCha12 block each, noise.cuh): an order of magnitude
-                # more work per explore than the constant FPU — one game per tree slot, a small warm-up
-                n_games = args.concurrent
-                e3.selfplay(cfg3, base_seed=2, n_games=4096, outputs=False)
-            else:
-                e3.selfplay(cfg3, base_seed=2, n_games=args.concurrent, outputs=False)
+            e3.selfplay(cfg3, base_seed=2, n_games=args.concurrent, outputs=False)
             t1 = time.perf_counter()
             r3 = e3.selfplay(cfg3, base_seed=2, n_games=n_games, first_game=args.concurrent, outputs=False)
             dt = time.perf_counter() - t1
@@ -303,6 +298,10 @@ def main():
                  "select_levels_per_explore": c3["select_levels"] / max(1, c3["explores"]),
                  "launch_shape": list(shape3),
                  "roofline": hbm_roofline(alg, r3["kernel_ms"], traffic, src, misses * FLOP_PER_EVAL)}
+            o["roofline_other"] = {"bound": "mfma", "achieved": misses * FLOP_PER_EVAL / (r3["kernel_ms"] * 1e-3) / 1e12,
+                                   "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": misses * FLOP_PER_EVAL / (r3["kernel_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                   "traffic": traffic, "traffic_source": src, "kernel_ms_avg": r3["kernel_ms"], "flop_per_leaf_eval": FLOP_PER_EVAL}
             if name == "reference_selfplay_config":
                 o["config"] = ("trained checkpoint tests/golden/c4net_trained_f32.npy + PolicyWithCache (2^28 entries) + "
                                "Fpu::Func(Normal(1.0, 0.1)) on the device (study-connect4/src/main.rs:37-49), %d explores" % args.explores)
@@ -316,10 +315,71 @@ def main():
 
     tpath = os.path.join(ROOT, "tests", "golden", "c4net_trained_f32.npy")
     trained_blob = np.load(tpath) if os.path.exists(tpath) else None
-    gx = max(args.concurrent, gps // 4)   # games of an extra leg's launch: a quarter of a step ...
-    gh = max(args.concurrent, gps // 2)   # ... half a step for the two legs with targets of their own (policy cache, trained network)
+    gx = max(args.concurrent, gps // 4)   # games of the two side measurements (replay outputs to the host, launch tail): a quarter of a step
+    gh = max(args.concurrent, gps // 2)   # games of every self-play leg with a roofline of its own: half a step (1,048,576 by default)
+
+    def leg_rooflines(counters, sample_games, n_games, kernel_ms, traffic_key, flop_per_eval, extra_alg_bytes=0.0):
+        """Both roofline objects of an extra leg from the event counts of a sample of its games (scaled to the launch), its kernel time
+        and — when profiles/rNN_pmc.json holds a pass of this leg on these kernel sources and this size — the HBM traffic the counters saw."""
+        scale = n_games / sample_games
+        secs = kernel_ms * 1e-3
+        flops = counters["policy_evals"] * scale * flop_per_eval
+        alg = algorithmic_bytes(counters) * scale + extra_alg_bytes
+        traffic, src = measured_traffic(args, traffic_key, n_games)
+        mf = {"bound": "mfma", "achieved": flops / secs / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+              "frac": flops / secs / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": src, "kernel_ms_avg": kernel_ms,
+              "flop_per_leaf_eval": flop_per_eval}
+        hb = hbm_roofline(alg, kernel_ms, traffic, src, flops)
+        return (mf, hb) if mf["frac"] >= hb["frac"] else (hb, mf)
+
+    def trained_leg(eng, n_games, first):
+        """a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see tests/golden/README):
+        priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the random-init network (SURVEY §8d asks
+        for both); same kernel"""
+        eng.load_weights(trained_blob)
+        eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=first, outputs=False)
+        t1 = time.perf_counter()
+        rt = eng.selfplay(cfg, base_seed=0, n_games=n_games, first_game=first + args.concurrent, outputs=False)
+        dt4 = time.perf_counter() - t1
+        shape4 = list(eng.last_launch_shape())
+        ct = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=first + args.concurrent, outputs=False, counters=True)["counters"]
+        near, other = leg_rooflines(ct, 32768, n_games, rt["kernel_ms"], "trained_traffic_bytes_per_launch", FLOP_PER_EVAL)
+        eng.load_weights(blob)
+        return {"games_per_s": n_games / dt4, "games": n_games, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
+                "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
+                "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
+                "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
+                "mfma_frac": (ct["policy_evals"] / 32768.0) * (n_games / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "launch_shape": shape4, "roofline": near, "roofline_other": other}
+
+    def conv_leg(eng, n_games, first):
+        """the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same engine, same
+        MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)"""
+        eng.load_weights_conv(make_conv_weights())
+        eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=first, outputs=False)
+        t1 = time.perf_counter()
+        rt = eng.selfplay(cfg, base_seed=0, n_games=n_games, first_game=first + args.concurrent, outputs=False)
+        dt5 = time.perf_counter() - t1
+        conv_shape = list(eng.last_launch_shape())
+        cc = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=first + args.concurrent, outputs=False, counters=True)["counters"]
+        evals_per_s = (cc["policy_evals"] / 32768.0) * (n_games / dt5)
+        near, other = leg_rooflines(cc, 32768, n_games, rt["kernel_ms"], "conv_traffic_bytes_per_launch", CONV_FLOP_PER_EVAL)
+        eng.load_weights(blob)
+        return {"network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
+                "games_per_s": n_games / dt5, "games": n_games, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
+                "flop_per_eval": CONV_FLOP_PER_EVAL,
+                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "launch_shape": conv_shape, "roofline": near, "roofline_other": other}
+
     if args.only_policy_cache:
         out = policy_cache_leg(gh, trained_blob, reference_mcts=True)
+        eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
+        if trained_blob is not None:
+            out["with_trained_weights"] = trained_leg(eng, gh, 0)
+        out["with_conv_policy"] = conv_leg(eng, gh, 4 * gh)
+        eng.close()
         if rank == 0:
             print(json.dumps(out), flush=True)
         return
@@ -396,7 +456,7 @@ def main():
                 loop_rec = {"games_per_iteration": r4["games"], "explores": 200, "ranks": world, "optimiser_steps": r4["optimiser_steps"],
                             "unique_positions": r4["unique"], "seconds": r4["seconds"],
                             "games_per_s_of_the_whole_iteration": r4["games"] / max(1e-9, r4["seconds"]["total"]),
-                            "collectives": "gather_object of the new positions to rank 0 + one %d-byte weight broadcast per iteration (%s)"
+                            "collectives": "one fixed-layout tensor gather of the new positions to rank 0 + one %d-byte weight broadcast per iteration (%s)"
                                            % (blob.size * 4, args.dist_backend if world > 1 else "none: one rank"),
                             "note": "the 1 -> 8 GPU curve of this loop has not been measured on an 8-GPU node (one GPU per box here)"}
         except Exception as ex:   # never lose the bench line over the learner leg
@@ -463,27 +523,11 @@ def main():
             out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
         next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
         extras = world == 1 and not args.no_extras
-        if extras and trained_blob is not None and fits("with_trained_weights", 3.2 * t_q + 8):
-            # a TRAINED network (tests/golden/c4net_trained_f32.npy, produced by examples/train_connect4.py — see
-            # tests/golden/README): priors are sharp, so trees are deep and narrow instead of the wide shallow trees of the
-            # random-init network (SURVEY §8d asks for both); same kernel
-            eng.load_weights(trained_blob)
-            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
-            t1 = time.perf_counter()
-            rt = eng.selfplay(cfg, base_seed=0, n_games=gh, first_game=next_first + args.concurrent, outputs=False)
-            dt4 = time.perf_counter() - t1
-            ct = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
+        if extras and trained_blob is not None and fits("with_trained_weights", 3.6 * t_q + 8):
+            out["with_trained_weights"] = trained_leg(eng, gh, next_first)
+            out["with_trained_weights"]["random_init_for_comparison"] = {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
+                                                                         "max_depth": c["max_depth"]}
             next_first += args.concurrent + gh
-            out["with_trained_weights"] = {
-                "games_per_s": gh / dt4, "games": gh, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
-                "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
-                "backprop_levels_per_explore": ct["backprop_levels"] / max(1, ct["explores"]),
-                "max_depth": ct["max_depth"], "leaf_evals_per_explore": ct["policy_evals"] / max(1, ct["explores"]),
-                "solved_leaf_share": ct["solved_hits"] / max(1, ct["explores"]),
-                "mfma_frac": (ct["policy_evals"] / 32768.0) * (gh / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "random_init_for_comparison": {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),
-                                               "max_depth": c["max_depth"]}}
-            eng.load_weights(blob)
         if extras and fits("with_replay_outputs_to_host", 1.2 * t_q + 6):
             # a launch with the replay outputs (positions, visit distributions, value targets, actions: 4.3 KB per game) copied to
             # host memory inside the timed region — the PCIe-inclusive rate (never `value`); kernel_ms is the same launch without
@@ -505,29 +549,12 @@ def main():
                 del ro
             else:
                 out["with_replay_outputs_to_host"] = {"skipped": "not enough host memory for the 4.3 KB per game of outputs"}
-        if world == 1 and not args.no_policy_cache and fits("with_policy_cache+reference_selfplay_config", 2.6 * t_q + 75):
+        if world == 1 and not args.no_policy_cache and fits("with_policy_cache+reference_selfplay_config", 5.0 * t_q + 40):
             # (a second engine beside the first: 2 x 60 GB of node pools + the 17 GB table fit the 288 GB of HBM)
             out.update(policy_cache_leg(gh, trained_blob if extras else None, reference_mcts=extras))
-        if extras and fits("with_conv_policy", 1.6 * t_q + 8):
-            # the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same
-            # engine, same MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)
-            eng.load_weights_conv(make_conv_weights())
-            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=next_first, outputs=False)
-            t1 = time.perf_counter()
-            rt = eng.selfplay(cfg, base_seed=0, n_games=gx, first_game=next_first + args.concurrent, outputs=False)
-            dt5 = time.perf_counter() - t1
-            conv_shape = list(eng.last_launch_shape())
-            cc = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=next_first + args.concurrent, outputs=False, counters=True)["counters"]
-            next_first += args.concurrent + gx
-            evals_per_s = (cc["policy_evals"] / 32768.0) * (gx / dt5)
-            out["with_conv_policy"] = {
-                "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
-                "games_per_s": gx / dt5, "games": gx, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
-                "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
-                "flop_per_eval": CONV_FLOP_PER_EVAL,
-                "mfma_frac": evals_per_s * CONV_FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "launch_shape": conv_shape}
-            eng.load_weights(blob)
+        if extras and fits("with_conv_policy", 3.0 * t_q + 8):
+            out["with_conv_policy"] = conv_leg(eng, gh, next_first)
+            next_first += args.concurrent + gh
         if extras and fits("launch_tail", 1.1 * t_q + 2):
             # the launch tail: a launch ends when its LAST game ends, so its final stretch runs on emptying tree slots. A launch of
             # a quarter of the games has the same tail on a quarter of the work: the difference between a full and a quarter launch

@@ -351,3 +351,78 @@ def test_epoch_kernel_modes_agree(tmp_path, golden_dir):
     for name in ("device_scope", "queued"):
         for k in ("w", "m", "v", "g", "l"):
             assert np.array_equal(outs["one_xcd"][k].view(np.uint32), outs[name][k].view(np.uint32)), (name, k)
+
+
+def test_learner_epochs_are_bit_reproducible_under_load(blob, gold):
+    """Long-run determinism stress of the three persistent learner kernels (train_epoch_kernel for Connect4Net,
+    train_conv_epoch_kernel_mw in f32 and in bf16 for Connect4ConvNet; loop body = alpha_zero.rs:72-94): 500 epochs in all, back to
+    back, WHILE self-play launches of a second engine keep arriving on the same GPU (half of the CUs taken, L2 / HBM shared — the
+    neighbours a learner has in the N-rank loop), and once per learner behind a launch that holds EVERY CU (the epoch kernel's
+    workers cannot all be resident: it waits, or falls back to queued launches from its snapshot). Every epoch must leave exactly
+    the bits of the undisturbed one — weights, both Adam moments, last gradient and per-step losses. A missing hazard wait, an LDS
+    reuse without a barrier or a stale cross-workgroup read shows up here as a flipped bit in some of the runs."""
+    import threading
+
+    import synthesis_amd as sa
+    from tests.test_gpu_convnet import conv_blob
+
+    my = gold["my_bb"].reshape(-1); op = gold["op_bb"].reshape(-1)
+    tpi = gold["target_pi"].reshape(-1, 9); tv = gold["target_v"].reshape(-1, 3)
+    # a few thousand positions: the goldens' positions repeated with rotated targets (the learner only sees arrays)
+    reps = max(1, 4096 // my.size)
+    my = np.tile(my, reps); op = np.tile(op, reps)
+    tpi = np.concatenate([np.roll(tpi, k, axis=0) for k in range(reps)]); tv = np.concatenate([np.roll(tv, k, axis=0) for k in range(reps)])
+    perm = np.random.default_rng(11).permutation(my.size).astype(np.int32)[: 192 * 32]
+
+    learn = sa.Engine(concurrent_games=64, max_explores=16)
+    learn.load_weights(blob)
+    small = sa.Engine(concurrent_games=2048, max_explores=200)     # 128 workgroups: half of the CUs
+    small.load_weights(blob)
+    big = sa.Engine(concurrent_games=65536, max_explores=200)      # one workgroup on every CU
+    big.load_weights(blob)
+    cfg = sa.parity_rollout_config(200)
+    stop = threading.Event()
+
+    def neighbours():
+        g = 0
+        while not stop.is_set():
+            small.selfplay(cfg, base_seed=5, n_games=4096, first_game=g, outputs=False)
+            g += 4096
+
+    def epoch(kind):
+        if kind == "mlp":
+            learn.trainer_init(blob)
+        else:
+            learn.trainer_init_conv(conv_blob())
+            if kind == "conv_bf16":
+                learn.trainer_set_precision("bf16")
+        learn.train_set_data(my, op, tpi, tv)
+        losses = learn.train_epoch(perm, 32, 1e-3)
+        st = learn.trainer_state()
+        return [st[k].view(np.uint32).copy() for k in ("weights", "m", "v", "grads")] + [losses.view(np.uint32).copy()]
+
+    refs = {kind: epoch(kind) for kind in ("mlp", "conv", "conv_bf16")}
+    th = threading.Thread(target=neighbours)
+    th.start()
+    try:
+        for kind, n in (("mlp", 168), ("conv", 166), ("conv_bf16", 166)):
+            for i in range(n):
+                got = epoch(kind)
+                for a, b, name in zip(got, refs[kind], ("weights", "m", "v", "grads", "losses")):
+                    assert np.array_equal(a, b), f"{kind}: epoch {i} differs from the undisturbed run in {name}"
+    finally:
+        stop.set()
+        th.join()
+    # behind a launch that holds every CU
+    for kind in ("mlp", "conv", "conv_bf16"):
+        box = {}
+        t2 = threading.Thread(target=lambda: box.update(r=big.selfplay(cfg, base_seed=9, n_games=196608, outputs=False)))
+        t2.start()
+        import time
+        time.sleep(0.3)
+        got = epoch(kind)
+        t2.join()
+        for a, b, name in zip(got, refs[kind], ("weights", "m", "v", "grads", "losses")):
+            assert np.array_equal(a, b), f"{kind}: epoch beside a full-chip launch differs in {name}"
+    for e in (learn, small, big):
+        e.close()

@@ -5,7 +5,7 @@
 # discussion quotes; distilled into gpurun_out/profiles_<tag>/ for copying into profiles/ (tracked).
 #   usage: tools/collect_profiles.sh r03 [fast]      ("fast": skip the SQ / TA / L2 passes)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 MODE=${2:-full}     # full | fast (no SQ / TA / L2 passes) | trace (only the kernel trace: refreshes <tag>_kernel_stats.csv)
 R=$PWD
 OUT=$R/gpurun_out/profiles_$TAG
@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 # the kernel trace runs the full default line (with its roofline objects); the counter passes only need the launches
 TRACE="bench.py --steps 2 --warmup 1 --full-warmup --no-cpu-baseline --no-4096 --no-policy-cache --no-extras --no-learner-loop"
 BENCH="bench.py --steps 1 --warmup 1 --skip-counted --no-learner-loop"
-CACHE="bench.py --only-policy-cache"
+CACHE="bench.py --only-extra-legs"
 run() {  # name, rocprof args..., -- program
   local name=$1; shift
   rm -rf $R/gpurun_out/prof_$name; mkdir -p $R/gpurun_out/prof_$name
@@ -29,11 +29,11 @@ run cwrite --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_cwrite -- 
 fi
 if [ "$MODE" = "full" ]; then
 run sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/prof_sq1 -- python3 $BENCH
-run sq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/gpurun_out/prof_sq2 -- python3 $BENCH
+run sq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/prof_sq2 -- python3 $BENCH
 run ta --pmc TA_TA_BUSY_sum TA_BUSY_avr --output-format csv -d $R/gpurun_out/prof_ta -- python3 $BENCH
 run l2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $R/gpurun_out/prof_l2 -- python3 $BENCH
 run csq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $R/gpurun_out/prof_csq1 -- python3 $CACHE
-run csq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/gpurun_out/prof_csq2 -- python3 $CACHE
+run csq2 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/prof_csq2 -- python3 $CACHE
 run cl2 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $R/gpurun_out/prof_cl2 -- python3 $CACHE
 fi
 cp $(ls -t $R/gpurun_out/prof_trace/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_kernel_stats.csv

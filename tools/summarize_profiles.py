@@ -43,7 +43,12 @@ def per_launch(name, pick, largest=True):
 # Fpu::Func configuration the general one (template arguments <MODE, COUNT, FAST, ...>)
 import re  # noqa: E402
 timed = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (true|1),", n) is not None
-# the reference's Fpu::Func configuration: its own instantiation (family 2) since round 3's last build, the general one (0) before
+# the extra legs of `bench.py --only-extra-legs`, told apart by their instantiation <MODE, COUNT, FAST, waves, PROF, POLICY>: PolicyWithCache
+# = the parity family on 12 waves, the trained network = the parity family on 16 waves, the conv network = POLICY 2, the reference's
+# Fpu::Func configuration = family 2 (the runtime-switched instantiation before round 4)
+leg_cache = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 12, (false|0), 0>", n) is not None
+leg_trained = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 16, (false|0), 0>", n) is not None
+leg_conv = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 16, (false|0), 2>", n) is not None
 timed_general = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (false|0|2),", n) is not None
 line = None
 for l in open(f"{out}/{tag}_bench_lines_under_profiler.jsonl"):
@@ -55,8 +60,12 @@ if os.path.exists(f"{out}/{tag}_cache_lines_under_profiler.jsonl"):
         cache_line = json.loads(l)
 f, nf = per_launch("pmc_fetch", timed)
 w, nw = per_launch("pmc_write", timed)
-cf, _ = per_launch("pmc_cfetch", timed)
-cw, _ = per_launch("pmc_cwrite", timed)
+cf, _ = per_launch("pmc_cfetch", leg_cache)
+cw, _ = per_launch("pmc_cwrite", leg_cache)
+tf, _ = per_launch("pmc_cfetch", leg_trained)
+tw, _ = per_launch("pmc_cwrite", leg_trained)
+vf, _ = per_launch("pmc_cfetch", leg_conv)
+vw, _ = per_launch("pmc_cwrite", leg_conv)
 rf, _ = per_launch("pmc_cfetch", timed_general)
 rw, _ = per_launch("pmc_cwrite", timed_general)
 ks = [r for r in csv.DictReader(open(f"{out}/{tag}_kernel_stats.csv")) if timed(r["Name"])]
@@ -77,14 +86,20 @@ summary = {
     "kernel_max_ms": float(ks[0]["MaxNs"]) / 1e6 if ks and "MaxNs" in ks[0] else None,
     "FETCH_SIZE_kb_per_launch": f.get("FETCH_SIZE"), "WRITE_SIZE_kb_per_launch": w.get("WRITE_SIZE"),
     "traffic_bytes_per_launch": traffic(f, w),
-    "cache_command": "python3 bench.py --only-policy-cache   (both legs; the largest dispatch of each kernel instantiation)",
+    "cache_command": "python3 bench.py --only-extra-legs   (four legs; the largest dispatch of each kernel instantiation)",
     "cache_FETCH_SIZE_kb_per_launch": cf.get("FETCH_SIZE"), "cache_WRITE_SIZE_kb_per_launch": cw.get("WRITE_SIZE"),
     "cache_traffic_bytes_per_launch": traffic(cf, cw),
     "reference_FETCH_SIZE_kb_per_launch": rf.get("FETCH_SIZE"), "reference_WRITE_SIZE_kb_per_launch": rw.get("WRITE_SIZE"),
     "reference_traffic_bytes_per_launch": traffic(rf, rw),
+    "trained_FETCH_SIZE_kb_per_launch": tf.get("FETCH_SIZE"), "trained_WRITE_SIZE_kb_per_launch": tw.get("WRITE_SIZE"),
+    "trained_traffic_bytes_per_launch": traffic(tf, tw),
+    "conv_FETCH_SIZE_kb_per_launch": vf.get("FETCH_SIZE"), "conv_WRITE_SIZE_kb_per_launch": vw.get("WRITE_SIZE"),
+    "conv_traffic_bytes_per_launch": traffic(vf, vw),
     "extra_leg_games": {
         "cache_traffic_bytes_per_launch": (cache_line or {}).get("with_policy_cache", {}).get("games"),
         "reference_traffic_bytes_per_launch": (cache_line or {}).get("reference_selfplay_config", {}).get("games"),
+        "trained_traffic_bytes_per_launch": (cache_line or {}).get("with_trained_weights", {}).get("games"),
+        "conv_traffic_bytes_per_launch": (cache_line or {}).get("with_conv_policy", {}).get("games"),
     },
 }
 json.dump(summary, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
@@ -101,6 +116,8 @@ def derive(sq, waves_per_simd):
         "valu_issue_non_mfma_if_INSTS_VALU_includes_mfma": (sq.get("SQ_INSTS_VALU", 0) - sq.get("SQ_INSTS_MFMA", 0)) * 4.0 / simd_cycles,
         "valu_issue_if_INSTS_VALU_excludes_mfma": sq.get("SQ_INSTS_VALU", 0) * 4.0 / simd_cycles,
         "l2_hit_rate": sq.get("TCC_HIT_sum", 0) / max(1.0, sq.get("TCC_REQ_sum", 1.0)),
+        "valu_mfma_coexec_share_of_simd_cycles": sq.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0) / simd_cycles if "SQ_VALU_MFMA_COEXEC_CYCLES" in sq else None,
+        "wait_any_share_of_wave_cycles": sq.get("SQ_WAIT_ANY", 0) / wave if "SQ_WAIT_ANY" in sq else None,
         "wait_inst_any_share_of_wave_cycles": sq.get("SQ_WAIT_INST_ANY", 0) / wave,
         "active_inst_any_share_of_wave_cycles": sq.get("SQ_ACTIVE_INST_ANY", 0) / wave,
     }
@@ -115,10 +132,10 @@ if sq:
     d["derived"] = derive(sq, 4)
 csq = {}
 for name in ("pmc_csq1", "pmc_csq2", "pmc_cl2"):
-    csq.update(per_launch(name, timed)[0])
+    csq.update(per_launch(name, leg_cache)[0])
 if csq:
-    d["policy_cache_leg"] = {"command": "python3 bench.py --only-policy-cache (the largest FAST self-play dispatch of each pass)",
-                             "counters_per_launch": csq, "derived": derive(csq, 4)}
+    d["policy_cache_leg"] = {"command": "python3 bench.py --only-extra-legs (the largest 12-wave parity-family dispatch of each pass)",
+                             "counters_per_launch": csq, "derived": derive(csq, 3)}
 if sq or csq:
     json.dump(d, open(f"{out}/{tag}_sq.json", "w"), indent=1)
 print(json.dumps(summary))
