@@ -311,10 +311,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
             if (P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, C.my, C.op, lg, v0, v1, v2);
             // root noise applies to the root's own expansion (mcts.rs:229-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
-            solved = lane_write_children(T.slab, C.blk, lmask, C.my, C.op, pr,
-                                         (!FAST && T.iter == 0 && C.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
-                                         P.mcts.noise_alpha, lane_noise_seed(),
-                                         cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag);
+            solved = (lane_write_children(T.slab, C.blk, lmask, C.my, C.op, pr,
+                                          (!FAST && T.iter == 0 && C.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
+                                          P.mcts.noise_alpha, lane_noise_seed(),
+                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag) & LEAF_ANY_SOLVED) != 0u;
         }
         lane_backprop<COUNT, FAST>(P.mcts, T, C.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, nullptr);
         if (fin) {

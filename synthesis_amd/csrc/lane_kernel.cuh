@@ -610,12 +610,15 @@ SYN_DEV void lane_softmaxes(uint32_t lmask, const float (&lg)[9], float (&pr)[9]
 }
 
 // The rest of visit() for the node expanded in phase A (mcts.rs:389-423): writes its block — one record per legal column
-// (terminal children already solved) with the priors `pr` of lane_softmaxes. Returns any_solved.
+// (terminal children already solved) with the priors `pr` of lane_softmaxes. Returns what backprop's solver walk needs to know
+// about the new node without reading its line back: LEAF_ANY_SOLVED (some child is terminal), LEAF_ANY_WIN (some child's mover made
+// four: the child is Lose(0), the new node Win(1)), LEAF_ALL_OVER (every child is terminal).
 // `hdr_flag` (out): the value for word 3 of the block's header — non-zero iff some prior lies outside the range the descent's
 // packed division is exact on (tiny but non-zero, or not finite); backprop writes the header (sums + this word).
 // Root noise (mcts.rs:229-269) applies when `noise_kind` != 0 (the caller passes it for the root's own expansion only):
 // 1 = PolicyNoise::Equal{weight}, 2 = PolicyNoise::Dirichlet{alpha, weight} sampled from the tree's stream (noise.cuh).
-SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lmask, uint64_t leaf_my, uint64_t leaf_op,
+enum : uint32_t { LEAF_ANY_SOLVED = 1u, LEAF_ANY_WIN = 2u, LEAF_ALL_OVER = 4u };
+SYN_DEV uint32_t lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lmask, uint64_t leaf_my, uint64_t leaf_op,
                                  const float (&pr)[9], int noise_kind, float noise_weight, float noise_alpha, uint64_t noise_seed,
                                  float y_unvisited, uint32_t& hdr_flag, bool store_twice = false) {
     const uint32_t nc = (uint32_t)__popc(lmask);
@@ -635,7 +638,7 @@ SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lma
     const bool last_cell = __popcll(occ) == 62;
     unsigned char* const rec0 = rec_ptr(slab, blk * 16u);
     uint32_t idx = 0;
-    bool any_solved = false, flag = false;
+    bool any_solved = false, flag = false, any_win = false, all_over = true;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const bool legal = ((lmask >> c) & 1u) != 0u;
@@ -659,6 +662,8 @@ SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lma
                 lp_fence();
             }
             any_solved = any_solved || over;
+            any_win = any_win || w;
+            all_over = all_over && over;
             idx++;
         }
     }
@@ -668,7 +673,7 @@ SYN_DEV bool lane_write_children(unsigned char* slab, uint32_t blk, uint32_t lma
             if (k >= nc) st_rec_none(slab, blk * 16u + k);
     }
     hdr_flag = flag ? 1u : 0u;
-    return any_solved;
+    return (any_solved ? LEAF_ANY_SOLVED : 0u) | (any_win ? LEAF_ANY_WIN : 0u) | (all_over ? LEAF_ALL_OVER : 0u);
 }
 
 // Both steps for callers that hold the value head's probabilities already (pc_kernel.cuh).
@@ -678,8 +683,8 @@ SYN_DEV bool lane_create_children(unsigned char* slab, uint32_t blk, const LaneL
     float pr[9];
     float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f;
     lane_softmaxes(X.legal_mask, lg, pr, false, u0, u1, u2);
-    return lane_write_children(slab, blk, X.legal_mask, leaf_my, leaf_op, pr, noise_kind, noise_weight, noise_alpha, noise_seed,
-                               y_unvisited, hdr_flag);
+    return (lane_write_children(slab, blk, X.legal_mask, leaf_my, leaf_op, pr, noise_kind, noise_weight, noise_alpha, noise_seed,
+                                y_unvisited, hdr_flag) & LEAF_ANY_SOLVED) != 0u;
 }
 
 SYN_DEV int wave_max_i32(int v) {
@@ -699,12 +704,19 @@ SYN_DEV int wave_max_i32(int v) {
 //            (win/lose swapped once per level climbed) and one visit, so the levels are independent; the node's sums
 //            come from the path log's second plane (the descent read them with the line it needed anyway), so four
 //            levels cost ONE round trip of coalesced rows and no random line read — only the dirtied lines remain.
-template <bool COUNT, int FAST>
 // `leaf_flag`: header word 3 of the node expanded in this pass (lane_create_children), 0 otherwise; every other visited node
 // keeps the word it has (a node that was never backpropagated into has no header yet: 0).
+// LEAF_KNOWN (the one-tree-per-lane kernel): the solver walk's FIRST level — the leaf itself — is decided without reading the
+// leaf's line. `leaf_code` != 0: the node was expanded in this pass and lane_write_children reported its children (it has no
+// visits, no sums and no solution of its own yet): a winning child makes it Win(1), else it is solved only if every child is
+// terminal (then a Draw(1)). `leaf_code` == 0: explore() stopped on a node that already was solved (mcts.rs:314-316, or a terminal
+// node's first visit): nothing below a solved node changes once it is solved — no descent passes through it — so the maximum over
+// its children that backprop recomputes (mcts.rs:441-449) is its own solution and, unless that is a Win, all its children are still
+// solved; only its sums are needed, and only if it was visited before (one 16-byte load).
+template <bool COUNT, int FAST, bool LEAF_KNOWN = false>
 SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float d0, float d1, float d2, bool solved,
                            bool active, const uint4* pl, uint32_t* ctr, uint32_t leaf_flag, unsigned long long* t_mid = nullptr,
-                           LaneProf* lp = nullptr) {
+                           LaneProf* lp = nullptr, uint32_t leaf_code = 0u) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     if (COUNT && active) {
@@ -715,55 +727,84 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
     // ---- phase 1
     if (cfg.solve() && solved && L >= 0) {
         uint4 pe = pl[L * 64];
+        bool first = LEAF_KNOWN;
         for (;;) {
             const uint32_t rec = pe.x, meta = pe.z;
             float N = bits_f32(pe.y);
             const uint32_t blk = pm_blk(meta), nc = pm_nc(meta);
-            // one line: the node's sums and its children's records; plus the next level's path entry
             const uint4* line = reinterpret_cast<const uint4*>(blk_ptr(slab, blk));
-            const uint4 hdr = line[0];
-            uint32_t d[28];
-#pragma unroll
-            for (int j = 0; j < 7; j++) {
-                const uint4 t = line[1 + j];
-                d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
-            }
-            const uint4 pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
-            if (lp_abl(lp, ABL_WALK_LD)) {
-                lp_fence();
-                uint32_t sink = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint4 t = line[j];
-                    sink ^= t.x ^ t.y ^ t.z ^ t.w;
-                }
-                asm volatile("" ::"v"(sink));
-            }
-            if (lp) {
-                const unsigned long long t0_ = lp_now();
-                lp_wait_vm(lp);
-                lp_step(lp, LP_W_WAIT, LP_W_ITERS, LP_W_LANES, lp_now() - t0_);
-            }
-            // a node that was never backpropagated into has nothing in its header yet
-            float W0 = N == 0.0f ? 0.0f : bits_f32(hdr.x), W1 = N == 0.0f ? 0.0f : bits_f32(hdr.y),
-                  W2 = N == 0.0f ? 0.0f : bits_f32(hdr.z);
-            bool all_solved = true;
-            uint32_t key = outcome_key(pm_solved(meta), pm_kind(meta), pe.w);
-            if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
-#pragma unroll
-            for (uint32_t i = 0; i < 9; i++) {
-                if (i < nc) {
-                    const uint32_t nf = d[3 * i + 2];
-                    all_solved = all_solved && nf_solved(nf);
-                    // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
-                    const uint32_t ck = nf_kind(nf);
-                    const uint32_t rk = nf_solved(nf) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
-                    key = rk > key ? rk : key;
-                }
-            }
-            bool bsome;
+            float W0 = 0.0f, W1 = 0.0f, W2 = 0.0f;
+            uint32_t w_old = 0u;
+            bool bsome, all_solved = true;
             uint32_t bkind, bturns;
-            outcome_from_key(key, bsome, bkind, bturns);
+            uint4 pe_next;
+            if (LEAF_KNOWN && first) {
+                // the leaf's own level (see the comment above the function)
+                pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
+                if (leaf_code == 0u && N != 0.0f) {
+                    const uint4 hdr = line[0];
+                    W0 = bits_f32(hdr.x); W1 = bits_f32(hdr.y); W2 = bits_f32(hdr.z);
+                    w_old = hdr.w;
+                }
+                if (leaf_code != 0u) {
+                    bsome = true;
+                    bkind = (leaf_code & LEAF_ANY_WIN) ? 2u : 1u;
+                    bturns = 1u;
+                    all_solved = (leaf_code & LEAF_ALL_OVER) != 0u;
+                    if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+                } else {
+                    bsome = pm_solved(meta);
+                    bkind = pm_kind(meta);
+                    bturns = pe.w;
+                    if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+                }
+                if (lp) lp_step(lp, LP_W_WAIT, LP_W_ITERS, LP_W_LANES, 0ull);
+            } else {
+                // one line: the node's sums and its children's records; plus the next level's path entry
+                const uint4 hdr = line[0];
+                uint32_t d[28];
+#pragma unroll
+                for (int j = 0; j < 7; j++) {
+                    const uint4 t = line[1 + j];
+                    d[4 * j] = t.x; d[4 * j + 1] = t.y; d[4 * j + 2] = t.z; d[4 * j + 3] = t.w;
+                }
+                pe_next = pl[(L > 0 ? L - 1 : 0) * 64];
+                if (lp_abl(lp, ABL_WALK_LD)) {
+                    lp_fence();
+                    uint32_t sink = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint4 t = line[j];
+                        sink ^= t.x ^ t.y ^ t.z ^ t.w;
+                    }
+                    asm volatile("" ::"v"(sink));
+                }
+                if (lp) {
+                    const unsigned long long t0_ = lp_now();
+                    lp_wait_vm(lp);
+                    lp_step(lp, LP_W_WAIT, LP_W_ITERS, LP_W_LANES, lp_now() - t0_);
+                }
+                // a node that was never backpropagated into has nothing in its header yet
+                W0 = N == 0.0f ? 0.0f : bits_f32(hdr.x);
+                W1 = N == 0.0f ? 0.0f : bits_f32(hdr.y);
+                W2 = N == 0.0f ? 0.0f : bits_f32(hdr.z);
+                w_old = hdr.w;
+                uint32_t key = outcome_key(pm_solved(meta), pm_kind(meta), pe.w);
+                if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+#pragma unroll
+                for (uint32_t i = 0; i < 9; i++) {
+                    if (i < nc) {
+                        const uint32_t nf = d[3 * i + 2];
+                        all_solved = all_solved && nf_solved(nf);
+                        // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
+                        const uint32_t ck = nf_kind(nf);
+                        const uint32_t rk = nf_solved(nf) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
+                        key = rk > key ? rk : key;
+                    }
+                }
+                outcome_from_key(key, bsome, bkind, bturns);
+            }
+            first = false;
             if (bsome && bkind == 2u) {
                 if (cfg.correct_values()) {
                     d0 = -W0;
@@ -786,7 +827,7 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
             W1 += d1;
             W2 += d2;
             N += 1.0f;
-            const uint32_t w3 = N != 1.0f ? hdr.w : (L == depth ? leaf_flag : 0u);  // (N was incremented above)
+            const uint32_t w3 = N != 1.0f ? w_old : (L == depth ? leaf_flag : 0u);  // (N was incremented above)
             *reinterpret_cast<float4*>(blk_ptr(slab, blk)) = make_float4(W0, W1, W2, bits_f32(w3));
             if (rec != REC_ROOT) {
                 // the node is (still) solved: its q slot carries the turn count, its record the outcome
@@ -1340,8 +1381,7 @@ SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, int
 // ---------------------------------------------------------------------------------------------- the kernel
 template <int NW>
 struct LaneLds {
-    static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
-    static constexpr size_t IDX_OFF = OUT_OFF + (size_t)NW * 1024;     // + 1 KB result patch per wave
+    static constexpr size_t IDX_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
     static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;        // + 64 B compaction index per wave
     static constexpr size_t PARK_OFF = FT_OFF + 64;                    // + the four feature shift tables (16 B each)
     static constexpr size_t BYTES = PARK_OFF + (size_t)NW * 64 * 20;   // + 5 parked dwords per lane (root boards, turn|rng)
@@ -1364,7 +1404,6 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    float* outw = reinterpret_cast<float*>(smem_raw + LaneLds<NW>::OUT_OFF) + wave * 256;
 
     if (POLICY == 0) stage_weight_image(wimg, P.wimg, tid, NT);
     if (POLICY == 2) stage_conv_image(wimg, P.wimg, tid, NT);
@@ -1509,28 +1548,29 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                     const f32x4 o2 = mlp_tile16_pipe(wimg, bimg, lane, FT, thi2, tlo2);
                     asm volatile("" ::"v"(o2));
                 }
-                o = NW >= 16 ? mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo) : mlp_tile16(wimg, bimg, lane, FT, thi, tlo);
+                o = mlp_tile16_pipe(wimg, bimg, lane, FT, thi, tlo);   // (the hand-pipelined tile at every wave count: the plain one spills around the crossbar fetches below)
             }
             // (raw outputs: the softmax over the three outcome logits runs per tree lane in phase C, lane_softmaxes)
             const unsigned long long lp_b1 = lp ? lp_now() : 0ull;
             if (lp) lp_add(lp, LP_B_TILE, lp_b1 - lp_b0);
-            const int q = lane >> 4;
-            if (q < 3) *reinterpret_cast<f32x4*>(outw + (lane & 15) * 16 + q * 4) = o;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (need && (rank >> 4) == j) {
-                const float* mine = outw + (rank & 15) * 16;
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(mine);
-                const f32x4 r1 = *reinterpret_cast<const f32x4*>(mine + 4);
-                const f32x4 r2 = *reinterpret_cast<const f32x4*>(mine + 8);
-                lg[0] = r0[0]; lg[1] = r0[1]; lg[2] = r0[2]; lg[3] = r0[3];
-                lg[4] = r1[0]; lg[5] = r1[1]; lg[6] = r1[2]; lg[7] = r1[3];
-                lg[8] = r2[0]; v0 = r2[1]; v1 = r2[2]; v2 = r2[3];
+            // The 12 outputs of position (rank & 15) sit in register r of lanes (rank & 15) + 16 q, q = 0..2: every lane fetches
+            // "its" twelve values through the LDS crossbar (ds_bpermute: no LDS memory, no barrier) and the lanes whose request was
+            // in this tile keep them. (Rounds 1-3 passed them through a 1 KB LDS patch per wave behind two wave barriers per tile.)
+            {
+                const int pos4 = (rank & 15) << 2;
+                float t12[12];
+#pragma unroll
+                for (int qq = 0; qq < 3; qq++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        t12[4 * qq + k] = bits_f32((uint32_t)__builtin_amdgcn_ds_bpermute(pos4 + 64 * qq, (int)f32_bits(o[k])));
+                const bool mine = need && (rank >> 4) == j;
+#pragma unroll
+                for (int c = 0; c < 9; c++) lg[c] = mine ? t12[c] : lg[c];
+                v0 = mine ? t12[9] : v0;
+                v1 = mine ? t12[10] : v1;
+                v2 = mine ? t12[11] : v2;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (lp) lp_add(lp, LP_B_SCATTER, lp_now() - lp_b1);
         }
 
@@ -1540,7 +1580,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 
         // ---- phase C
         bool solved = X.solved;
-        uint32_t leaf_flag = 0;
+        uint32_t leaf_flag = 0, leaf_code = 0;
         if (need || hit) {
             // the leaf's two softmaxes (RolloutPolicy delivers outcome probabilities already), then — with the probabilities —
             // the PolicyWithCache entry of a position the network has just evaluated
@@ -1560,15 +1600,16 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
             if (POLICY != 1 && P.cache != nullptr && need) cache_insert(P.cache, P.cache_shift, Wk.my, Wk.op, lg, v0, v1, v2);
             // PolicyNoise::Equal applies to the root's own expansion (mcts.rs:258-269): the first pass of a tree
             const CfgView<FAST> cv{P.mcts};
-            solved = lane_write_children(T.slab, Wk.blk, X.legal_mask, Wk.my, Wk.op, pr,
+            leaf_code = lane_write_children(T.slab, Wk.blk, X.legal_mask, Wk.my, Wk.op, pr,
                                          (FAST == 0 && T.iter == 0 && Wk.level == 0) ? P.mcts.noise : 0, P.mcts.noise_weight,
                                          P.mcts.noise_alpha, lane_noise_seed(),
                                          cv.fpu_const() ? cv.fpu_value() : 0.0f, leaf_flag, lp_abl(lp, ABL_CHILD_ST));
+            solved = (leaf_code & LEAF_ANY_SOLVED) != 0u;
             if (lp) lp_add(lp, LP_C_WRITE, lp_now() - lp_c0);
         }
         SYN_LAP(pC1)
         unsigned long long tmid = 0;
-        lane_backprop<COUNT, FAST>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, PROF ? &tmid : nullptr, lp);
+        lane_backprop<COUNT, FAST, true>(P.mcts, T, Wk.level, v0, v1, v2, solved, fin, pl, ctr, leaf_flag, PROF ? &tmid : nullptr, lp, leaf_code);
         if (PROF) { pC2 += tmid - pT; pT = tmid; }
         SYN_LAP(pC)
         if (fin) {
