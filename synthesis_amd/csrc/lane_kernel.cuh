@@ -652,25 +652,25 @@ SYN_DEV uint32_t lane_write_children(unsigned char* slab, uint32_t blk, uint32_t
         }
         const bool w = (win_drop & (0x7Full << (7 * c))) != 0ull;  // won(child.op_bb): the mover's stones plus this one (connect4.rs:224-229)
         const bool over = w || last_cell;
-        // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost; turns 0
-        if (legal) {
-            flag = flag || !(p == 0.0f || (p >= PRIOR_SAFE_MIN && p <= 2.0f));
-            *reinterpret_cast<lu3*>(rec0 + idx * 12u) = lu3{over ? 0u : f32_bits(y_unvisited), f32_bits(p), nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u)};
-            if (store_twice) {
-                lp_fence();
-                *reinterpret_cast<lu3*>(rec0 + idx * 12u) = lu3{over ? 0u : f32_bits(y_unvisited), f32_bits(p), nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u)};
-                lp_fence();
-            }
-            any_solved = any_solved || over;
-            any_win = any_win || w;
-            all_over = all_over && over;
-            idx++;
+        // Outcome::from(reward(child.player())): the mover won -> the child's side to move lost; turns 0.
+        // Every COLUMN stores exactly one record, without a branch: a legal column the record of its child (slot idx, in ascending
+        // column order), a full column one of the "no child" records {-inf, 0, 0} that fill the slots behind the last child (slot
+        // nc + the number of full columns before it) — the nine stores cover the nine slots exactly once.
+        const uint32_t slot = legal ? idx : nc + ((uint32_t)c - idx);
+        const uint32_t r_qt = legal ? (over ? 0u : f32_bits(y_unvisited)) : 0xFF800000u;
+        const uint32_t r_p = legal ? f32_bits(p) : 0u;
+        const uint32_t r_nf = legal ? nf_make(0u, over, 0u, over ? (w ? 0u : 1u) : 0u) : 0u;
+        *reinterpret_cast<lu3*>(rec0 + slot * 12u) = lu3{r_qt, r_p, r_nf};
+        if (store_twice) {
+            lp_fence();
+            *reinterpret_cast<lu3*>(rec0 + slot * 12u) = lu3{r_qt, r_p, r_nf};
+            lp_fence();
         }
-    }
-    if (__ballot(nc < 9u) != 0ull) {  // late game: some columns are full
-#pragma unroll
-        for (uint32_t k = 1; k < 9; k++)
-            if (k >= nc) st_rec_none(slab, blk * 16u + k);
+        flag = flag || (legal && !(p == 0.0f || (p >= PRIOR_SAFE_MIN && p <= 2.0f)));
+        any_solved = any_solved || (legal && over);
+        any_win = any_win || (legal && w);
+        all_over = all_over && (!legal || over);
+        idx += legal ? 1u : 0u;
     }
     hdr_flag = flag ? 1u : 0u;
     return (any_solved ? LEAF_ANY_SOLVED : 0u) | (any_win ? LEAF_ANY_WIN : 0u) | (all_over ? LEAF_ALL_OVER : 0u);
