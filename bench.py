@@ -607,11 +607,14 @@ def main():
                     lg = e2.selfplay_lockstep(cfg, base_seed=3, n_games=4096)
                     dt_g = time.perf_counter() - t1
                     sg = lg["stats"]
+                    played = np.arange(63)[None, :] < r2s["plies"][:, None]   # (entries past a game's last ply are unspecified)
                     out["at_4096_concurrent_games"]["lockstep_host_trees"].update({
                         "games": 4096, "games_per_s": 4096 / dt_g, "selfplay_seconds": dt_g,
                         "selfplay_seconds_in_policy_eval": sg["seconds_policy"], "selfplay_policy_eval_launches": sg["rounds"],
                         "selfplay_leaf_evals_per_s": sg["positions_evaluated"] / dt_g,
-                        "games_identical_to_fused_selfplay": bool(all(np.array_equal(lg[k], r2s[k]) for k in ("plies", "final_kind", "actions", "root_nodes")))})
+                        "games_identical_to_fused_selfplay": bool(
+                            np.array_equal(lg["plies"], r2s["plies"]) and np.array_equal(lg["final_kind"], r2s["final_kind"]) and
+                            all(np.array_equal(lg[k][played], r2s[k][played]) for k in ("actions", "root_nodes", "states_bb", "pis", "vs")))})
             except Exception as ex:  # noqa: BLE001
                 out["at_4096_concurrent_games"]["lockstep_host_trees"] = {"error": str(ex)[:200]}
             e2.close()
