@@ -77,12 +77,14 @@ class LearningLoop:
         self.games_played = 0
         self.iterations_done = 0
 
-    # one replay position on the wire: my_bb, op_bb (u64), gid (i64), pi[9], v[3] (f32) = 72 bytes, no pickling
-    _POS = np.dtype([("my", "<u8"), ("op", "<u8"), ("gid", "<i8"), ("pi", "<f4", (9,)), ("v", "<f4", (3,))])
+    # one replay position on the wire: my_bb, op_bb (u64), gid (i64), pi[9], v[3] (f32) = 72 bytes, no pickling. A rank's buffer is
+    # five contiguous sections [my | op | gid | pi | v] of `cap` positions each (five block copies to pack, views to unpack).
+    _FIELDS = (("my", np.uint64, 1), ("op", np.uint64, 1), ("gid", np.int64, 1), ("pi", np.float32, 9), ("v", np.float32, 3))
+    _POS_BYTES = 72
 
     def _gather_positions(self, new):
         """The ranks' new positions to the learner's rank (in rank order = game order) as ONE fixed-layout tensor gather: the
-        counts travel first (one all_gather of an int64 per rank), then every rank contributes a buffer of the largest count —
+        counts travel first (one all_gather of an int64 per rank), then every rank contributes a buffer sized for the largest count —
         device buffers under RCCL, host buffers under gloo. (The round-3 form pickled a dict of arrays per rank: rank 0 unpickled
         8 x 18 MB per iteration.)"""
         t = self._torch
@@ -94,18 +96,28 @@ class LearningLoop:
         self.dist.all_gather(counts, cnt)
         counts = [int(c.item()) for c in counts]
         cap = max(max(counts), 1)
-        rec = np.zeros(cap, self._POS)
-        for k in ("my", "op", "gid", "pi", "v"):
-            rec[k][:n] = new[k]
-        mine = t.from_numpy(rec.view(np.uint8).reshape(-1))
+        buf = np.empty(cap * self._POS_BYTES, np.uint8)
+        off = 0
+        for name, dt, width in self._FIELDS:
+            sec = buf[off: off + cap * np.dtype(dt).itemsize * width].view(dt)
+            sec[: n * width] = np.ascontiguousarray(new[name], dtype=dt).reshape(-1)
+            off += cap * np.dtype(dt).itemsize * width
+        mine = t.from_numpy(buf)
         if on_gpu:
             mine = mine.to(dev)
         parts = [t.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
         self.dist.gather(mine, parts, dst=0)
         if self.rank != 0:
             return new
-        out = [p_.cpu().numpy().view(self._POS)[:c] for p_, c in zip(parts, counts)]
-        return {k: np.concatenate([o[k] for o in out]) for k in ("my", "op", "pi", "v", "gid")}
+        out = {name: [] for name, _, _ in self._FIELDS}
+        for p_, c in zip(parts, counts):
+            raw = p_.cpu().numpy()
+            off = 0
+            for name, dt, width in self._FIELDS:
+                sec = raw[off: off + cap * np.dtype(dt).itemsize * width].view(dt)[: c * width]
+                out[name].append(sec.reshape(c, width) if width > 1 else sec)
+                off += cap * np.dtype(dt).itemsize * width
+        return {k: np.concatenate(v) for k, v in out.items()}
 
     def iteration(self, cfg, games_per_train, games_to_keep, epochs, batch_size):
         """One pass of the loop body (alpha_zero.rs:42-100). Returns this rank's record of it (rank 0's has the learner's numbers)."""
