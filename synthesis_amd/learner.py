@@ -93,8 +93,10 @@ class LearningLoop:
         dev = self._wbuf.device
         cnt = t.tensor([n], dtype=t.int64, device=dev)
         counts = [t.zeros(1, dtype=t.int64, device=dev) for _ in range(self.world)]
-        self.dist.all_gather(counts, cnt)
+        t_w = time.perf_counter()
+        self.dist.all_gather(counts, cnt)     # (also where a rank waits for the slowest rank's self-play to end)
         counts = [int(c.item()) for c in counts]
+        self._last_gather_wait = time.perf_counter() - t_w
         cap = max(max(counts), 1)
         buf = np.empty(cap * self._POS_BYTES, np.uint8)
         off = 0
@@ -133,9 +135,10 @@ class LearningLoop:
         new = dict(my=sp["states_bb"][..., 0][mask], op=sp["states_bb"][..., 1][mask], pi=sp["pis"][mask], v=sp["vs"][mask],
                    gid=(first + np.arange(count))[:, None].repeat(63, 1)[mask])
         t1 = time.perf_counter()
+        self._last_gather_wait = 0.0
         if self.dist is not None:
             new = self._gather_positions(new)
-        t_gather = time.perf_counter() - t1
+        t_gather = time.perf_counter() - t1 - self._last_gather_wait   # pack + gather + unpack, without the wait for the slowest rank
         self.games_played += games_per_train
         lr = _lr_at(self.lr_schedule, it)
         rec = dict(iteration=it + 1, lr=lr, games=int(games_per_train), games_this_rank=int(count),
@@ -176,7 +179,8 @@ class LearningLoop:
             self.engine.trainer_publish_weights()   # one rank: the learner's image is copied on the device
         t_bcast = time.perf_counter() - t4
         self.iterations_done += 1
-        rec["seconds"] = dict(selfplay=round(t_play, 4), gather=round(t_gather, 4), dedup=round(t_dedup, 4), train=round(t_train, 4),
+        rec["seconds"] = dict(selfplay=round(t_play, 4), wait_for_ranks=round(self._last_gather_wait, 4), gather=round(t_gather, 4),
+                              dedup=round(t_dedup, 4), train=round(t_train, 4),
                               broadcast=round(t_bcast, 4), total=round(time.perf_counter() - t0, 4))
         return rec
 
