@@ -205,3 +205,26 @@ def test_lockstep_selfplay_on_the_gpu_equals_the_fused_selfplay(oracle, golden_d
         eng.selfplay_lockstep(sa.parity_rollout_config(8, mcts_cfg=sa.reference_selfplay_mcts_config()), 1, 4)
     assert e.value.code == -5
     eng.close()
+
+
+def test_lockstep_host_code_is_clean_under_asan_and_ubsan(oracle, golden_dir, tmp_path):
+    """The host side above the C ABI (product code: include/synthesis_amd_lockstep.hpp — trees, worker pool, StdRng, the self-play
+    loop) under AddressSanitizer + UndefinedBehaviorSanitizer: the harness rebuilt with both, searches on 4 threads and whole games
+    on 3; any report aborts the binary. (GPU sanitizers are unavailable on the pool; the oracle side has its own such test.)"""
+    exe = str(tmp_path / "lockstep_harness_san")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-ffp-contract=off",
+                           "-pthread", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "lockstep_harness.cpp"),
+                           "-o", exe, "-L" + odir, "-loracle", "-Wl,-rpath," + odir])
+    blob = str(tmp_path / "blob.f32")
+    np.load(os.path.join(golden_dir, "c4net_blob_f32.npy")).astype("<f4").tofile(blob)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    from tests.test_gpu_parity import random_positions
+    my, op = random_positions(oracle, 24, seed=5, max_moves=40)
+    roots = str(tmp_path / "roots.u64")
+    np.concatenate([my, op]).astype("<u8").tofile(roots)
+    for args in (["c4", blob, roots, "60", "0", "4", str(tmp_path / "o1.bin")], ["c4", blob, roots, "40", "1", "2", str(tmp_path / "o2.bin")],
+                 ["selfplay", blob, "6", "40", "0", "3", "9", "0", str(tmp_path / "o3.bin")],
+                 ["selfplay", blob, "4", "30", "3", "2", "1", "7", str(tmp_path / "o4.bin")], ["nim"], ["nimthrow"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, " ".join(args) + "\n" + p.stdout[-1500:] + p.stderr[-3000:]
