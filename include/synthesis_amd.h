@@ -188,8 +188,8 @@ int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t 
  * all n searches advance in lock step, and every round's leaves go through ONE syn_policy_eval_batch launch. This is the driver a
  * caller with a different Game impl instantiates; for Connect4 the fused syn_mcts_search is the fast path and this entry point
  * exists to hold the driver to it: results are identical, field for field. host_threads: threads for the tree phases (0 = the
- * host's hardware concurrency, at most 32). cfg: SYN_FPU_NORMAL and SYN_NOISE_DIRICHLET return SYN_ERR_UNSUPPORTED (their
- * draws are defined on the device path's per-tree streams). stats may be NULL. */
+ * host's hardware concurrency, at most 32). cfg: SYN_FPU_NORMAL draws what syn_mcts_search draws (root i: tree stream (i, turn 0));
+ * SYN_NOISE_DIRICHLET returns SYN_ERR_UNSUPPORTED (its gamma sampler lives on the device path). stats may be NULL. */
 typedef struct syn_lockstep_stats {
     uint64_t rounds;               /* syn_policy_eval_batch launches */
     uint64_t positions_evaluated;  /* leaves over all rounds */
@@ -204,7 +204,8 @@ int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const ui
  * syn_policy_eval_batch launch per round, run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) on
  * the host with game g's own StdRng::seed_from_u64(base_seed + g) (include/synthesis_amd_lockstep.hpp::lockstep_selfplay).
  * Arguments and outputs are syn_selfplay_run's; the games are identical to that call's, move for move and float for float.
- * host_threads as above; SYN_FPU_NORMAL / SYN_NOISE_DIRICHLET: SYN_ERR_UNSUPPORTED; stats may be NULL. */
+ * host_threads as above; SYN_FPU_NORMAL (the reference's own self-play configuration) included — the host trees take the
+ * draws of syn_selfplay_run's trees; SYN_NOISE_DIRICHLET: SYN_ERR_UNSUPPORTED; stats may be NULL. */
 int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game, int n_games,
                               int host_threads, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
                               uint32_t* root_nodes, uint8_t* final_kind, syn_lockstep_stats* stats);

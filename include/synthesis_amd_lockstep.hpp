@@ -21,8 +21,10 @@
 //
 // Numerics: the f32 expression order of mcts.rs, exp / ln through the same deterministic restatements the device and the oracle
 // use (det_expf / det_logf below). Compile with -ffp-contract=off for bit parity with syn_mcts_search (tests/test_lockstep.py
-// holds this driver to the oracle and to the device search). Fpu::Normal and PolicyNoise::Dirichlet need the per-tree random
-// streams of the device path and are not offered here: Error(SYN_ERR_UNSUPPORTED).
+// holds this driver to the oracle and to the device search). Fpu::Normal (the reference's own self-play configuration,
+// study-connect4/src/main.rs:43-47) draws from the same counter-based per-tree stream as the device path (the draw
+// is a pure function of tree seed, scan number and child slot, restated below). PolicyNoise::Dirichlet needs the device path's
+// gamma sampler and is not offered here: Error(SYN_ERR_UNSUPPORTED).
 #pragma once
 #include <cmath>
 #include <condition_variable>
@@ -99,6 +101,44 @@ inline float det_logf(float x) {
     y = std::fmaf(-0.5f, z, y);
     const float r = f + y;
     return std::fmaf(fe, 0.693359375f, r);
+}
+
+// ---- Fpu::Normal draws (study-connect4/src/main.rs:43-47 samples thread_rng; this build's reproducible definition, the same
+// one csrc/noise.cuh computes on the device) ------------------------------------------------------------------------------------
+constexpr uint64_t NOISE_GOLDEN = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t NOISE_FPU_TAG = 0xF9C5A7B3E1D20F4Bull;
+inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// the seed of one tree's streams: `stream` names the game (or the root of a batched search), `turn` the move within it
+inline uint64_t noise_tree_seed(uint64_t stream, uint32_t turn) {
+    return mix64((stream ^ 0x5851F42D4C957F2Dull) + (uint64_t)(turn + 1u) * NOISE_GOLDEN);
+}
+inline uint64_t noise_splitmix64(uint64_t seed, uint32_t index) { return mix64(seed + (uint64_t)(index + 1u) * NOISE_GOLDEN); }
+// standard normal from 23 random bits k: u = (2k+1)/2^24, z = sqrt(2) erfinv(2u-1), Giles' single-precision erfinv with every
+// step an IEEE f32 operation
+inline float det_std_normal(uint32_t k) {
+    const float x = std::fmaf((float)(2u * k + 1u), 1.1920928955078125e-07f, -1.0f);
+    const float w = -det_logf((1.0f - x) * (1.0f + x));
+    static const float central[9] = {2.81022636e-08f, 3.43273939e-07f, -3.5233877e-06f, -4.39150654e-06f, 0.00021858087f,
+                                     -0.00125372503f, -0.00417768164f, 0.246640727f, 1.50140941f};
+    static const float tail[9] = {-0.000200214257f, 0.000100950558f, 0.00134934322f, -0.00367342844f, 0.00573950773f,
+                                  -0.0076224613f, 0.00943887047f, 1.00167406f, 2.83297682f};
+    const bool in_tail = !(w < 5.0f);
+    const float t = in_tail ? std::sqrt(w) - 3.0f : w - 2.5f;
+    const float* coef = in_tail ? tail : central;
+    float p = coef[0];
+    for (int i = 1; i < 9; i++) p = std::fmaf(p, t, coef[i]);
+    return (p * x) * 1.41421356f;
+}
+// draw number (scan, slot) of a tree: SplitMix64 output 5 scan + slot/2 of the stream seeded tree_seed ^ NOISE_FPU_TAG; an even
+// slot takes bits 41..63 of it, an odd slot bits 9..31
+inline float noise_fpu_normal(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std_dev) {
+    const uint64_t bits = noise_splitmix64(tree_seed ^ NOISE_FPU_TAG, 5u * scan + (slot >> 1));
+    const uint32_t k = (slot & 1u) ? ((uint32_t)bits >> 9) : (uint32_t)(bits >> 41);
+    return mean + std_dev * det_std_normal(k);
 }
 
 // rand 0.8.3 `StdRng` as far as run_game draws from it (alpha_zero.rs:189,281,286-287): ChaCha with 12 rounds keyed by rand_core
@@ -323,9 +363,11 @@ public:
     };
 
     // MCTS::with_capacity(explores + 1, cfg, policy, game) followed by explore_n(explores): nothing runs before advance()
-    LockstepTree(const MCTSConfig& cfg, const G& game, int explores) : cfg_(cfg), explores_(explores) {
-        if (cfg.fpu == Fpu::Normal || cfg.root_policy_noise == PolicyNoise::Dirichlet)
-            throw Error(SYN_ERR_UNSUPPORTED, "lockstep MCTS: Fpu::Normal / PolicyNoise::Dirichlet draw from the device path's per-tree streams");
+    // noise_seed: detail::noise_tree_seed(stream, turn) of this tree — read only by Fpu::Normal
+    LockstepTree(const MCTSConfig& cfg, const G& game, int explores, uint64_t noise_seed = 0)
+        : cfg_(cfg), explores_(explores), noise_seed_(noise_seed) {
+        if (cfg.root_policy_noise == PolicyNoise::Dirichlet)
+            throw Error(SYN_ERR_UNSUPPORTED, "lockstep MCTS: PolicyNoise::Dirichlet draws from the device path's gamma sampler");
         nodes_.reserve((size_t)explores + 1);
         Node root;
         root.game = game;
@@ -334,7 +376,9 @@ public:
 
     // The next move's tree in the same storage (run_game builds a fresh MCTS per move, alpha_zero.rs:240-241): the node arena keeps
     // its capacity, so a game allocates once.
-    void reset(const G& game) {
+    void reset(const G& game, uint64_t noise_seed = 0) {
+        noise_seed_ = noise_seed;
+        fpu_scans_ = 0;
         nodes_.clear();
         Node root;
         root.game = game;
@@ -508,26 +552,32 @@ private:
         }
     }
 
-    uint32_t select_best_child(const Node& parent) const {  // mcts.rs:327-341: the first maximum wins, NaN never replaces
+    uint32_t select_best_child(const Node& parent) {  // mcts.rs:327-341: the first maximum wins, NaN never replaces
         uint32_t best = 0;
-        bool have = false;
+        bool have = false, drew = false;
         float best_value = 0.0f;
         for (uint32_t id = parent.first_child; id < parent.last_child(); id++) {
             const Node& child = nodes_[id];
-            const float value = exploit_value(parent, child) + explore_value(parent, child);
+            const float value = exploit_value(parent, child, id - parent.first_child, drew) + explore_value(parent, child);
             if (!have || value > best_value) {
                 have = true;
                 best = id;
                 best_value = value;
             }
         }
+        if (drew) fpu_scans_++;  // a scan that took at least one Fpu::Normal draw uses up one scan number of the tree's stream
         return best;
     }
 
-    float exploit_value(const Node& parent, const Node& child) const {  // mcts.rs:343-359
+    float exploit_value(const Node& parent, const Node& child, uint32_t slot, bool& drew) const {  // mcts.rs:343-359
         if (child.solution.some)
             return cfg_.select_solved_nodes ? child.solution.outcome.reversed().value() : -std::numeric_limits<float>::infinity();
-        if (child.num_children == 0) return cfg_.fpu == Fpu::Const ? cfg_.fpu_value : parent.q();
+        if (child.num_children == 0) {
+            if (cfg_.fpu == Fpu::Const) return cfg_.fpu_value;
+            if (cfg_.fpu == Fpu::ParentQ) return parent.q();
+            drew = true;  // Fpu::Func(|| Normal(mean, std)) (main.rs:43-47)
+            return detail::noise_fpu_normal(noise_seed_, fpu_scans_, slot, cfg_.fpu_value, cfg_.fpu_std);
+        }
         return -child.q();
     }
 
@@ -580,6 +630,8 @@ private:
 
     MCTSConfig cfg_;
     int explores_ = 0, done_ = 0;
+    uint64_t noise_seed_ = 0;  // Fpu::Normal: the tree's seed and the number of scans that drew so far
+    uint32_t fpu_scans_ = 0;
     bool constructed_ = false;
     uint32_t pending_ = 0;
     bool pending_any_solved_ = false;
@@ -588,15 +640,16 @@ private:
 
 // `explores` explores from every root, all trees advancing together: per round one eval_batch call with the leaves of every tree
 // that still needs one. threads = host threads for the tree phases (0: hardware concurrency, at most 32). rounds_out / evals_out:
-// eval_batch calls and positions evaluated.
+// eval_batch calls and positions evaluated. noise_stream: root i's Fpu::Normal draws come from stream noise_stream + i, turn 0 —
+// syn_mcts_search's numbering with noise_stream = 0.
 template <class G, int N>
 std::vector<LockstepTree<G, N>> lockstep_search(BatchPolicy<G, N>& policy, const MCTSConfig& cfg, const std::vector<G>& roots,
                                                 int explores, int threads = 0, size_t* rounds_out = nullptr,
-                                                size_t* evals_out = nullptr) {
+                                                size_t* evals_out = nullptr, uint64_t noise_stream = 0) {
     if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<LockstepTree<G, N>> trees;
     trees.reserve(roots.size());
-    for (const G& g : roots) trees.emplace_back(cfg, g, explores);
+    for (const G& g : roots) trees.emplace_back(cfg, g, explores, detail::noise_tree_seed(noise_stream + (uint64_t)trees.size(), 0u));
     std::vector<const G*> want(trees.size(), nullptr);
     std::vector<const G*> batch;
     std::vector<uint32_t> owner;
@@ -642,7 +695,8 @@ struct LockstepGameRecord {
 
 // `num_games` games [first_game, first_game + num_games), all in flight at once: every game searches its current position on its own
 // host tree, the leaves of all games go through one eval_batch per round, a game whose search is over plays its move
-// (sample_action on its own StdRng::seed_from_u64(seed + game index): the per-game seeding of syn_selfplay_run),
+// (sample_action on its own StdRng::seed_from_u64(seed + game index): the per-game seeding of syn_selfplay_run; the
+// Fpu::Normal draws of move `turn` from the tree stream (seed + game index, turn)),
 // starts the next move's tree and keeps going until it, too, stands on a leaf. Identical, game for game and float for float, to
 // syn_selfplay_run on the same policy (tests/test_lockstep.py).
 template <class G, int N>
@@ -653,12 +707,14 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& polic
     struct StateInfo { int turn; float t; std::array<float, 3> q, z; };   // alpha_zero.rs:211-227
     struct Play {
         G game;
+        uint64_t stream;
         detail::StdRng rng;
         LockstepTree<G, N> tree;
         int num_turns = 0;
         bool over = false;
         std::vector<StateInfo> infos;
-        Play(const MCTSConfig& m, int explores, uint64_t s) : game(), rng(s), tree(m, G(), explores) {}
+        Play(const MCTSConfig& m, int explores, uint64_t s) : game(), stream(s), rng(s), tree(m, G(), explores) {}
+        void next_tree() { tree.reset(game, detail::noise_tree_seed(stream, (uint32_t)num_turns)); }
     };
     std::vector<LockstepGameRecord<G, N>> out(num_games);
     std::vector<Play> plays;
@@ -732,7 +788,7 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& polic
             if (const G* leaf = p.tree.advance()) return leaf;
             play_move(p, out[g]);
             if (p.over) return nullptr;
-            p.tree.reset(p.game);
+            p.next_tree();
         }
     };
 
@@ -743,7 +799,7 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& polic
     size_t rounds = 0, evals = 0;
     for (size_t g = 0; g < num_games; g++) {
         live[g] = (uint32_t)g;
-        plays[g].tree.reset(plays[g].game);
+        plays[g].next_tree();
     }
     detail::WorkerPool pool(threads);
     while (!live.empty()) {

@@ -28,11 +28,15 @@ int host_mcts_config(syn_engine* h, const syn_mcts_config* cfg, const char* who,
     using namespace synthesis;
     if (cfg->exploration != SYN_EXPLORATION_UCT && cfg->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration");
-    if (cfg->fpu == SYN_FPU_NORMAL || cfg->root_policy_noise == SYN_NOISE_DIRICHLET) {
-        const std::string msg = std::string(who) + ": SYN_FPU_NORMAL / SYN_NOISE_DIRICHLET draw from the device path's per-tree streams";
+    if (cfg->root_policy_noise == SYN_NOISE_DIRICHLET) {
+        const std::string msg = std::string(who) + ": SYN_NOISE_DIRICHLET draws from the device path's gamma sampler (syn_mcts_search / "
+                                                   "syn_selfplay_run)";
         return syn_internal_fail(h, SYN_ERR_UNSUPPORTED, msg.c_str());
     }
-    if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q) return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu");
+    if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q && cfg->fpu != SYN_FPU_NORMAL)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu");
+    if (cfg->fpu == SYN_FPU_NORMAL && !(cfg->fpu_std >= 0.0f && cfg->fpu_std < 1e30f && cfg->fpu_value == cfg->fpu_value))
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_FPU_NORMAL needs a finite mean and 0 <= std < 1e30");
     if (cfg->root_policy_noise != SYN_NOISE_NONE && cfg->root_policy_noise != SYN_NOISE_EQUAL)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown root policy noise");
     m.exploration = (Exploration)cfg->exploration;
@@ -119,29 +123,8 @@ extern "C" int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cf
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_mcts_search_lockstep");
     if (action_selection != SYN_ACTION_Q && action_selection != SYN_ACTION_NUM_VISITS)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection");
-    if (cfg->exploration != SYN_EXPLORATION_UCT && cfg->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
-        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration");
-    if (cfg->fpu == SYN_FPU_NORMAL || cfg->root_policy_noise == SYN_NOISE_DIRICHLET)
-        return syn_internal_fail(h, SYN_ERR_UNSUPPORTED,
-                                 "syn_mcts_search_lockstep: SYN_FPU_NORMAL / SYN_NOISE_DIRICHLET draw from the device path's per-tree "
-                                 "streams (syn_mcts_search)");
-    if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q)
-        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu");
-    if (cfg->root_policy_noise != SYN_NOISE_NONE && cfg->root_policy_noise != SYN_NOISE_EQUAL)
-        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown root policy noise");
     MCTSConfig m;
-    m.exploration = (Exploration)cfg->exploration;
-    m.c = cfg->c;
-    m.solve = cfg->solve != 0;
-    m.correct_values_on_solve = cfg->correct_values_on_solve != 0;
-    m.select_solved_nodes = cfg->select_solved_nodes != 0;
-    m.auto_extend = cfg->auto_extend != 0;
-    m.fpu = (Fpu)cfg->fpu;
-    m.fpu_value = cfg->fpu_value;
-    m.root_policy_noise = (PolicyNoise)cfg->root_policy_noise;
-    m.noise_alpha = cfg->noise_alpha;
-    m.noise_weight = cfg->noise_weight;
-    m.fpu_std = cfg->fpu_std;
+    if (const int rc = host_mcts_config(h, cfg, "syn_mcts_search_lockstep", m)) return rc;
     try {
         std::vector<Connect4> roots;
         roots.reserve((size_t)n);

@@ -132,6 +132,7 @@ int main(int argc, char** argv) {
                             rc.mcts_cfg.exploration = Exploration::Uct; rc.mcts_cfg.c = 1.4f; rc.mcts_cfg.fpu = Fpu::ParentQ; }
         if (variant == 3) { rc.value_target = ValueTarget::QtoZ; rc.value_target_from = 0.1f; rc.value_target_to = 0.9f;
                             rc.mcts_cfg.root_policy_noise = PolicyNoise::Equal; rc.mcts_cfg.noise_weight = 0.25f; }
+        if (variant == 4) { rc.mcts_cfg.fpu = Fpu::Normal; rc.mcts_cfg.fpu_value = 1.0f; rc.mcts_cfg.fpu_std = 0.1f; }
         OraclePolicy policy;
         policy.blob = blob.data();
         size_t rounds = 0, evals = 0;
@@ -175,6 +176,8 @@ int main(int argc, char** argv) {
     if (variant == 2) { cfg.root_policy_noise = PolicyNoise::Equal; cfg.noise_weight = 0.25f; cfg.auto_extend = false; cfg.select_solved_nodes = false; }
     if (variant == 3) { cfg.solve = false; cfg.fpu_value = 0.5f; }
     if (variant == 4) { cfg.correct_values_on_solve = false; cfg.c = 1.5f; }
+    if (variant == 5) { cfg.fpu = Fpu::Normal; cfg.fpu_value = 1.0f; cfg.fpu_std = 0.1f; }   // study-connect4/src/main.rs:43-47
+    if (variant == 6) { cfg.exploration = Exploration::Uct; cfg.c = 1.4f; cfg.fpu = Fpu::Normal; cfg.fpu_value = 0.5f; cfg.fpu_std = 0.3f; }
     std::vector<Connect4> roots;
     for (size_t i = 0; i < n; i++) roots.push_back(Connect4::from_bitboards(bb[i], bb[n + i]));
     OraclePolicy policy;

@@ -23,6 +23,8 @@ VARIANTS = {
     2: dict(noise=1, noise_weight=0.25, auto_extend=0, select_solved_nodes=0),
     3: dict(solve=0, fpu_value=0.5),
     4: dict(correct_values_on_solve=0, c=1.5),
+    5: dict(fpu=2, fpu_value=1.0, fpu_std=0.1),   # the reference's own self-play configuration (study-connect4/src/main.rs:37-49)
+    6: dict(exploration=0, c=1.4, fpu=2, fpu_value=0.5, fpu_std=0.3),
 }
 
 
@@ -56,7 +58,8 @@ def test_lockstep_trees_equal_the_sequential_oracle(harness, oracle, golden_dir)
     my[0] = 0; op[0] = 0
     roots = str(d / "roots.u64")
     np.concatenate([my, op]).astype("<u8").tofile(roots)
-    for variant, explores, threads in ((0, 0, 1), (0, 1, 1), (0, 150, 4), (1, 90, 1), (2, 120, 3), (3, 100, 1), (4, 100, 2)):
+    for variant, explores, threads in ((0, 0, 1), (0, 1, 1), (0, 150, 4), (1, 90, 1), (2, 120, 3), (3, 100, 1), (4, 100, 2),
+                                      (5, 0, 1), (5, 150, 3), (6, 90, 2)):
         out = str(d / f"out{variant}_{explores}.bin")
         p = subprocess.run([exe, "c4", blobf, roots, str(explores), str(variant), str(threads), out], capture_output=True,
                            text=True, timeout=600)
@@ -78,6 +81,7 @@ SELFPLAY_VARIANTS = {
     1: dict(value_target=0, stop_games_when_solved=1, action=0),
     2: dict(value_target=2, vt_p=0.25, random_actions_until=3, sample_actions_until=10, mcts=dict(exploration=0, c=1.4, fpu=1)),
     3: dict(value_target=3, vt_from=0.1, vt_to=0.9, mcts=dict(noise=1, noise_weight=0.25)),
+    4: dict(mcts=dict(fpu=2, fpu_value=1.0, fpu_std=0.1)),
 }
 
 
@@ -113,7 +117,8 @@ def test_lockstep_selfplay_equals_the_sequential_oracle(harness, oracle, golden_
 
     exe, blobf, d = harness
     blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
-    for variant, games, explores, threads, seed, first in ((0, 12, 60, 3, 7, 0), (1, 8, 50, 1, 99, 5), (2, 8, 40, 2, 3, 0), (3, 8, 40, 4, 11, 2)):
+    for variant, games, explores, threads, seed, first in ((0, 12, 60, 3, 7, 0), (1, 8, 50, 1, 99, 5), (2, 8, 40, 2, 3, 0), (3, 8, 40, 4, 11, 2),
+                                                         (4, 10, 60, 3, 31, 7)):
         out = str(d / f"sp{variant}.bin")
         p = subprocess.run([exe, "selfplay", blobf, str(games), str(explores), str(variant), str(threads), str(seed), str(first), out],
                            capture_output=True, text=True, timeout=900)
@@ -168,7 +173,9 @@ def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
     my, op = random_positions(oracle, 4096, seed=99, max_moves=50)
     my[0] = 0; op[0] = 0
     for scfg, okw, explores in ((sa.parity_mcts_config(), dict(), 64),
-                                (sa.MCTSConfig(exploration=sa.Exploration.Uct, c=1.4, fpu=sa.Fpu.ParentQ), dict(exploration=0, c=1.4, fpu=1), 40)):
+                                (sa.MCTSConfig(exploration=sa.Exploration.Uct, c=1.4, fpu=sa.Fpu.ParentQ), dict(exploration=0, c=1.4, fpu=1), 40),
+                                # the reference's own configuration: Fpu::Func(|| Normal(1.0, 0.1)) on the host trees, the same draws
+                                (sa.reference_selfplay_mcts_config(), dict(fpu=2, fpu_value=1.0, fpu_std=0.1), 64)):
         got = eng.mcts_search_lockstep(scfg, my, op, explores)
         stats = got.pop("stats")
         fused = eng.mcts_search(scfg, my, op, explores)
@@ -176,9 +183,9 @@ def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
         ref = oracle.c4_mcts_search(parity_mcts_config(**okw), blob, my[:256], op[:256], explores, nn_mode=oracle.ACC_FMA)
         assert_search_equal({k: got[k][:256] for k in SEARCH_KEYS}, ref, "lockstep vs oracle")
         assert 1 <= stats["rounds"] <= explores + 1 and stats["positions_evaluated"] <= 4096 * (explores + 1)
-    # the draws of Fpu::Func / Dirichlet live on the device path only
+    # the Dirichlet draws live on the device path only
     with pytest.raises(sa.SynthesisAmdError) as e:
-        eng.mcts_search_lockstep(sa.reference_selfplay_mcts_config(), my[:4], op[:4], 8)
+        eng.mcts_search_lockstep(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25), my[:4], op[:4], 8)
     assert e.value.code == -5
     eng.close()
 
@@ -201,8 +208,14 @@ def test_lockstep_selfplay_on_the_gpu_equals_the_fused_selfplay(oracle, golden_d
     ref = oracle.c4_selfplay(parity_rollout_config(48), blob, 77, 64, first_game=3, nn_mode=oracle.ACC_FMA)
     assert_games_equal({k: v[:64] for k, v in got.items()}, ref, "lockstep self-play vs oracle")
     assert stats["rounds"] >= 49 and stats["positions_evaluated"] <= int(got["plies"].sum()) * 49
+    # the reference's own self-play configuration (study-connect4/src/main.rs:37-49) on the host trees
+    rcfg = sa.parity_rollout_config(48, mcts_cfg=sa.reference_selfplay_mcts_config())
+    got = eng.selfplay_lockstep(rcfg, 5, 1024, first_game=11)
+    got.pop("stats")
+    assert_games_equal(got, eng.selfplay(rcfg, 5, 1024, first_game=11), "lockstep self-play vs fused, Fpu::Func")
     with pytest.raises(sa.SynthesisAmdError) as e:
-        eng.selfplay_lockstep(sa.parity_rollout_config(8, mcts_cfg=sa.reference_selfplay_mcts_config()), 1, 4)
+        eng.selfplay_lockstep(sa.parity_rollout_config(8, mcts_cfg=sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3,
+                                                                                noise_weight=0.25)), 1, 4)
     assert e.value.code == -5
     eng.close()
 
@@ -225,6 +238,7 @@ def test_lockstep_host_code_is_clean_under_asan_and_ubsan(oracle, golden_dir, tm
     np.concatenate([my, op]).astype("<u8").tofile(roots)
     for args in (["c4", blob, roots, "60", "0", "4", str(tmp_path / "o1.bin")], ["c4", blob, roots, "40", "1", "2", str(tmp_path / "o2.bin")],
                  ["selfplay", blob, "6", "40", "0", "3", "9", "0", str(tmp_path / "o3.bin")],
-                 ["selfplay", blob, "4", "30", "3", "2", "1", "7", str(tmp_path / "o4.bin")], ["nim"], ["nimthrow"]):
+                 ["selfplay", blob, "4", "30", "3", "2", "1", "7", str(tmp_path / "o4.bin")],
+                 ["selfplay", blob, "4", "40", "4", "2", "2", "0", str(tmp_path / "o5.bin")], ["nim"], ["nimthrow"]):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, " ".join(args) + "\n" + p.stdout[-1500:] + p.stderr[-3000:]
