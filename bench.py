@@ -578,9 +578,10 @@ def main():
             dt = time.perf_counter() - t1
             out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
                                                "games": 16384, "plies_per_game": float(r2["plies"].mean())}
-            # configs[1] as worded — host trees in lock step, one batched Policy::eval launch per round
-            # (include/synthesis_amd_lockstep.hpp behind syn_mcts_search_lockstep) — beside the fused search on the same 4,096 roots
-            # (mid-game positions of the self-play run above): the form a caller with another Game impl would use
+            # configs[1] as worded — host trees, batched Policy::eval launches (include/synthesis_amd_lockstep.hpp behind
+            # syn_mcts_search_lockstep: one worker thread per usable CPU, each with two halves of its trees taking turns, the workers'
+            # leaves combined into one launch on one evaluation context) — beside the fused search on the same 4,096 roots (mid-game
+            # positions of the self-play run above): the form a caller with another Game impl would use
             try:
                 r2s = e2.selfplay(cfg, base_seed=3, n_games=4096)
                 ply = np.minimum(r2s["plies"] - 1, 8)
@@ -597,19 +598,21 @@ def main():
                 out["at_4096_concurrent_games"]["lockstep_host_trees"] = {
                     "roots": 4096, "explores": args.explores, "searches_per_s": 4096 / dt_l, "leaf_evals_per_s": st["positions_evaluated"] / dt_l,
                     "policy_eval_launches": st["rounds"], "seconds": dt_l, "seconds_in_policy_eval": st["seconds_policy"],
-                    "host_threads": "hardware concurrency (at most 32)",
+                    "host_threads": "what the process may use (hardware concurrency cut to the cgroup CPU quota), at most 32",
                     "identical_to_fused_search": bool(all(np.array_equal(ls[k], fs[k]) for k in ("child_N", "child_W", "best_action", "num_nodes"))),
                     "fused_search_on_the_same_roots": {"searches_per_s": 4096 / dt_f, "seconds": dt_f}}
                 if fits("lockstep_selfplay", 40):
-                    # ... and whole games in that form (syn_selfplay_run_lockstep = run_n_games over the host trees): 4,096 concurrent
-                    # games, one batched Policy::eval launch per round; held to the fused kernel's games on the same seeds
+                    # ... and whole games in that form (syn_selfplay_run_lockstep = run_n_games over the host trees): the fused leg's
+                    # shape — 16,384 games over 4,096 slots, a finished game's slot takes the next game — held to the fused kernel's
+                    # games on the same seeds
                     t1 = time.perf_counter()
-                    lg = e2.selfplay_lockstep(cfg, base_seed=3, n_games=4096)
+                    lg = e2.selfplay_lockstep(cfg, base_seed=3, n_games=16384)
                     dt_g = time.perf_counter() - t1
                     sg = lg["stats"]
+                    r2s = e2.selfplay(cfg, base_seed=3, n_games=16384)
                     played = np.arange(63)[None, :] < r2s["plies"][:, None]   # (entries past a game's last ply are unspecified)
                     out["at_4096_concurrent_games"]["lockstep_host_trees"].update({
-                        "games": 4096, "games_per_s": 4096 / dt_g, "selfplay_seconds": dt_g,
+                        "games": 16384, "concurrent_games": 4096, "games_per_s": 16384 / dt_g, "selfplay_seconds": dt_g,
                         "selfplay_seconds_in_policy_eval": sg["seconds_policy"], "selfplay_policy_eval_launches": sg["rounds"],
                         "selfplay_leaf_evals_per_s": sg["positions_evaluated"] / dt_g,
                         "games_identical_to_fused_selfplay": bool(

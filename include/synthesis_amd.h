@@ -135,6 +135,25 @@ int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* 
 int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my_bb, const uint64_t* d_op_bb, int n,
                                  float* d_logits, float* d_value, int sync);
 
+/* Replaces: one worker's policy object. gather_experience gives every worker thread its own policy (alpha_zero.rs:192-198:
+ * VarStore, P::new, cache — "one policy per thread, &mut self eval"); an evaluation context is that object on the GPU: its own
+ * stream, pinned staging and device scratch, reading the engine's weight image (loaded once, syn_load_weights*). Contexts of one
+ * engine may be used at the same time from different host threads — one thread per context at a time; the engine handle's
+ * own calls stay single-threaded as before. Loading other weights while a context has a batch in flight is the caller's race.
+ *   submit: copies the n positions and launches their evaluation; returns without waiting (one batch in flight per context).
+ *   wait:   blocks until the submitted batch is done and copies logits[n*9] / value[n*3] out (syn_policy_eval_batch's outputs,
+ *           bit for bit).  eval = submit + wait.
+ * A call is latency (n = 1 from a Rust `impl Policy`; the leaves of a few hundred trees from a self-play worker): the positions
+ * are read and small results written across the host link in place, no transfer commands. Errors: the usual codes, the text in
+ * syn_eval_ctx_last_error(ctx) (not in the engine's slot). Destroy every context before syn_engine_destroy. */
+typedef struct syn_eval_ctx syn_eval_ctx;
+int syn_eval_ctx_create(syn_engine* h, syn_eval_ctx** out);
+int syn_eval_ctx_submit(syn_eval_ctx* ctx, const uint64_t* my_bb, const uint64_t* op_bb, int n);
+int syn_eval_ctx_wait(syn_eval_ctx* ctx, float* logits, float* value);
+int syn_eval_ctx_eval(syn_eval_ctx* ctx, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits, float* value);
+const char* syn_eval_ctx_last_error(const syn_eval_ctx* ctx);
+int syn_eval_ctx_destroy(syn_eval_ctx* ctx);
+
 /* Replaces: Game::features (connect4.rs:235-258) for n states: out[n*63], index row*9 + col. */
 int syn_features_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* out);
 
@@ -185,24 +204,27 @@ int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t 
 /* Replaces: the same reference call as syn_mcts_search — MCTS::with_capacity + explore_n for n roots (mcts.rs:123-147) — in the
  * reference's own division of labour (BASELINE.json configs[1] as worded: concurrent games, batched leaf inference): the trees
  * live on the HOST (include/synthesis_amd_lockstep.hpp: MCTS<G, P, N> restated over any Game, Policy::eval taken out of visit()),
- * all n searches advance in lock step, and every round's leaves go through ONE syn_policy_eval_batch launch. This is the driver a
- * caller with a different Game impl instantiates; for Connect4 the fused syn_mcts_search is the fast path and this entry point
- * exists to hold the driver to it: results are identical, field for field. host_threads: threads for the tree phases (0 = the
- * host's hardware concurrency, at most 32). cfg: SYN_FPU_NORMAL draws what syn_mcts_search draws (root i: tree stream (i, turn 0));
+ * and the leaves go to the GPU in batches: the roots are divided among host_threads workers (gather_experience's worker model,
+ * alpha_zero.rs:132-154); a worker runs its trees in two halves that take turns — one half's leaves are being evaluated while it
+ * advances the other — and the batches the workers hand in are combined into one launch on one evaluation context
+ * (syn_eval_ctx_*). This is the driver a caller with a different Game impl instantiates; for Connect4 the fused syn_mcts_search
+ * is the fast path and this entry point exists to hold the driver to it: results are identical, field for field. host_threads:
+ * 0 = what the process may use (hardware concurrency cut to a cgroup CPU quota), at most 32. cfg: SYN_FPU_NORMAL draws what syn_mcts_search draws (root i: tree stream (i, turn 0));
  * SYN_NOISE_DIRICHLET returns SYN_ERR_UNSUPPORTED (its gamma sampler lives on the device path). stats may be NULL. */
 typedef struct syn_lockstep_stats {
-    uint64_t rounds;               /* syn_policy_eval_batch launches */
-    uint64_t positions_evaluated;  /* leaves over all rounds */
+    uint64_t rounds;               /* evaluation launches (combined batches) */
+    uint64_t positions_evaluated;  /* leaves over all launches */
     double seconds_total;
-    double seconds_policy;         /* of which inside syn_policy_eval_batch (copies + kernel) */
+    double seconds_policy;         /* host time inside the evaluation context's calls (staging, launch, waiting for the GPU) */
 } syn_lockstep_stats;
 int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const uint64_t* my_bb, const uint64_t* op_bb, int n,
                              int explores, int action_selection, int host_threads, syn_search_result* results,
                              syn_lockstep_stats* stats);
-/* Replaces: run_n_games (alpha_zero.rs:181-209) in the same division of labour — BASELINE.json configs[1] as worded: n_games
- * concurrent games, every game's MCTS on the HOST (one tree per move, alpha_zero.rs:240-244), the leaves of all games through one
- * syn_policy_eval_batch launch per round, run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) on
- * the host with game g's own StdRng::seed_from_u64(base_seed + g) (include/synthesis_amd_lockstep.hpp::lockstep_selfplay).
+/* Replaces: run_n_games (alpha_zero.rs:181-209) in the same division of labour — BASELINE.json configs[1] as worded: concurrent
+ * games (syn_selfplay_run's shape: n_games jobs over the engine's concurrent_games slots, a finished game's slot takes the next
+ * game), every game's MCTS on the HOST (one tree per move, alpha_zero.rs:240-244), the leaves batched to the GPU as above,
+ * run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) on the host with game g's own
+ * StdRng::seed_from_u64(base_seed + g) (include/synthesis_amd_lockstep.hpp::lockstep_selfplay_sharded).
  * Arguments and outputs are syn_selfplay_run's; the games are identical to that call's, move for move and float for float.
  * host_threads as above; SYN_FPU_NORMAL (the reference's own self-play configuration) included — the host trees take the
  * draws of syn_selfplay_run's trees; SYN_NOISE_DIRICHLET: SYN_ERR_UNSUPPORTED; stats may be NULL. */

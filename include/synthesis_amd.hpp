@@ -122,6 +122,7 @@ public:
     }
     std::vector<int> iter_actions() const {  // legal columns, ascending
         std::vector<int> a;
+        a.reserve(WIDTH);
         for (int c = 0; c < WIDTH; c++)
             if (height(c) < HEIGHT) a.push_back(c);
         return a;

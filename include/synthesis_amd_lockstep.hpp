@@ -17,7 +17,9 @@
 //   synthesis::lockstep_search              `MCTS::with_capacity(explores + 1, ..) + explore_n(explores)` for many roots
 //   synthesis::lockstep_selfplay            run_n_games (alpha_zero.rs:181-209) over such trees: run_game / sample_action /
 //                                           fill_state_info / store_rewards (alpha_zero.rs:229-338), one StdRng per game
-//   synthesis::HipBatchPolicy               BatchPolicy<Connect4, 9> over syn_policy_eval_batch
+//   synthesis::lockstep_*_sharded           the same with one policy per host thread (gather_experience's worker model)
+//   synthesis::CombiningPolicy<G, N>        one (GPU) policy shared by the workers of a sharded driver: their batches go out combined
+//   synthesis::HipBatchPolicy               BatchPolicy<Connect4, 9> over an evaluation context of the engine (syn_eval_ctx_*)
 //
 // Numerics: the f32 expression order of mcts.rs, exp / ln through the same deterministic restatements the device and the oracle
 // use (det_expf / det_logf below). Compile with -ffp-contract=off for bit parity with syn_mcts_search (tests/test_lockstep.py
@@ -26,12 +28,16 @@
 // is a pure function of tree seed, scan number and child slot, restated below). PolicyNoise::Dirichlet needs the device path's
 // gamma sampler and is not offered here: Error(SYN_ERR_UNSUPPORTED).
 #pragma once
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
 #include <cstring>
 #include <exception>
 #include <functional>
+#include <memory>
 #include <mutex>
+#include <numeric>
 #include <thread>
 
 #include "synthesis_amd.hpp"
@@ -212,12 +218,36 @@ private:
     int pos_ = 16;
 };
 
-// A fixed set of host threads that run fn(i) for i in [0, n), contiguous chunks (trees are independent). One pool lives for a whole
-// search: its two phases per round would otherwise start and join `threads` threads 2 x (explores + 1) times.
+// Host threads this process may actually run at once: the hardware concurrency, cut to a cgroup CPU quota if there is one (a
+// container with 16 CPUs' worth of time on a 256-thread host: more runnable threads than quota get throttled in the middle of a
+// round and every other thread waits for them at the round's end).
+inline int usable_host_threads() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+        long long quota = 0, period = 0;
+        if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+            n = std::min(n, (unsigned)std::max(1ll, (quota + period - 1) / period));
+        std::fclose(f);
+    } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        long long quota = 0, period = 100000;
+        const bool have = std::fscanf(g, "%lld", &quota) == 1;
+        std::fclose(g);
+        if (FILE* pf = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(pf, "%lld", &period) != 1) period = 100000;
+            std::fclose(pf);
+        }
+        if (have && quota > 0 && period > 0) n = std::min(n, (unsigned)std::max(1ll, (quota + period - 1) / period));
+    }
+    return (int)std::min(32u, n);
+}
+
+// A fixed set of host threads that run fn(i) for i in [0, n) (trees are independent): the indices are handed out in small blocks
+// from a shared counter, so a thread that drew cheap trees takes more of them. One pool lives for a whole search: its phase per
+// round would otherwise start and join `threads` threads explores + 1 times.
 class WorkerPool {
 public:
     explicit WorkerPool(int threads) : nthreads_((size_t)(threads < 1 ? 1 : threads)) {
-        for (size_t k = 1; k < nthreads_; k++) workers_.emplace_back([this, k] { loop(k); });
+        for (size_t k = 1; k < nthreads_; k++) workers_.emplace_back([this] { loop(); });
     }
     ~WorkerPool() {
         {
@@ -242,13 +272,15 @@ public:
             std::lock_guard<std::mutex> lk(mu_);
             job_ = &f;
             n_ = n;
+            grain_ = std::max<size_t>(1, n / (nthreads_ * 8));
+            next_.store(0, std::memory_order_relaxed);
             pending_ = nthreads_ - 1;
             generation_++;
         }
         cv_.notify_all();
         std::exception_ptr mine = nullptr;
         try {
-            chunk(0, f, n);
+            drain(f, n, grain_);
         } catch (...) {
             mine = std::current_exception();   // (the workers still hold a pointer to f: wait for them before unwinding)
         }
@@ -264,14 +296,19 @@ public:
     }
 
 private:
-    void chunk(size_t k, const std::function<void(size_t)>& f, size_t n) const {
-        for (size_t i = n * k / nthreads_; i < n * (k + 1) / nthreads_; i++) f(i);
+    void drain(const std::function<void(size_t)>& f, size_t n, size_t grain) {
+        for (;;) {
+            const size_t b = next_.fetch_add(grain, std::memory_order_relaxed);
+            if (b >= n) return;
+            const size_t e = std::min(n, b + grain);
+            for (size_t i = b; i < e; i++) f(i);
+        }
     }
-    void loop(size_t k) {
+    void loop() {
         size_t seen = 0;
         for (;;) {
             const std::function<void(size_t)>* f;
-            size_t n;
+            size_t n, grain;
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 cv_.wait(lk, [&] { return generation_ != seen; });
@@ -279,10 +316,12 @@ private:
                 if (stop_) return;
                 f = job_;
                 n = n_;
+                grain = grain_;
             }
             try {
-                chunk(k, *f, n);
+                drain(*f, n, grain);
             } catch (...) {
+                next_.store(n, std::memory_order_relaxed);   // nobody starts another block of a failed phase
                 std::lock_guard<std::mutex> lk(mu_);
                 if (!error_) error_ = std::current_exception();
             }
@@ -298,22 +337,24 @@ private:
     std::mutex mu_;
     std::condition_variable cv_, done_;
     const std::function<void(size_t)>* job_ = nullptr;
-    size_t n_ = 0, pending_ = 0, generation_ = 0;
+    size_t n_ = 0, grain_ = 1, pending_ = 0, generation_ = 0;
+    std::atomic<size_t> next_{0};
     bool stop_ = false;
     std::exception_ptr error_ = nullptr;
 };
+
 }  // namespace detail
 
 // ---- game.rs:9-62 ---------------------------------------------------------------------------------------------------------
 struct Outcome {
     enum Kind : uint8_t { Lose = 0, Draw = 1, Win = 2 };  // (the index of Into<usize>, mcts.rs:10-18)
     Kind kind = Draw;
-    uint32_t turns = 0;
+    uint16_t turns = 0;   // (usize in the reference; a game is over after Game::MAX_TURNS plies — 16 bits keep a tree node in one cache line)
 
     static Outcome from_reward(float value) {  // impl From<f32>
         return Outcome{value > 0.0f ? Win : (value < 0.0f ? Lose : Draw), 0};
     }
-    Outcome reversed() const { return Outcome{kind == Win ? Lose : (kind == Lose ? Win : Draw), turns + 1}; }
+    Outcome reversed() const { return Outcome{kind == Win ? Lose : (kind == Lose ? Win : Draw), (uint16_t)(turns + 1)}; }
     float value() const { return kind == Win ? 1.0f : (kind == Draw ? 0.0f : -1.0f); }
     // impl Ord: a win in fewer turns is greater; draws and losses in more turns are greater; Win > Draw > Lose
     static int cmp(const Outcome& a, const Outcome& b) {
@@ -341,21 +382,26 @@ struct BatchPolicy {
     virtual ~BatchPolicy() = default;
     // logits[i][0..N), value[i][0..3) = policy.eval(*games[i])
     virtual void eval_batch(const std::vector<const G*>& games, float* logits, float* value) = 0;
+    // The same call in two parts, for a policy that computes elsewhere (a GPU): begin() may return before the answers exist,
+    // end() returns when logits / value of the last begin() are filled. One batch in flight at a time. The drivers evaluate one half
+    // of a thread's trees this way while the thread advances the other half. (Default: begin() does it all.)
+    virtual void eval_batch_begin(const std::vector<const G*>& games, float* logits, float* value) { eval_batch(games, logits, value); }
+    virtual void eval_batch_end() {}
 };
 
 // ---- one tree ---------------------------------------------------------------------------------------------------------------
 template <class G, int N>
 class LockstepTree {
 public:
-    struct Node {  // mcts.rs:28-39
+    struct Node {  // mcts.rs:28-39 (field order: no padding — 64 bytes for Connect4, a node per cache line's worth)
         uint32_t parent = 0, first_child = 0;
-        uint8_t num_children = 0;
         G game;
-        Solution solution;
-        uint8_t action = 0;
-        float action_prob = 0.0f;
         float outcome_probs[3] = {0.0f, 0.0f, 0.0f};
         float num_visits = 0.0f;
+        float action_prob = 0.0f;
+        Solution solution;
+        uint8_t num_children = 0;
+        uint8_t action = 0;
 
         float q() const { return (outcome_probs[2] - outcome_probs[0]) / num_visits; }
         bool is_unvisited() const { return num_children == 0 && !solution.some; }
@@ -556,9 +602,12 @@ private:
         uint32_t best = 0;
         bool have = false, drew = false;
         float best_value = 0.0f;
+        // the parent's share of explore_value (mcts.rs:364, 368) is the same for every child: once per scan
+        const float visits = cfg_.exploration == Exploration::Uct ? std::sqrt(cfg_.c * detail::det_logf(parent.num_visits))
+                                                                  : std::sqrt(parent.num_visits);
         for (uint32_t id = parent.first_child; id < parent.last_child(); id++) {
             const Node& child = nodes_[id];
-            const float value = exploit_value(parent, child, id - parent.first_child, drew) + explore_value(parent, child);
+            const float value = exploit_value(parent, child, id - parent.first_child, drew) + explore_value(visits, child);
             if (!have || value > best_value) {
                 have = true;
                 best = id;
@@ -581,12 +630,8 @@ private:
         return -child.q();
     }
 
-    float explore_value(const Node& parent, const Node& child) const {  // mcts.rs:361-372
-        if (cfg_.exploration == Exploration::Uct) {
-            const float visits = std::sqrt(cfg_.c * detail::det_logf(parent.num_visits));
-            return visits / std::sqrt(child.num_visits);
-        }
-        const float visits = std::sqrt(parent.num_visits);
+    float explore_value(float visits, const Node& child) const {  // mcts.rs:361-372
+        if (cfg_.exploration == Exploration::Uct) return visits / std::sqrt(child.num_visits);
         return cfg_.c * child.action_prob * visits / (1.0f + child.num_visits);
     }
 
@@ -638,46 +683,159 @@ private:
     std::vector<Node> nodes_;
 };
 
-// `explores` explores from every root, all trees advancing together: per round one eval_batch call with the leaves of every tree
-// that still needs one. threads = host threads for the tree phases (0: hardware concurrency, at most 32). rounds_out / evals_out:
-// eval_batch calls and positions evaluated. noise_stream: root i's Fpu::Normal draws come from stream noise_stream + i, turn 0 —
-// syn_mcts_search's numbering with noise_stream = 0.
+namespace detail {
+// The round structure of every driver below. Units [first, first + count) are trees (or game slots): step_unit(u, logits, value)
+// hands unit u the answer for its last leaf (nullptr: it had none) and runs it to its next leaf (returned) or to its end
+// (nullptr). With a pool: per round one phase over all live units, then one eval_batch with their leaves. Without (one thread):
+// the units form two halves that take turns — while one half's leaves are with the policy (eval_batch_begin ... _end), the
+// thread runs the other half. Units never interact, so the schedule changes no result.
+template <class G, int N, class StepUnit>
+void run_rounds(BatchPolicy<G, N>& policy, uint32_t first, uint32_t count, WorkerPool* pool, StepUnit&& step_unit, size_t& rounds,
+                size_t& evals) {
+    struct Half {
+        std::vector<uint32_t> live;   // units still running; after step(): the ones standing on a leaf, in batch order
+        std::vector<const G*> batch;
+        std::vector<float> logits, value;
+        bool have_results = false;
+    };
+    Half halves[2];
+    const uint32_t split = (pool == nullptr && count >= 16) ? count / 2 : count;
+    for (uint32_t i = 0; i < count; i++) halves[i < split ? 0 : 1].live.push_back(first + i);
+    std::vector<const G*> want(count, nullptr);
+    auto step = [&](Half& h) {
+        auto body = [&](size_t k) {
+            const uint32_t u = h.live[k];
+            want[u - first] = step_unit(u, h.have_results ? &h.logits[k * (size_t)N] : nullptr, h.have_results ? &h.value[k * 3] : nullptr);
+        };
+        if (pool) pool->run(h.live.size(), body);
+        else
+            for (size_t k = 0; k < h.live.size(); k++) body(k);
+        size_t kept = 0;
+        h.batch.clear();
+        for (uint32_t u : h.live)
+            if (want[u - first]) {
+                h.batch.push_back(want[u - first]);
+                h.live[kept++] = u;
+            }
+        h.live.resize(kept);
+        h.logits.resize(kept * (size_t)N);
+        h.value.resize(kept * 3);
+        h.have_results = false;
+    };
+    step(halves[0]);
+    if (halves[1].live.empty()) {
+        Half& h = halves[0];
+        while (!h.live.empty()) {
+            rounds++;
+            evals += h.batch.size();
+            policy.eval_batch(h.batch, h.logits.data(), h.value.data());
+            h.have_results = true;
+            step(h);
+        }
+        return;
+    }
+    step(halves[1]);
+    bool in_flight = false;
+    auto begin = [&](Half& h) {
+        rounds++;
+        evals += h.batch.size();
+        policy.eval_batch_begin(h.batch, h.logits.data(), h.value.data());
+        in_flight = true;
+    };
+    auto end = [&](Half& h) {
+        in_flight = false;
+        policy.eval_batch_end();
+        h.have_results = true;
+    };
+    try {
+        if (!halves[0].live.empty()) begin(halves[0]);
+        for (int cur = 0;; cur ^= 1) {
+            Half& a = halves[cur];        // with the policy (if it has leaves at all)
+            Half& b = halves[cur ^ 1];    // its leaves are ready
+            if (!a.live.empty()) end(a);
+            if (!b.live.empty()) begin(b);
+            if (!a.live.empty()) step(a);  // beside b's evaluation
+            if (a.live.empty() && b.live.empty()) break;
+        }
+    } catch (...) {
+        if (in_flight) try { policy.eval_batch_end(); } catch (...) {}   // leave the policy with nothing in flight
+        throw;
+    }
+}
+
+// fn(s) for s in [0, shards), every shard on its own thread (shard 0 on the caller's); the first exception is rethrown after all
+// have returned.
+template <class F>
+void run_shards(size_t shards, F&& fn) {
+    std::vector<std::exception_ptr> errors(shards, nullptr);
+    std::vector<std::thread> threads;
+    auto guarded = [&](size_t s) {
+        try {
+            fn(s);
+        } catch (...) {
+            errors[s] = std::current_exception();
+        }
+    };
+    for (size_t s = 1; s < shards; s++) threads.emplace_back(guarded, s);
+    if (shards > 0) guarded(0);
+    for (auto& t : threads) t.join();
+    for (auto& e : errors)
+        if (e) std::rethrow_exception(e);
+}
+}  // namespace detail
+
+// `explores` explores from every root: MCTS::with_capacity + explore_n (mcts.rs:123-147) for all of them, the leaves batched.
+// threads = host threads for the trees (0: what this process may use, at most 32): with more than one, a round is one phase over
+// all trees on a pool and one eval_batch with their leaves; with one, the trees take turns in two halves (run_rounds above).
+// rounds_out / evals_out: eval_batch calls and positions evaluated. noise_stream: root i's Fpu::Normal draws come from stream
+// noise_stream + i, turn 0 — syn_mcts_search's numbering with noise_stream = 0.
 template <class G, int N>
 std::vector<LockstepTree<G, N>> lockstep_search(BatchPolicy<G, N>& policy, const MCTSConfig& cfg, const std::vector<G>& roots,
                                                 int explores, int threads = 0, size_t* rounds_out = nullptr,
                                                 size_t* evals_out = nullptr, uint64_t noise_stream = 0) {
-    if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads <= 0) threads = detail::usable_host_threads();
     std::vector<LockstepTree<G, N>> trees;
     trees.reserve(roots.size());
     for (const G& g : roots) trees.emplace_back(cfg, g, explores, detail::noise_tree_seed(noise_stream + (uint64_t)trees.size(), 0u));
-    std::vector<const G*> want(trees.size(), nullptr);
-    std::vector<const G*> batch;
-    std::vector<uint32_t> owner;
-    std::vector<float> logits, value;
     size_t rounds = 0, evals = 0;
-    std::vector<uint32_t> live(trees.size());
-    for (size_t i = 0; i < trees.size(); i++) live[i] = (uint32_t)i;
-    detail::WorkerPool pool(threads);
-    while (!live.empty()) {
-        pool.run(live.size(), [&](size_t k) { want[live[k]] = trees[live[k]].advance(); });
-        batch.clear();
-        owner.clear();
-        for (uint32_t t : live)
-            if (want[t]) {
-                batch.push_back(want[t]);
-                owner.push_back(t);
-            }
-        if (batch.empty()) break;
-        logits.resize(batch.size() * (size_t)N);
-        value.resize(batch.size() * 3);
-        policy.eval_batch(batch, logits.data(), value.data());
-        rounds++;
-        evals += batch.size();
-        pool.run(owner.size(), [&](size_t k) { trees[owner[k]].supply(&logits[k * (size_t)N], &value[k * 3]); });
-        live = owner;  // a tree that returned nullptr is finished
+    auto step_tree = [&trees](uint32_t t, const float* logits, const float* value) {
+        if (logits) trees[t].supply(logits, value);   // the rest of visit(): softmax, backprop
+        return trees[t].advance();
+    };
+    if (threads > 1) {
+        detail::WorkerPool pool(threads);
+        detail::run_rounds<G, N>(policy, 0u, (uint32_t)trees.size(), &pool, step_tree, rounds, evals);
+    } else {
+        detail::run_rounds<G, N>(policy, 0u, (uint32_t)trees.size(), nullptr, step_tree, rounds, evals);
     }
     if (rounds_out) *rounds_out = rounds;
     if (evals_out) *evals_out = evals;
+    return trees;
+}
+
+// The same with one policy object PER HOST THREAD — the reference's worker model (alpha_zero.rs:192-198: every worker thread owns
+// its policy): the roots are split into policies.size() contiguous shards, every shard runs on its own thread over its own policy
+// (two halves taking turns), nothing is shared and no thread waits for another. Results as lockstep_search's.
+template <class G, int N>
+std::vector<LockstepTree<G, N>> lockstep_search_sharded(const std::vector<BatchPolicy<G, N>*>& policies, const MCTSConfig& cfg,
+                                                        const std::vector<G>& roots, int explores, size_t* rounds_out = nullptr,
+                                                        size_t* evals_out = nullptr, uint64_t noise_stream = 0) {
+    if (policies.empty()) throw Error(SYN_ERR_INVALID_ARGUMENT, "lockstep_search_sharded: no policies");
+    std::vector<LockstepTree<G, N>> trees;
+    trees.reserve(roots.size());
+    for (const G& g : roots) trees.emplace_back(cfg, g, explores, detail::noise_tree_seed(noise_stream + (uint64_t)trees.size(), 0u));
+    const size_t shards = policies.size(), n = trees.size();
+    std::vector<size_t> rounds(shards, 0), evals(shards, 0);
+    auto step_tree = [&trees](uint32_t t, const float* logits, const float* value) {
+        if (logits) trees[t].supply(logits, value);
+        return trees[t].advance();
+    };
+    detail::run_shards(shards, [&](size_t s) {
+        const size_t lo = n * s / shards, hi = n * (s + 1) / shards;
+        detail::run_rounds<G, N>(*policies[s], (uint32_t)lo, (uint32_t)(hi - lo), nullptr, step_tree, rounds[s], evals[s]);
+    });
+    if (rounds_out) *rounds_out = std::accumulate(rounds.begin(), rounds.end(), (size_t)0);
+    if (evals_out) *evals_out = std::accumulate(evals.begin(), evals.end(), (size_t)0);
     return trees;
 }
 
@@ -693,36 +851,75 @@ struct LockstepGameRecord {
     Outcome final_outcome;                       // for the side to move in the final position (alpha_zero.rs:258)
 };
 
-// `num_games` games [first_game, first_game + num_games), all in flight at once: every game searches its current position on its own
-// host tree, the leaves of all games go through one eval_batch per round, a game whose search is over plays its move
-// (sample_action on its own StdRng::seed_from_u64(seed + game index): the per-game seeding of syn_selfplay_run, DESIGN.md §7; the
-// Fpu::Normal draws of move `turn` from the tree stream (seed + game index, turn)),
-// starts the next move's tree and keeps going until it, too, stands on a leaf. Identical, game for game and float for float, to
-// syn_selfplay_run on the same policy (tests/test_lockstep.py).
+namespace detail {
+// run_n_games for one worker (alpha_zero.rs:181-209) over host trees: `slots` games in flight, each on its own tree; a game whose
+// search is over plays its move (run_game's loop body, alpha_zero.rs:246-264), starts the next move's tree and goes on until it
+// stands on a leaf; a game that ends hands its slot to the next game index of the run (a counter shared by all workers).
 template <class G, int N>
-std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& policy, const RolloutConfig& cfg, size_t num_games,
-                                                        uint64_t seed, uint64_t first_game = 0, int threads = 0,
-                                                        size_t* rounds_out = nullptr, size_t* evals_out = nullptr) {
-    if (threads <= 0) threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+class SelfplayWorker {
+public:
+    struct Shared {   // one run: the games [first_game, first_game + num_games), their records, the next index to start
+        const RolloutConfig& cfg;
+        uint64_t seed, first_game;
+        size_t num_games;
+        std::vector<LockstepGameRecord<G, N>>& out;
+        std::atomic<size_t> next{0};
+    };
+    SelfplayWorker(Shared& shared, size_t slots) : shared_(shared), cfg_(shared.cfg) {
+        plays_.reserve(slots);
+        for (size_t i = 0; i < slots; i++) {
+            const size_t g = shared_.next.fetch_add(1, std::memory_order_relaxed);
+            if (g >= shared_.num_games) break;
+            plays_.emplace_back(cfg_.mcts_cfg, cfg_.num_explores);
+            plays_.back().start(g, shared_.seed + shared_.first_game + (uint64_t)g);
+        }
+    }
+    size_t slots() const { return plays_.size(); }
+    // run_rounds' step_unit: slot u takes the answer for its leaf and runs to its next leaf; nullptr: the slot has no game left
+    const G* step(uint32_t u, const float* logits, const float* value) {
+        Play& p = plays_[u];
+        if (logits) p.tree.supply(logits, value);
+        for (;;) {
+            if (const G* leaf = p.tree.advance()) return leaf;
+            play_move(p, shared_.out[p.index]);
+            if (!p.over) {
+                p.next_tree();
+                continue;
+            }
+            const size_t g = shared_.next.fetch_add(1, std::memory_order_relaxed);
+            if (g >= shared_.num_games) return nullptr;
+            p.start(g, shared_.seed + shared_.first_game + (uint64_t)g);
+        }
+    }
+
+private:
     struct StateInfo { int turn; float t; std::array<float, 3> q, z; };   // alpha_zero.rs:211-227
     struct Play {
         G game;
-        uint64_t stream;
-        detail::StdRng rng;
+        size_t index = 0;     // which game of the run
+        uint64_t stream = 0;  // seed + game index: its StdRng (alpha_zero.rs:189 per game) and its trees' noise streams
+        StdRng rng;
         LockstepTree<G, N> tree;
         int num_turns = 0;
         bool over = false;
         std::vector<StateInfo> infos;
-        Play(const MCTSConfig& m, int explores, uint64_t s) : game(), stream(s), rng(s), tree(m, G(), explores) {}
-        void next_tree() { tree.reset(game, detail::noise_tree_seed(stream, (uint32_t)num_turns)); }
+        Play(const MCTSConfig& m, int explores) : game(), rng(0), tree(m, G(), explores) {}
+        void start(size_t g, uint64_t s) {
+            game = G();
+            index = g;
+            stream = s;
+            rng = StdRng(s);
+            num_turns = 0;
+            over = false;
+            infos.clear();
+            next_tree();
+        }
+        // the next move's MCTS (run_game builds a fresh one per move, alpha_zero.rs:240-241) in the same arena
+        void next_tree() { tree.reset(game, noise_tree_seed(stream, (uint32_t)num_turns)); }
     };
-    std::vector<LockstepGameRecord<G, N>> out(num_games);
-    std::vector<Play> plays;
-    plays.reserve(num_games);
-    for (size_t g = 0; g < num_games; g++) plays.emplace_back(cfg.mcts_cfg, cfg.num_explores, seed + first_game + (uint64_t)g);
 
     // the part of run_game's loop body behind explore_n (alpha_zero.rs:246-264), then the game's end (266-267)
-    auto play_move = [&cfg](Play& p, LockstepGameRecord<G, N>& rec) {
+    void play_move(Play& p, LockstepGameRecord<G, N>& rec) const {
         const std::array<float, N> search_policy = p.tree.target_policy();
         rec.states.push_back(p.game);
         rec.pis.push_back(search_policy);
@@ -730,13 +927,13 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& polic
         rec.root_nodes.push_back((uint32_t)p.tree.num_nodes());
         p.infos.push_back(StateInfo{p.num_turns + 1, 0.0f, p.tree.target_q(), {0.0f, 0.0f, 0.0f}});
         // sample_action (alpha_zero.rs:270-294)
-        const int best = p.tree.best_action(cfg.action);
+        const int best = p.tree.best_action(cfg_.action);
         const Solution best_solution = p.tree.solution(best);
         int action;
-        if (p.num_turns < cfg.random_actions_until) {
+        if (p.num_turns < cfg_.random_actions_until) {
             const std::vector<int> legal = p.game.iter_actions();
             action = legal[p.rng.gen_range_u8((uint32_t)legal.size())];
-        } else if (p.num_turns < cfg.sample_actions_until && (!best_solution.some || !cfg.stop_games_when_solved)) {
+        } else if (p.num_turns < cfg_.sample_actions_until && (!best_solution.some || !cfg_.stop_games_when_solved)) {
             action = p.rng.weighted_index(search_policy);
         } else {
             action = best;
@@ -747,7 +944,7 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& polic
         if (is_over) {
             solution.some = true;
             solution.outcome = Outcome::from_reward(p.game.reward(p.game.player()));
-        } else if (!cfg.stop_games_when_solved) {
+        } else if (!cfg_.stop_games_when_solved) {
             solution.some = false;
         }
         p.num_turns++;
@@ -766,81 +963,235 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& polic
         for (int i = 0; i < num_turns; i++) {
             const StateInfo& st = p.infos[(size_t)i];
             std::array<float, 3> v{};
-            switch (cfg.value_target) {
+            switch (cfg_.value_target) {
                 case ValueTarget::Q: v = st.q; break;
                 case ValueTarget::Z: v = st.z; break;
                 case ValueTarget::QZaverage:
-                    for (int k = 0; k < 3; k++) v[k] = st.q[k] * cfg.value_target_p + st.z[k] * (1.0f - cfg.value_target_p);
+                    for (int k = 0; k < 3; k++) v[k] = st.q[k] * cfg_.value_target_p + st.z[k] * (1.0f - cfg_.value_target_p);
                     break;
                 case ValueTarget::QtoZ: {
-                    const float pp = (1.0f - st.t) * cfg.value_target_from + st.t * cfg.value_target_to;
+                    const float pp = (1.0f - st.t) * cfg_.value_target_from + st.t * cfg_.value_target_to;
                     for (int k = 0; k < 3; k++) v[k] = st.q[k] * (1.0f - pp) + st.z[k] * pp;
                     break;
                 }
             }
             rec.vs[(size_t)i] = v;
         }
-    };
-    // a game runs until it stands on a leaf (returned) or has ended (nullptr)
-    auto advance_game = [&](size_t g) -> const G* {
-        Play& p = plays[g];
-        for (;;) {
-            if (const G* leaf = p.tree.advance()) return leaf;
-            play_move(p, out[g]);
-            if (p.over) return nullptr;
-            p.next_tree();
-        }
-    };
-
-    std::vector<const G*> want(num_games, nullptr);
-    std::vector<const G*> batch;
-    std::vector<uint32_t> owner, live(num_games);
-    std::vector<float> logits, value;
-    size_t rounds = 0, evals = 0;
-    for (size_t g = 0; g < num_games; g++) {
-        live[g] = (uint32_t)g;
-        plays[g].next_tree();
     }
-    detail::WorkerPool pool(threads);
-    while (!live.empty()) {
-        pool.run(live.size(), [&](size_t k) { want[live[k]] = advance_game(live[k]); });
-        batch.clear();
-        owner.clear();
-        for (uint32_t g : live)
-            if (want[g]) {
-                batch.push_back(want[g]);
-                owner.push_back(g);
-            }
-        if (batch.empty()) break;
-        logits.resize(batch.size() * (size_t)N);
-        value.resize(batch.size() * 3);
-        policy.eval_batch(batch, logits.data(), value.data());
-        rounds++;
-        evals += batch.size();
-        pool.run(owner.size(), [&](size_t k) { plays[owner[k]].tree.supply(&logits[k * (size_t)N], &value[k * 3]); });
-        live = owner;
+
+    Shared& shared_;
+    const RolloutConfig& cfg_;
+    std::vector<Play> plays_;
+};
+}  // namespace detail
+
+// `num_games` games [first_game, first_game + num_games), `concurrent` of them in flight at a time (0: all): every game searches
+// its current position on its own host tree, the leaves go to the policy in batches, a game whose search is over plays its move
+// (sample_action on its own StdRng::seed_from_u64(seed + game index): the per-game seeding of syn_selfplay_run, DESIGN.md §7; the
+// Fpu::Normal draws of move `turn` from the tree stream (seed + game index, turn)), starts the next move's tree and keeps going
+// until it, too, stands on a leaf; a finished game's slot takes the next game of the run. threads as lockstep_search's.
+// Identical, game for game and float for float, to syn_selfplay_run on the same policy (tests/test_lockstep.py) — a game depends
+// on its index only, not on what runs beside it.
+template <class G, int N>
+std::vector<LockstepGameRecord<G, N>> lockstep_selfplay(BatchPolicy<G, N>& policy, const RolloutConfig& cfg, size_t num_games,
+                                                        uint64_t seed, uint64_t first_game = 0, int threads = 0,
+                                                        size_t* rounds_out = nullptr, size_t* evals_out = nullptr,
+                                                        size_t concurrent = 0) {
+    if (threads <= 0) threads = detail::usable_host_threads();
+    std::vector<LockstepGameRecord<G, N>> out(num_games);
+    typename detail::SelfplayWorker<G, N>::Shared shared{cfg, seed, first_game, num_games, out};
+    detail::SelfplayWorker<G, N> worker(shared, concurrent == 0 ? num_games : std::min(concurrent, num_games));
+    size_t rounds = 0, evals = 0;
+    auto step = [&worker](uint32_t u, const float* logits, const float* value) { return worker.step(u, logits, value); };
+    if (threads > 1) {
+        detail::WorkerPool pool(threads);
+        detail::run_rounds<G, N>(policy, 0u, (uint32_t)worker.slots(), &pool, step, rounds, evals);
+    } else {
+        detail::run_rounds<G, N>(policy, 0u, (uint32_t)worker.slots(), nullptr, step, rounds, evals);
     }
     if (rounds_out) *rounds_out = rounds;
     if (evals_out) *evals_out = evals;
     return out;
 }
 
-// BatchPolicy<Connect4, 9> on the GPU: one syn_policy_eval_batch call per round
+// The same with one policy object per host thread — gather_experience's worker model (alpha_zero.rs:132-154, 192-198): the
+// `concurrent` slots are divided among policies.size() workers, every worker runs its slots on its own thread over its own policy
+// (two halves taking turns) and draws the next game index from the run's shared counter when one of its games ends. No thread
+// waits for another; the records are lockstep_selfplay's.
+template <class G, int N>
+std::vector<LockstepGameRecord<G, N>> lockstep_selfplay_sharded(const std::vector<BatchPolicy<G, N>*>& policies, const RolloutConfig& cfg,
+                                                                size_t num_games, uint64_t seed, uint64_t first_game = 0,
+                                                                size_t concurrent = 0, size_t* rounds_out = nullptr,
+                                                                size_t* evals_out = nullptr) {
+    if (policies.empty()) throw Error(SYN_ERR_INVALID_ARGUMENT, "lockstep_selfplay_sharded: no policies");
+    std::vector<LockstepGameRecord<G, N>> out(num_games);
+    typename detail::SelfplayWorker<G, N>::Shared shared{cfg, seed, first_game, num_games, out};
+    const size_t shards = policies.size(), slots = concurrent == 0 ? num_games : std::min(concurrent, num_games);
+    std::vector<size_t> rounds(shards, 0), evals(shards, 0);
+    detail::run_shards(shards, [&](size_t s) {
+        detail::SelfplayWorker<G, N> worker(shared, slots * (s + 1) / shards - slots * s / shards);
+        auto step = [&worker](uint32_t u, const float* logits, const float* value) { return worker.step(u, logits, value); };
+        detail::run_rounds<G, N>(*policies[s], 0u, (uint32_t)worker.slots(), nullptr, step, rounds[s], evals[s]);
+    });
+    if (rounds_out) *rounds_out = std::accumulate(rounds.begin(), rounds.end(), (size_t)0);
+    if (evals_out) *evals_out = std::accumulate(evals.begin(), evals.end(), (size_t)0);
+    return out;
+}
+
+// One policy object shared by several host threads, each of which sees a BatchPolicy of its own (worker(i)): the batches the
+// workers hand in are COMBINED — whatever has been handed in while the policy was busy goes to it as one batch, so the policy
+// (a GPU) sees few large calls instead of many small ones, and no worker waits for a worker, only for its own answers.
+// (gather_experience gives every worker its own policy, alpha_zero.rs:192-198; a GPU policy is better shared: a launch costs the
+// same for 100 positions as for 4,000.) The inner policy is only ever called by one thread at a time.
+template <class G, int N>
+class CombiningPolicy {
+public:
+    CombiningPolicy(BatchPolicy<G, N>& inner, size_t workers) : inner_(inner) {
+        for (size_t i = 0; i < workers; i++) workers_.emplace_back(new Worker(*this));
+    }
+    BatchPolicy<G, N>& worker(size_t i) { return *workers_[i]; }
+    std::vector<BatchPolicy<G, N>*> workers() {
+        std::vector<BatchPolicy<G, N>*> v;
+        for (auto& w : workers_) v.push_back(w.get());
+        return v;
+    }
+    size_t combined_calls() const { return calls_; }   // calls of the inner policy
+
+private:
+    struct Request {
+        const std::vector<const G*>* games = nullptr;
+        float* logits = nullptr;
+        float* value = nullptr;
+        bool done = true;
+        std::exception_ptr error = nullptr;
+    };
+    struct Worker : BatchPolicy<G, N> {
+        CombiningPolicy& owner;
+        Request req;
+        explicit Worker(CombiningPolicy& o) : owner(o) {}
+        void eval_batch(const std::vector<const G*>& games, float* logits, float* value) override {
+            eval_batch_begin(games, logits, value);
+            eval_batch_end();
+        }
+        void eval_batch_begin(const std::vector<const G*>& games, float* logits, float* value) override {
+            req.games = &games;
+            req.logits = logits;
+            req.value = value;
+            req.done = false;
+            req.error = nullptr;
+            owner.hand_in(req);
+        }
+        void eval_batch_end() override { owner.collect(req); }
+    };
+
+    // (mu_ held) everything handed in so far goes to the inner policy as one batch
+    void launch_locked() {
+        in_flight_.swap(queue_);
+        all_games_.clear();
+        for (const Request* r : in_flight_) all_games_.insert(all_games_.end(), r->games->begin(), r->games->end());
+        all_logits_.resize(all_games_.size() * (size_t)N);
+        all_value_.resize(all_games_.size() * 3);
+        calls_++;
+        try {
+            inner_.eval_batch_begin(all_games_, all_logits_.data(), all_value_.data());
+        } catch (...) {
+            launch_error_ = std::current_exception();   // reported to the batch's owners when it is collected
+        }
+    }
+    void hand_in(Request& r) {
+        std::lock_guard<std::mutex> lk(mu_);
+        queue_.push_back(&r);
+        if (in_flight_.empty() && !finishing_) launch_locked();
+    }
+    void collect(Request& r) {
+        std::unique_lock<std::mutex> lk(mu_);
+        while (!r.done) {
+            if (in_flight_.empty() || finishing_) {   // (r is in the queue behind a batch somebody else is finishing)
+                cv_.wait(lk);
+                continue;
+            }
+            // this thread finishes the batch in flight: waits for the inner policy, hands the answers out, launches what has queued up
+            finishing_ = true;
+            std::exception_ptr err = launch_error_;
+            launch_error_ = nullptr;
+            lk.unlock();
+            if (!err) {
+                try {
+                    inner_.eval_batch_end();
+                } catch (...) {
+                    err = std::current_exception();
+                }
+            }
+            size_t at = 0;
+            for (Request* q : in_flight_) {
+                const size_t n = q->games->size();
+                if (!err) {
+                    std::memcpy(q->logits, &all_logits_[at * (size_t)N], n * (size_t)N * sizeof(float));
+                    std::memcpy(q->value, &all_value_[at * 3], n * 3 * sizeof(float));
+                }
+                at += n;
+            }
+            lk.lock();
+            for (Request* q : in_flight_) {
+                q->error = err;
+                q->done = true;
+            }
+            in_flight_.clear();
+            finishing_ = false;
+            if (!queue_.empty()) launch_locked();
+            cv_.notify_all();
+        }
+        if (r.error) std::rethrow_exception(r.error);
+    }
+
+    BatchPolicy<G, N>& inner_;
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<Request*> queue_, in_flight_;
+    bool finishing_ = false;
+    std::exception_ptr launch_error_ = nullptr;
+    std::vector<const G*> all_games_;
+    std::vector<float> all_logits_, all_value_;
+    size_t calls_ = 0;
+};
+
+// BatchPolicy<Connect4, 9> on the GPU: one worker's policy = one evaluation context of the engine (syn_eval_ctx: its own stream
+// and staging, the engine's weights). Several of them on one engine serve several host threads at once, one thread each.
 class HipBatchPolicy : public BatchPolicy<Connect4, 9> {
 public:
-    explicit HipBatchPolicy(syn_engine* h) : h_(h) {}
-    explicit HipBatchPolicy(Engine& e) : h_(e.handle()) {}
+    explicit HipBatchPolicy(syn_engine* h) {
+        const int rc = syn_eval_ctx_create(h, &ctx_);
+        if (rc != SYN_OK) throw Error(rc, syn_last_error(h));
+    }
+    explicit HipBatchPolicy(Engine& e) : HipBatchPolicy(e.handle()) {}
+    ~HipBatchPolicy() override { syn_eval_ctx_destroy(ctx_); }
+    HipBatchPolicy(const HipBatchPolicy&) = delete;
+    HipBatchPolicy& operator=(const HipBatchPolicy&) = delete;
+
     void eval_batch(const std::vector<const Connect4*>& games, float* logits, float* value) override {
+        eval_batch_begin(games, logits, value);
+        eval_batch_end();
+    }
+    void eval_batch_begin(const std::vector<const Connect4*>& games, float* logits, float* value) override {
         my_.resize(games.size());
         op_.resize(games.size());
         for (size_t i = 0; i < games.size(); i++) { my_[i] = games[i]->my_bb(); op_[i] = games[i]->op_bb(); }
-        const int rc = syn_policy_eval_batch(h_, my_.data(), op_.data(), (int)games.size(), logits, value);
-        if (rc != SYN_OK) throw Error(rc, syn_last_error(h_));
+        logits_ = logits;
+        value_ = value;
+        const int rc = syn_eval_ctx_submit(ctx_, my_.data(), op_.data(), (int)games.size());
+        if (rc != SYN_OK) throw Error(rc, syn_eval_ctx_last_error(ctx_));
+    }
+    void eval_batch_end() override {
+        const int rc = syn_eval_ctx_wait(ctx_, logits_, value_);
+        if (rc != SYN_OK) throw Error(rc, syn_eval_ctx_last_error(ctx_));
     }
 
 private:
-    syn_engine* h_;
+    syn_eval_ctx* ctx_ = nullptr;
     std::vector<uint64_t> my_, op_;
+    float* logits_ = nullptr;
+    float* value_ = nullptr;
 };
 
 }  // namespace synthesis

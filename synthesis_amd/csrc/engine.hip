@@ -135,6 +135,10 @@ struct syn_engine {
     // scratch for host-pointer entry points
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    size_t eval_zero_copy_in = 32768;  // syn_policy_eval_batch: up to this many positions are read / written in the pinned buffer itself
+    size_t eval_zero_copy_out = 4096;
+    void* h_stage = nullptr;           // pinned, device-mapped host staging for the host-pointer entry points (syn_policy_eval_batch)
+    size_t stage_bytes = 0;
     std::string err;
     float last_kernel_ms = 0.0f;
     int last_launches = 0;
@@ -176,6 +180,7 @@ static int fail(syn_engine* h, int code, const char* fmt, ...) {
 
 // for the library's host-only translation units (lockstep_capi.cpp)
 extern "C" int syn_internal_fail(syn_engine* h, int code, const char* msg) { return fail(h, code, "%s", msg); }
+extern "C" int syn_internal_concurrent_games(const syn_engine* h) { return h ? h->slots : 0; }
 
 #define HIP_TRY(h, call)                                                                          \
     do {                                                                                          \
@@ -192,6 +197,19 @@ static int ensure_scratch(syn_engine* h, size_t bytes) {
     size_t want = bytes + bytes / 4 + 4096;
     HIP_TRY(h, hipMalloc(&h->d_scratch, want));
     h->scratch_bytes = want;
+    return SYN_OK;
+}
+
+// Pinned (page-locked, device-mapped) host memory of at least `bytes`: the caller's pageable buffers are copied through it, so that
+// the transfers are one asynchronous DMA each — or none: a kernel may read and write it in place.
+static int ensure_stage(syn_engine* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return SYN_OK;
+    if (h->h_stage) HIP_TRY(h, hipHostFree(h->h_stage));
+    h->h_stage = nullptr;
+    h->stage_bytes = 0;
+    size_t want = bytes + bytes / 4 + 4096;
+    HIP_TRY(h, hipHostMalloc(&h->h_stage, want, hipHostMallocDefault));
+    h->stage_bytes = want;
     return SYN_OK;
 }
 
@@ -738,6 +756,7 @@ int syn_engine_destroy(syn_engine* h) {
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->h_pin) hipHostFree(h->h_pin);
+    if (h->h_stage) hipHostFree(h->h_stage);
     delete h;
     return SYN_OK;
 }
@@ -779,6 +798,37 @@ int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats) {
     return SYN_OK;
 }
 
+// The evaluation kernel of the engine's network on `st` (any stream of the engine's device): n positions, pointers the device can
+// read / write (device memory or pinned, device-mapped host memory).
+static hipError_t launch_policy_eval(const syn_engine* h, hipStream_t st, const uint64_t* d_my, const uint64_t* d_op, int n,
+                                     float* d_logits, float* d_value) {
+    // Two waves per SIMD (512 threads): one wave's LDS reads / feature math overlap the other's MFMAs. Large batches (every
+    // wave gets several tiles) run three waves per SIMD, which also hides the loads and stores around the tiles.
+    const int ntiles = (n + 15) / 16;
+    hipError_t e;
+#define SYN_LAUNCH_EVAL(KERNEL, NT, LDS)                                                                                       \
+    {                                                                                                                          \
+        auto k = KERNEL<NT>;                                                                                                   \
+        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS))) != \
+            hipSuccess)                                                                                                        \
+            return e;                                                                                                          \
+        int grid = (ntiles + NT / 64 - 1) / (NT / 64);                                                                         \
+        if (grid > h->num_cus) grid = h->num_cus;                                                                              \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), (LDS), st, h->d_wimg, reinterpret_cast<const unsigned long long*>(d_my),    \
+                           reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                           \
+    }
+    if (h->net_kind == 1) {
+        // (16 waves per CU measured the same 46 % of the MFMA peak as 8: the tile is issue-bound, not latency-bound)
+        SYN_LAUNCH_EVAL(policy_eval_conv_kernel, 512, (size_t)ConvGeom::IMG_FLOATS * 4)
+    } else if (ntiles >= h->num_cus * 12 * 4) {
+        SYN_LAUNCH_EVAL(policy_eval_kernel, 768, (size_t)MlpGeom::IMG_FLOATS * 4)
+    } else {
+        SYN_LAUNCH_EVAL(policy_eval_kernel, 512, (size_t)MlpGeom::IMG_FLOATS * 4)
+    }
+#undef SYN_LAUNCH_EVAL
+    return hipGetLastError();
+}
+
 int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint64_t* d_op, int n, float* d_logits,
                                  float* d_value, int sync) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
@@ -787,40 +837,8 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint
     if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
     if (n == 0) return SYN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    // Two waves per SIMD (512 threads): one wave's LDS reads / feature math overlap the other's MFMAs. Large batches (every
-    // wave gets several tiles) run three waves per SIMD, which also hides the loads and stores around the tiles.
-    const size_t lds = (size_t)MlpGeom::IMG_FLOATS * 4;
-    const int ntiles = (n + 15) / 16;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-#define SYN_LAUNCH_EVAL(NT)                                                                                          \
-    {                                                                                                                \
-        auto k = policy_eval_kernel<NT>;                                                                             \
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds));                                                                   \
-        int grid = (ntiles + NT / 64 - 1) / (NT / 64);                                                               \
-        if (grid > h->num_cus) grid = h->num_cus;                                                                    \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, h->stream, h->d_wimg,                                       \
-                           reinterpret_cast<const unsigned long long*>(d_my),                                        \
-                           reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                 \
-    }
-    if (h->net_kind == 1) {
-        const size_t clds = (size_t)ConvGeom::IMG_FLOATS * 4;
-#define SYN_LAUNCH_CEVAL(NT)                                                                                         \
-    {                                                                                                                \
-        auto k = policy_eval_conv_kernel<NT>;                                                                        \
-        HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)clds));                                                                  \
-        int grid = (ntiles + NT / 64 - 1) / (NT / 64);                                                               \
-        if (grid > h->num_cus) grid = h->num_cus;                                                                    \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), clds, h->stream, h->d_wimg,                                      \
-                           reinterpret_cast<const unsigned long long*>(d_my),                                        \
-                           reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                 \
-    }
-        SYN_LAUNCH_CEVAL(512)  // (16 waves per CU measured the same 46 % of the MFMA peak as 8: the tile is issue-bound, not latency-bound)
-#undef SYN_LAUNCH_CEVAL
-    } else if (ntiles >= h->num_cus * 12 * 4) SYN_LAUNCH_EVAL(768) else SYN_LAUNCH_EVAL(512)
-#undef SYN_LAUNCH_EVAL
-    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, launch_policy_eval(h, h->stream, d_my, d_op, n, d_logits, d_value));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->last_launches = 1;
     if (sync) {
@@ -828,6 +846,115 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint
         HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     }
     return SYN_OK;
+}
+
+// ---- evaluation contexts: one worker's policy (alpha_zero.rs:192-198 gives every worker thread of gather_experience its own) ----
+// A context owns a stream, pinned staging and device scratch, and reads the engine's weight image; contexts of one engine run
+// side by side from different host threads. Errors stay in the context (the engine's error slot belongs to the engine's thread).
+struct syn_eval_ctx {
+    syn_engine* h = nullptr;
+    hipStream_t stream = nullptr;
+    void* h_stage = nullptr;   // [my n][op n][logits 9n][value 3n]
+    void* d_out = nullptr;     // results of batches too large to be written across the host link in place
+    size_t cap = 0;            // positions the two buffers hold
+    int pending = 0;           // positions of the submitted batch (0 = none)
+    bool out_in_place = false;
+    std::string err;
+};
+static int ctx_fail(syn_eval_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    c->err = what;
+    if (e != hipSuccess) c->err += std::string(": ") + hipGetErrorString(e);
+    return code;
+}
+#define CTX_TRY(c, call)                                                  \
+    do {                                                                  \
+        hipError_t e_ = (call);                                           \
+        if (e_ != hipSuccess) return ctx_fail(c, SYN_ERR_HIP, #call, e_); \
+    } while (0)
+
+int syn_eval_ctx_create(syn_engine* h, syn_eval_ctx** out) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!out) return fail(h, SYN_ERR_INVALID_ARGUMENT, "syn_eval_ctx_create: out is NULL");
+    *out = nullptr;
+    HIP_TRY(h, hipSetDevice(h->device));
+    syn_eval_ctx* c = new (std::nothrow) syn_eval_ctx;
+    if (!c) return fail(h, SYN_ERR_HIP, "out of host memory");
+    c->h = h;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(h, SYN_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return SYN_OK;
+}
+
+int syn_eval_ctx_destroy(syn_eval_ctx* c) {
+    if (!c) return SYN_OK;
+    hipSetDevice(c->h->device);
+    if (c->stream) {
+        hipStreamSynchronize(c->stream);
+        hipStreamDestroy(c->stream);
+    }
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->d_out) hipFree(c->d_out);
+    delete c;
+    return SYN_OK;
+}
+
+const char* syn_eval_ctx_last_error(const syn_eval_ctx* c) { return c ? c->err.c_str() : "context is NULL"; }
+
+int syn_eval_ctx_submit(syn_eval_ctx* c, const uint64_t* my_bb, const uint64_t* op_bb, int n) {
+    if (!c) return SYN_ERR_INVALID_ARGUMENT;
+    if (n < 0 || (n > 0 && (!my_bb || !op_bb))) return ctx_fail(c, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_eval_ctx_submit");
+    if (c->pending != 0) return ctx_fail(c, SYN_ERR_INVALID_ARGUMENT, "syn_eval_ctx_submit: the previous batch has not been waited for");
+    syn_engine* h = c->h;
+    if (!h->has_weights) return ctx_fail(c, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+    if (n == 0) return SYN_OK;
+    CTX_TRY(c, hipSetDevice(h->device));
+    const size_t nb = (size_t)n;
+    if (nb > c->cap) {
+        CTX_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->h_stage) CTX_TRY(c, hipHostFree(c->h_stage));
+        if (c->d_out) CTX_TRY(c, hipFree(c->d_out));
+        c->h_stage = c->d_out = nullptr;
+        c->cap = 0;
+        const size_t want = nb + nb / 4 + 256;
+        CTX_TRY(c, hipHostMalloc(&c->h_stage, want * 64, hipHostMallocDefault));
+        CTX_TRY(c, hipMalloc(&c->d_out, want * 48));
+        c->cap = want;
+    }
+    uint64_t* s_my = static_cast<uint64_t*>(c->h_stage);
+    uint64_t* s_op = s_my + nb;
+    float* s_logits = reinterpret_cast<float*>(s_op + nb);
+    std::memcpy(s_my, my_bb, nb * 8);
+    std::memcpy(s_op, op_bb, nb * 8);
+    // the positions are read across the host link in place (16 B each); small results are written in place, larger ones come back
+    // with one DMA (syn_policy_eval_batch, measured)
+    c->out_in_place = nb <= h->eval_zero_copy_out;
+    float* o_logits = c->out_in_place ? s_logits : static_cast<float*>(c->d_out);
+    CTX_TRY(c, launch_policy_eval(h, c->stream, s_my, s_op, n, o_logits, o_logits + nb * 9));
+    if (!c->out_in_place) CTX_TRY(c, hipMemcpyAsync(s_logits, c->d_out, nb * 48, hipMemcpyDeviceToHost, c->stream));
+    c->pending = n;
+    return SYN_OK;
+}
+
+int syn_eval_ctx_wait(syn_eval_ctx* c, float* logits, float* value) {
+    if (!c) return SYN_ERR_INVALID_ARGUMENT;
+    if (c->pending == 0) return SYN_OK;
+    if (!logits || !value) return ctx_fail(c, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_eval_ctx_wait");
+    const size_t nb = (size_t)c->pending;
+    c->pending = 0;
+    CTX_TRY(c, hipStreamSynchronize(c->stream));
+    const float* s_logits = reinterpret_cast<const float*>(static_cast<const uint64_t*>(c->h_stage) + 2 * nb);
+    std::memcpy(logits, s_logits, nb * 36);
+    std::memcpy(value, s_logits + nb * 9, nb * 12);
+    return SYN_OK;
+}
+
+int syn_eval_ctx_eval(syn_eval_ctx* c, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits, float* value) {
+    const int rc = syn_eval_ctx_submit(c, my_bb, op_bb, n);
+    return rc != SYN_OK ? rc : syn_eval_ctx_wait(c, logits, value);
 }
 
 int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits,
@@ -846,13 +973,42 @@ int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* 
     uint64_t* d_op = d_my + nb;
     float* d_logits = reinterpret_cast<float*>(d_op + nb);
     float* d_value = d_logits + nb * 9;
-    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
-    rc = syn_policy_eval_batch_device(h, d_my, d_op, n, d_logits, d_value, 0);
+    constexpr size_t EVAL_STAGE_MAX = 32768;  // beyond it the two host copies cost more than the runtime's pageable path (measured)
+    if (const char* ev = debug_env("SYN_EVAL_ZC_IN")) h->eval_zero_copy_in = (size_t)std::atoll(ev);
+    if (const char* ev = debug_env("SYN_EVAL_ZC_OUT")) h->eval_zero_copy_out = (size_t)std::atoll(ev);
+    if (nb > EVAL_STAGE_MAX || debug_env("SYN_EVAL_PAGEABLE") != nullptr) {
+        // beyond the staging buffer's size the runtime's own chunked transfers from / to the pageable buffers
+        HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+        rc = syn_policy_eval_batch_device(h, d_my, d_op, n, d_logits, d_value, 0);
+        if (rc != SYN_OK) return rc;
+        HIP_TRY(h, hipMemcpyAsync(logits, d_logits, nb * 36, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(value, d_value, nb * 12, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
+        return SYN_OK;
+    }
+    // Through pinned, device-mapped host memory: a call is latency, not bandwidth (a Rust `impl Policy` adaptor calls with n = 1,
+    // a lock-step driver with the leaves of one round). Pageable transfers cost a staging copy and a synchronisation each inside
+    // the runtime — four per call; here the positions are read by the kernel in place (16 B per position over the host link) and
+    // small results are written in place, larger ones come back with one DMA.
+    rc = ensure_stage(h, nb * (16 + 48));
     if (rc != SYN_OK) return rc;
-    HIP_TRY(h, hipMemcpyAsync(logits, d_logits, nb * 36, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(h, hipMemcpyAsync(value, d_value, nb * 12, hipMemcpyDeviceToHost, h->stream));
+    uint64_t* s_my = static_cast<uint64_t*>(h->h_stage);
+    uint64_t* s_op = s_my + nb;
+    float* s_logits = reinterpret_cast<float*>(s_op + nb);
+    float* s_value = s_logits + nb * 9;
+    std::memcpy(s_my, my_bb, nb * 8);
+    std::memcpy(s_op, op_bb, nb * 8);
+    const bool in_place_in = nb <= h->eval_zero_copy_in, in_place_out = nb <= h->eval_zero_copy_out;
+    if (!in_place_in) HIP_TRY(h, hipMemcpyAsync(d_my, s_my, nb * 16, hipMemcpyHostToDevice, h->stream));
+    rc = syn_policy_eval_batch_device(h, in_place_in ? s_my : d_my, in_place_in ? s_op : d_op, n, in_place_out ? s_logits : d_logits,
+                                      in_place_out ? s_value : d_value, 0);
+    if (rc != SYN_OK) return rc;
+    if (!in_place_out) HIP_TRY(h, hipMemcpyAsync(s_logits, d_logits, nb * 48, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    std::memcpy(logits, s_logits, nb * 36);
+    std::memcpy(value, s_value, nb * 12);
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     return SYN_OK;
 }

@@ -1,24 +1,50 @@
 // synthesis_amd — syn_mcts_search_lockstep: the host-tree, GPU-policy form of the search (include/synthesis_amd_lockstep.hpp)
-// behind the C ABI. Host code only; it sits ABOVE the boundary and uses nothing but public entry points (syn_policy_eval_batch)
-// plus the library's error slot. Compiled with -ffp-contract=off like the rest: every f32 operation of the tree arithmetic rounds
+// behind the C ABI. Host code only; it sits ABOVE the boundary and uses nothing but public entry points (syn_eval_ctx_*: one
+// evaluation context per host thread) plus the library's error slot and the engine's slot count. Compiled with -ffp-contract=off like the rest: every f32 operation of the tree arithmetic rounds
 // where mcts.rs's expression order says.
 #include <chrono>
 #include <exception>
+#include <memory>
 
 #include "../../include/synthesis_amd_lockstep.hpp"
 
 extern "C" int syn_internal_fail(syn_engine* h, int code, const char* msg);  // engine.hip: fills syn_last_error
+extern "C" int syn_internal_concurrent_games(const syn_engine* h);           // engine.hip: syn_engine_config::concurrent_games
 
 namespace {
+// one worker's policy: an evaluation context of the engine, with the time its thread spent blocked in it
 struct TimedPolicy : synthesis::BatchPolicy<synthesis::Connect4, 9> {
     synthesis::HipBatchPolicy inner;
     double seconds = 0.0;
     explicit TimedPolicy(syn_engine* h) : inner(h) {}
-    void eval_batch(const std::vector<const synthesis::Connect4*>& games, float* logits, float* value) override {
+    template <class F>
+    void timed(F&& f) {
         const auto t0 = std::chrono::steady_clock::now();
-        inner.eval_batch(games, logits, value);
+        f();
         seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+    void eval_batch(const std::vector<const synthesis::Connect4*>& games, float* logits, float* value) override {
+        timed([&] { inner.eval_batch(games, logits, value); });
+    }
+    void eval_batch_begin(const std::vector<const synthesis::Connect4*>& games, float* logits, float* value) override {
+        timed([&] { inner.eval_batch_begin(games, logits, value); });
+    }
+    void eval_batch_end() override {
+        timed([&] { inner.eval_batch_end(); });
+    }
+};
+
+// host_threads workers (0: what the process may use) over ONE evaluation context: their batches go to the GPU combined
+struct Workers {
+    TimedPolicy gpu;
+    synthesis::CombiningPolicy<synthesis::Connect4, 9> combined;
+    std::vector<synthesis::BatchPolicy<synthesis::Connect4, 9>*> policies;
+    static size_t count(int host_threads, size_t units) {
+        const size_t t = (size_t)(host_threads > 0 ? host_threads : synthesis::detail::usable_host_threads());
+        return std::max<size_t>(1, std::min(t, (units + 31) / 32));   // a worker wants a few dozen trees for its two halves
+    }
+    Workers(syn_engine* h, int host_threads, size_t units) : gpu(h), combined(gpu, count(host_threads, units)), policies(combined.workers()) {}
+    double seconds_policy() const { return gpu.seconds; }   // host time inside the context's calls (launch + waiting for the GPU)
 };
 }  // namespace
 
@@ -80,10 +106,13 @@ extern "C" int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config
     rc.value_target_to = cfg->value_target_to;
     rc.action = (ActionSelection)cfg->action;
     try {
-        TimedPolicy policy(h);
+        // syn_selfplay_run's shape: n_games jobs over the engine's concurrent_games slots — here divided among the host workers
+        const size_t concurrent = std::min<size_t>((size_t)n_games, (size_t)std::max(1, syn_internal_concurrent_games(h)));
+        Workers workers(h, host_threads, concurrent);
         size_t rounds = 0, evals = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        const auto games = lockstep_selfplay<Connect4, 9>(policy, rc, (size_t)n_games, base_seed, first_game, host_threads, &rounds, &evals);
+        const auto games = lockstep_selfplay_sharded<Connect4, 9>(workers.policies, rc, (size_t)n_games, base_seed, first_game, concurrent,
+                                                                  &rounds, &evals);
         const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         constexpr size_t T = Connect4::MAX_TURNS;
         for (size_t g = 0; g < games.size(); g++) {
@@ -101,13 +130,13 @@ extern "C" int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config
             }
         }
         if (stats) {
-            stats->rounds = rounds;
+            stats->rounds = workers.combined.combined_calls();
             stats->positions_evaluated = evals;
             stats->seconds_total = total;
-            stats->seconds_policy = policy.seconds;
+            stats->seconds_policy = workers.seconds_policy();
         }
     } catch (const Error& e) {
-        return e.code;
+        return syn_internal_fail(h, e.code, e.what());
     } catch (const std::exception& e) {
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, e.what());
     }
@@ -134,10 +163,10 @@ extern "C" int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cf
             roots.push_back(Connect4::from_bitboards(my_bb[i], op_bb[i]));
             if (roots.back().is_over()) return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "a root is not a searchable Connect4 position");
         }
-        TimedPolicy policy(h);
+        Workers workers(h, host_threads, roots.size());
         size_t rounds = 0, evals = 0;
         const auto t0 = std::chrono::steady_clock::now();
-        const auto trees = lockstep_search<Connect4, 9>(policy, m, roots, explores, host_threads, &rounds, &evals);
+        const auto trees = lockstep_search_sharded<Connect4, 9>(workers.policies, m, roots, explores, &rounds, &evals);
         const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         for (int i = 0; i < n; i++) {
             const auto& t = trees[(size_t)i];
@@ -166,13 +195,13 @@ extern "C" int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cf
             results[i] = r;
         }
         if (stats) {
-            stats->rounds = rounds;
+            stats->rounds = workers.combined.combined_calls();
             stats->positions_evaluated = evals;
             stats->seconds_total = total;
-            stats->seconds_policy = policy.seconds;
+            stats->seconds_policy = workers.seconds_policy();
         }
     } catch (const Error& e) {
-        return e.code;  // (the failed C-ABI call left its text in syn_last_error)
+        return syn_internal_fail(h, e.code, e.what());
     } catch (const std::exception& e) {
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, e.what());
     }

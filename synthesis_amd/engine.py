@@ -18,7 +18,8 @@ CONV_NUM_PARAMS = 12412  # Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
     "syn_load_weights_conv",
-    "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_features_batch", "syn_linear_forward",
+    "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_eval_ctx_create", "syn_eval_ctx_submit", "syn_eval_ctx_wait",
+    "syn_eval_ctx_eval", "syn_eval_ctx_last_error", "syn_eval_ctx_destroy", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_selfplay_run_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
@@ -98,6 +99,13 @@ def load_library():
     lib.syn_policy_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.syn_policy_eval_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_int]
+    lib.syn_eval_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.syn_eval_ctx_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.syn_eval_ctx_wait.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.syn_eval_ctx_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.syn_eval_ctx_last_error.restype = C.c_char_p
+    lib.syn_eval_ctx_last_error.argtypes = [C.c_void_p]
+    lib.syn_eval_ctx_destroy.argtypes = [C.c_void_p]
     lib.syn_features_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.syn_linear_forward.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_int]
@@ -160,6 +168,46 @@ def shard_games(n_games, rank, world_size):
     return first, count
 
 
+class EvalContext:
+    """syn_eval_ctx: Policy::eval for a batch (policies/traits.rs:4-6) on its own stream — eval(), or submit() ... wait()."""
+
+    def __init__(self, engine):
+        self._engine = engine
+        self._lib = engine._lib
+        self._c = C.c_void_p()
+        engine._check(self._lib.syn_eval_ctx_create(engine._h, C.byref(self._c)))
+        self._n = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SynthesisAmdError(rc, (self._lib.syn_eval_ctx_last_error(self._c) or b"").decode())
+
+    def submit(self, my_bb, op_bb):
+        my = np.ascontiguousarray(my_bb, dtype=np.uint64).ravel()
+        op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
+        if my.size != op.size:
+            raise ValueError("my_bb and op_bb must have the same length")
+        self._check(self._lib.syn_eval_ctx_submit(self._c, _p(my), _p(op), int(my.size)))
+        self._n = int(my.size)
+
+    def wait(self):
+        logits = np.zeros((self._n, 9), np.float32)
+        value = np.zeros((self._n, 3), np.float32)
+        self._check(self._lib.syn_eval_ctx_wait(self._c, _p(logits), _p(value)))
+        return logits, value
+
+    def eval(self, my_bb, op_bb):
+        self.submit(my_bb, op_bb)
+        return self.wait()
+
+    def close(self):
+        if self._c is not None and self._c.value:
+            self._lib.syn_eval_ctx_destroy(self._c)
+            self._c = C.c_void_p()
+            if self in getattr(self._engine, "_contexts", []):
+                self._engine._contexts.remove(self)
+
+
 class Engine:
     """One handle = one GPU + one stream (the reference's one policy per worker thread, alpha_zero.rs:192-198)."""
 
@@ -177,8 +225,19 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
+            for ctx in list(getattr(self, "_contexts", [])):
+                ctx.close()
             self._lib.syn_engine_destroy(self._h)
             self._h = C.c_void_p()
+
+    def eval_context(self):
+        """One worker's policy object (alpha_zero.rs:192-198: every worker thread owns its policy): an evaluation context of this
+        engine — own stream and staging, this engine's weights. Contexts may be used from different threads at the same time."""
+        ctx = EvalContext(self)
+        if not hasattr(self, "_contexts"):
+            self._contexts = []
+        self._contexts.append(ctx)
+        return ctx
 
     def __del__(self):
         try:

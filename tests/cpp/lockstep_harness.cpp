@@ -5,9 +5,13 @@
 //   lockstep_harness nim
 //   lockstep_harness selfplay <blob.f32> <games> <explores> <variant> <threads> <seed> <first_game> <out.bin>
 //   lockstep_harness rng <seed> <words>
+// <threads> < 0: the sharded drivers with -threads policies (one per host thread). Environment: LS_CONCURRENT = games in flight
+// (self-play; default all), LS_ASYNC = 1: a policy whose eval_batch_begin() computes on another thread until eval_batch_end(),
+// LS_COMBINE = 1: the sharded drivers' workers share ONE policy through a CombiningPolicy.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <memory>
 #include <stdexcept>
 
 #include "synthesis_amd_lockstep.hpp"
@@ -27,6 +31,36 @@ struct OraclePolicy : BatchPolicy<Connect4, 9> {
         calls++;
         positions += games.size();
     }
+};
+
+// the split form really split: begin() starts the evaluation on another thread, end() joins it — what a GPU policy does
+struct AsyncOraclePolicy : OraclePolicy {
+    std::thread worker;
+    void eval_batch_begin(const std::vector<const Connect4*>& games, float* logits, float* value) override {
+        worker = std::thread([this, &games, logits, value] { OraclePolicy::eval_batch(games, logits, value); });
+    }
+    void eval_batch_end() override { worker.join(); }
+};
+// n policies for n workers — or (LS_COMBINE = 1) one policy behind a CombiningPolicy with n workers
+struct Policies {
+    std::vector<std::unique_ptr<OraclePolicy>> owned;
+    std::unique_ptr<CombiningPolicy<Connect4, 9>> combined;
+    std::vector<BatchPolicy<Connect4, 9>*> list;
+    Policies(size_t n, const float* blob) {
+        const char* a = std::getenv("LS_ASYNC");
+        const char* c = std::getenv("LS_COMBINE");
+        const bool combine = c && c[0] == '1';
+        for (size_t i = 0; i < (combine ? 1 : n); i++) {
+            owned.emplace_back(a && a[0] == '1' ? new AsyncOraclePolicy : new OraclePolicy);
+            owned.back()->blob = blob;
+            list.push_back(owned.back().get());
+        }
+        if (combine) {
+            combined.reset(new CombiningPolicy<Connect4, 9>(*owned[0], n));
+            list = combined->workers();
+        }
+    }
+    size_t calls() const { size_t c = 0; for (const auto& p : owned) c += p->calls; return c; }
 };
 
 // Take 1, 2 or 3 stones; whoever takes the last stone wins. Game<3>.
@@ -133,11 +167,15 @@ int main(int argc, char** argv) {
         if (variant == 3) { rc.value_target = ValueTarget::QtoZ; rc.value_target_from = 0.1f; rc.value_target_to = 0.9f;
                             rc.mcts_cfg.root_policy_noise = PolicyNoise::Equal; rc.mcts_cfg.noise_weight = 0.25f; }
         if (variant == 4) { rc.mcts_cfg.fpu = Fpu::Normal; rc.mcts_cfg.fpu_value = 1.0f; rc.mcts_cfg.fpu_std = 0.1f; }
-        OraclePolicy policy;
-        policy.blob = blob.data();
+        const int threads = std::atoi(argv[6]);
+        const char* conc = std::getenv("LS_CONCURRENT");
+        const size_t concurrent = conc ? (size_t)std::atoll(conc) : 0;
+        Policies policies(threads < 0 ? (size_t)-threads : 1, blob.data());
         size_t rounds = 0, evals = 0;
-        const auto recs = lockstep_selfplay<Connect4, 9>(policy, rc, games, std::strtoull(argv[7], nullptr, 10),
-                                                         std::strtoull(argv[8], nullptr, 10), std::atoi(argv[6]), &rounds, &evals);
+        const uint64_t seed = std::strtoull(argv[7], nullptr, 10), first_game = std::strtoull(argv[8], nullptr, 10);
+        const auto recs = threads < 0 ? lockstep_selfplay_sharded<Connect4, 9>(policies.list, rc, games, seed, first_game, concurrent, &rounds, &evals)
+                                      : lockstep_selfplay<Connect4, 9>(*policies.list[0], rc, games, seed, first_game, threads, &rounds, &evals,
+                                                                       concurrent);
         // out.bin: per game [plies i32][final_kind i32] then 63 x {my u64, op u64, pi f32[9], v f32[3], action u32, root_nodes u32}
         std::ofstream of(argv[9], std::ios::binary);
         for (const auto& r : recs) {
@@ -158,7 +196,7 @@ int main(int argc, char** argv) {
                 of.write(reinterpret_cast<const char*>(u), 8);
             }
         }
-        std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policy.calls);
+        std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policies.calls());
         return 0;
     }
     if (argc != 8 || std::string(argv[1]) != "c4") return 2;
@@ -180,10 +218,10 @@ int main(int argc, char** argv) {
     if (variant == 6) { cfg.exploration = Exploration::Uct; cfg.c = 1.4f; cfg.fpu = Fpu::Normal; cfg.fpu_value = 0.5f; cfg.fpu_std = 0.3f; }
     std::vector<Connect4> roots;
     for (size_t i = 0; i < n; i++) roots.push_back(Connect4::from_bitboards(bb[i], bb[n + i]));
-    OraclePolicy policy;
-    policy.blob = blob.data();
+    Policies policies(threads < 0 ? (size_t)-threads : 1, blob.data());
     size_t rounds = 0, evals = 0;
-    const auto trees = lockstep_search<Connect4, 9>(policy, cfg, roots, explores, threads, &rounds, &evals);
+    const auto trees = threads < 0 ? lockstep_search_sharded<Connect4, 9>(policies.list, cfg, roots, explores, &rounds, &evals)
+                                   : lockstep_search<Connect4, 9>(*policies.list[0], cfg, roots, explores, threads, &rounds, &evals);
     std::vector<syn_search_result> out(n);
     for (size_t i = 0; i < n; i++) {
         const auto& t = trees[i];
@@ -212,6 +250,6 @@ int main(int argc, char** argv) {
     }
     std::ofstream of(argv[7], std::ios::binary);
     of.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * sizeof(syn_search_result)));
-    std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policy.calls);
+    std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policies.calls());
     return 0;
 }

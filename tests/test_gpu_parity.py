@@ -154,6 +154,59 @@ def test_policy_eval_large_batch_consistency(engine, oracle, blob):
     assert np.array_equal(logits[:512], fl) and np.array_equal(value[:512], fv)
 
 
+def test_policy_eval_transfer_paths_and_contexts(engine, oracle, blob):
+    """syn_policy_eval_batch reads the positions in pinned host memory in place and, by batch size, writes the results in place
+    (<= 4,096), fetches them with one DMA (<= 32,768) or uses the pageable transfers (beyond): every boundary gives the oracle's
+    bits. Evaluation contexts (syn_eval_ctx: one worker's policy, alpha_zero.rs:192-198) give the same bits — one batch in flight
+    each, four of them from four host threads at once, beside the engine's own call."""
+    import threading
+    import synthesis_amd as sa
+
+    my, op = random_positions(oracle, 4099, seed=12)
+    fl, fv = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    reps = 9   # 36,891 positions: past the pinned path's end
+    big_my, big_op = np.tile(my, reps), np.tile(op, reps)
+    big_l, big_v = np.tile(fl, (reps, 1)), np.tile(fv, (reps, 1))
+    for n in (4096, 4097, 20000, 32768, 32769, len(big_my)):
+        l, v = engine.policy_eval(big_my[:n], big_op[:n])
+        assert np.array_equal(l.view(np.uint32), big_l[:n].view(np.uint32)) and np.array_equal(v.view(np.uint32), big_v[:n].view(np.uint32)), n
+    ctxs = [engine.eval_context() for _ in range(4)]
+    for n in (0, 1, 17, 4096, 4097, 33000):
+        l, v = ctxs[0].eval(big_my[:n], big_op[:n])
+        assert l.shape == (n, 9) and np.array_equal(l.view(np.uint32), big_l[:n].view(np.uint32)) and np.array_equal(v.view(np.uint32), big_v[:n].view(np.uint32))
+    # submit ... wait with other work on the engine's own stream in between; a second submit before the wait is refused
+    ctxs[1].submit(my[:700], op[:700])
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        ctxs[1].submit(my[:5], op[:5])
+    assert e.value.code == -1 and "waited" in str(e.value)
+    l0, v0 = engine.policy_eval(my[:300], op[:300])
+    l1, v1 = ctxs[1].wait()
+    assert np.array_equal(l1, fl[:700]) and np.array_equal(v1, fv[:700]) and np.array_equal(l0, fl[:300]) and np.array_equal(v0, fv[:300])
+    errors = []
+
+    def worker(k):
+        try:
+            rs = np.random.RandomState(k)
+            for _ in range(150):
+                lo = int(rs.randint(0, 3000)); n = int(rs.randint(1, 1000))
+                l, v = ctxs[k].eval(my[lo:lo + n], op[lo:lo + n])
+                if not (np.array_equal(l, fl[lo:lo + n]) and np.array_equal(v, fv[lo:lo + n])):
+                    errors.append((k, lo, n))
+        except Exception as ex:   # noqa: BLE001
+            errors.append((k, repr(ex)))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for _ in range(50):   # the engine's own entry point beside them
+        l, v = engine.policy_eval(my[:513], op[:513])
+        assert np.array_equal(l, fl[:513]) and np.array_equal(v, fv[:513])
+    for t in threads:
+        t.join()
+    assert errors == []
+    for c in ctxs:
+        c.close()
+
+
 # ------------------------------------------------------------------------------------------------ slimnn layers
 def test_slimnn_layer_kats_on_gpu(engine, oracle, golden_dir):
     """slimnn/src/conv.rs:92-602, linear.rs:105-112 through the GPU kernels; also bit-exact vs the oracle's slimnn mode."""

@@ -59,17 +59,22 @@ def test_lockstep_trees_equal_the_sequential_oracle(harness, oracle, golden_dir)
     roots = str(d / "roots.u64")
     np.concatenate([my, op]).astype("<u8").tofile(roots)
     for variant, explores, threads in ((0, 0, 1), (0, 1, 1), (0, 150, 4), (1, 90, 1), (2, 120, 3), (3, 100, 1), (4, 100, 2),
-                                      (5, 0, 1), (5, 150, 3), (6, 90, 2)):
-        out = str(d / f"out{variant}_{explores}.bin")
-        p = subprocess.run([exe, "c4", blobf, roots, str(explores), str(variant), str(threads), out], capture_output=True,
-                           text=True, timeout=600)
+                                      (5, 0, 1), (5, 150, 3), (6, 90, 2),
+                                      # one policy per host thread (lockstep_search_sharded): 3 shards of the 80 roots
+                                      (0, 120, -3), (5, 100, -4), (1, 60, -40)):
+        out = str(d / f"out{variant}_{explores}_{threads}.bin")
+        # (-40 stands for: four workers sharing ONE policy through a CombiningPolicy)
+        p = subprocess.run([exe, "c4", blobf, roots, str(explores), str(variant), str(max(threads, -4)), out], capture_output=True,
+                           text=True, timeout=600, env=dict(os.environ, LS_COMBINE="1" if threads == -40 else "0"))
         assert p.returncode == 0, p.stdout + p.stderr
         got = records(out, len(my))
         ref = oracle.c4_mcts_search(parity_mcts_config(**VARIANTS[variant]), blob, my, op, explores, nn_mode=oracle.ACC_FMA)
         assert_search_equal(got, ref, f"lockstep variant {variant} explores {explores}")
         rounds, evals, calls = [int(x) for x in p.stdout.split()[1::2]]
-        # one batched call per round, and rounds are bounded by the deepest tree: construction + explores
-        assert calls == rounds <= explores + 1 and evals <= len(my) * (explores + 1)
+        # one batched call per round, and rounds are bounded by the deepest tree: construction + explores — per group of trees that
+        # shares its calls: all of them on a pool, two halves taking turns on one thread, two halves per shard
+        groups = 1 if threads > 1 else 2 * abs(max(threads, -4))
+        assert calls <= rounds <= groups * (explores + 1) and evals <= len(my) * (explores + 1)
 
 
 SELFPLAY_DTYPE = np.dtype([("bb", np.uint64, (2,)), ("pi", np.float32, (9,)), ("v", np.float32, (3,)), ("action", np.uint32),
@@ -117,11 +122,19 @@ def test_lockstep_selfplay_equals_the_sequential_oracle(harness, oracle, golden_
 
     exe, blobf, d = harness
     blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
-    for variant, games, explores, threads, seed, first in ((0, 12, 60, 3, 7, 0), (1, 8, 50, 1, 99, 5), (2, 8, 40, 2, 3, 0), (3, 8, 40, 4, 11, 2),
-                                                         (4, 10, 60, 3, 31, 7)):
-        out = str(d / f"sp{variant}.bin")
+    runs = [(0, 12, 60, 3, 7, 0, {}), (1, 8, 50, 1, 99, 5, {}), (2, 8, 40, 2, 3, 0, {}), (3, 8, 40, 4, 11, 2, {}), (4, 10, 60, 3, 31, 7, {}),
+            # many games: a pool over all of them; one thread, two halves taking turns; a policy whose begin() really returns early
+            (0, 700, 6, 4, 13, 0, {}), (4, 515, 9, 1, 2, 40, {}), (2, 300, 8, 1, 21, 0, dict(LS_ASYNC="1")),
+            # one policy per host thread (lockstep_selfplay_sharded), and fewer slots than games: a finished game's slot takes the
+            # next game index, whichever worker gets there first — every game still depends on its index only
+            (0, 400, 8, -3, 5, 9, {}), (4, 300, 8, -4, 77, 0, dict(LS_CONCURRENT="64", LS_ASYNC="1")),
+            (1, 90, 10, 1, 8, 0, dict(LS_CONCURRENT="20")), (3, 200, 6, 3, 8, 3, dict(LS_CONCURRENT="70")),
+            # the workers share one policy: their batches go to it combined (CombiningPolicy — what syn_selfplay_run_lockstep runs)
+            (0, 500, 8, -4, 6, 0, dict(LS_COMBINE="1")), (4, 400, 8, -5, 9, 2, dict(LS_COMBINE="1", LS_ASYNC="1", LS_CONCURRENT="150"))]
+    for variant, games, explores, threads, seed, first, env in runs:
+        out = str(d / f"sp{variant}_{games}_{threads}.bin")
         p = subprocess.run([exe, "selfplay", blobf, str(games), str(explores), str(variant), str(threads), str(seed), str(first), out],
-                           capture_output=True, text=True, timeout=900)
+                           capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
         assert p.returncode == 0, p.stdout + p.stderr
         rec = np.fromfile(out, GAME_DTYPE)
         assert rec.shape == (games,)
@@ -133,7 +146,7 @@ def test_lockstep_selfplay_equals_the_sequential_oracle(harness, oracle, golden_
                                  nn_mode=oracle.ACC_FMA)
         assert_games_equal(got, ref, f"lockstep self-play variant {variant}")
         rounds, evals, calls = [int(x) for x in p.stdout.split()[1::2]]
-        assert calls == rounds and evals <= int(ref["plies"].sum()) * (explores + 1)
+        assert (calls <= rounds if env.get("LS_COMBINE") else calls == rounds) and evals <= int(ref["plies"].sum()) * (explores + 1)
 
 
 def test_lockstep_driver_is_generic_over_the_game(harness):
@@ -182,7 +195,8 @@ def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
         assert_search_equal(got, fused, "lockstep vs fused")
         ref = oracle.c4_mcts_search(parity_mcts_config(**okw), blob, my[:256], op[:256], explores, nn_mode=oracle.ACC_FMA)
         assert_search_equal({k: got[k][:256] for k in SEARCH_KEYS}, ref, "lockstep vs oracle")
-        assert 1 <= stats["rounds"] <= explores + 1 and stats["positions_evaluated"] <= 4096 * (explores + 1)
+        # (launches: at most explores + 1 per half of a worker's trees, 32 workers at most)
+        assert 1 <= stats["rounds"] <= 64 * (explores + 1) and stats["positions_evaluated"] <= 4096 * (explores + 1)
     # the Dirichlet draws live on the device path only
     with pytest.raises(sa.SynthesisAmdError) as e:
         eng.mcts_search_lockstep(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25), my[:4], op[:4], 8)
@@ -239,6 +253,34 @@ def test_lockstep_host_code_is_clean_under_asan_and_ubsan(oracle, golden_dir, tm
     for args in (["c4", blob, roots, "60", "0", "4", str(tmp_path / "o1.bin")], ["c4", blob, roots, "40", "1", "2", str(tmp_path / "o2.bin")],
                  ["selfplay", blob, "6", "40", "0", "3", "9", "0", str(tmp_path / "o3.bin")],
                  ["selfplay", blob, "4", "30", "3", "2", "1", "7", str(tmp_path / "o4.bin")],
-                 ["selfplay", blob, "4", "40", "4", "2", "2", "0", str(tmp_path / "o5.bin")], ["nim"], ["nimthrow"]):
-        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=env)
+                 ["selfplay", blob, "4", "40", "4", "2", "2", "0", str(tmp_path / "o5.bin")],
+                 ["selfplay", blob, "530", "4", "2", "3", "5", "0", str(tmp_path / "o6.bin")],
+                 ["selfplay", blob, "200", "5", "4", "-3", "5", "0", str(tmp_path / "o7.bin")],
+                 ["c4", blob, roots, "30", "5", "-2", str(tmp_path / "o8.bin")], ["nim"], ["nimthrow"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600, env=dict(env, LS_CONCURRENT="48", LS_ASYNC="1"))
+        assert p.returncode == 0, " ".join(args) + "\n" + p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_lockstep_host_threads_are_race_free_under_tsan(oracle, golden_dir, tmp_path):
+    """The worker pool (blocks of trees from a shared counter), the sharded drivers (one policy and one thread per shard, game indices
+    from a shared counter), a policy that computes on another thread between eval_batch_begin() and _end() while its caller advances
+    the other half of its trees, and the exception hand-over, under ThreadSanitizer: any report fails the run."""
+    exe = str(tmp_path / "lockstep_harness_tsan")
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-pthread",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "lockstep_harness.cpp"),
+                           "-o", exe, "-L" + odir, "-loracle", "-Wl,-rpath," + odir])
+    blob = str(tmp_path / "blob.f32")
+    np.load(os.path.join(golden_dir, "c4net_blob_f32.npy")).astype("<f4").tofile(blob)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66")
+    from tests.test_gpu_parity import random_positions
+    my, op = random_positions(oracle, 200, seed=6, max_moves=40)
+    roots = str(tmp_path / "roots.u64")
+    np.concatenate([my, op]).astype("<u8").tofile(roots)
+    for args in (["c4", blob, roots, "30", "5", "4", str(tmp_path / "o1.bin")],
+                 ["selfplay", blob, "530", "4", "2", "3", "5", "0", str(tmp_path / "o2.bin")],
+                 ["selfplay", blob, "140", "6", "4", "4", "1", "0", str(tmp_path / "o3.bin")],
+                 ["selfplay", blob, "300", "5", "0", "-4", "1", "0", str(tmp_path / "o4.bin")],
+                 ["c4", blob, roots, "30", "0", "-3", str(tmp_path / "o5.bin")], ["nimthrow"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=dict(env, LS_CONCURRENT="90", LS_ASYNC="1", LS_COMBINE="1" if args[0] == "selfplay" else "0"))
         assert p.returncode == 0, " ".join(args) + "\n" + p.stdout[-1500:] + p.stderr[-3000:]
