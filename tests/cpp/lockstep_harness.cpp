@@ -5,6 +5,7 @@
 //   lockstep_harness nim
 //   lockstep_harness selfplay <blob.f32> <games> <explores> <variant> <threads> <seed> <first_game> <out.bin>
 //   lockstep_harness rng <seed> <words>
+//   lockstep_harness policythrow [end]
 // <threads> < 0: the sharded drivers with -threads policies (one per host thread). Environment: LS_CONCURRENT = games in flight
 // (self-play; default all), LS_ASYNC = 1: a policy whose eval_batch_begin() computes on another thread until eval_batch_end(),
 // LS_COMBINE = 1: the sharded drivers' workers share ONE policy through a CombiningPolicy.
@@ -128,6 +129,63 @@ int main(int argc, char** argv) {
         for (auto& g : ok) g.stones = 5;
         const auto trees = lockstep_search<ThrowingNim, 3>(policy, MCTSConfig{}, ok, 50, 4);
         std::printf("second search %zu trees, root solved %d\n", trees.size(), trees[0].root().solution.some ? 1 : 0);
+        return 0;
+    }
+    if (argc >= 2 && std::string(argv[1]) == "policythrow") {
+        // a policy that fails in its 40th call — in begin() or, with a second argument, in end() — under every driver shape: the
+        // error reaches the caller (no worker left waiting for answers that never come), and the policy can be used again
+        struct FailingPolicy : BatchPolicy<Nim, 3> {
+            size_t calls = 0, fail_at = 40;
+            bool in_end = false, armed = false;
+            void fill(const std::vector<const Nim*>& games, float* logits, float* value) {
+                for (size_t i = 0; i < games.size(); i++) {
+                    for (int k = 0; k < 3; k++) logits[i * 3 + k] = 0.0f;
+                    value[i * 3 + 0] = value[i * 3 + 1] = value[i * 3 + 2] = 1.0f / 3.0f;
+                }
+            }
+            void eval_batch(const std::vector<const Nim*>& games, float* logits, float* value) override {
+                eval_batch_begin(games, logits, value);
+                eval_batch_end();
+            }
+            void eval_batch_begin(const std::vector<const Nim*>& games, float* logits, float* value) override {
+                fill(games, logits, value);
+                if (++calls == fail_at) {
+                    if (!in_end) throw std::runtime_error("policy failed in begin");
+                    armed = true;
+                }
+            }
+            void eval_batch_end() override {
+                if (armed) {
+                    armed = false;
+                    throw std::runtime_error("policy failed in end");
+                }
+            }
+        };
+        const bool in_end = argc >= 3;
+        std::vector<Nim> roots(600);
+        for (size_t i = 0; i < roots.size(); i++) roots[i].stones = 9 + (int)(i % 7);
+        for (int shape = 0; shape < 4; shape++) {   // pool; one thread, two halves; sharded; sharded over one combined policy
+            FailingPolicy policy;
+            policy.in_end = in_end;
+            FailingPolicy p2, p3;
+            p2.fail_at = p3.fail_at = 1u << 30;
+            std::vector<BatchPolicy<Nim, 3>*> three{&policy, &p2, &p3};
+            CombiningPolicy<Nim, 3> combined(policy, 5);
+            try {
+                if (shape == 0) lockstep_search<Nim, 3>(policy, MCTSConfig{}, roots, 80, 4);
+                if (shape == 1) lockstep_search<Nim, 3>(policy, MCTSConfig{}, roots, 80, 1);
+                if (shape == 2) lockstep_search_sharded<Nim, 3>(three, MCTSConfig{}, roots, 80);
+                if (shape == 3) lockstep_search_sharded<Nim, 3>(combined.workers(), MCTSConfig{}, roots, 80);
+                std::printf("shape %d: no exception\n", shape);
+                return 1;
+            } catch (const std::runtime_error& e) {
+                std::printf("shape %d: caught %s\n", shape, e.what());
+            }
+            policy.fail_at = 1u << 30;
+            const auto trees = shape == 3 ? lockstep_search_sharded<Nim, 3>(combined.workers(), MCTSConfig{}, roots, 20)
+                                          : lockstep_search<Nim, 3>(policy, MCTSConfig{}, roots, 20, shape == 0 ? 4 : 1);
+            std::printf("shape %d: again %zu trees\n", shape, trees.size());
+        }
         return 0;
     }
     if (argc >= 2 && std::string(argv[1]) == "nim") {

@@ -175,6 +175,18 @@ def test_lockstep_pool_hands_a_worker_threads_exception_to_the_caller(harness):
     assert p.stdout.splitlines() == ["caught seven stones", "second search 128 trees, root solved 1"]
 
 
+def test_lockstep_policy_failure_reaches_the_caller(harness):
+    """A BatchPolicy that throws — in eval_batch_begin() or in eval_batch_end() — under the pool driver, the two-halves driver, the
+    sharded driver and the sharded driver over one CombiningPolicy: the caller gets the exception (no worker is left waiting for
+    answers that never come), and the same policy object serves the next search."""
+    exe, _, _ = harness
+    for extra in ([], ["end"]):
+        p = subprocess.run([exe, "policythrow"] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        where = "end" if extra else "begin"
+        assert p.stdout.splitlines() == [ln for k in range(4) for ln in (f"shape {k}: caught policy failed in {where}", f"shape {k}: again 600 trees")]
+
+
 @pytest.mark.gpu
 def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
     import synthesis_amd as sa
@@ -281,6 +293,6 @@ def test_lockstep_host_threads_are_race_free_under_tsan(oracle, golden_dir, tmp_
                  ["selfplay", blob, "530", "4", "2", "3", "5", "0", str(tmp_path / "o2.bin")],
                  ["selfplay", blob, "140", "6", "4", "4", "1", "0", str(tmp_path / "o3.bin")],
                  ["selfplay", blob, "300", "5", "0", "-4", "1", "0", str(tmp_path / "o4.bin")],
-                 ["c4", blob, roots, "30", "0", "-3", str(tmp_path / "o5.bin")], ["nimthrow"]):
+                 ["c4", blob, roots, "30", "0", "-3", str(tmp_path / "o5.bin")], ["nimthrow"], ["policythrow"], ["policythrow", "end"]):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=900, env=dict(env, LS_CONCURRENT="90", LS_ASYNC="1", LS_COMBINE="1" if args[0] == "selfplay" else "0"))
         assert p.returncode == 0, " ".join(args) + "\n" + p.stdout[-1500:] + p.stderr[-3000:]
