@@ -209,8 +209,8 @@ int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t 
  * advances the other — and the batches the workers hand in are combined into one launch on one evaluation context
  * (syn_eval_ctx_*). This is the driver a caller with a different Game impl instantiates; for Connect4 the fused syn_mcts_search
  * is the fast path and this entry point exists to hold the driver to it: results are identical, field for field. host_threads:
- * 0 = what the process may use (hardware concurrency cut to a cgroup CPU quota), at most 32. cfg: SYN_FPU_NORMAL draws what syn_mcts_search draws (root i: tree stream (i, turn 0));
- * SYN_NOISE_DIRICHLET returns SYN_ERR_UNSUPPORTED (its gamma sampler lives on the device path). stats may be NULL. */
+ * 0 = what the process may use (hardware concurrency cut to a cgroup CPU quota), at most 32. cfg: every configuration syn_mcts_search takes — SYN_FPU_NORMAL and SYN_NOISE_DIRICHLET
+ * draw what syn_mcts_search draws (root i: tree stream (i, turn 0)). stats may be NULL. */
 typedef struct syn_lockstep_stats {
     uint64_t rounds;               /* evaluation launches (combined batches) */
     uint64_t positions_evaluated;  /* leaves over all launches */
@@ -226,8 +226,8 @@ int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const ui
  * run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) on the host with game g's own
  * StdRng::seed_from_u64(base_seed + g) (include/synthesis_amd_lockstep.hpp::lockstep_selfplay_sharded).
  * Arguments and outputs are syn_selfplay_run's; the games are identical to that call's, move for move and float for float.
- * host_threads as above; SYN_FPU_NORMAL (the reference's own self-play configuration) included — the host trees take the
- * draws of syn_selfplay_run's trees; SYN_NOISE_DIRICHLET: SYN_ERR_UNSUPPORTED; stats may be NULL. */
+ * host_threads as above; SYN_FPU_NORMAL (the reference's own self-play configuration) and SYN_NOISE_DIRICHLET included — the
+ * host trees take the draws of syn_selfplay_run's trees; stats may be NULL. */
 int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game, int n_games,
                               int host_threads, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
                               uint32_t* root_nodes, uint8_t* final_kind, syn_lockstep_stats* stats);

@@ -208,13 +208,19 @@ private:
     syn_engine* h_ = nullptr;
 };
 
+// One worker's policy (alpha_zero.rs:192-198: every worker thread owns its policy): an evaluation context of the engine — its own
+// stream and pinned staging, the engine's weights — so several HipPolicy objects on one Engine serve several host threads at once.
 class HipPolicy : public Policy<Connect4, 9> {
 public:
-    explicit HipPolicy(Engine& e) : e_(e) {}
+    explicit HipPolicy(Engine& e) : e_(e) { e_.check(syn_eval_ctx_create(e_.handle(), &ctx_)); }
+    ~HipPolicy() override { syn_eval_ctx_destroy(ctx_); }
+    HipPolicy(const HipPolicy&) = delete;
+    HipPolicy& operator=(const HipPolicy&) = delete;
     std::pair<std::array<float, 9>, std::array<float, 3>> eval(const Connect4& game) override {
         const uint64_t my = game.my_bb(), op = game.op_bb();
         std::pair<std::array<float, 9>, std::array<float, 3>> out;
-        e_.check(syn_policy_eval_batch(e_.handle(), &my, &op, 1, out.first.data(), out.second.data()));
+        const int rc = syn_eval_ctx_eval(ctx_, &my, &op, 1, out.first.data(), out.second.data());
+        if (rc != SYN_OK) throw Error(rc, syn_eval_ctx_last_error(ctx_));
         return out;
     }
     // n positions per call: logits[n][9], value[n][3]
@@ -230,6 +236,7 @@ public:
 
 private:
     Engine& e_;
+    syn_eval_ctx* ctx_ = nullptr;
 };
 
 // ---- ReplayBuffer (data.rs:107-235) --------------------------------------------------------------------------------------

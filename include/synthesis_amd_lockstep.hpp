@@ -25,8 +25,8 @@
 // use (det_expf / det_logf below). Compile with -ffp-contract=off for bit parity with syn_mcts_search (tests/test_lockstep.py
 // holds this driver to the oracle and to the device search). Fpu::Normal (the reference's own self-play configuration,
 // study-connect4/src/main.rs:43-47) draws from the same counter-based per-tree stream as the device path (the draw
-// is a pure function of tree seed, scan number and child slot, restated below). PolicyNoise::Dirichlet needs the device path's
-// gamma sampler and is not offered here: Error(SYN_ERR_UNSUPPORTED).
+// is a pure function of tree seed, scan number and child slot, restated below), PolicyNoise::Dirichlet from the device path's
+// per-tree generator and gamma sampler (NoiseRng below): every MCTSConfig of the reference runs here.
 #pragma once
 #include <atomic>
 #include <cmath>
@@ -41,6 +41,7 @@
 #include <thread>
 
 #include "synthesis_amd.hpp"
+#include "synthesis_amd_zig_tables.hpp"
 
 namespace synthesis {
 
@@ -167,6 +168,10 @@ public:
         if (pos_ == 16) refill();
         return buf_[pos_++];
     }
+    uint64_t next_u64() {   // rand_core BlockRng::next_u64: the next two words of the stream, low word first
+        const uint64_t lo = next_u32();
+        return lo | ((uint64_t)next_u32() << 32);
+    }
     uint64_t words_drawn() const { return drawn_blocks_ * 16 - (uint64_t)(16 - pos_); }
     uint32_t gen_range_u8(uint32_t n) {
         const uint32_t zone = 0xFFFFFFFFu - (0xFFFFFFFFu - n + 1u) % n;
@@ -217,6 +222,124 @@ private:
     uint64_t drawn_blocks_ = 0;
     int pos_ = 16;
 };
+
+// ---- PolicyNoise::Dirichlet (mcts.rs:241-256: Dirichlet::new_with_size(alpha, n).sample(&mut thread_rng)) ---------------------
+// rand_distr 0.4's algorithms — Dirichlet = normalised Gamma(alpha, 1) draws, Gamma by Marsaglia-Tsang (shape < 1 boosted by
+// U^(1/shape), shape = 1 by inversion), its standard normal by the 256-layer ziggurat — on a StdRng per tree seeded
+// tree_seed ^ NOISE_DIRICHLET_TAG instead of thread_rng; exp / ln through deterministic restatements. The same definition as
+// csrc/noise.cuh: the device path and the host trees draw the same sample for the same tree.
+constexpr uint64_t NOISE_DIRICHLET_TAG = 0xD1A1C4E7D1A1C4E7ull;
+inline double bits_f64(uint64_t u) { double f; std::memcpy(&f, &u, 8); return f; }
+inline uint64_t f64_bits(double f) { uint64_t u; std::memcpy(&u, &f, 8); return u; }
+inline double det_exp64(double x) {
+    if (x != x) return x;
+    if (x < -700.0) return 0.0;
+    if (x > 700.0) return bits_f64(0x7FF0000000000000ull);
+    const double k = std::rint(x * 1.4426950408889634);
+    double r = std::fma(k, -6.93147180369123816490e-01, x);
+    r = std::fma(k, -1.90821492927058770002e-10, r);
+    // exp(r) on |r| <= ln2 / 2: Taylor to r^13, Horner
+    static const double inv_fact[12] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+                                        1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0};
+    double p = 1.0 / 6227020800.0;
+    for (int i = 0; i < 12; i++) p = std::fma(p, r, inv_fact[i]);
+    p = std::fma(p, r, 1.0);
+    const long long ki = (long long)k;
+    const double s1 = bits_f64((uint64_t)(1023 + ki / 2) << 52), s2 = bits_f64((uint64_t)(1023 + (ki - ki / 2)) << 52);
+    return p * s1 * s2;
+}
+inline double det_log64(double x) {
+    if (x != x || x < 0.0) return bits_f64(0x7FF8000000000000ull);
+    if (x == 0.0) return bits_f64(0xFFF0000000000000ull);
+    uint64_t b = f64_bits(x);
+    if (b == 0x7FF0000000000000ull) return x;
+    int e = 0;
+    if (b < 0x0010000000000000ull) {
+        x = x * 4503599627370496.0;
+        b = f64_bits(x);
+        e = -52;
+    }
+    e += (int)(b >> 52) - 1023;
+    double m = bits_f64((b & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e += 1;
+    }
+    // ln m = 2 atanh(s), s = (m - 1) / (m + 1): odd series to s^25
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 25.0;
+    for (int d = 23; d >= 3; d -= 2) p = std::fma(p, z, 1.0 / (double)d);
+    p = std::fma(p, z, 1.0);
+    const double lm = 2.0 * s * p;
+    const double fe = (double)e;
+    return std::fma(fe, 6.93147180369123816490e-01, std::fma(fe, 1.90821492927058770002e-10, lm));
+}
+class NoiseRng {
+public:
+    explicit NoiseRng(uint64_t seed) : g_(seed) {}
+    float gamma(float shape) {   // gamma.rs Gamma::new(shape, 1.0).sample
+        if (shape == 1.0f) return (float)(-det_log64(open01_f64())) * 1.0f;
+        if (shape < 1.0f) {
+            const float inv_shape = 1.0f / shape;
+            const float s1 = shape + 1.0f;
+            const float d = s1 - 0.33333334f, c = 1.0f / std::sqrt(9.0f * d);
+            const float u = open01_f32();
+            return gamma_large(d, c) * det_expf(inv_shape * det_logf(u));
+        }
+        const float d = shape - 0.33333334f, c = 1.0f / std::sqrt(9.0f * d);
+        return gamma_large(d, c);
+    }
+
+private:
+    double gen_f64() { return (double)(g_.next_u64() >> 11) * (1.0 / 9007199254740992.0); }
+    double open01_f64() { return bits_f64((g_.next_u64() >> 12) | 0x3FF0000000000000ull) - (1.0 - 1.1102230246251565e-16); }
+    float open01_f32() { return bits_f32((g_.next_u32() >> 9) | 0x3F800000u) - (1.0f - 5.9604645e-08f); }
+    double standard_normal() {   // normal.rs StandardNormal + utils.rs ziggurat (symmetric)
+        for (;;) {
+            const uint64_t bits = g_.next_u64();
+            const uint32_t i = (uint32_t)bits & 0xFFu;
+            const double u = bits_f64((bits >> 12) | 0x4000000000000000ull) - 3.0;
+            const double x = u * ZIG_NORM_X[i];
+            const double ax = x < 0.0 ? -x : x;
+            if (ax < ZIG_NORM_X[i + 1]) return x;
+            if (i == 0u) {   // the tail beyond R
+                double tx = 1.0, ty = 0.0;
+                while (-2.0 * ty < tx * tx) {
+                    const double a = open01_f64();
+                    const double b = open01_f64();
+                    tx = det_log64(a) / ZIG_NORM_R;
+                    ty = det_log64(b);
+                }
+                return u < 0.0 ? tx - ZIG_NORM_R : ZIG_NORM_R - tx;
+            }
+            if (ZIG_NORM_F[i + 1] + (ZIG_NORM_F[i] - ZIG_NORM_F[i + 1]) * gen_f64() < det_exp64(-x * x / 2.0)) return x;
+        }
+    }
+    float gamma_large(float d, float c) {   // GammaLargeShape::sample, scale 1
+        for (;;) {
+            const float x = (float)standard_normal();
+            const float v_cbrt = 1.0f + c * x;
+            if (v_cbrt <= 0.0f) continue;
+            const float v = v_cbrt * v_cbrt * v_cbrt;
+            const float u = open01_f32();
+            const float x_sqr = x * x;
+            if (u < 1.0f - 0.0331f * x_sqr * x_sqr || det_logf(u) < 0.5f * x_sqr + d * (1.0f - v + det_logf(v))) return d * v * 1.0f;
+        }
+    }
+    StdRng g_;
+};
+// the root's noise vector: n Gamma(alpha) draws divided by their sum (dirichlet.rs), in child order
+inline void noise_dirichlet(uint64_t tree_seed, float alpha, uint32_t n, float* out) {
+    NoiseRng g(tree_seed ^ NOISE_DIRICHLET_TAG);
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < n; i++) {
+        out[i] = g.gamma(alpha);
+        sum += out[i];
+    }
+    const float invacc = 1.0f / sum;
+    for (uint32_t i = 0; i < n; i++) out[i] = out[i] * invacc;
+}
 
 // Host threads this process may actually run at once: the hardware concurrency, cut to a cgroup CPU quota if there is one (a
 // container with 16 CPUs' worth of time on a 256-thread host: more runnable threads than quota get throttled in the middle of a
@@ -409,11 +532,11 @@ public:
     };
 
     // MCTS::with_capacity(explores + 1, cfg, policy, game) followed by explore_n(explores): nothing runs before advance()
-    // noise_seed: detail::noise_tree_seed(stream, turn) of this tree — read only by Fpu::Normal
+    // noise_seed: detail::noise_tree_seed(stream, turn) of this tree — read by Fpu::Normal and PolicyNoise::Dirichlet
     LockstepTree(const MCTSConfig& cfg, const G& game, int explores, uint64_t noise_seed = 0)
         : cfg_(cfg), explores_(explores), noise_seed_(noise_seed) {
-        if (cfg.root_policy_noise == PolicyNoise::Dirichlet)
-            throw Error(SYN_ERR_UNSUPPORTED, "lockstep MCTS: PolicyNoise::Dirichlet draws from the device path's gamma sampler");
+        if (cfg.root_policy_noise == PolicyNoise::Dirichlet && !(cfg.noise_alpha > 0.0f))
+            throw Error(SYN_ERR_INVALID_ARGUMENT, "PolicyNoise::Dirichlet needs alpha > 0");
         nodes_.reserve((size_t)explores + 1);
         Node root;
         root.game = game;
@@ -595,6 +718,13 @@ private:
             const float w = cfg_.noise_weight, noise = 1.0f / (float)nodes_[0].num_children;
             for (uint32_t c = nodes_[0].first_child; c < nodes_[0].last_child(); c++)
                 nodes_[c].action_prob = nodes_[c].action_prob * (1.0f - w) + w * noise;
+        }
+        if (cfg_.root_policy_noise == PolicyNoise::Dirichlet && nodes_[0].num_children >= 2) {   // mcts.rs:241-256
+            float noise[N];
+            detail::noise_dirichlet(noise_seed_, cfg_.noise_alpha, nodes_[0].num_children, noise);
+            uint32_t k = 0;
+            for (uint32_t c = nodes_[0].first_child; c < nodes_[0].last_child(); c++, k++)
+                nodes_[c].action_prob = nodes_[c].action_prob * (1.0f - cfg_.noise_weight) + cfg_.noise_weight * noise[k];
         }
     }
 

@@ -50,21 +50,20 @@ struct Workers {
 
 namespace {
 // syn_mcts_config -> MCTSConfig for the host trees; 0 or the error code left in syn_last_error
-int host_mcts_config(syn_engine* h, const syn_mcts_config* cfg, const char* who, synthesis::MCTSConfig& m) {
+int host_mcts_config(syn_engine* h, const syn_mcts_config* cfg, synthesis::MCTSConfig& m) {
     using namespace synthesis;
     if (cfg->exploration != SYN_EXPLORATION_UCT && cfg->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration");
-    if (cfg->root_policy_noise == SYN_NOISE_DIRICHLET) {
-        const std::string msg = std::string(who) + ": SYN_NOISE_DIRICHLET draws from the device path's gamma sampler (syn_mcts_search / "
-                                                   "syn_selfplay_run)";
-        return syn_internal_fail(h, SYN_ERR_UNSUPPORTED, msg.c_str());
-    }
     if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q && cfg->fpu != SYN_FPU_NORMAL)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu");
     if (cfg->fpu == SYN_FPU_NORMAL && !(cfg->fpu_std >= 0.0f && cfg->fpu_std < 1e30f && cfg->fpu_value == cfg->fpu_value))
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_FPU_NORMAL needs a finite mean and 0 <= std < 1e30");
-    if (cfg->root_policy_noise != SYN_NOISE_NONE && cfg->root_policy_noise != SYN_NOISE_EQUAL)
+    if (cfg->root_policy_noise != SYN_NOISE_NONE && cfg->root_policy_noise != SYN_NOISE_EQUAL && cfg->root_policy_noise != SYN_NOISE_DIRICHLET)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown root policy noise");
+    if (cfg->root_policy_noise != SYN_NOISE_NONE && !(cfg->noise_weight >= 0.0f))
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "PolicyNoise weight must be >= 0");
+    if (cfg->root_policy_noise == SYN_NOISE_DIRICHLET && !(cfg->noise_alpha > 0.0f && cfg->noise_alpha < 1e30f))
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_NOISE_DIRICHLET needs 0 < alpha < 1e30 (Dirichlet::new_with_size)");
     m.exploration = (Exploration)cfg->exploration;
     m.c = cfg->c;
     m.solve = cfg->solve != 0;
@@ -94,7 +93,7 @@ extern "C" int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config
     if (cfg->num_explores < 0 || cfg->random_actions_until < 0 || cfg->sample_actions_until < 0)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "num_explores / random_actions_until / sample_actions_until must be >= 0");
     RolloutConfig rc;
-    const int cr = host_mcts_config(h, &cfg->mcts_cfg, "syn_selfplay_run_lockstep", rc.mcts_cfg);
+    const int cr = host_mcts_config(h, &cfg->mcts_cfg, rc.mcts_cfg);
     if (cr != SYN_OK) return cr;
     rc.num_explores = cfg->num_explores;
     rc.random_actions_until = cfg->random_actions_until;
@@ -153,7 +152,7 @@ extern "C" int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cf
     if (action_selection != SYN_ACTION_Q && action_selection != SYN_ACTION_NUM_VISITS)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown action selection");
     MCTSConfig m;
-    if (const int rc = host_mcts_config(h, cfg, "syn_mcts_search_lockstep", m)) return rc;
+    if (const int rc = host_mcts_config(h, cfg, m)) return rc;
     try {
         std::vector<Connect4> roots;
         roots.reserve((size_t)n);

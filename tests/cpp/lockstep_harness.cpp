@@ -225,6 +225,8 @@ int main(int argc, char** argv) {
         if (variant == 3) { rc.value_target = ValueTarget::QtoZ; rc.value_target_from = 0.1f; rc.value_target_to = 0.9f;
                             rc.mcts_cfg.root_policy_noise = PolicyNoise::Equal; rc.mcts_cfg.noise_weight = 0.25f; }
         if (variant == 4) { rc.mcts_cfg.fpu = Fpu::Normal; rc.mcts_cfg.fpu_value = 1.0f; rc.mcts_cfg.fpu_std = 0.1f; }
+        if (variant == 5) { rc.mcts_cfg.root_policy_noise = PolicyNoise::Dirichlet; rc.mcts_cfg.noise_alpha = 0.3f; rc.mcts_cfg.noise_weight = 0.25f;
+                            rc.mcts_cfg.fpu = Fpu::Normal; rc.mcts_cfg.fpu_value = 1.0f; rc.mcts_cfg.fpu_std = 0.1f; }
         const int threads = std::atoi(argv[6]);
         const char* conc = std::getenv("LS_CONCURRENT");
         const size_t concurrent = conc ? (size_t)std::atoll(conc) : 0;
@@ -274,6 +276,10 @@ int main(int argc, char** argv) {
     if (variant == 4) { cfg.correct_values_on_solve = false; cfg.c = 1.5f; }
     if (variant == 5) { cfg.fpu = Fpu::Normal; cfg.fpu_value = 1.0f; cfg.fpu_std = 0.1f; }   // study-connect4/src/main.rs:43-47
     if (variant == 6) { cfg.exploration = Exploration::Uct; cfg.c = 1.4f; cfg.fpu = Fpu::Normal; cfg.fpu_value = 0.5f; cfg.fpu_std = 0.3f; }
+    if (variant == 7) { cfg.root_policy_noise = PolicyNoise::Dirichlet; cfg.noise_alpha = 0.3f; cfg.noise_weight = 0.25f; }   // mcts.rs:241-256
+    if (variant == 8) { cfg.root_policy_noise = PolicyNoise::Dirichlet; cfg.noise_alpha = 1.0f; cfg.noise_weight = 0.5f;
+                        cfg.fpu = Fpu::Normal; cfg.fpu_value = 1.0f; cfg.fpu_std = 0.1f; }
+    if (variant == 9) { cfg.root_policy_noise = PolicyNoise::Dirichlet; cfg.noise_alpha = 2.5f; cfg.noise_weight = 0.25f; cfg.auto_extend = false; }
     std::vector<Connect4> roots;
     for (size_t i = 0; i < n; i++) roots.push_back(Connect4::from_bitboards(bb[i], bb[n + i]));
     Policies policies(threads < 0 ? (size_t)-threads : 1, blob.data());

@@ -25,6 +25,9 @@ VARIANTS = {
     4: dict(correct_values_on_solve=0, c=1.5),
     5: dict(fpu=2, fpu_value=1.0, fpu_std=0.1),   # the reference's own self-play configuration (study-connect4/src/main.rs:37-49)
     6: dict(exploration=0, c=1.4, fpu=2, fpu_value=0.5, fpu_std=0.3),
+    7: dict(noise=2, noise_alpha=0.3, noise_weight=0.25),     # PolicyNoise::Dirichlet (mcts.rs:241-256): alpha < 1, = 1, > 1
+    8: dict(noise=2, noise_alpha=1.0, noise_weight=0.5, fpu=2, fpu_value=1.0, fpu_std=0.1),
+    9: dict(noise=2, noise_alpha=2.5, noise_weight=0.25, auto_extend=0),
 }
 
 
@@ -61,7 +64,8 @@ def test_lockstep_trees_equal_the_sequential_oracle(harness, oracle, golden_dir)
     for variant, explores, threads in ((0, 0, 1), (0, 1, 1), (0, 150, 4), (1, 90, 1), (2, 120, 3), (3, 100, 1), (4, 100, 2),
                                       (5, 0, 1), (5, 150, 3), (6, 90, 2),
                                       # one policy per host thread (lockstep_search_sharded): 3 shards of the 80 roots
-                                      (0, 120, -3), (5, 100, -4), (1, 60, -40)):
+                                      (0, 120, -3), (5, 100, -4), (1, 60, -40),
+                                      (7, 0, 1), (7, 120, 2), (8, 100, -3), (9, 90, 1)):
         out = str(d / f"out{variant}_{explores}_{threads}.bin")
         # (-40 stands for: four workers sharing ONE policy through a CombiningPolicy)
         p = subprocess.run([exe, "c4", blobf, roots, str(explores), str(variant), str(max(threads, -4)), out], capture_output=True,
@@ -87,6 +91,7 @@ SELFPLAY_VARIANTS = {
     2: dict(value_target=2, vt_p=0.25, random_actions_until=3, sample_actions_until=10, mcts=dict(exploration=0, c=1.4, fpu=1)),
     3: dict(value_target=3, vt_from=0.1, vt_to=0.9, mcts=dict(noise=1, noise_weight=0.25)),
     4: dict(mcts=dict(fpu=2, fpu_value=1.0, fpu_std=0.1)),
+    5: dict(mcts=dict(noise=2, noise_alpha=0.3, noise_weight=0.25, fpu=2, fpu_value=1.0, fpu_std=0.1)),
 }
 
 
@@ -129,6 +134,7 @@ def test_lockstep_selfplay_equals_the_sequential_oracle(harness, oracle, golden_
             # next game index, whichever worker gets there first — every game still depends on its index only
             (0, 400, 8, -3, 5, 9, {}), (4, 300, 8, -4, 77, 0, dict(LS_CONCURRENT="64", LS_ASYNC="1")),
             (1, 90, 10, 1, 8, 0, dict(LS_CONCURRENT="20")), (3, 200, 6, 3, 8, 3, dict(LS_CONCURRENT="70")),
+            (5, 40, 50, 2, 17, 4, {}), (5, 260, 10, -3, 3, 0, dict(LS_COMBINE="1")),
             # the workers share one policy: their batches go to it combined (CombiningPolicy — what syn_selfplay_run_lockstep runs)
             (0, 500, 8, -4, 6, 0, dict(LS_COMBINE="1")), (4, 400, 8, -5, 9, 2, dict(LS_COMBINE="1", LS_ASYNC="1", LS_CONCURRENT="150"))]
     for variant, games, explores, threads, seed, first, env in runs:
@@ -209,10 +215,14 @@ def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
         assert_search_equal({k: got[k][:256] for k in SEARCH_KEYS}, ref, "lockstep vs oracle")
         # (launches: at most explores + 1 per half of a worker's trees, 32 workers at most)
         assert 1 <= stats["rounds"] <= 64 * (explores + 1) and stats["positions_evaluated"] <= 4096 * (explores + 1)
-    # the Dirichlet draws live on the device path only
+    # PolicyNoise::Dirichlet on the host trees: the device path's sample for the same tree
+    dcfg = sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25, fpu=sa.Fpu.Func, fpu_value=1.0, fpu_std=0.1)
+    got = eng.mcts_search_lockstep(dcfg, my, op, 48)
+    got.pop("stats")
+    assert_search_equal(got, eng.mcts_search(dcfg, my, op, 48), "lockstep vs fused, Dirichlet + Fpu::Func")
     with pytest.raises(sa.SynthesisAmdError) as e:
-        eng.mcts_search_lockstep(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25), my[:4], op[:4], 8)
-    assert e.value.code == -5
+        eng.mcts_search_lockstep(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.0, noise_weight=0.25), my[:4], op[:4], 8)
+    assert e.value.code == -1
     eng.close()
 
 
@@ -239,10 +249,10 @@ def test_lockstep_selfplay_on_the_gpu_equals_the_fused_selfplay(oracle, golden_d
     got = eng.selfplay_lockstep(rcfg, 5, 1024, first_game=11)
     got.pop("stats")
     assert_games_equal(got, eng.selfplay(rcfg, 5, 1024, first_game=11), "lockstep self-play vs fused, Fpu::Func")
-    with pytest.raises(sa.SynthesisAmdError) as e:
-        eng.selfplay_lockstep(sa.parity_rollout_config(8, mcts_cfg=sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3,
-                                                                                noise_weight=0.25)), 1, 4)
-    assert e.value.code == -5
+    dcfg = sa.parity_rollout_config(32, mcts_cfg=sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.3, noise_weight=0.25))
+    got = eng.selfplay_lockstep(dcfg, 8, 512)
+    got.pop("stats")
+    assert_games_equal(got, eng.selfplay(dcfg, 8, 512), "lockstep self-play vs fused, Dirichlet root noise")
     eng.close()
 
 
