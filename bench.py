@@ -567,6 +567,29 @@ def main():
             steady = (gps - gx) / max(1e-9, t_step - dt2)    # games/s of the tail-free three quarters of a step
             out["launch_tail"] = {"games_per_s_at_quarter_games_per_step": gx / dt2, "steady_state_games_per_s": steady,
                                   "tail_share_of_a_step": max(0.0, 1.0 - games_per_s / steady)}
+        if extras and fits("policy_eval_call", 3):
+            # the boundary as a CALL — Policy::eval for a batch from pageable host buffers, host link included (never `value`): what a
+            # Rust `impl Policy` (n = 1) or a host-tree worker (hundreds of leaves) pays per call; syn_eval_ctx_eval is the same path on
+            # a context's own stream
+            try:
+                rs = np.random.RandomState(3)
+                a = rs.randint(0, 2 ** 62, 4096, dtype=np.uint64)
+                b = rs.randint(0, 2 ** 62, 4096, dtype=np.uint64)
+                pm, po = a & ~b, b & ~a
+                ctx = eng.eval_context()
+                call = {}
+                for n in (1, 256, 4096):
+                    for name, fn in (("syn_policy_eval_batch", eng.policy_eval), ("syn_eval_ctx_eval", ctx.eval)):
+                        fn(pm[:n], po[:n])
+                        t1 = time.perf_counter()
+                        for _ in range(200):
+                            fn(pm[:n], po[:n])
+                        call.setdefault(name, {})[str(n)] = round((time.perf_counter() - t1) / 200 * 1e6, 1)
+                ctx.close()
+                out["policy_eval_call"] = {"us_per_call_by_positions": call, "includes": "ctypes + numpy output allocation (~3 us), staging, launch, "
+                                           "kernel, synchronisation; positions and results cross the host link in place (pinned, mapped memory)"}
+            except Exception as ex:  # noqa: BLE001
+                out["policy_eval_call"] = {"error": str(ex)[:200]}
         if world == 1 and not args.no_4096 and fits("at_4096_concurrent_games", 15):
             # BASELINE configs[1] names 4096 concurrent games: same engine code at 16 trees per CU (latency-optimised
             # kernel, weights in registers), one 16,384-game step, reported beside the headline configuration

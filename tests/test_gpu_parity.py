@@ -182,6 +182,16 @@ def test_policy_eval_transfer_paths_and_contexts(engine, oracle, blob):
     l0, v0 = engine.policy_eval(my[:300], op[:300])
     l1, v1 = ctxs[1].wait()
     assert np.array_equal(l1, fl[:700]) and np.array_equal(v1, fv[:700]) and np.array_equal(l0, fl[:300]) and np.array_equal(v0, fv[:300])
+    # a context of an engine without weights: the engine's error code, the text in the context's own slot; wait() without a batch: nothing
+    bare = sa.Engine(concurrent_games=64, max_explores=8)
+    c0 = bare.eval_context()
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        c0.eval(my[:3], op[:3])
+    assert e.value.code == -4 and "syn_load_weights" in str(e.value)
+    bare.load_weights(blob)
+    l, v = c0.eval(my[:3], op[:3])
+    assert np.array_equal(l, fl[:3]) and np.array_equal(v, fv[:3])
+    bare.close()   # (closes its contexts first)
     errors = []
 
     def worker(k):
