@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -135,6 +136,7 @@ struct syn_engine {
     // scratch for host-pointer entry points
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
+    std::atomic<bool> eval_attr_set[3] = {{false}, {false}, {false}};   // launch_policy_eval: the kernels' LDS attribute is set
     size_t eval_zero_copy_in = 32768;  // syn_policy_eval_batch: up to this many positions are read / written in the pinned buffer itself
     size_t eval_zero_copy_out = 4096;
     void* h_stage = nullptr;           // pinned, device-mapped host staging for the host-pointer entry points (syn_policy_eval_batch)
@@ -800,18 +802,21 @@ int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats) {
 
 // The evaluation kernel of the engine's network on `st` (any stream of the engine's device): n positions, pointers the device can
 // read / write (device memory or pinned, device-mapped host memory).
-static hipError_t launch_policy_eval(const syn_engine* h, hipStream_t st, const uint64_t* d_my, const uint64_t* d_op, int n,
+static hipError_t launch_policy_eval(syn_engine* h, hipStream_t st, const uint64_t* d_my, const uint64_t* d_op, int n,
                                      float* d_logits, float* d_value) {
     // Two waves per SIMD (512 threads): one wave's LDS reads / feature math overlap the other's MFMAs. Large batches (every
     // wave gets several tiles) run three waves per SIMD, which also hides the loads and stores around the tiles.
     const int ntiles = (n + 15) / 16;
     hipError_t e;
-#define SYN_LAUNCH_EVAL(KERNEL, NT, LDS)                                                                                       \
+#define SYN_LAUNCH_EVAL(KERNEL, NT, LDS, SLOT)                                                                                 \
     {                                                                                                                          \
         auto k = KERNEL<NT>;                                                                                                   \
-        if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS))) != \
-            hipSuccess)                                                                                                        \
-            return e;                                                                                                          \
+        if (!h->eval_attr_set[SLOT].load(std::memory_order_acquire)) { /* once per engine: the call costs a microsecond */     \
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                         (int)(LDS))) != hipSuccess)                                                           \
+                return e;                                                                                                      \
+            h->eval_attr_set[SLOT].store(true, std::memory_order_release);                                                     \
+        }                                                                                                                      \
         int grid = (ntiles + NT / 64 - 1) / (NT / 64);                                                                         \
         if (grid > h->num_cus) grid = h->num_cus;                                                                              \
         hipLaunchKernelGGL(k, dim3(grid), dim3(NT), (LDS), st, h->d_wimg, reinterpret_cast<const unsigned long long*>(d_my),    \
@@ -819,11 +824,11 @@ static hipError_t launch_policy_eval(const syn_engine* h, hipStream_t st, const 
     }
     if (h->net_kind == 1) {
         // (16 waves per CU measured the same 46 % of the MFMA peak as 8: the tile is issue-bound, not latency-bound)
-        SYN_LAUNCH_EVAL(policy_eval_conv_kernel, 512, (size_t)ConvGeom::IMG_FLOATS * 4)
+        SYN_LAUNCH_EVAL(policy_eval_conv_kernel, 512, (size_t)ConvGeom::IMG_FLOATS * 4, 0)
     } else if (ntiles >= h->num_cus * 12 * 4) {
-        SYN_LAUNCH_EVAL(policy_eval_kernel, 768, (size_t)MlpGeom::IMG_FLOATS * 4)
+        SYN_LAUNCH_EVAL(policy_eval_kernel, 768, (size_t)MlpGeom::IMG_FLOATS * 4, 1)
     } else {
-        SYN_LAUNCH_EVAL(policy_eval_kernel, 512, (size_t)MlpGeom::IMG_FLOATS * 4)
+        SYN_LAUNCH_EVAL(policy_eval_kernel, 512, (size_t)MlpGeom::IMG_FLOATS * 4, 2)
     }
 #undef SYN_LAUNCH_EVAL
     return hipGetLastError();

@@ -52,6 +52,30 @@ def main():
         if n <= 65536:
             l2, v2 = eng.policy_eval(np.concatenate([my, my]), np.concatenate([op, op]))
             assert np.array_equal(l2[:n].view(np.uint32), logits.view(np.uint32)) and np.array_equal(v2[n:].view(np.uint32), value.view(np.uint32))
+    # the context path, split: submit (staging + launch, returns at once) and wait (until the answers are copied out)
+    ctx = eng.eval_context()
+    lib, c = eng._lib, ctx._c
+    out["ctx_submit_us"], out["ctx_wait_us"] = {}, {}
+    for n in (1, 256, 4096):
+        a = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
+        b = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
+        my, op = a & ~b, b & ~a
+        logits = np.zeros((n, 9), np.float32)
+        value = np.zeros((n, 3), np.float32)
+        pm, po, pl, pv = _p(my), _p(op), _p(logits), _p(value)
+        ts = tw = 0.0
+        for i in range(205):
+            t0 = time.perf_counter()
+            lib.syn_eval_ctx_submit(c, pm, po, n)
+            t1 = time.perf_counter()
+            lib.syn_eval_ctx_wait(c, pl, pv)
+            t2 = time.perf_counter()
+            if i >= 5:
+                ts += t1 - t0
+                tw += t2 - t1
+        out["ctx_submit_us"][str(n)] = round(ts / 200 * 1e6, 2)
+        out["ctx_wait_us"][str(n)] = round(tw / 200 * 1e6, 2)
+    ctx.close()
     eng.close()
     print(json.dumps(out))
 
