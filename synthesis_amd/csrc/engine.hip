@@ -18,6 +18,7 @@
 
 #include "../../include/synthesis_amd.h"
 #include "engine_kernels.cuh"
+#include "eval_small.cuh"
 #include "lane_kernel.cuh"
 #include "lane2_kernel.cuh"
 #include "pc_kernel.cuh"
@@ -137,6 +138,7 @@ struct syn_engine {
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
     std::atomic<bool> eval_attr_set[3] = {{false}, {false}, {false}};   // launch_policy_eval: the kernels' LDS attribute is set
+    size_t eval_poll_max = 1024;       // contexts: batches up to this size signal completion through pinned memory (SYN_DEBUG=1 SYN_EVAL_POLL_MAX)
     size_t eval_zero_copy_in = 32768;  // syn_policy_eval_batch: up to this many positions are read / written in the pinned buffer itself
     size_t eval_zero_copy_out = 4096;
     void* h_stage = nullptr;           // pinned, device-mapped host staging for the host-pointer entry points (syn_policy_eval_batch)
@@ -682,6 +684,7 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     h->slots = ((cfg->concurrent_games + 15) / 16) * 16;
     h->max_explores = cfg->max_explores;
+    if (const char* ev = debug_env("SYN_EVAL_POLL_MAX")) h->eval_poll_max = (size_t)std::atoll(ev);
     // nodes.len() <= 1 + 9*(explores+1), rounded up to keep slabs 16-byte-record aligned per 4 nodes
     h->cap = (uint32_t)(1 + 9 * (cfg->max_explores + 1));
     h->cap = (h->cap + 3u) & ~3u;
@@ -800,6 +803,9 @@ int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats) {
     return SYN_OK;
 }
 
+constexpr size_t EVAL_TILE_LDS = 14 * 64 * 16;   // policy_eval_tile_kernel: the two activation-exchange buffers
+constexpr size_t EVAL_TILE_MAX = 4096;           // ... is used up to this many positions (256 tiles: one per CU)
+
 // The evaluation kernel of the engine's network on `st` (any stream of the engine's device): n positions, pointers the device can
 // read / write (device memory or pinned, device-mapped host memory).
 static hipError_t launch_policy_eval(syn_engine* h, hipStream_t st, const uint64_t* d_my, const uint64_t* d_op, int n,
@@ -822,7 +828,12 @@ static hipError_t launch_policy_eval(syn_engine* h, hipStream_t st, const uint64
         hipLaunchKernelGGL(k, dim3(grid), dim3(NT), (LDS), st, h->d_wimg, reinterpret_cast<const unsigned long long*>(d_my),    \
                            reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                           \
     }
-    if (h->net_kind == 1) {
+    if (h->net_kind == 0 && (size_t)n <= EVAL_TILE_MAX) {
+        // at most a tile per CU: the latency kernel (eval_small.cuh), one workgroup per tile, no weight staging
+        hipLaunchKernelGGL(policy_eval_tile_kernel, dim3((unsigned)ntiles), dim3(256), EVAL_TILE_LDS, st, h->d_wimg,
+                           reinterpret_cast<const unsigned long long*>(d_my), reinterpret_cast<const unsigned long long*>(d_op), n, d_logits,
+                           d_value, nullptr, nullptr, 0u);
+    } else if (h->net_kind == 1) {
         // (16 waves per CU measured the same 46 % of the MFMA peak as 8: the tile is issue-bound, not latency-bound)
         SYN_LAUNCH_EVAL(policy_eval_conv_kernel, 512, (size_t)ConvGeom::IMG_FLOATS * 4, 0)
     } else if (ntiles >= h->num_cus * 12 * 4) {
@@ -864,6 +875,10 @@ struct syn_eval_ctx {
     size_t cap = 0;            // positions the two buffers hold
     int pending = 0;           // positions of the submitted batch (0 = none)
     bool out_in_place = false;
+    unsigned* d_done = nullptr;   // the latency kernels' completion protocol (eval_small.cuh): workgroups finished, device word
+    unsigned* h_flag = nullptr;   // ... and the word in pinned host memory the last one stores the call's sequence number into
+    unsigned seq = 0;
+    bool polled = false;          // the submitted batch signals through h_flag
     std::string err;
 };
 static int ctx_fail(syn_eval_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
@@ -886,10 +901,14 @@ int syn_eval_ctx_create(syn_engine* h, syn_eval_ctx** out) {
     if (!c) return fail(h, SYN_ERR_HIP, "out of host memory");
     c->h = h;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_done), 64);
+    if (e == hipSuccess) e = hipMemset(c->d_done, 0, 64);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), 64, hipHostMallocDefault);
     if (e != hipSuccess) {
-        delete c;
-        return fail(h, SYN_ERR_HIP, "hipStreamCreateWithFlags failed: %s", hipGetErrorString(e));
+        syn_eval_ctx_destroy(c);
+        return fail(h, SYN_ERR_HIP, "syn_eval_ctx_create: %s", hipGetErrorString(e));
     }
+    *c->h_flag = 0u;
     *out = c;
     return SYN_OK;
 }
@@ -903,6 +922,8 @@ int syn_eval_ctx_destroy(syn_eval_ctx* c) {
     }
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->d_out) hipFree(c->d_out);
+    if (c->d_done) hipFree(c->d_done);
+    if (c->h_flag) hipHostFree(c->h_flag);
     delete c;
     return SYN_OK;
 }
@@ -938,8 +959,19 @@ int syn_eval_ctx_submit(syn_eval_ctx* c, const uint64_t* my_bb, const uint64_t* 
     // with one DMA (syn_policy_eval_batch, measured)
     c->out_in_place = nb <= h->eval_zero_copy_out;
     float* o_logits = c->out_in_place ? s_logits : static_cast<float*>(c->d_out);
-    CTX_TRY(c, launch_policy_eval(h, c->stream, s_my, s_op, n, o_logits, o_logits + nb * 9));
-    if (!c->out_in_place) CTX_TRY(c, hipMemcpyAsync(s_logits, c->d_out, nb * 48, hipMemcpyDeviceToHost, c->stream));
+    c->polled = c->out_in_place && h->net_kind == 0 && nb <= h->eval_poll_max;
+    if (c->polled) {
+        // the latency kernels: their last workgroup stores this call's number into pinned memory, syn_eval_ctx_wait polls it
+        c->seq += 1u;
+        const unsigned long long* k_my = reinterpret_cast<const unsigned long long*>(s_my);
+        const unsigned long long* k_op = reinterpret_cast<const unsigned long long*>(s_op);
+        hipLaunchKernelGGL(policy_eval_tile_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), EVAL_TILE_LDS, c->stream, h->d_wimg, k_my, k_op,
+                           n, o_logits, o_logits + nb * 9, c->d_done, c->h_flag, c->seq);
+        CTX_TRY(c, hipGetLastError());
+    } else {
+        CTX_TRY(c, launch_policy_eval(h, c->stream, s_my, s_op, n, o_logits, o_logits + nb * 9));
+        if (!c->out_in_place) CTX_TRY(c, hipMemcpyAsync(s_logits, c->d_out, nb * 48, hipMemcpyDeviceToHost, c->stream));
+    }
     c->pending = n;
     return SYN_OK;
 }
@@ -950,7 +982,22 @@ int syn_eval_ctx_wait(syn_eval_ctx* c, float* logits, float* value) {
     if (!logits || !value) return ctx_fail(c, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_eval_ctx_wait");
     const size_t nb = (size_t)c->pending;
     c->pending = 0;
-    CTX_TRY(c, hipStreamSynchronize(c->stream));
+    bool done = false;
+    if (c->polled) {
+        // ~2 ms of polling (a call is tens of microseconds); a kernel that does not report falls through to the stream, where a
+        // fault shows as an error
+        const volatile unsigned* flag = c->h_flag;
+        for (int spin = 0; spin < 200000 && !done; spin++) {
+            done = *flag == c->seq;
+            if (!done) __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!done) {
+        CTX_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->polled && *static_cast<const volatile unsigned*>(c->h_flag) != c->seq)
+            return ctx_fail(c, SYN_ERR_HIP, "the evaluation kernel finished without reporting completion");
+    }
     const float* s_logits = reinterpret_cast<const float*>(static_cast<const uint64_t*>(c->h_stage) + 2 * nb);
     std::memcpy(logits, s_logits, nb * 36);
     std::memcpy(value, s_logits + nb * 9, nb * 12);

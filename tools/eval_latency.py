@@ -56,7 +56,7 @@ def main():
     ctx = eng.eval_context()
     lib, c = eng._lib, ctx._c
     out["ctx_submit_us"], out["ctx_wait_us"] = {}, {}
-    for n in (1, 256, 4096):
+    for n in (1, 256, 512, 1024, 2048, 4096):
         a = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
         b = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
         my, op = a & ~b, b & ~a
