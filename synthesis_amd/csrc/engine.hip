@@ -139,10 +139,8 @@ struct syn_engine {
     size_t scratch_bytes = 0;
     std::atomic<bool> eval_attr_set[3] = {{false}, {false}, {false}};   // launch_policy_eval: the kernels' LDS attribute is set
     size_t eval_poll_max = 1024;       // contexts: batches up to this size signal completion through pinned memory (SYN_DEBUG=1 SYN_EVAL_POLL_MAX)
-    size_t eval_zero_copy_in = 32768;  // syn_policy_eval_batch: up to this many positions are read / written in the pinned buffer itself
-    size_t eval_zero_copy_out = 4096;
-    void* h_stage = nullptr;           // pinned, device-mapped host staging for the host-pointer entry points (syn_policy_eval_batch)
-    size_t stage_bytes = 0;
+    size_t eval_zero_copy_out = 4096;  // contexts: results of up to this many positions are written into the pinned buffer by the kernel itself
+    struct syn_eval_ctx* eval_ctx = nullptr;   // syn_policy_eval_batch's own evaluation context (created on first use)
     std::string err;
     float last_kernel_ms = 0.0f;
     int last_launches = 0;
@@ -201,19 +199,6 @@ static int ensure_scratch(syn_engine* h, size_t bytes) {
     size_t want = bytes + bytes / 4 + 4096;
     HIP_TRY(h, hipMalloc(&h->d_scratch, want));
     h->scratch_bytes = want;
-    return SYN_OK;
-}
-
-// Pinned (page-locked, device-mapped) host memory of at least `bytes`: the caller's pageable buffers are copied through it, so that
-// the transfers are one asynchronous DMA each — or none: a kernel may read and write it in place.
-static int ensure_stage(syn_engine* h, size_t bytes) {
-    if (bytes <= h->stage_bytes) return SYN_OK;
-    if (h->h_stage) HIP_TRY(h, hipHostFree(h->h_stage));
-    h->h_stage = nullptr;
-    h->stage_bytes = 0;
-    size_t want = bytes + bytes / 4 + 4096;
-    HIP_TRY(h, hipHostMalloc(&h->h_stage, want, hipHostMallocDefault));
-    h->stage_bytes = want;
     return SYN_OK;
 }
 
@@ -685,6 +670,7 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
     h->slots = ((cfg->concurrent_games + 15) / 16) * 16;
     h->max_explores = cfg->max_explores;
     if (const char* ev = debug_env("SYN_EVAL_POLL_MAX")) h->eval_poll_max = (size_t)std::atoll(ev);
+    if (const char* ev = debug_env("SYN_EVAL_ZC_OUT")) h->eval_zero_copy_out = (size_t)std::atoll(ev);
     // nodes.len() <= 1 + 9*(explores+1), rounded up to keep slabs 16-byte-record aligned per 4 nodes
     h->cap = (uint32_t)(1 + 9 * (cfg->max_explores + 1));
     h->cap = (h->cap + 3u) & ~3u;
@@ -727,6 +713,7 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
 int syn_engine_destroy(syn_engine* h) {
     if (!h) return SYN_OK;
     hipSetDevice(h->device);
+    if (h->eval_ctx) syn_eval_ctx_destroy(h->eval_ctx);
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_stat);
     hipFree(h->d_wimg);
@@ -761,7 +748,6 @@ int syn_engine_destroy(syn_engine* h) {
     if (h->stream) hipStreamDestroy(h->stream);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->h_pin) hipHostFree(h->h_pin);
-    if (h->h_stage) hipHostFree(h->h_stage);
     delete h;
     return SYN_OK;
 }
@@ -1017,7 +1003,24 @@ int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* 
     if (!h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
     if (n == 0) return SYN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
-    size_t nb = (size_t)n;
+    const size_t nb = (size_t)n;
+    constexpr size_t EVAL_STAGE_MAX = 32768;  // beyond it two host copies cost more than the runtime's pageable path (measured)
+    if (nb <= EVAL_STAGE_MAX && debug_env("SYN_EVAL_PAGEABLE") == nullptr) {
+        // A call of this size is latency, not bandwidth (a Rust `impl Policy` adaptor calls with n = 1, a host-tree driver with the
+        // leaves of one round): the engine's own evaluation context — positions read and small results written in pinned host
+        // memory in place, the latency kernel, completion polled (syn_eval_ctx_* above). Pageable transfers cost a staging copy and
+        // a synchronisation each inside the runtime, four per call.
+        if (!h->eval_ctx) {
+            const int rc = syn_eval_ctx_create(h, &h->eval_ctx);
+            if (rc != SYN_OK) return rc;
+        }
+        const int rc = syn_eval_ctx_eval(h->eval_ctx, my_bb, op_bb, n, logits, value);
+        if (rc != SYN_OK) return fail(h, rc, "%s", h->eval_ctx->err.c_str());
+        h->last_launches = 1;
+        h->last_kernel_ms = 0.0f;   // (not measured on this path: no events in a latency call)
+        return SYN_OK;
+    }
+    // large batches: the runtime's own chunked transfers from / to the pageable buffers around the throughput kernel
     int rc = ensure_scratch(h, nb * (8 + 8 + 36 + 12) + 256);
     if (rc != SYN_OK) return rc;
     char* base = static_cast<char*>(h->d_scratch);
@@ -1025,42 +1028,13 @@ int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* 
     uint64_t* d_op = d_my + nb;
     float* d_logits = reinterpret_cast<float*>(d_op + nb);
     float* d_value = d_logits + nb * 9;
-    constexpr size_t EVAL_STAGE_MAX = 32768;  // beyond it the two host copies cost more than the runtime's pageable path (measured)
-    if (const char* ev = debug_env("SYN_EVAL_ZC_IN")) h->eval_zero_copy_in = (size_t)std::atoll(ev);
-    if (const char* ev = debug_env("SYN_EVAL_ZC_OUT")) h->eval_zero_copy_out = (size_t)std::atoll(ev);
-    if (nb > EVAL_STAGE_MAX || debug_env("SYN_EVAL_PAGEABLE") != nullptr) {
-        // beyond the staging buffer's size the runtime's own chunked transfers from / to the pageable buffers
-        HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
-        rc = syn_policy_eval_batch_device(h, d_my, d_op, n, d_logits, d_value, 0);
-        if (rc != SYN_OK) return rc;
-        HIP_TRY(h, hipMemcpyAsync(logits, d_logits, nb * 36, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(value, d_value, nb * 12, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
-        return SYN_OK;
-    }
-    // Through pinned, device-mapped host memory: a call is latency, not bandwidth (a Rust `impl Policy` adaptor calls with n = 1,
-    // a lock-step driver with the leaves of one round). Pageable transfers cost a staging copy and a synchronisation each inside
-    // the runtime — four per call; here the positions are read by the kernel in place (16 B per position over the host link) and
-    // small results are written in place, larger ones come back with one DMA.
-    rc = ensure_stage(h, nb * (16 + 48));
+    HIP_TRY(h, hipMemcpyAsync(d_my, my_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(d_op, op_bb, nb * 8, hipMemcpyHostToDevice, h->stream));
+    rc = syn_policy_eval_batch_device(h, d_my, d_op, n, d_logits, d_value, 0);
     if (rc != SYN_OK) return rc;
-    uint64_t* s_my = static_cast<uint64_t*>(h->h_stage);
-    uint64_t* s_op = s_my + nb;
-    float* s_logits = reinterpret_cast<float*>(s_op + nb);
-    float* s_value = s_logits + nb * 9;
-    std::memcpy(s_my, my_bb, nb * 8);
-    std::memcpy(s_op, op_bb, nb * 8);
-    const bool in_place_in = nb <= h->eval_zero_copy_in, in_place_out = nb <= h->eval_zero_copy_out;
-    if (!in_place_in) HIP_TRY(h, hipMemcpyAsync(d_my, s_my, nb * 16, hipMemcpyHostToDevice, h->stream));
-    rc = syn_policy_eval_batch_device(h, in_place_in ? s_my : d_my, in_place_in ? s_op : d_op, n, in_place_out ? s_logits : d_logits,
-                                      in_place_out ? s_value : d_value, 0);
-    if (rc != SYN_OK) return rc;
-    if (!in_place_out) HIP_TRY(h, hipMemcpyAsync(s_logits, d_logits, nb * 48, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(logits, d_logits, nb * 36, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(value, d_value, nb * 12, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    std::memcpy(logits, s_logits, nb * 36);
-    std::memcpy(value, s_value, nb * 12);
     HIP_TRY(h, hipEventElapsedTime(&h->last_kernel_ms, h->ev0, h->ev1));
     return SYN_OK;
 }
