@@ -256,6 +256,24 @@ def test_lockstep_selfplay_on_the_gpu_equals_the_fused_selfplay(oracle, golden_d
     eng.close()
 
 
+@pytest.mark.gpu
+def test_lockstep_selfplay_reference_configuration_at_the_bench_shape(golden_dir):
+    """The host-tree leg at the shape bench.py times it — 4,096 slots, 800 explores, more games than slots (a finished game's slot
+    takes the next game) — in the configuration the reference itself plays (trained checkpoint, Fpu::Func(Normal(1.0, 0.1)),
+    study-connect4/src/main.rs:37-49): every game equals the fused kernel's, which test_gpu_bench_shape.py holds to the oracle."""
+    import synthesis_amd as sa
+
+    blob = np.load(os.path.join(golden_dir, "c4net_trained_f32.npy"))
+    eng = sa.Engine(concurrent_games=4096, max_explores=800)
+    eng.load_weights(blob)
+    cfg = sa.parity_rollout_config(800, mcts_cfg=sa.reference_selfplay_mcts_config())
+    got = eng.selfplay_lockstep(cfg, 2024, 6144, first_game=100)
+    stats = got.pop("stats")
+    assert_games_equal(got, eng.selfplay(cfg, 2024, 6144, first_game=100), "host trees vs fused kernel, reference configuration, bench shape")
+    assert stats["positions_evaluated"] <= int(got["plies"].sum()) * 801
+    eng.close()
+
+
 def test_lockstep_host_code_is_clean_under_asan_and_ubsan(oracle, golden_dir, tmp_path):
     """The host side above the C ABI (product code: include/synthesis_amd_lockstep.hpp — trees, worker pool, StdRng, the self-play
     loop) under AddressSanitizer + UndefinedBehaviorSanitizer: the harness rebuilt with both, searches on 4 threads and whole games
