@@ -699,12 +699,15 @@ int syn_engine_create(const syn_engine_config* cfg, int device, syn_engine** out
         h->cache_log2 = cfg->policy_cache_log2;
         const size_t bytes = (size_t)64 << h->cache_log2;
         if ((e = hipMalloc(&h->d_cache, bytes)) != hipSuccess) return bail("hipMalloc(policy cache)", e);
-        if ((e = hipMemset(h->d_cache, 0, bytes)) != hipSuccess) return bail("hipMemset(policy cache)", e);  // empty: an all-zero entry never verifies
+        // empty: an all-zero entry never verifies. (On the engine's own stream: a memset on the null stream is asynchronous to the host
+        // and not ordered against a non-blocking stream's launches.)
+        if ((e = hipMemsetAsync(h->d_cache, 0, bytes, h->stream)) != hipSuccess) return bail("hipMemsetAsync(policy cache)", e);
     }
     if ((e = hipMalloc(&h->d_cache_stats, 16)) != hipSuccess) return bail("hipMalloc(cache stats)", e);
     if ((e = hipMalloc(&h->d_wimg, MlpGeom::IMG_FLOATS * sizeof(float))) != hipSuccess) return bail("hipMalloc(wimg)", e);
     if ((e = hipMalloc(&h->d_job_next, 64)) != hipSuccess) return bail("hipMalloc(job)", e);
-    if ((e = hipMemset(h->d_job_next, 0, 64)) != hipSuccess) return bail("hipMemset(job)", e);  // syn_progress before the first launch reads zeros
+    if ((e = hipMemsetAsync(h->d_job_next, 0, 64, h->stream)) != hipSuccess) return bail("hipMemsetAsync(job)", e);  // syn_progress before the first launch reads zeros
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
     if ((e = hipMalloc(&h->d_counters, sizeof(DevCounters))) != hipSuccess) return bail("hipMalloc(counters)", e);
     *out = h;
     return SYN_OK;
@@ -888,7 +891,8 @@ int syn_eval_ctx_create(syn_engine* h, syn_eval_ctx** out) {
     c->h = h;
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_done), 64);
-    if (e == hipSuccess) e = hipMemset(c->d_done, 0, 64);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_done, 0, 64, c->stream);   // (stream-ordered in front of the context's kernels)
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_flag), 64, hipHostMallocDefault);
     if (e != hipSuccess) {
         syn_eval_ctx_destroy(c);
@@ -981,8 +985,14 @@ int syn_eval_ctx_wait(syn_eval_ctx* c, float* logits, float* value) {
     }
     if (!done) {
         CTX_TRY(c, hipStreamSynchronize(c->stream));
-        if (c->polled && *static_cast<const volatile unsigned*>(c->h_flag) != c->seq)
-            return ctx_fail(c, SYN_ERR_HIP, "the evaluation kernel finished without reporting completion");
+        if (c->polled && *static_cast<const volatile unsigned*>(c->h_flag) != c->seq) {
+            unsigned done_word = 0xFFFFFFFFu;
+            hipMemcpy(&done_word, c->d_done, 4, hipMemcpyDeviceToHost);
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "the evaluation kernel finished without reporting completion (n %zu, call %u, word in pinned memory %u, "
+                          "workgroups counted %u)", nb, c->seq, *static_cast<const volatile unsigned*>(c->h_flag), done_word);
+            return ctx_fail(c, SYN_ERR_HIP, msg);
+        }
     }
     const float* s_logits = reinterpret_cast<const float*>(static_cast<const uint64_t*>(c->h_stage) + 2 * nb);
     std::memcpy(logits, s_logits, nb * 36);
