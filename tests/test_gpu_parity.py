@@ -217,6 +217,28 @@ def test_policy_eval_transfer_paths_and_contexts(engine, oracle, blob):
         c.close()
 
 
+def test_a_new_context_is_ready_for_its_first_call_while_the_null_stream_is_busy(engine, oracle, blob):
+    """Contexts created and used at once, 150 times, while torch's default stream is kept busy. Background: a context's workgroup
+    counter used to be zeroed with hipMemset on the null stream — asynchronous to the host and not ordered against the context's
+    non-blocking stream — and inside the full GPU suite (never in a test alone, and not under this load either) the zeroing landed
+    in the context's first kernel: "call 1, workgroups counted 0", the completion word never written. The zeroing is now
+    stream-ordered; the full suite is the regression test, this one keeps the create -> first call path under load."""
+    import torch
+
+    my, op = random_positions(oracle, 128, seed=21)
+    fl, fv = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    x = torch.randn(4096, 4096, device="cuda")
+    for _ in range(150):
+        y = x @ x
+        y = y @ x   # a few milliseconds of work queued on the (blocking) default stream
+        c = engine.eval_context()
+        l, v = c.eval(my, op)
+        assert np.array_equal(l, fl) and np.array_equal(v, fv)
+        c.close()
+    torch.cuda.synchronize()
+    del x, y
+
+
 # ------------------------------------------------------------------------------------------------ slimnn layers
 def test_slimnn_layer_kats_on_gpu(engine, oracle, golden_dir):
     """slimnn/src/conv.rs:92-602, linear.rs:105-112 through the GPU kernels; also bit-exact vs the oracle's slimnn mode."""
