@@ -146,7 +146,9 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my_bb, const u
  *           bit for bit).  eval = submit + wait.
  * A call is latency (n = 1 from a Rust `impl Policy`; the leaves of a few hundred trees from a self-play worker): the positions
  * are read and small results written across the host link in place, no transfer commands. Errors: the usual codes, the text in
- * syn_eval_ctx_last_error(ctx) (not in the engine's slot). Destroy every context before syn_engine_destroy. */
+ * syn_eval_ctx_last_error(ctx) (not in the engine's slot; a text starting with "note:" beside SYN_OK reports a completion word that
+ * went missing — the answers were complete, the context has switched to waiting on its stream). Destroy every context before
+ * syn_engine_destroy. */
 typedef struct syn_eval_ctx syn_eval_ctx;
 int syn_eval_ctx_create(syn_engine* h, syn_eval_ctx** out);
 int syn_eval_ctx_submit(syn_eval_ctx* ctx, const uint64_t* my_bb, const uint64_t* op_bb, int n);

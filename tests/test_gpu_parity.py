@@ -239,6 +239,28 @@ def test_a_new_context_is_ready_for_its_first_call_while_the_null_stream_is_busy
     del x, y
 
 
+def test_a_missing_completion_word_costs_time_not_answers(engine, oracle, blob, monkeypatch):
+    """The polled completion's way out: with the context's workgroup counter started off wrong (debug knob) the kernel never writes
+    the completion word; syn_eval_ctx_wait gives up polling after ~2 ms, drains the stream — the kernel has finished, its results
+    are complete — returns them, leaves a note in the context's error slot and waits on the stream from then on."""
+    my, op = random_positions(oracle, 300, seed=23)
+    fl, fv = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_FMA)
+    monkeypatch.setenv("SYN_DEBUG", "1")
+    monkeypatch.setenv("SYN_EVAL_BREAK_COUNTER", "1")
+    c = engine.eval_context()
+    monkeypatch.delenv("SYN_EVAL_BREAK_COUNTER")
+    for n in (128, 5, 300, 128):
+        l, v = c.eval(my[:n], op[:n])
+        assert np.array_equal(l, fl[:n]) and np.array_equal(v, fv[:n])
+    note = (engine._lib.syn_eval_ctx_last_error(c._c) or b"").decode()
+    assert "without reporting completion" in note and "call 1" in note
+    c.close()
+    c2 = engine.eval_context()   # a healthy context leaves no note
+    l, v = c2.eval(my[:128], op[:128])
+    assert np.array_equal(l, fl[:128]) and (engine._lib.syn_eval_ctx_last_error(c2._c) or b"") == b""
+    c2.close()
+
+
 # ------------------------------------------------------------------------------------------------ slimnn layers
 def test_slimnn_layer_kats_on_gpu(engine, oracle, golden_dir):
     """slimnn/src/conv.rs:92-602, linear.rs:105-112 through the GPU kernels; also bit-exact vs the oracle's slimnn mode."""
