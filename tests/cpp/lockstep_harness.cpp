@@ -6,6 +6,7 @@
 //   lockstep_harness selfplay <blob.f32> <games> <explores> <variant> <threads> <seed> <first_game> <out.bin>
 //   lockstep_harness rng <seed> <words>
 //   lockstep_harness policythrow [end]
+//   lockstep_harness threads
 // <threads> < 0: the sharded drivers with -threads policies (one per host thread). Environment: LS_CONCURRENT = games in flight
 // (self-play; default all), LS_ASYNC = 1: a policy whose eval_batch_begin() computes on another thread until eval_batch_end(),
 // LS_COMBINE = 1: the sharded drivers' workers share ONE policy through a CombiningPolicy.
@@ -129,6 +130,10 @@ int main(int argc, char** argv) {
         for (auto& g : ok) g.stones = 5;
         const auto trees = lockstep_search<ThrowingNim, 3>(policy, MCTSConfig{}, ok, 50, 4);
         std::printf("second search %zu trees, root solved %d\n", trees.size(), trees[0].root().solution.some ? 1 : 0);
+        return 0;
+    }
+    if (argc >= 2 && std::string(argv[1]) == "threads") {   // what the drivers take for threads = 0
+        std::printf("%d\n", detail::usable_host_threads());
         return 0;
     }
     if (argc >= 2 && std::string(argv[1]) == "policythrow") {

@@ -181,6 +181,21 @@ def test_lockstep_pool_hands_a_worker_threads_exception_to_the_caller(harness):
     assert p.stdout.splitlines() == ["caught seven stones", "second search 128 trees, root solved 1"]
 
 
+def test_lockstep_default_thread_count_respects_the_cpu_quota(harness):
+    """threads = 0: the hardware concurrency cut to a cgroup CPU quota (more runnable threads than quota get throttled mid-round), at
+    most 32."""
+    exe, _, _ = harness
+    n = int(subprocess.run([exe, "threads"], capture_output=True, text=True, timeout=60).stdout)
+    limit = min(32, os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            limit = min(limit, max(1, -(-int(quota) // int(period))))
+    except OSError:
+        pass
+    assert 1 <= n <= limit
+
+
 def test_lockstep_policy_failure_reaches_the_caller(harness):
     """A BatchPolicy that throws — in eval_batch_begin() or in eval_batch_end() — under the pool driver, the two-halves driver, the
     sharded driver and the sharded driver over one CombiningPolicy: the caller gets the exception (no worker is left waiting for
