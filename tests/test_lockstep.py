@@ -181,6 +181,24 @@ def test_lockstep_pool_hands_a_worker_threads_exception_to_the_caller(harness):
     assert p.stdout.splitlines() == ["caught seven stones", "second search 128 trees, root solved 1"]
 
 
+def test_example_for_a_callers_own_game_builds_and_solves(tmp_path):
+    """examples/host_trees_custom_game.cpp — what a caller with another Game writes: builds with the documented command line, the
+    single-thread and the sharded driver agree, and every root is solved the way the game's theory says (a multiple of four is
+    lost; otherwise take stones mod 4)."""
+    exe = str(tmp_path / "host_trees")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-ffp-contract=off", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "host_trees_custom_game.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout.splitlines()
+    assert len(out) == 13
+    for line in out[:12]:
+        stones = int(line.split()[0])
+        take = int(line.split("take")[1].split()[0])
+        again = int(line.rsplit("take", 1)[1].strip(" )"))
+        assert ("lost" in line) == (stones % 4 == 0) and take == again
+        if stones % 4:
+            assert take == stones % 4
+
+
 def test_lockstep_default_thread_count_respects_the_cpu_quota(harness):
     """threads = 0: the hardware concurrency cut to a cgroup CPU quota (more runnable threads than quota get throttled mid-round), at
     most 32."""
