@@ -115,3 +115,47 @@ def test_cpp_host_matches_oracle(harness, oracle, golden_dir):
 
     # error behaviour: wrong blob size -> SYN_ERR_INVALID_ARGUMENT; an eighth stone in a column -> the same code
     assert [c[0] for c in by["caught"]] == ["-1", "-1"] and "no_error" not in by
+
+
+@pytest.fixture(scope="module")
+def c_example(tmp_path_factory, golden_dir):
+    """examples/policy_eval_worker.c built with the command line its header documents (plain C against include/synthesis_amd.h)."""
+    d = tmp_path_factory.mktemp("cexample")
+    exe = str(d / "policy_eval_worker")
+    lib = os.path.join(ROOT, "synthesis_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "policy_eval_worker.c"), "-o", exe, "-L" + lib, "-lsynthesis_amd",
+                           "-Wl,-rpath," + lib])
+    blob = str(d / "blob.f32")
+    np.load(os.path.join(golden_dir, "c4net_blob_f32.npy")).astype("<f4").tofile(blob)
+    return exe, blob
+
+
+def test_c_example_builds_and_fails_loudly_without_a_gpu(c_example):
+    import torch
+
+    exe, blob = c_example
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    p = subprocess.run([exe, blob], capture_output=True, text=True)
+    assert p.returncode == 1 and p.stderr.strip() != ""
+
+
+@pytest.mark.gpu
+def test_c_example_workers_get_the_oracles_bits(c_example, oracle, golden_dir):
+    """Three worker threads, each with its own evaluation context on one engine: Policy::eval one position per call and as a
+    submitted batch — every printed float is the oracle's, bit for bit."""
+    exe, blobf = c_example
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    p = subprocess.run([exe, blobf], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = p.stdout.splitlines()
+    assert len(lines) == 15
+    for line in lines:
+        tok = line.split()
+        w, pos = int(tok[1]), int(tok[3].rstrip(":"))
+        r = oracle.c4_play([(w + i) % 9 for i in range(pos + 1)])
+        fl, fv = oracle.c4net_eval(blob, [r["my_bb"]], [r["op_bb"]], mode=oracle.ACC_FMA)
+        got = np.array([int(t, 16) for t in tok[4:16]], np.uint32)
+        assert np.array_equal(got[:9], fl[0].view(np.uint32)) and np.array_equal(got[9:], fv[0].view(np.uint32))
+        assert tok[-2:] == ["batch", "same"]
