@@ -32,3 +32,13 @@ def oracle():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def free_port():
+    """A TCP port nobody listens on right now, for the rendezvous of a torch.distributed.run child (a fixed number collides with a
+    previous run's socket in TIME_WAIT or with another job on the host)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -14,6 +14,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """a TCP port nobody listens on right now (the rendezvous of a torch.distributed.run child): a fixed number collides with a
+    previous run's socket in TIME_WAIT or with another job on the host"""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def header_text():
     return open(os.path.join(ROOT, "include", "synthesis_amd.h")).read()
 
@@ -153,10 +163,11 @@ def test_multi_rank_reduce_under_gloo(tmp_path):
     """The N>1 path of bench.py (barrier, MAX of elapsed, SUM of counters) with world_size 2 on CPU (gloo)."""
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-         "127.0.0.1", "--master-port", "29533", str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
+         "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
     line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
     assert float(line[1]) == 2.0          # MAX over ranks of (1.0, 2.0)
     assert int(line[2]) == 1000           # SUM of per-rank game counts
@@ -223,10 +234,11 @@ def test_learning_loop_collectives_under_gloo(tmp_path):
     script = tmp_path / "loop_worker.py"
     script.write_text(LOOP_WORKER)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    port = _free_port()
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-         "127.0.0.1", "--master-port", "29541", str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
+         "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
     two = sorted((json.loads(l.split(" ", 1)[1]) for l in out.splitlines() if l.startswith("LOOP")), key=lambda d: d["rank"])
     one = json.loads([l for l in subprocess.check_output([sys.executable, str(script), ROOT], env=env, stderr=subprocess.STDOUT,
                                                           timeout=300).decode().splitlines() if l.startswith("LOOP")][0].split(" ", 1)[1])

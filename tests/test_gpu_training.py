@@ -6,6 +6,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import free_port
+
 pytestmark = pytest.mark.gpu
 
 
@@ -251,7 +253,7 @@ def test_data_parallel_learner_two_ranks(oracle, blob, gold, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "tests", "dp_learner_worker.py"), str(tmp_path)]
+           "--master-port", str(free_port()), os.path.join(root, "tests", "dp_learner_worker.py"), str(tmp_path)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
@@ -291,7 +293,7 @@ def test_training_example_keeps_two_ranks_identical(tmp_path, net, mode):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    port = {"mlp": 29547, "conv": 29549}[net] + (10 if mode == "loop" else 0)
+    port = free_port()
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     common = ["--iterations", "2", "--games-per-train", "601", "--explores", "40", "--epochs", "1", "--concurrent", "512",
               "--dist-backend", "gloo", "--net", net] + (["--data-parallel"] if mode == "data-parallel" else [])
