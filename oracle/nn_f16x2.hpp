@@ -1,0 +1,305 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the shipped product path.
+//
+// CPU restatement of the "f16x2" arithmetic of Connect4Net (the two-term f16 split the HIP engine can run the network of
+// study-connect4/src/policies.rs:28-59 in; layer semantics slimnn/src/linear.rs:17-25).  This is NOT the reference's arithmetic: the
+// reference evaluates y = x W^T + b in f32 (libtorch, unspecified order).  It is a second DEFINITION of the same function whose
+// results agree with ACC_SLIMNN / torch-f64 to f32 rounding noise (tests hold it to that), restated here so that MCTS parity tests can
+// compare visit counts exactly when the engine runs in this mode.  PARITY UNPINNED against the reference (as Connect4Net itself is:
+// no reference test exercises it).
+//
+// Definition (all scalings are exact powers of two):
+//   plan      s[0] = 8;  t[l] = 14 - ceil_log2(max |W_l|);  bound_l = max_o (b_o + sum_i m(w_oi) ub_i), m = |.| for layer 1 (|x| <= 1),
+//             max(., 0) after (0 <= x <= ub), ub' = max(bound per unit, 0), sums in f64, i ascending;  s[l+1] = min(24, 15 - ceil_log2(bound_l)).
+//   operands  w' = w 2^t:  w_hi = RNE_f16(w'), w_lo = RNE_f16(w' - w_hi);  features x' = x 2^8 in {+-256, +-(25.59375 + 1638 2^-18)};
+//             activations  a = med3(acc 2^(s[l+1] - s[l] - t[l]), 0, 65504) (NaN -> 0): x_hi = RNE_f16(a), x_lo = RNE_f16(a - x_hi).
+//   layer     acc_o = b_o 2^(s+t);  for every block kb of 32 inputs, in this order:  acc = M(acc, w_hi, x_hi); acc = M(acc, w_hi, x_lo);
+//             acc = M(acc, w_lo, x_hi)   (a fourth, M(acc, w_lo, x_lo), only in the 4-product variant)
+//   M(c,a,b)  one v_mfma_f32_16x16x32_f16: see mfma_f16_k32() below for the accumulation model and what pins it.
+//   inputs of a block, in the instruction's k order (k = 8 q + jj): unit 32 kb + 16 (jj >> 2) + 4 q + (jj & 3); layer 1: board bit
+//             p = 16 q + 8 kb + jj, i.e. feature (p % 7) * 9 + p / 7; inputs past the layer's width carry zero weights.
+//   outputs   raw_o = acc_o 2^-(s[4] + t[4]); logits = raw[0..9], value = softmax(raw[9..12]) as in nn.hpp.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "connect4.hpp"
+
+namespace oracle {
+
+// IEEE binary16 <-> binary32 in integer arithmetic (no _Float16: the oracle builds with any C++17 compiler).
+// Round to nearest even, gradual underflow, overflow to infinity — what v_cvt_f16_f32 / v_cvt_pk_f16_f32 do in the default mode.
+inline uint16_t f16_bits_rne(float x) {
+    uint32_t u; std::memcpy(&u, &x, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t mag = u & 0x7FFFFFFFu;
+    if (mag >= 0x7F800000u) return sign | (mag > 0x7F800000u ? 0x7E00u : 0x7C00u);   // NaN (quiet) / infinity
+    const int e = (int)(mag >> 23) - 127;
+    if (e > 15) return sign | 0x7C00u;                                                   // >= 2^16: infinity (65520 and up handled below)
+    uint32_t m = (mag & 0x7FFFFFu) | (mag >= 0x00800000u ? 0x800000u : 0u);             // 24-bit significand, value = m 2^(e - 23) (e = -126 for subnormals)
+    const int ee = mag >= 0x00800000u ? e : -126;
+    // target grid: normal f16 keeps 11 bits (lsb 2^(ee - 10)), but never finer than 2^-24
+    int drop = 13;                                   // 24 -> 11 bits
+    if (ee < -14) drop += -14 - ee;
+    if (drop > 31) return sign;                      // far below half the smallest subnormal
+    const uint32_t keep = m >> drop, rem = m & ((1u << drop) - 1u), half = 1u << (drop - 1);
+    uint32_t r = keep + ((rem > half || (rem == half && (keep & 1u))) ? 1u : 0u);
+    if (ee < -14) return sign | (uint16_t)r;         // subnormal (r may reach 0x400 = the smallest normal: same encoding)
+    // normal: r in [0x400, 0x800]; exponent field = ee + 15, r's leading bit adds 1 to it through the carry below
+    uint32_t out = ((uint32_t)(ee + 14) << 10) + r;  // (ee + 15 - 1) << 10 + (0x400 | mantissa)
+    if (out >= 0x7C00u) out = 0x7C00u;
+    return sign | (uint16_t)out;
+}
+inline float f16_value(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t u;
+    if (e == 0x1F) u = sign | 0x7F800000u | (m << 13);
+    else if (e) u = sign | ((e + 112u) << 23) | (m << 13);
+    else if (!m) u = sign;
+    else { int sh = __builtin_clz(m) - 21; u = sign | ((uint32_t)(113 - sh) << 23) | ((m << (sh + 13)) & 0x7FFFFFu); }
+    float f; std::memcpy(&f, &u, 4);
+    return f;
+}
+inline int ceil_log2_pos(double v) {
+    int e;
+    const double m = std::frexp(v, &e);
+    return m == 0.5 ? e - 1 : e;
+}
+
+// ---- exact accumulation -------------------------------------------------------------------------------------------------------
+// 320-bit two's-complement fixed point, lsb 2^-192: holds any sum of f32 values and f16 x f16 products exactly.
+struct Fixed320 {
+    uint64_t w[5] = {0, 0, 0, 0, 0};
+    static constexpr int LSB = -192;
+    void add_scaled(uint64_t mant, int exp2, bool neg) {   // += (-1)^neg mant 2^exp2, exp2 >= LSB
+        if (!mant) return;
+        const int sh = exp2 - LSB, limb = sh >> 6, bit = sh & 63;
+        uint64_t part[5] = {0, 0, 0, 0, 0};
+        if (limb < 5) part[limb] = mant << bit;
+        if (bit && limb + 1 < 5) part[limb + 1] = mant >> (64 - bit);
+        unsigned __int128 carry = 0;
+        if (!neg) {
+            for (int i = 0; i < 5; i++) { carry += (unsigned __int128)w[i] + part[i]; w[i] = (uint64_t)carry; carry >>= 64; }
+        } else {
+            unsigned __int128 borrow = 0;
+            for (int i = 0; i < 5; i++) {
+                const unsigned __int128 sub = (unsigned __int128)part[i] + borrow;
+                borrow = (unsigned __int128)w[i] < sub ? 1 : 0;
+                w[i] = (uint64_t)((unsigned __int128)w[i] - sub);
+            }
+        }
+    }
+    void add_f32(float f) {
+        uint32_t u; std::memcpy(&u, &f, 4);
+        const uint32_t e = (u >> 23) & 0xFF, m = u & 0x7FFFFF;
+        if (e == 0) add_scaled(m, -149, u >> 31);
+        else add_scaled(m | 0x800000u, (int)e - 150, u >> 31);
+    }
+    void add_f16_product(uint16_t a, uint16_t b) {
+        auto dec = [](uint16_t h, uint32_t& m, int& e) { const uint32_t ee = (h >> 10) & 0x1F, mm = h & 0x3FF; if (ee == 0) { m = mm; e = -24; } else { m = mm | 0x400u; e = (int)ee - 25; } };
+        uint32_t ma, mb; int ea, eb;
+        dec(a, ma, ea); dec(b, mb, eb);
+        add_scaled((uint64_t)ma * mb, ea + eb, ((a ^ b) >> 15) & 1);
+    }
+    // round to nearest even f32 (overflow -> inf not handled: callers stay far inside the range)
+    float to_f32_rne() const {
+        uint64_t a[5];
+        const bool neg = w[4] >> 63;
+        if (neg) { unsigned __int128 c = 1; for (int i = 0; i < 5; i++) { c += (uint64_t)~w[i]; a[i] = (uint64_t)c; c >>= 64; } }
+        else for (int i = 0; i < 5; i++) a[i] = w[i];
+        int msb = -1;
+        for (int i = 4; i >= 0 && msb < 0; i--) if (a[i]) msb = 64 * i + 63 - __builtin_clzll(a[i]);
+        if (msb < 0) return 0.0f;
+        auto bit_at = [&](int p) -> uint32_t { return p < 0 ? 0u : (uint32_t)((a[p >> 6] >> (p & 63)) & 1); };
+        int low = msb - 23;                                    // position of the result's lsb
+        const int min_low = -149 - LSB;                        // subnormal grid
+        if (low < min_low) low = min_low;
+        uint64_t mant = 0;
+        for (int p = msb; p >= low; p--) mant = (mant << 1) | bit_at(p);
+        const uint32_t half = bit_at(low - 1);
+        bool sticky = false;
+        for (int p = low - 2; p >= 0 && !sticky; p--) sticky = bit_at(p);
+        if (half && (sticky || (mant & 1))) mant++;
+        const double r = std::ldexp((double)mant, low + LSB);
+        return (float)(neg ? -r : r);
+    }
+};
+
+// One v_mfma_f32_16x16x32_f16 output: c + sum_k a[k] b[k], k in the instruction's order.
+// MODEL (pinned by tools/ubench/mfma_f16_split.hip on MI355X, profiles/r05_f16_split.txt): see F16X2_GROUP below.
+// group = 32: all 32 products and the accumulator summed exactly, one round-to-nearest-even to f32.
+// group = g < 32: the accumulator takes the exact sum of g consecutive products at a time, one rounding per group.
+#ifndef F16X2_GROUP
+#define F16X2_GROUP 32
+#endif
+inline float mfma_f16_k32(float c, const uint16_t* a, const uint16_t* b, int group = F16X2_GROUP) {
+    float acc = c;
+    for (int k0 = 0; k0 < 32; k0 += group) {
+        // fast path: everything is a multiple of 2^-64 below 2^62 -> one signed 128-bit integer
+        const float ac = std::fabs(acc);
+        if (ac == 0.0f || (ac >= 0x1p-40f && ac < 0x1p60f)) {
+            __int128 S = 0;
+            {
+                uint32_t u; std::memcpy(&u, &acc, 4);
+                if (ac != 0.0f) {
+                    const __int128 m = (u & 0x7FFFFF) | 0x800000u;
+                    const int sh = (int)((u >> 23) & 0xFF) - 150 + 64;   // >= 1
+                    S = (u >> 31) ? -(m << sh) : (m << sh);
+                }
+            }
+            for (int k = k0; k < k0 + group; k++) {
+                const uint16_t x = a[k], y = b[k];
+                const uint32_t ex = (x >> 10) & 0x1F, ey = (y >> 10) & 0x1F;
+                const int64_t mx = ex ? ((x & 0x3FF) | 0x400) : (x & 0x3FF), my = ey ? ((y & 0x3FF) | 0x400) : (y & 0x3FF);
+                const int sh = (int)(ex ? ex : 1) + (int)(ey ? ey : 1) - 50 + 64;   // product = mx my 2^(ex' + ey' - 50), >= 2^-48
+                const __int128 p = (__int128)(mx * my) << sh;
+                S += ((x ^ y) & 0x8000) ? -p : p;
+            }
+            if (S == 0) { acc = 0.0f; continue; }
+            const bool neg = S < 0;
+            unsigned __int128 U = neg ? (unsigned __int128)(-S) : (unsigned __int128)S;
+            int msb = 127;
+            while (!((U >> msb) & 1)) msb--;
+            const int drop = msb - 23;
+            uint64_t keep;
+            if (drop > 0) {
+                keep = (uint64_t)(U >> drop);
+                const unsigned __int128 rem = U & (((unsigned __int128)1 << drop) - 1), half = (unsigned __int128)1 << (drop - 1);
+                if (rem > half || (rem == half && (keep & 1))) keep++;
+            } else keep = (uint64_t)(U << (-drop));
+            const double r = std::ldexp((double)keep, drop - 64);
+            acc = (float)(neg ? -r : r);
+        } else {
+            Fixed320 F;
+            F.add_f32(acc);
+            for (int k = k0; k < k0 + group; k++) F.add_f16_product(a[k], b[k]);
+            acc = F.to_f32_rne();
+        }
+    }
+    return acc;
+}
+
+struct F16x2Net {
+    static constexpr int NL = 5;
+    static constexpr int DIMS[NL + 1] = {63, 128, 96, 64, 48, 12};
+    static constexpr int NKB[NL] = {2, 4, 3, 2, 2};
+    int s[NL], t[NL], cexp[4], out_exp;
+    double bound[NL];
+    std::vector<uint16_t> w_hi[NL], w_lo[NL];   // [o][32 NKB] in the instruction's k order per block (zero padded)
+    std::vector<float> bias[NL];                 // b 2^(s+t)
+    bool ok = false;
+
+    static int unit_of_slot(int kb, int q, int jj) { return 32 * kb + 16 * (jj >> 2) + 4 * q + (jj & 3); }
+    // layer 1: the sixteen inputs of lane group q are board bits p = 16 q + 8 kb + jj (bit p = row + 7 col); feature = row * 9 + col; p = 63: none
+    static int feature_of_slot(int kb, int q, int jj) { const int p = 16 * q + 8 * kb + jj; return p < 63 ? (p % 7) * 9 + p / 7 : -1; }
+    static int unit_of_k(int l, int kb, int k) { return l == 0 ? feature_of_slot(kb, k >> 3, k & 7) : unit_of_slot(kb, k >> 3, k & 7); }
+
+    explicit F16x2Net(const float* blob) {
+        std::vector<double> ub(63, 1.0), nb;
+        size_t off = 0;
+        s[0] = 8;
+        ok = true;
+        for (int l = 0; l < NL; l++) {
+            const int K = DIMS[l], O = DIMS[l + 1];
+            const float* W = blob + off;
+            const float* b = W + (size_t)K * O;
+            off += (size_t)K * O + O;
+            double wmax = 0;
+            for (size_t i = 0; i < (size_t)K * O; i++) { if (!std::isfinite(W[i])) ok = false; wmax = std::fmax(wmax, std::fabs((double)W[i])); }
+            t[l] = wmax > 0 ? 14 - ceil_log2_pos(wmax) : 0;
+            if (t[l] > 40) t[l] = 40;
+            nb.assign(O, 0.0);
+            double B = 0;
+            for (int o = 0; o < O; o++) {
+                double acc = (double)b[o];
+                for (int i = 0; i < K; i++) {
+                    const double w = (double)W[(size_t)o * K + i];
+                    acc += (l == 0 ? std::fabs(w) : (w > 0 ? w : 0.0)) * ub[i];
+                }
+                nb[o] = acc > 0 ? acc : 0.0;
+                B = std::fmax(B, l == 4 ? std::fabs(acc) : nb[o]);
+            }
+            bound[l] = B;
+            ub = nb;
+            const int e_acc = s[l] + t[l];
+            if (e_acc < -60 || e_acc > 60) ok = false;
+            if (l < 4) {
+                s[l + 1] = 15 - ceil_log2_pos(std::fmax(B, 1e-30));
+                if (s[l + 1] > 24) s[l + 1] = 24;
+                cexp[l] = s[l + 1] - e_acc;
+            } else out_exp = -e_acc;
+            const int KP = 32 * NKB[l];
+            w_hi[l].assign((size_t)O * KP, 0); w_lo[l].assign((size_t)O * KP, 0);
+            for (int o = 0; o < O; o++)
+                for (int kb = 0; kb < NKB[l]; kb++)
+                    for (int k = 0; k < 32; k++) {
+                        const int i = unit_of_k(l, kb, k);
+                        if (i < 0 || i >= K) continue;
+                        const float ws = std::ldexp(W[(size_t)o * K + i], t[l]);
+                        const uint16_t hi = f16_bits_rne(ws);
+                        w_hi[l][(size_t)o * KP + 32 * kb + k] = hi;
+                        w_lo[l][(size_t)o * KP + 32 * kb + k] = f16_bits_rne(ws - f16_value(hi));
+                    }
+            bias[l].resize(O);
+            for (int o = 0; o < O; o++) bias[l][o] = std::ldexp(b[o], e_acc);
+        }
+    }
+
+    // policies.rs:28-44 on one state; out12 = the 12 raw outputs. nprod = 3 (shipped) or 4.
+    void forward(uint64_t my, uint64_t op, float* out12, int nprod = 3, int group = F16X2_GROUP) const {
+        // features (connect4.rs:235-258) times 2^8 as f16 pairs
+        uint64_t bottom = 0;
+        for (int c = 0; c < 9; c++) bottom |= 1ull << (7 * c);
+        const uint64_t occ = my | op, nf = ((occ << 1) | bottom) & ~occ & ((1ull << 63) - 1);
+        uint16_t xh[128], xl[128];
+        for (int f = 0; f < 128; f++) { xh[f] = 0; xl[f] = 0; }
+        const uint16_t c_hi = f16_bits_rne(0.1f * 256.0f), c_lo = f16_bits_rne(0.1f * 256.0f - f16_value(c_hi));
+        for (int f = 0; f < 63; f++) {
+            const int row = f / 9, col = f % 9;
+            const uint64_t bit = 1ull << (row + 7 * col);
+            const bool occupied = occ & bit, positive = (my & bit) || (!occupied && (nf & bit));
+            const uint16_t sign = positive ? 0 : 0x8000;
+            xh[f] = (occupied ? 0x5C00 : c_hi) | sign;
+            xl[f] = occupied ? 0 : (c_lo | sign);
+        }
+        float acc[128];
+        for (int l = 0; l < NL; l++) {
+            const int O = DIMS[l + 1], KP = 32 * NKB[l];
+            for (int o = 0; o < O; o++) {
+                float c = bias[l][o];
+                for (int kb = 0; kb < NKB[l]; kb++) {
+                    uint16_t bh[32], bl[32];
+                    for (int k = 0; k < 32; k++) {
+                        const int i = unit_of_k(l, kb, k);
+                        // layer 1's padding slot (board bit 63: never set) reads as an empty, not-next-free cell on the device: -25.6 against a zero weight
+                        bh[k] = i >= 0 ? xh[i] : (uint16_t)(c_hi | 0x8000);
+                        bl[k] = i >= 0 ? xl[i] : (uint16_t)(c_lo | 0x8000);
+                    }
+                    const uint16_t* ah = &w_hi[l][(size_t)o * KP + 32 * kb];
+                    const uint16_t* al = &w_lo[l][(size_t)o * KP + 32 * kb];
+                    c = mfma_f16_k32(c, ah, bh, group);
+                    c = mfma_f16_k32(c, ah, bl, group);
+                    c = mfma_f16_k32(c, al, bh, group);
+                    if (nprod == 4) c = mfma_f16_k32(c, al, bl, group);
+                }
+                acc[o] = c;
+            }
+            if (l < 4) {
+                const float cs = std::ldexp(1.0f, cexp[l]);
+                for (int f = 0; f < 128; f++) { xh[f] = 0; xl[f] = 0; }
+                for (int o = 0; o < O; o++) {
+                    float a = acc[o] * cs;
+                    a = (a != a) ? 0.0f : (a < 0.0f ? 0.0f : (a > 65504.0f ? 65504.0f : a));
+                    xh[o] = f16_bits_rne(a);
+                    xl[o] = f16_bits_rne(a - f16_value(xh[o]));
+                }
+            } else {
+                const float os = std::ldexp(1.0f, out_exp);
+                for (int o = 0; o < 12; o++) out12[o] = acc[o] * os;
+            }
+        }
+    }
+};
+
+}  // namespace oracle

@@ -1,0 +1,539 @@
+// Experiment: Connect4Net off the f32 vector datapath with a TWO-TERM f16 SPLIT on
+// v_mfma_f32_16x16x32_f16.  W = W_hi + W_lo, x = x_hi + x_lo (f16 each, exact power-of-two scales per layer), products
+// hi*hi + hi*lo + lo*hi (+ lo*lo as an option), f32 accumulation.  One stand-alone program, four measurements:
+//   (iv) how the instruction accumulates: designed probes + 2^20 random dot products against CPU models (exact sum / single rounding,
+//        sequential fma, grouped), raw tiles dumped for offline study;
+//   (i)  max |delta| of the 12 outputs against an f64 evaluation, slimnn's f32 order and today's f32-MFMA tile, on the random-init
+//        blob and the trained checkpoint, 2^20 reachable positions;
+//   (ii) cycles per 16-position tile, one wave alone and 1..4 waves per SIMD, beside today's f32 tile in the same harness;
+//   (iii) bit-identical outputs across runs and wave counts.
+// Build (repo root):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -Isynthesis_amd/csrc -Ioracle -pthread \
+//                        -o tools/ubench/mfma_f16_split tools/ubench/mfma_f16_split.hip
+// Run on the GPU box:  tools/ubench/mfma_f16_split tests/golden gpurun_out/f16split
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "mlp.cuh"
+#include "f16x2_tile.cuh"
+#include "nn_f16x2.hpp"
+
+using namespace syn;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+// ====================================================================================================================== host helpers
+static uint64_t sm64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static std::vector<float> load_npy_f32(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) { printf("cannot open %s\n", path.c_str()); exit(2); }
+    unsigned char hdr[10];
+    if (fread(hdr, 1, 10, f) != 10) exit(2);
+    int hl = hdr[8] | (hdr[9] << 8);
+    fseek(f, 10 + hl, SEEK_SET);
+    std::vector<float> v;
+    float buf[4096];
+    size_t n;
+    while ((n = fread(buf, 4, 4096, f)) > 0) v.insert(v.end(), buf, buf + n);
+    fclose(f);
+    return v;
+}
+static uint16_t f32_to_f16_bits(float x) { _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float f16_bits_to_f32(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+// host Connect4 (study-connect4/src/connect4.rs:37-83,221-233) for reachable positions
+static bool h_won(uint64_t bb) {
+    uint64_t d1 = bb & (bb >> 6) & (bb >> 12) & (bb >> 18) & c4::D1_MASK;
+    uint64_t d2 = bb & (bb >> 8) & (bb >> 16) & (bb >> 24) & c4::D2_MASK;
+    uint64_t h = bb & (bb >> 7) & (bb >> 14) & (bb >> 21) & c4::H_MASK;
+    uint64_t v = bb & (bb >> 1) & (bb >> 2) & (bb >> 3) & c4::V_MASK;
+    return (v | h | d1 | d2) != 0;
+}
+static void reachable_positions(size_t n, uint64_t seed, std::vector<uint64_t>& my, std::vector<uint64_t>& op) {
+    my.resize(n); op.resize(n);
+    uint64_t s = seed;
+    for (size_t i = 0; i < n;) {
+        int plies = (int)(sm64(s) % 45);
+        uint64_t m = 0, o = 0;
+        bool ok = true;
+        for (int t = 0; t < plies && ok; t++) {
+            uint64_t occ = m | o;
+            int legal[9], nl = 0;
+            for (int c = 0; c < 9; c++) if (!((occ >> (6 + 7 * c)) & 1)) legal[nl++] = c;
+            if (!nl) { ok = false; break; }
+            int c = legal[sm64(s) % nl];
+            int hgt = __builtin_popcountll(occ & (0x7Full << (7 * c)));
+            m ^= 1ull << (hgt + 7 * c);
+            std::swap(m, o);
+            if (h_won(o)) ok = false;
+        }
+        if (!ok || ((m | o) == c4::FULL)) continue;
+        my[i] = m; op[i] = o; i++;
+    }
+}
+static void host_features(uint64_t my, uint64_t op, float* x) {   // connect4.rs:235-258
+    uint64_t occ = my | op;
+    uint64_t nf = ((occ << 1) | c4::FAB_ROW) & ~occ & c4::FULL;
+    for (int f = 0; f < 63; f++) {
+        int row = f / 9, col = f % 9;
+        uint64_t bit = 1ull << (row + 7 * col);
+        float v = -0.1f;
+        if (nf & bit) v = 0.1f;
+        if (op & bit) v = -1.0f;
+        if (my & bit) v = 1.0f;
+        x[f] = v;
+    }
+}
+static const int DIMS[6] = {63, 128, 96, 64, 48, 12};
+template <class T>
+static void host_forward(const float* blob, const float* x63, T* out12, bool separate_mul_add) {
+    T a[128], c[128];
+    for (int i = 0; i < 63; i++) a[i] = (T)x63[i];
+    size_t off = 0;
+    for (int l = 0; l < 5; l++) {
+        const int I = DIMS[l], O = DIMS[l + 1];
+        const float* W = blob + off; const float* b = W + (size_t)I * O; off += (size_t)I * O + O;
+        for (int o = 0; o < O; o++) c[o] = (T)b[o];
+        for (int i = 0; i < I; i++)
+            for (int o = 0; o < O; o++) {
+                if (separate_mul_add) { T p = a[i] * (T)W[(size_t)o * I + i]; c[o] += p; }   // slimnn/src/linear.rs:17-25
+                else c[o] += a[i] * (T)W[(size_t)o * I + i];
+            }
+        for (int o = 0; o < O; o++) a[o] = (l < 4) ? (c[o] > (T)0 ? c[o] : (T)0) : c[o];
+    }
+    for (int o = 0; o < 12; o++) out12[o] = a[o];
+}
+template <class F>
+static void parallel_for(size_t n, F f) {
+    unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back([=] { for (size_t i = t; i < n; i += nt) f(i); });
+    for (auto& t : th) t.join();
+}
+
+// ====================================================================================================================== (iv) probe kernel
+// one wave = one MFMA: A[16][32] f16 row-major, B[32][16] f16 (k-major), C[16][16] f32 -> D[16][16]
+__global__ __launch_bounds__(64) void probe_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ B, const float* __restrict__ Cm,
+                                                   float* __restrict__ D, int ntiles) {
+    const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint16_t* a = A + (size_t)t * 512; const uint16_t* b = B + (size_t)t * 512; const float* c = Cm + (size_t)t * 256;
+        f16x8 av, bv; f32x4 cv;
+        for (int jj = 0; jj < 8; jj++) {
+            uint16_t ua = a[i * 32 + 8 * q + jj], ub = b[(8 * q + jj) * 16 + i];
+            av[jj] = __builtin_bit_cast(_Float16, ua); bv[jj] = __builtin_bit_cast(_Float16, ub);
+        }
+        for (int r = 0; r < 4; r++) cv[r] = c[(4 * q + r) * 16 + i];
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, cv, 0, 0, 0);
+        for (int r = 0; r < 4; r++) D[(size_t)t * 256 + (4 * q + r) * 16 + i] = d[r];
+    }
+}
+
+// ---- exact arithmetic on the host: fixed point with 2^-64 lsb in a signed 128-bit integer (|values| < 2^62)
+typedef __int128 i128;
+static const int FX = 64;
+static i128 fx_from_double_exact(double v) {          // v must be a multiple of 2^-64 and |v| < 2^62
+    if (v == 0) return 0;
+    int e; double m = std::frexp(v, &e);              // v = m * 2^e, 0.5 <= |m| < 1
+    int64_t mi = (int64_t)std::ldexp(m, 53);           // 53-bit integer
+    int sh = e - 53 + FX;
+    if (sh >= 0) return (i128)mi << sh;
+    // must be exact
+    return (i128)(mi >> (-sh));
+}
+static float fx_round_to_f32(i128 v, bool rtz) {      // RNE (or truncation) of v * 2^-64 to f32 (normal range assumed; tiny -> exact enough)
+    if (v == 0) return 0.0f;
+    bool neg = v < 0; unsigned __int128 u = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    int msb = 127; while (!((u >> msb) & 1)) msb--;
+    int drop = msb - 23;                               // keep 24 bits
+    unsigned __int128 keep = drop > 0 ? (u >> drop) : (u << (-drop));
+    if (drop > 0 && !rtz) {
+        unsigned __int128 rem = u & (((unsigned __int128)1 << drop) - 1), half = (unsigned __int128)1 << (drop - 1);
+        if (rem > half || (rem == half && (keep & 1))) keep++;
+    }
+    double r = std::ldexp((double)(uint64_t)keep, drop - FX);
+    return (float)(neg ? -r : r);
+}
+struct Models { float exact1, seqfma, g2, g4, g8, g16, g8t, s4, exact_rtz; };
+static Models host_models(const uint16_t* a /*32, k order*/, const uint16_t* b, float c) {
+    double p[32];
+    for (int k = 0; k < 32; k++) p[k] = (double)f16_bits_to_f32(a[k]) * (double)f16_bits_to_f32(b[k]);   // exact (22 bits)
+    Models m;
+    i128 S = fx_from_double_exact((double)c);
+    for (int k = 0; k < 32; k++) S += fx_from_double_exact(p[k]);
+    m.exact1 = fx_round_to_f32(S, false); m.exact_rtz = fx_round_to_f32(S, true);
+    float s = c;
+    for (int k = 0; k < 32; k++) s = std::fma(f16_bits_to_f32(a[k]), f16_bits_to_f32(b[k]), s);
+    m.seqfma = s;
+    auto grouped = [&](int g, bool rtz) {
+        float acc = c;
+        for (int k0 = 0; k0 < 32; k0 += g) {
+            i128 T = fx_from_double_exact((double)acc);
+            for (int k = k0; k < k0 + g; k++) T += fx_from_double_exact(p[k]);
+            acc = fx_round_to_f32(T, rtz);
+        }
+        return acc;
+    };
+    m.g2 = grouped(2, false); m.g4 = grouped(4, false); m.g8 = grouped(8, false); m.g16 = grouped(16, false); m.g8t = grouped(8, true);
+    {   // strided groups: pass jj takes k = jj, jj+8, jj+16, jj+24 ... as 8 groups of 4
+        float acc = c;
+        for (int jj = 0; jj < 8; jj++) {
+            i128 T = fx_from_double_exact((double)acc);
+            for (int qq = 0; qq < 4; qq++) T += fx_from_double_exact(p[8 * qq + jj]);
+            acc = fx_round_to_f32(T, false);
+        }
+        m.s4 = acc;
+    }
+    return m;
+}
+
+static void run_probe(const std::string& outdir) {
+    printf("\n=== (iv) how v_mfma_f32_16x16x32_f16 accumulates ===\n");
+    // ---- designed probes: tile row 0 / column 0 carries the case, everything else zero
+    struct Case { const char* name; float c; std::vector<std::pair<int, std::pair<float, float>>> terms; };
+    std::vector<Case> cases;
+    auto T = [](int k, float a, float b) { return std::make_pair(k, std::make_pair(a, b)); };
+    const float P24 = 16777216.0f;
+    cases.push_back({"layout: c=0, k=5 only 3*7", 0.f, {T(5, 3, 7)}});
+    cases.push_back({"c=2^24 + one 1.0 (half ulp, tie->even: 2^24)", P24, {T(0, 1, 1)}});
+    cases.push_back({"c=2^24 + two 1.0 in k=0,1 (exact 2^24+2)", P24, {T(0, 1, 1), T(1, 1, 1)}});
+    cases.push_back({"c=2^24 + two 1.0 in k=0,8", P24, {T(0, 1, 1), T(8, 1, 1)}});
+    cases.push_back({"c=2^24 + two 1.0 in k=0,4", P24, {T(0, 1, 1), T(4, 1, 1)}});
+    cases.push_back({"c=2^24 + two 1.0 in k=0,16", P24, {T(0, 1, 1), T(16, 1, 1)}});
+    cases.push_back({"c=2^24 + two 1.0 in k=7,24", P24, {T(7, 1, 1), T(24, 1, 1)}});
+    cases.push_back({"c=2^24 + two 1.0 in k=0,31", P24, {T(0, 1, 1), T(31, 1, 1)}});
+    { Case c{"c=2^24 + 32 x 0.5 (exact 2^24+16)", P24, {}}; for (int k = 0; k < 32; k++) c.terms.push_back(T(k, 1, 0.5f)); cases.push_back(c); }
+    { Case c{"c=2^24 + 32 x 0.25 (exact 2^24+8)", P24, {}}; for (int k = 0; k < 32; k++) c.terms.push_back(T(k, 0.5f, 0.5f)); cases.push_back(c); }
+    { Case c{"c=2^24 + 32 x 2^-6 (exact sum 0.5: stays 2^24)", P24, {}}; for (int k = 0; k < 32; k++) c.terms.push_back(T(k, 0.125f, 0.125f)); cases.push_back(c); }
+    { Case c{"c=2^24 + 32 x (2^-5+..) = 1+2^-5 (> half ulp: 2^24+2 if exact)", P24, {}}; for (int k = 0; k < 32; k++) c.terms.push_back(T(k, 0.125f, 0.25f)); c.terms.push_back(T(0, 0.125f, 0.25f)); cases.push_back(c); }
+    cases.push_back({"c=1 + 2^-24 (tie -> 1)", 1.f, {T(0, 0x1p-12f, 0x1p-12f)}});
+    cases.push_back({"c=1 + 2^-24 + 2^-30 (RNE: 1+2^-23, RTZ: 1)", 1.f, {T(0, 0x1p-12f, 0x1p-12f), T(1, 0x1p-15f, 0x1p-15f)}});
+    cases.push_back({"c=1 + 2^-24 + 2^-40", 1.f, {T(0, 0x1p-12f, 0x1p-12f), T(1, 0x1p-20f, 0x1p-20f)}});
+    cases.push_back({"c=1 + 2^-24 + 2^-48 (min normal squared 2^-28.. here 2^-24*2^-24)", 1.f, {T(0, 0x1p-12f, 0x1p-12f), T(9, 0x1p-24f, 0x1p-24f)}});
+    cases.push_back({"c=0: 2^20 - 2^20 + 2^-10 (exact 2^-10)", 0.f, {T(0, 1024.f, 1024.f), T(1, -1024.f, 1024.f), T(2, 0x1p-5f, 0x1p-5f)}});
+    cases.push_back({"c=0: 2^30 - 2^30 + 2^-20 (exact 2^-20)", 0.f, {T(0, 32768.f, 32768.f), T(1, -32768.f, 32768.f), T(2, 0x1p-10f, 0x1p-10f)}});
+    cases.push_back({"c=0: 2^30 (k=0) - 2^30 (k=8) + 2^-20 (k=16)", 0.f, {T(0, 32768.f, 32768.f), T(8, -32768.f, 32768.f), T(16, 0x1p-10f, 0x1p-10f)}});
+    cases.push_back({"c=0: 2^30 - 2^30 + 2^-28 (k=0,1,2)", 0.f, {T(0, 32768.f, 32768.f), T(1, -32768.f, 32768.f), T(2, 0x1p-14f, 0x1p-14f)}});
+    cases.push_back({"c=-2^30: + 2^30 (k=0) + 2^-20 (k=1)", -1073741824.f, {T(0, 32768.f, 32768.f), T(1, 0x1p-10f, 0x1p-10f)}});
+    cases.push_back({"c=2^30: - 2^30 (k=0) + 2^-20 (k=1)", 1073741824.f, {T(0, -32768.f, 32768.f), T(1, 0x1p-10f, 0x1p-10f)}});
+    cases.push_back({"subnormal a: c=0, a=2^-24 (f16 subnormal) * b=1", 0.f, {T(0, 0x1p-24f, 1.f)}});
+    cases.push_back({"subnormal a*b: 2^-24 * 2^-24 = 2^-48", 0.f, {T(0, 0x1p-24f, 0x1p-24f)}});
+    cases.push_back({"f32 subnormal c = 2^-140 + 0", 0x1p-140f, {}});
+    cases.push_back({"c=1 + 3 x 2^-25 in k=0,1,2 (sum 1.5 half-ulps: 1+2^-23 if summed first)", 1.f, {T(0, 0x1p-12f, 0x1p-13f), T(1, 0x1p-12f, 0x1p-13f), T(2, 0x1p-12f, 0x1p-13f)}});
+    cases.push_back({"c=1 + 3 x 2^-25 in k=0,8,16", 1.f, {T(0, 0x1p-12f, 0x1p-13f), T(8, 0x1p-12f, 0x1p-13f), T(16, 0x1p-12f, 0x1p-13f)}});
+    cases.push_back({"c=1 + 3 x 2^-25 in k=0,4,12", 1.f, {T(0, 0x1p-12f, 0x1p-13f), T(4, 0x1p-12f, 0x1p-13f), T(12, 0x1p-12f, 0x1p-13f)}});
+    cases.push_back({"c=2^-24: products 1 (k=0) and -1 (k=1): c survives?", 0x1p-24f, {T(0, 1.f, 1.f), T(1, -1.f, 1.f)}});
+    cases.push_back({"c=2^-30: products 1 (k=0) and -1 (k=9)", 0x1p-30f, {T(0, 1.f, 1.f), T(9, -1.f, 1.f)}});
+    cases.push_back({"c=2^-40: products 1 (k=0) and -1 (k=1)", 0x1p-40f, {T(0, 1.f, 1.f), T(1, -1.f, 1.f)}});
+    cases.push_back({"c=0: 1 (k=0) + 2^-24 (k=1) + 2^-24 (k=2) -> 1+2^-23 if exact", 0.f, {T(0, 1.f, 1.f), T(1, 0x1p-12f, 0x1p-12f), T(2, 0x1p-12f, 0x1p-12f)}});
+    cases.push_back({"c=0: 1 (k=0) + 2^-25 x 4 (k=1..4) -> 1+2^-23 if exact", 0.f, {T(0, 1.f, 1.f), T(1, 0x1p-12f, 0x1p-13f), T(2, 0x1p-12f, 0x1p-13f), T(3, 0x1p-12f, 0x1p-13f), T(4, 0x1p-12f, 0x1p-13f)}});
+    cases.push_back({"c=0: 1 (k=0) + 2^-30 x 1 -> 1 ; plus (1+2^-10)^2 check exactness of product: (1+2^-10)^2 = 1+2^-9+2^-20", 0.f, {T(3, 1.0009765625f, 1.0009765625f)}});
+    const int NC = (int)cases.size();
+    std::vector<uint16_t> hA((size_t)NC * 512, 0), hB((size_t)NC * 512, 0);
+    std::vector<float> hC((size_t)NC * 256, 0.f), hD((size_t)NC * 256);
+    for (int t = 0; t < NC; t++) {
+        hC[(size_t)t * 256] = cases[t].c;
+        for (auto& tm : cases[t].terms) {
+            // several terms on the same k are not possible: a later one on the same k moves to the next free k
+            int k = tm.first;
+            while (hA[(size_t)t * 512 + k] != 0) k = (k + 1) & 31;
+            hA[(size_t)t * 512 + k] = f32_to_f16_bits(tm.second.first);
+            hB[(size_t)t * 512 + k * 16] = f32_to_f16_bits(tm.second.second);
+        }
+    }
+    uint16_t *dA, *dB; float *dC, *dD;
+    const int NT = 1 << 12;   // tiles of random data per regime (1 << 20 dot products each)
+    CK(hipMalloc(&dA, (size_t)NT * 1024)); CK(hipMalloc(&dB, (size_t)NT * 1024)); CK(hipMalloc(&dC, (size_t)NT * 1024)); CK(hipMalloc(&dD, (size_t)NT * 1024));
+    CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dC, hC.data(), hC.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(probe_kernel, dim3(NC), dim3(64), 0, 0, dA, dB, dC, dD, NC);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hD.data(), dD, hD.size() * 4, hipMemcpyDeviceToHost));
+    printf("designed probes (D[0][0]; every other output of the tile must be 0):\n");
+    for (int t = 0; t < NC; t++) {
+        uint16_t a[32], b[32];
+        for (int k = 0; k < 32; k++) { a[k] = hA[(size_t)t * 512 + k]; b[k] = hB[(size_t)t * 512 + k * 16]; }
+        bool want_models = std::fabs(cases[t].c) == 0 || (std::fabs(cases[t].c) >= 0x1p-40f && std::fabs(cases[t].c) < 0x1p60f);
+        Models m{}; if (want_models) m = host_models(a, b, cases[t].c);
+        int stray = 0; for (int e = 1; e < 256; e++) stray += hD[(size_t)t * 256 + e] != 0.f;
+        printf("  %-78s D=%.10g (%a)  exact1=%a seqfma=%a g4=%a g8=%a%s\n", cases[t].name, hD[(size_t)t * 256], hD[(size_t)t * 256], m.exact1, m.seqfma, m.g4, m.g8,
+               stray ? "  STRAY NONZERO OUTPUTS" : "");
+    }
+    // ---- random regimes
+    const char* regimes[] = {"network-like (a ~ N(0,1)*2^12, b = |N|*2^8, c ~ N*2^22)", "wide (random finite f16 bit patterns, |c| in [2^-20, 2^30])",
+                             "cancelling (pairs +p, -p*(1+eps), small c)", "all-positive same-exponent (a,b in [1,2), c in [32,64))"};
+    std::vector<uint16_t> rA((size_t)NT * 512), rB((size_t)NT * 512); std::vector<float> rC((size_t)NT * 256), rD((size_t)NT * 256);
+    for (int reg = 0; reg < 4; reg++) {
+        uint64_t s = 1000 + reg;
+        auto gauss = [&]() { double u1 = ((sm64(s) >> 11) + 1) * (1.0 / 9007199254740993.0), u2 = (sm64(s) >> 11) * (1.0 / 9007199254740992.0); return std::sqrt(-2 * std::log(u1)) * std::cos(6.283185307179586 * u2); };
+        for (size_t i = 0; i < rA.size(); i++) {
+            if (reg == 0) { rA[i] = f32_to_f16_bits((float)(gauss() * 4096)); rB[i] = f32_to_f16_bits((float)(std::fabs(gauss()) * 256)); }
+            else if (reg == 1) { uint16_t u; do u = (uint16_t)sm64(s); while ((u & 0x7C00) == 0x7C00); rA[i] = u; do u = (uint16_t)sm64(s); while ((u & 0x7C00) == 0x7C00 || (u & 0x7C00) > 0x5C00); rB[i] = u; }
+            else if (reg == 2) { rA[i] = f32_to_f16_bits((float)(gauss() * 64)); rB[i] = f32_to_f16_bits((float)(gauss() * 64)); }
+            else { rA[i] = 0x3C00 | (sm64(s) & 0x3FF); rB[i] = 0x3C00 | (sm64(s) & 0x3FF); }
+        }
+        if (reg == 2)   // make k odd the near-negative of k even for the A rows (same B): strong cancellation
+            for (int t = 0; t < NT; t++) for (int i = 0; i < 16; i++) for (int k = 0; k < 32; k += 2) {
+                rA[(size_t)t * 512 + i * 32 + k + 1] = rA[(size_t)t * 512 + i * 32 + k] ^ 0x8000 ^ (uint16_t)(sm64(s) & 3);
+                for (int j = 0; j < 16; j++) rB[(size_t)t * 512 + (k + 1) * 16 + j] = rB[(size_t)t * 512 + k * 16 + j];
+            }
+        for (size_t i = 0; i < rC.size(); i++) {
+            if (reg == 0) rC[i] = (float)(gauss() * 4194304.0);
+            else if (reg == 1) { int e = (int)(sm64(s) % 50) - 20; rC[i] = (float)std::ldexp(1.0 + (sm64(s) >> 41) * 0x1p-23, e) * ((sm64(s) & 1) ? -1.f : 1.f); }
+            else if (reg == 2) rC[i] = (float)(gauss() * 0.01);
+            else rC[i] = 32.f + (sm64(s) >> 41) * 0x1p-18f;
+            if (rC[i] != 0 && std::fabs(rC[i]) < 0x1p-20f) rC[i] = 0x1p-20f;
+        }
+        CK(hipMemcpy(dA, rA.data(), rA.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, rB.data(), rB.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(dC, rC.data(), rC.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(probe_kernel, dim3(1024), dim3(64), 0, 0, dA, dB, dC, dD, NT);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(rD.data(), dD, rD.size() * 4, hipMemcpyDeviceToHost));
+        // second run: bit-identical?
+        std::vector<float> rD2(rD.size());
+        hipLaunchKernelGGL(probe_kernel, dim3(333), dim3(64), 0, 0, dA, dB, dC, dD, NT);
+        CK(hipDeviceSynchronize()); CK(hipMemcpy(rD2.data(), dD, rD2.size() * 4, hipMemcpyDeviceToHost));
+        bool same = !memcmp(rD.data(), rD2.data(), rD.size() * 4);
+        std::vector<long> mism(9, 0); std::vector<double> maxulp(9, 0);
+        std::vector<Models> mods((size_t)NT * 256);
+        parallel_for((size_t)NT * 256, [&](size_t e) {
+            size_t t = e >> 8; int i = (e >> 4) & 15, j = e & 15;
+            uint16_t a[32], b[32];
+            for (int k = 0; k < 32; k++) { a[k] = rA[t * 512 + i * 32 + k]; b[k] = rB[t * 512 + k * 16 + j]; }
+            mods[e] = host_models(a, b, rC[t * 256 + i * 16 + j]);
+        });
+        for (size_t e = 0; e < mods.size(); e++) {
+            const float d = rD[e]; const Models& m = mods[e];
+            const float v[9] = {m.exact1, m.seqfma, m.g2, m.g4, m.g8, m.g16, m.g8t, m.s4, m.exact_rtz};
+            for (int q = 0; q < 9; q++) if (memcmp(&d, &v[q], 4)) { mism[q]++; double u = std::fabs((double)d - v[q]) / std::max(1e-300, (double)std::fabs(std::nextafterf(std::fabs(d), INFINITY) - std::fabs(d))); maxulp[q] = std::max(maxulp[q], u); }
+        }
+        printf("regime %d: %s  (%d outputs; two launches bit-identical: %s)\n   mismatches vs model [max ulp]:", reg, regimes[reg], NT * 256, same ? "yes" : "NO");
+        const char* mn[9] = {"exact+1RNE", "seq-fma", "group2", "group4", "group8", "group16", "group8-rtz", "strided4", "exact+rtz"};
+        for (int q = 0; q < 9; q++) printf("  %s=%ld[%.2g]", mn[q], mism[q], maxulp[q]);
+        printf("\n");
+        // dump a slice for offline study
+        const int ND = 512;
+        std::string fn = outdir + "/probe_regime" + std::to_string(reg) + ".bin";
+        if (FILE* f = fopen(fn.c_str(), "wb")) {
+            fwrite(rA.data(), 2, (size_t)ND * 512, f); fwrite(rB.data(), 2, (size_t)ND * 512, f); fwrite(rC.data(), 4, (size_t)ND * 256, f); fwrite(rD.data(), 4, (size_t)ND * 256, f);
+            fclose(f);
+        }
+    }
+    // dump the designed probes too
+    if (FILE* f = fopen((outdir + "/probe_designed.bin").c_str(), "wb")) {
+        fwrite(hA.data(), 2, hA.size(), f); fwrite(hB.data(), 2, hB.size(), f); fwrite(hC.data(), 4, hC.size(), f); fwrite(hD.data(), 4, hD.size(), f); fclose(f);
+    }
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dD);
+}
+
+// ====================================================================================================================== tile kernels
+// Every wave walks tiles t = wave_global, wave_global + total_waves, ...; raw 12 outputs per position; cycles of the tile loop per wave.
+template <int NPROD>
+__global__ __launch_bounds__(1024) void f16_tiles_kernel(const uint32_t* __restrict__ g_img, const uint64_t* __restrict__ my, const uint64_t* __restrict__ op,
+                                                         int ntiles, float* __restrict__ out, unsigned long long* __restrict__ cyc, float out_scale) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    for (int i = threadIdx.x; i < F16Geom::IMG_WORDS / 4; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds_img)[i] = reinterpret_cast<const uint4*>(g_img)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    int done = 0;
+    for (int t = blockIdx.x * nw + wave; t < ntiles; t += gridDim.x * nw, done++) {
+        const size_t p = (size_t)t * 16 + (lane & 15);
+        uint64_t hi, lo;
+        feature_boards(my[p], op[p], hi, lo);
+        f32x4 o = f16x2_tile16<NPROD>(lds_img, lane, hi, lo);
+        const int q = lane >> 4;
+        if (q < 3) {
+            f32x4 w; for (int r = 0; r < 4; r++) w[r] = o[r] * out_scale;
+            *reinterpret_cast<f32x4*>(out + p * 12 + 4 * q) = w;
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) { cyc[(blockIdx.x * nw + wave) * 2] = t1 - t0; cyc[(blockIdx.x * nw + wave) * 2 + 1] = done; }
+}
+template <int VARIANT>   // 0 = mlp_tile16_pipe, 1 = mlp_tile16
+__global__ __launch_bounds__(1024) void f32_tiles_kernel(const float* __restrict__ g_img, const uint64_t* __restrict__ my, const uint64_t* __restrict__ op,
+                                                         int ntiles, float* __restrict__ out, unsigned long long* __restrict__ cyc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_raw[];
+    float* lds_img = reinterpret_cast<float*>(lds_raw);
+    stage_weight_image(lds_img, g_img, threadIdx.x, blockDim.x);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const FeatureTable FT = make_feature_table(lane >> 4);
+    unsigned long long t0 = __builtin_readcyclecounter();
+    int done = 0;
+    for (int t = blockIdx.x * nw + wave; t < ntiles; t += gridDim.x * nw, done++) {
+        const size_t p = (size_t)t * 16 + (lane & 15);
+        uint64_t hi, lo;
+        feature_boards(my[p], op[p], hi, lo);
+        f32x4 o = VARIANT == 0 ? mlp_tile16_pipe(lds_img, lds_img + MlpGeom::W_FLOATS, lane, FT, hi, lo)
+                               : mlp_tile16(lds_img, lds_img + MlpGeom::W_FLOATS, lane, FT, hi, lo);
+        const int q = lane >> 4;
+        if (q < 3) *reinterpret_cast<f32x4*>(out + p * 12 + 4 * q) = o;
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) { cyc[(blockIdx.x * nw + wave) * 2] = t1 - t0; cyc[(blockIdx.x * nw + wave) * 2 + 1] = done; }
+}
+
+static void build_f32_image(const float* blob, std::vector<float>& img) {   // same layout as engine.hip build_weight_image
+    img.assign(MlpGeom::IMG_FLOATS, 0.0f);
+    size_t off = 0;
+    for (int l = 0; l < MlpGeom::NL; l++) {
+        const int K = MlpGeom::K[l], O = MlpGeom::O[l], S4 = MlpGeom::S4[l], NOB = MlpGeom::NOB[l];
+        const float* W = blob + off; const float* b = W + (size_t)K * O; off += (size_t)K * O + O;
+        for (int s4 = 0; s4 < S4; s4++) for (int ob = 0; ob < NOB; ob++) for (int lane = 0; lane < 64; lane++) for (int r = 0; r < 4; r++) {
+            int i = lane & 15, q = lane >> 4, unit = mlp_unit_of_row(l, ob, i), k = 16 * s4 + 4 * r + q;
+            img[MlpGeom::W_OFF[l] + ((s4 * NOB + ob) * 64 + lane) * 4 + r] = (unit < O && k < K) ? W[(size_t)unit * K + k] : 0.0f;
+        }
+        for (int ob = 0; ob < NOB; ob++) for (int q = 0; q < 4; q++) for (int r = 0; r < 4; r++) {
+            int unit = mlp_unit_of_row(l, ob, 4 * q + r);
+            img[MlpGeom::W_FLOATS + MlpGeom::B_OFF[l] + (ob * 4 + q) * 4 + r] = unit < O ? b[unit] : 0.0f;
+        }
+    }
+}
+
+struct Stats { double max_logit = 0, max_value = 0; };
+static void softmax3(const double* x, double* y) { double m = std::max(x[0], std::max(x[1], x[2])), s = 0; for (int i = 0; i < 3; i++) { y[i] = std::exp(x[i] - m); s += y[i]; } for (int i = 0; i < 3; i++) y[i] /= s; }
+template <class TA, class TB>
+static Stats compare(const TA* a, const TB* b, size_t n) {
+    Stats s;
+    for (size_t p = 0; p < n; p++) {
+        double va[3], vb[3], xa[3], xb[3];
+        for (int o = 0; o < 9; o++) s.max_logit = std::max(s.max_logit, std::fabs((double)a[p * 12 + o] - (double)b[p * 12 + o]));
+        for (int o = 0; o < 3; o++) { xa[o] = a[p * 12 + 9 + o]; xb[o] = b[p * 12 + 9 + o]; }
+        softmax3(xa, va); softmax3(xb, vb);
+        for (int o = 0; o < 3; o++) s.max_value = std::max(s.max_value, std::fabs(va[o] - vb[o]));
+    }
+    return s;
+}
+
+int main(int argc, char** argv) {
+    const std::string golden = argc > 1 ? argv[1] : "tests/golden", outdir = argc > 2 ? argv[2] : "gpurun_out/f16split";
+    (void)!system(("mkdir -p " + outdir).c_str());
+    if (argc > 3 && !strcmp(argv[3], "cpu")) {   // no GPU: the CPU restatement against f64 (sanity of the definition itself)
+        std::vector<uint64_t> my, op; reachable_positions(4096, 42, my, op);
+        for (const char* blobname : {"c4net_blob_f32", "c4net_trained_f32"}) {
+            std::vector<float> blob = load_npy_f32(golden + "/" + blobname + ".npy");
+            oracle::F16x2Net net(blob.data());
+            std::vector<double> ref64(4096 * 12); std::vector<float> sim(4096 * 12), sim8(4096 * 12);
+            parallel_for(4096, [&](size_t p) { float x[63]; host_features(my[p], op[p], x); host_forward<double>(blob.data(), x, &ref64[p * 12], false); net.forward(my[p], op[p], &sim[p * 12], 3); net.forward(my[p], op[p], &sim8[p * 12], 3, 8); });
+            Stats a = compare(sim.data(), ref64.data(), 4096), b = compare(sim8.data(), sim.data(), 4096);
+            printf("%s: CPU f16x2 (exact-sum model) vs f64: %.3e / %.3e ; group-8 model vs exact-sum model: %.3e / %.3e\n", blobname, a.max_logit, a.max_value, b.max_logit, b.max_value);
+        }
+        return 0;
+    }
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s, %d CUs\n", prop.name, prop.multiProcessorCount);
+    run_probe(outdir);
+
+    const size_t NP = 1 << 20;
+    std::vector<uint64_t> my, op;
+    reachable_positions(NP, 42, my, op);
+    uint64_t *d_my, *d_op; float* d_out; unsigned long long* d_cyc; uint32_t* d_img; float* d_img32;
+    CK(hipMalloc(&d_my, NP * 8)); CK(hipMalloc(&d_op, NP * 8)); CK(hipMalloc(&d_out, NP * 48)); CK(hipMalloc(&d_cyc, 1 << 20));
+    CK(hipMalloc(&d_img, F16Geom::IMG_WORDS * 4)); CK(hipMalloc(&d_img32, MlpGeom::IMG_FLOATS * 4));
+    CK(hipMemcpy(d_my, my.data(), NP * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_op, op.data(), NP * 8, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute((const void*)f16_tiles_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, F16Geom::IMG_WORDS * 4));
+    CK(hipFuncSetAttribute((const void*)f16_tiles_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, F16Geom::IMG_WORDS * 4));
+    CK(hipFuncSetAttribute((const void*)f32_tiles_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom::IMG_FLOATS * 4));
+    CK(hipFuncSetAttribute((const void*)f32_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom::IMG_FLOATS * 4));
+    const int ntiles = (int)(NP / 16), CUS = prop.multiProcessorCount;
+
+    for (const char* blobname : {"c4net_blob_f32", "c4net_trained_f32"}) {
+        std::vector<float> blob = load_npy_f32(golden + "/" + blobname + ".npy");
+        if (blob.size() != 30492) { printf("unexpected blob size %zu\n", blob.size()); return 2; }
+        printf("\n=== blob %s ===\n", blobname);
+        // ---- host references
+        std::vector<double> ref64(NP * 12); std::vector<float> refsl(NP * 12);
+        parallel_for(NP, [&](size_t p) { float x[63]; host_features(my[p], op[p], x); host_forward<double>(blob.data(), x, &ref64[p * 12], false); host_forward<float>(blob.data(), x, &refsl[p * 12], true); });
+        double maxlogit = 0; for (size_t p = 0; p < NP; p++) for (int o = 0; o < 9; o++) maxlogit = std::max(maxlogit, std::fabs(ref64[p * 12 + o]));
+        // ---- today's f32 tile
+        std::vector<float> img32; build_f32_image(blob.data(), img32);
+        CK(hipMemcpy(d_img32, img32.data(), img32.size() * 4, hipMemcpyHostToDevice));
+        std::vector<float> out32(NP * 12);
+        hipLaunchKernelGGL(f32_tiles_kernel<0>, dim3(CUS), dim3(512), MlpGeom::IMG_FLOATS * 4, 0, d_img32, d_my, d_op, ntiles, d_out, d_cyc);
+        CK(hipDeviceSynchronize()); CK(hipMemcpy(out32.data(), d_out, NP * 48, hipMemcpyDeviceToHost));
+        // ---- f16x2 image
+        F16Image im; build_f16x2_image(blob.data(), im);
+        printf("scales: feature 2^%d;", im.s[0]);
+        for (int l = 0; l < 5; l++) printf(" L%d: weights 2^%d, bound %.3g, rescale 2^%d |", l + 1, im.t[l], im.bound[l], im.cexp[l]);
+        printf(" out 2^%d\n", im.out_exp);
+        CK(hipMemcpy(d_img, im.words.data(), F16Geom::IMG_WORDS * 4, hipMemcpyHostToDevice));
+        std::vector<float> out3(NP * 12), out4(NP * 12), tmp(NP * 12);
+        const float oscale = std::ldexp(1.0f, im.out_exp);
+        hipLaunchKernelGGL(f16_tiles_kernel<3>, dim3(CUS), dim3(512), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale);
+        CK(hipDeviceSynchronize()); CK(hipMemcpy(out3.data(), d_out, NP * 48, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(f16_tiles_kernel<4>, dim3(CUS), dim3(512), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale);
+        CK(hipDeviceSynchronize()); CK(hipMemcpy(out4.data(), d_out, NP * 48, hipMemcpyDeviceToHost));
+        // ---- (i) errors
+        printf("(i) max |delta| over %zu reachable positions (max |logit| %.3g): logits / value probabilities\n", NP, maxlogit);
+        auto line = [&](const char* n, Stats s) { printf("    %-44s %.3e / %.3e\n", n, s.max_logit, s.max_value); };
+        line("slimnn f32 order (host) vs f64", compare(refsl.data(), ref64.data(), NP));
+        line("f32 MFMA tile (today) vs f64", compare(out32.data(), ref64.data(), NP));
+        line("f32 MFMA tile (today) vs slimnn order", compare(out32.data(), refsl.data(), NP));
+        line("f16x2, 3 products vs f64", compare(out3.data(), ref64.data(), NP));
+        line("f16x2, 3 products vs slimnn order", compare(out3.data(), refsl.data(), NP));
+        line("f16x2, 3 products vs f32 MFMA tile", compare(out3.data(), out32.data(), NP));
+        line("f16x2, 4 products vs f64", compare(out4.data(), ref64.data(), NP));
+        line("f16x2, 4 products vs slimnn order", compare(out4.data(), refsl.data(), NP));
+        // CPU restatement of the whole tile (exact products, one RNE per MFMA = the model to be confirmed by (iv))
+        {
+            const size_t NS = 1 << 16;
+            std::vector<float> sim(NS * 12);
+            oracle::F16x2Net net(blob.data());
+            bool plan_same = net.ok && net.out_exp == im.out_exp;
+            for (int l = 0; l < 5; l++) plan_same = plan_same && net.s[l] == im.s[l] && net.t[l] == im.t[l] && (l == 4 || net.cexp[l] == im.cexp[l]);
+            printf("     oracle's plan equals the product's: %s\n", plan_same ? "yes" : "NO");
+            parallel_for(NS, [&](size_t p) { net.forward(my[p], op[p], &sim[p * 12], 3); });
+            size_t bad = 0; for (size_t e = 0; e < NS * 12; e++) bad += memcmp(&sim[e], &out3[e], 4) != 0;
+            printf("(iv) whole-network CPU restatement (exact sum of a 32-term MFMA + accumulator, one RNE): %zu of %zu outputs differ from the device's bits (3 products)\n", bad, NS * 12);
+            parallel_for(NS, [&](size_t p) { net.forward(my[p], op[p], &sim[p * 12], 4); });
+            bad = 0; for (size_t e = 0; e < NS * 12; e++) bad += memcmp(&sim[e], &out4[e], 4) != 0;
+            printf("     same with 4 products: %zu of %zu differ\n", bad, NS * 12);
+        }
+        // ---- (iii) determinism: runs, wave counts, grid sizes
+        bool det = true;
+        for (int nw : {1, 4, 8, 12, 16}) for (int grid : {CUS, 2 * CUS + 3}) {
+            hipLaunchKernelGGL(f16_tiles_kernel<3>, dim3(grid), dim3(64 * nw), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale);
+            CK(hipDeviceSynchronize()); CK(hipMemcpy(tmp.data(), d_out, NP * 48, hipMemcpyDeviceToHost));
+            if (memcmp(tmp.data(), out3.data(), NP * 48)) { det = false; printf("    NOT bit-identical at %d waves, grid %d\n", nw, grid); }
+        }
+        printf("(iii) outputs bit-identical across 10 launches (1/4/8/12/16 waves per workgroup, two grid sizes): %s\n", det ? "yes" : "NO");
+        // ---- (ii) cycles per tile
+        printf("(ii) cycles per 16-position tile (s_memtime over the tile loop incl. position loads and output stores; %d tiles):\n", ntiles);
+        for (int nw : {1, 4, 8, 12, 16}) {
+            auto report = [&](const char* name) {
+                CK(hipDeviceSynchronize());
+                std::vector<unsigned long long> c((size_t)CUS * nw * 2);
+                CK(hipMemcpy(c.data(), d_cyc, c.size() * 8, hipMemcpyDeviceToHost));
+                double cyc = 0, tiles = 0; for (size_t w = 0; w < c.size() / 2; w++) { cyc += c[2 * w]; tiles += c[2 * w + 1]; }
+                printf("    %-22s %2d waves/CU: %8.0f cycles per tile and wave  -> %7.0f cycles of one SIMD per tile\n", name, nw, cyc / tiles, cyc / tiles / std::max(1.0, nw / 4.0));
+            };
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            auto timed = [&](const char* name, auto launch) {
+                launch(); CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0)); for (int r = 0; r < 5; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                report(name);
+                printf("        wall: %.3f ms per %zu positions = %.3f G evaluations/s\n", ms / 5, NP, NP / (ms / 5) * 1e-6);
+            };
+            timed("f32 pipe tile (today)", [&] { hipLaunchKernelGGL(f32_tiles_kernel<0>, dim3(CUS), dim3(64 * nw), MlpGeom::IMG_FLOATS * 4, 0, d_img32, d_my, d_op, ntiles, d_out, d_cyc); });
+            timed("f16x2, 3 products", [&] { hipLaunchKernelGGL(f16_tiles_kernel<3>, dim3(CUS), dim3(64 * nw), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale); });
+            timed("f16x2, 4 products", [&] { hipLaunchKernelGGL(f16_tiles_kernel<4>, dim3(CUS), dim3(64 * nw), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale); });
+        }
+    }
+    return 0;
+}
