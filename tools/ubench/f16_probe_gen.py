@@ -1,0 +1,124 @@
+"""Designed probes for the accumulation behaviour of v_mfma_f32_16x16x32_f16 (tools/ubench/mfma_f16_split probe <in> <out>).
+
+Each case is one dot product  c + sum_k a[k] b[k]  placed on the diagonal of a 16x16 tile (row i of A, column i of B, C[i][i]); 16 cases
+per tile.  Writes tools/ubench/probe_in.bin (travels to the GPU box) and tools/ubench/probe_cases.json (case descriptions for the
+offline analysis, tools/ubench/f16_probe_fit.py).
+"""
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def f16(sign, e, mant):
+    """bits of (-1)^sign (1 + mant/1024) 2^e; e in [-24, 15] (below -14: exact subnormal only when mant bits allow)"""
+    if e >= -14:
+        return (sign << 15) | ((e + 15) << 10) | mant
+    # subnormal: value = m 2^-24 with m = (1024 + mant) >> (-14 - e) ... only exact if the shifted-out bits are zero
+    sh = -14 - e
+    full = 1024 + mant
+    assert full % (1 << sh) == 0, "inexact subnormal"
+    return (sign << 15) | (full >> sh)
+
+
+def split_exp(total):
+    """two f16 exponents (each in [-24, 15]) adding up to `total`, preferring normal numbers"""
+    ea = max(-14, min(15, total // 2))
+    eb = total - ea
+    if eb > 15:
+        ea += eb - 15; eb = 15
+    if eb < -24:
+        ea += eb + 24; eb = -24
+    assert -24 <= ea <= 15 and -24 <= eb <= 15, total
+    return ea, eb
+
+
+cases = []
+
+
+def add(label, c, terms, **meta):
+    cases.append(dict(label=label, c=float(np.float32(c)), terms=[(int(k), int(a), int(b)) for k, a, b in terms], **meta))
+
+
+def prod(k, sign, total_exp, ma=0, mb=0):
+    ea, eb = split_exp(total_exp)
+    if ea < -14 or eb < -14:
+        ma = mb = 0   # keep subnormal operands exact
+    return (k, f16(sign, ea, ma), f16(0, eb, mb))
+
+
+BIG = 30
+# A: product against product inside one pass
+for (kb, ks, kc) in ((0, 1, 2), (0, 7, 3), (2, 3, 0), (0, 4, 1), (5, 0, 6)):
+    for n in range(0, 59):
+        for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF)):
+            for sg in (0, 1):
+                add("A", 0.0, [prod(kb, 0, BIG), prod(kc, 1, BIG), prod(ks, sg, BIG - n, ma, mb)], n=n, ma=ma, mb=mb, sign=sg, pos=(kb, ks, kc))
+# B: accumulator cancels against a product, small product survives
+for cs in (0, 1):
+    for n in range(0, 59):
+        for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF)):
+            for sg in (0, 1):
+                add("B", (-1.0 if cs else 1.0) * 2.0 ** BIG, [prod(0, 1 - cs, BIG), prod(1, sg, BIG - n, ma, mb)], n=n, ma=ma, mb=mb, sign=sg, csign=cs)
+# C: two products cancel, small accumulator survives
+for n in range(0, 64):
+    for m24 in (0x800000, 0x800001, 0xFFFFFF, 0xC00001):
+        for sg in (0, 1):
+            c = (-1.0 if sg else 1.0) * m24 * 2.0 ** (BIG - n - 23)
+            add("C", c, [prod(0, 0, BIG), prod(1, 1, BIG)], n=n, m24=m24, sign=sg)
+# D: a tie at the accumulator's half ulp plus something small
+for ks in (1, 7):
+    for n in range(25, 72):
+        for sg in (0, 1):
+            add("D", 2.0 ** BIG, [prod(0, 0, BIG - 24), prod(ks, sg, BIG - n)], n=n, sign=sg, ks=ks)
+# E: one big product and m small ones
+for small in (24, 25, 26, 27):
+    for m in range(1, 8):
+        for k0 in (0, 7):
+            ks = [k for k in range(8) if k != k0][:m]
+            add("E", 0.0, [prod(k0, 0, 0)] + [prod(k, 0, -small) for k in ks], m=m, small=small, k0=k0)
+            add("E", 0.0, [prod(k0, 0, 0)] + [prod(k, 1, -small) for k in ks], m=-m, small=small, k0=k0)
+# F: two products (and optionally an accumulator) with an exponent gap
+for g in range(0, 34):
+    for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF), (0x155, 0x2AA)):
+        for sg in (0, 1):
+            add("F", 0.0, [prod(0, 0, 10, 0x3FF, 0x3FF), prod(1, sg, 10 - g, ma, mb)], g=g, ma=ma, mb=mb, sign=sg)
+            add("F2", 3.0 * 2.0 ** 8, [prod(0, 0, 10, 0x3FF, 0x3FF), prod(1, sg, 10 - g, ma, mb)], g=g, ma=ma, mb=mb, sign=sg)
+# G: random single-pass cases (k < 8 only), with and without an accumulator, several exponent spreads
+rs = np.random.RandomState(5)
+for spread in (2, 6, 12, 20, 30):
+    for i in range(1200):
+        terms = []
+        for k in range(8):
+            ea = int(rs.randint(-spread // 2, spread // 2 + 1)); eb = int(rs.randint(-spread // 2, spread // 2 + 1))
+            terms.append((k, f16(int(rs.randint(2)), max(-14, min(15, ea)), int(rs.randint(1024))), f16(0, max(-14, min(15, eb)), int(rs.randint(1024)))))
+        if i % 3 == 0:
+            c = 0.0
+        else:
+            c = float(np.float32((1 + rs.randint(1 << 23) / float(1 << 23)) * 2.0 ** int(rs.randint(-spread, spread + 1)) * (1 if rs.randint(2) else -1)))
+        add("G", c, terms, spread=spread)
+# H: random full 32-term cases with moderate spread (validates the four-pass chaining of a single-pass model)
+for i in range(2000):
+    terms = []
+    for k in range(32):
+        terms.append((k, f16(int(rs.randint(2)), int(rs.randint(-6, 7)), int(rs.randint(1024))), f16(0, int(rs.randint(-6, 7)), int(rs.randint(1024)))))
+    c = float(np.float32((1 + rs.randint(1 << 23) / float(1 << 23)) * 2.0 ** int(rs.randint(-12, 13)) * (1 if rs.randint(2) else -1)))
+    add("H", c, terms)
+
+ntiles = (len(cases) + 15) // 16
+A = np.zeros((ntiles, 16, 32), np.uint16); B = np.zeros((ntiles, 32, 16), np.uint16); C = np.zeros((ntiles, 16, 16), np.float32)
+for idx, cs in enumerate(cases):
+    t, i = divmod(idx, 16)
+    C[t, i, i] = cs["c"]
+    for k, a, b in cs["terms"]:
+        assert A[t, i, k] == 0
+        A[t, i, k] = a; B[t, k, i] = b
+with open(os.path.join(HERE, "probe_in.bin"), "wb") as f:
+    for t in range(ntiles):
+        f.write(A[t].tobytes()); f.write(B[t].tobytes()); f.write(C[t].tobytes())
+json.dump(cases, open(os.path.join(HERE, "probe_cases.json"), "w"))
+print(len(cases), "cases,", ntiles, "tiles")
