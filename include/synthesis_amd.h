@@ -123,6 +123,34 @@ int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats);
  * syn_load_weights / syn_trainer_publish_weights switch back to Connect4Net. Empties the policy cache. */
 int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats);
 
+/* The arithmetic Connect4Net is evaluated in. The reference's own is f32 (libtorch `y = x W^T + b`, study-connect4/src/policies.rs:
+ * 28-44; slimnn/src/linear.rs:17-25 in its Rust-only form); both choices below compute that function and differ in rounding only.
+ *   SYN_NET_ARITH_F32   (default) every product and sum in f32 on v_mfma_f32_16x16x4_f32, ascending input order, fused
+ *                       multiply-add per term: bit for bit oracle/nn.hpp's ACC_FMA, within 1e-5 of slimnn's order.
+ *   SYN_NET_ARITH_F16X2 every weight and activation as a pair of f16 numbers (hi + lo, 22-23 significand bits, exact power-of-two
+ *                       scales chosen per checkpoint from a bound on the activations), products hi.hi + hi.lo + lo.hi on
+ *                       v_mfma_f32_16x16x32_f16 with f32 accumulation: 5.3x fewer matrix-pipe cycles per evaluation. Bit for bit
+ *                       oracle/nn_f16x2.hpp (which restates the instruction's accumulation, identified on MI355X); as close to
+ *                       an f64 evaluation as the f32 arithmetic is (profiles/r05_f16_split.txt: 1.0e-7 against 1.0e-7 on the
+ *                       random-init network, 1.8e-4 against 2.3e-4 on logits of magnitude 258 of a trained one).
+ * The choice holds for syn_policy_eval_batch*, syn_eval_ctx_*, syn_mcts_search and syn_selfplay_run until changed; it empties the
+ * policy cache. F16X2 needs Connect4Net (not Connect4ConvNet: SYN_ERR_UNSUPPORTED), max_explores <= 7280 (lane-per-tree kernels) and
+ * finite parameters. Results under the two arithmetics differ in the last bits of the logits, so searches may differ where two
+ * moves are within rounding of each other — which is why the choice is the caller's and never made silently. */
+enum { SYN_NET_ARITH_F32 = 0, SYN_NET_ARITH_F16X2 = 1 };
+int syn_set_network_arithmetic(syn_engine* h, int arithmetic);
+/* The scales of the f16x2 plan of the engine's current Connect4Net (valid = 0 when there is none): layer l's inputs are multiplied
+ * by 2^activation_exp[l], its weights by 2^weight_exp[l]; bound[l] = the bound on layer l's outputs the next exponent was chosen
+ * from; raw outputs = accumulators * 2^out_exp. arithmetic / plan may be NULL. */
+typedef struct syn_f16x2_plan {
+    int valid;
+    int activation_exp[5];
+    int weight_exp[5];
+    int out_exp;
+    double bound[5];
+} syn_f16x2_plan;
+int syn_get_network_arithmetic(syn_engine* h, int* arithmetic, syn_f16x2_plan* plan);
+
 /* ---- leaf evaluation ------------------------------------------------------------------------------------------- */
 
 /* Replaces: Policy::eval (study-connect4/src/policies.rs:47-59) for n states at once. State i is the position with

@@ -11,7 +11,10 @@
 //   ACC_SLIMNN : separate multiply and add, input index ascending — exactly slimnn's loop (canonical restatement).
 //   ACC_FMA    : same ascending order with a fused multiply-add per term — the order/rounding the HIP engine's
 //                f32 MFMA path produces bit for bit. Used so that MCTS visit counts can be compared exactly.
-// The two modes agree to ~1e-6; north_star's 1e-5 tolerance is asserted between the engine and ACC_SLIMNN.
+//   ACC_F16X2  : (Connect4Net only) the engine's SYN_NET_ARITH_F16X2 arithmetic bit for bit — every operand a pair of f16 numbers,
+//                products on v_mfma_f32_16x16x32_f16, whose accumulation nn_f16x2.hpp restates. A third definition of the same
+//                function (not the reference's arithmetic); as close to an f64 evaluation as the f32 modes are.
+// The modes agree to ~1e-6; north_star's 1e-5 tolerance is asserted between the engine and ACC_SLIMNN.
 // Parity: Linear/Conv2d/ReLU pinned by slimnn's KATs (linear.rs:105-112, conv.rs:92-602, activations.rs:70-75);
 // Connect4Net has no test in the reference -> PARITY UNPINNED there (torch-generated goldens in tests/golden/).
 #pragma once
@@ -20,12 +23,15 @@
 #include <cstdint>
 #include <vector>
 
+#include <memory>
+
 #include "connect4.hpp"
 #include "det_math.hpp"
+#include "nn_f16x2.hpp"
 
 namespace oracle {
 
-enum AccMode : int { ACC_SLIMNN = 0, ACC_FMA = 1 };
+enum AccMode : int { ACC_SLIMNN = 0, ACC_FMA = 1, ACC_F16X2 = 2 };
 
 // W is [O][I] row-major (slimnn `weight: [[f32; I]; O]`, same as torch nn.Linear.weight).
 inline void linear_forward(int I, int O, const float* W, const float* b, const float* x, float* out, int mode) {
@@ -114,8 +120,26 @@ struct Connect4Net {
     }
     const float* bias(int l) const { return weight(l) + (size_t)DIMS[l] * DIMS[l + 1]; }
 
+    // ACC_F16X2: the plan and the split operands, built from the blob on first use (one Connect4Net object per thread)
+    mutable std::shared_ptr<F16x2Net> f16;
+    mutable const float* f16_blob = nullptr;
+    const F16x2Net& f16_net() const {
+        if (!f16 || f16_blob != blob) { f16 = std::make_shared<F16x2Net>(blob); f16_blob = blob; }
+        return *f16;
+    }
+
     // policies.rs:28-44 on a single state; out12 = the 12 raw outputs
     void forward(const float* x63, float* out12) const {
+        if (mode == ACC_F16X2) {   // the f16x2 arithmetic starts from the bitboards: +1 = mine, -1 = theirs (connect4.rs:235-258)
+            uint64_t my = 0, op = 0;
+            for (int f = 0; f < 63; f++) {
+                const uint64_t bit = 1ull << ((f / 9) + 7 * (f % 9));
+                if (x63[f] == 1.0f) my |= bit;
+                if (x63[f] == -1.0f) op |= bit;
+            }
+            f16_net().forward(my, op, out12);
+            return;
+        }
         float a[128], c[128];
         const float* in = x63;
         float* bufs[2] = {a, c};
@@ -130,8 +154,11 @@ struct Connect4Net {
     // Policy::eval (policies.rs:47-59): raw policy logits, softmaxed outcome distribution [lose, draw, win].
     void eval(const Connect4& game, float logits[9], float value[3]) const {
         float x[63], out[12];
-        game.features(x);
-        forward(x, out);
+        if (mode == ACC_F16X2) f16_net().forward(game.my_bb, game.op_bb, out);
+        else {
+            game.features(x);
+            forward(x, out);
+        }
         for (int i = 0; i < 9; i++) logits[i] = out[i];
         softmax_stable(out + 9, value, 3);
     }

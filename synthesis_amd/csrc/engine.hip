@@ -72,6 +72,8 @@ SYN_LANES2(MODE_SELFPLAY, true)
 SYN_LANES_FAST_LIST(SYN_X)
 SYN_LANES_GEN_LIST(SYN_X)
 SYN_LANES_REF_LIST(SYN_X)
+SYN_LANES_F16_LIST(SYN_X)
+SYN_LANES_F16_GEN_LIST(SYN_X)
 #undef SYN_X
 }  // namespace syn
 
@@ -112,6 +114,12 @@ struct syn_engine {
     uint4* d_edge = nullptr;
     float* d_wimg = nullptr;
     int net_kind = 0;  // which network d_wimg holds: 0 = Connect4Net (mlp.cuh), 1 = Connect4ConvNet (convnet.cuh)
+    // Connect4Net in the f16x2 arithmetic (f16x2_tile.cuh; syn_set_network_arithmetic): its image, the parameters it is built from
+    // (host copy, refreshed by syn_load_weights / syn_trainer_publish_weights) and whether the image is current
+    int net_arith = SYN_NET_ARITH_F32;
+    uint32_t* d_wimg16 = nullptr;
+    std::vector<float> host_blob;
+    bool img16_current = false;
     bool has_weights = false;
     int* d_job_next = nullptr;
     uint4* d_cache = nullptr;      // PolicyWithCache table (policy_cache_log2 > 0)
@@ -137,7 +145,7 @@ struct syn_engine {
     // scratch for host-pointer entry points
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
-    std::atomic<bool> eval_attr_set[3] = {{false}, {false}, {false}};   // launch_policy_eval: the kernels' LDS attribute is set
+    std::atomic<bool> eval_attr_set[5] = {{false}, {false}, {false}, {false}, {false}};   // launch_policy_eval: the kernels' LDS attribute is set
     size_t eval_poll_max = 1024;       // contexts: batches up to this size signal completion through pinned memory (SYN_DEBUG=1 SYN_EVAL_POLL_MAX)
     size_t eval_zero_copy_out = 4096;  // contexts: results of up to this many positions are written into the pinned buffer by the kernel itself
     struct syn_eval_ctx* eval_ctx = nullptr;   // syn_policy_eval_batch's own evaluation context (created on first use)
@@ -457,6 +465,13 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         // Connect4ConvNet (convnet.cuh) is evaluated by the lane-per-tree kernels only: 4 waves per workgroup up to 256 trees
         // per CU, 8 up to 512, 16 beyond
         const bool conv = h->net_kind == 1;
+        // Connect4Net in the f16x2 arithmetic (f16x2_tile.cuh) is evaluated by the lane-per-tree kernels only, at every size
+        const bool f16x2 = !conv && h->net_arith == SYN_NET_ARITH_F16X2 && P.wimg == reinterpret_cast<const float*>(h->d_wimg16);
+        if (f16x2) {
+            if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
+            if (debug_env("SYN_LANES") == nullptr || !(nw == 4 || nw == 8 || nw == 12 || nw == 16))
+                nw = want_slots > h->num_cus * 768 ? 16 : (want_slots > h->num_cus * 512 ? 12 : (want_slots > h->num_cus * 256 ? 8 : 4));
+        }
         if (conv) {
             if (h->cap > LANE_MAX_CAP) return hipErrorInvalidValue;
             nw = want_slots > h->num_cus * 512 ? 16 : (want_slots > h->num_cus * 256 ? 8 : 4);
@@ -524,6 +539,29 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             // the reference's own self-play configuration (Fpu::Func folded at compile time: mcts.cuh cfg_family) has instantiations of
             // its own at 8 and 16 waves
             const bool ref_family = !conv && (!PROF || (MODE == MODE_SELFPLAY && !COUNT)) && cfg_family(P.mcts) == 2 && (nw == 8 || nw == 12 || nw == 16);
+            if (f16x2) {
+                // family 1 / 2 at every wave count, the runtime-switched configurations at 4 and 8 waves (nw was capped above)
+                const int fam = cfg_family(P.mcts);
+#define SYN_LAUNCH_LH(NW, FAST, PROFV)                                                                             \
+    {                                                                                                              \
+        auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROFV, 3>;                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LaneLds<NW>::BYTES);   \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), LaneLds<NW>::BYTES, h->stream, PL);                      \
+    }
+                constexpr bool PROFH = PROF && MODE == MODE_SELFPLAY && !COUNT;
+                if (fam == 2) {
+                    if (nw == 4) SYN_LAUNCH_LH(4, 2, false) else if (nw == 8) SYN_LAUNCH_LH(8, 2, false)
+                    else if (nw == 12) SYN_LAUNCH_LH(12, 2, false) else SYN_LAUNCH_LH(16, 2, false)
+                } else if (fast) {
+                    if (nw == 4) SYN_LAUNCH_LH(4, true, false) else if (nw == 8) SYN_LAUNCH_LH(8, true, false)
+                    else if (nw == 12) SYN_LAUNCH_LH(12, true, PROFH) else SYN_LAUNCH_LH(16, true, PROFH)
+                } else {
+                    if (nw == 4) SYN_LAUNCH_LH(4, false, false) else SYN_LAUNCH_LH(8, false, false)
+                }
+#undef SYN_LAUNCH_LH
+            } else
             if (ref_family) {
                 if (nw == 8) SYN_LAUNCH_LR(8) else if (nw == 12) SYN_LAUNCH_LR(12) else SYN_LAUNCH_LR(16)
             } else
@@ -720,6 +758,7 @@ int syn_engine_destroy(syn_engine* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     hipFree(h->d_stat);
     hipFree(h->d_wimg);
+    hipFree(h->d_wimg16);
     hipFree(h->d_job_next);
     hipFree(h->d_path);
     hipFree(h->d_vw);
@@ -755,6 +794,22 @@ int syn_engine_destroy(syn_engine* h) {
     return SYN_OK;
 }
 
+// The f16x2 image of the engine's Connect4Net (f16x2_tile.cuh: build_f16x2_image from the host copy of the parameters), built on
+// first use after the parameters changed.
+static int ensure_f16x2_image(syn_engine* h) {
+    if (h->img16_current) return SYN_OK;
+    if (h->net_kind != 0 || h->host_blob.size() != (size_t)MlpGeom::NUM_PARAMS)
+        return fail(h, SYN_ERR_UNSUPPORTED, "the f16x2 arithmetic exists for Connect4Net only");
+    F16Image im;
+    if (!build_f16x2_image(h->host_blob.data(), im))
+        return fail(h, SYN_ERR_UNSUPPORTED, "these parameters have no f16x2 plan (non-finite values or scales outside the f32-safe window)");
+    if (!h->d_wimg16) HIP_TRY(h, hipMalloc(&h->d_wimg16, (size_t)F16Geom::IMG_WORDS * 4));
+    HIP_TRY(h, hipMemcpyAsync(h->d_wimg16, im.words.data(), (size_t)F16Geom::IMG_WORDS * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->img16_current = true;
+    return SYN_OK;
+}
+
 int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (!blob) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob is NULL");
@@ -770,6 +825,49 @@ int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
     if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));
     h->has_weights = true;
     h->net_kind = 0;
+    h->host_blob.assign(blob, blob + n_floats);
+    h->img16_current = false;
+    if (h->net_arith == SYN_NET_ARITH_F16X2) return ensure_f16x2_image(h);
+    return SYN_OK;
+}
+
+int syn_set_network_arithmetic(syn_engine* h, int arithmetic) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (arithmetic != SYN_NET_ARITH_F32 && arithmetic != SYN_NET_ARITH_F16X2)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown network arithmetic %d", arithmetic);
+    if (arithmetic == h->net_arith) return SYN_OK;
+    if (arithmetic == SYN_NET_ARITH_F16X2) {
+        if (h->cap > LANE_MAX_CAP)
+            return fail(h, SYN_ERR_UNSUPPORTED, "the f16x2 arithmetic runs in the lane-per-tree kernels: max_explores must be <= %u",
+                        (LANE_MAX_CAP - 1u) / 9u - 1u);
+        if (h->has_weights && h->net_kind != 0)
+            return fail(h, SYN_ERR_UNSUPPORTED, "the f16x2 arithmetic exists for Connect4Net only (the engine holds Connect4ConvNet)");
+    }
+    HIP_TRY(h, hipSetDevice(h->device));
+    h->net_arith = arithmetic;
+    // PolicyWithCache entries belong to the arithmetic that produced them: the two differ in the last bits
+    if (h->d_cache) {
+        HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    if (arithmetic == SYN_NET_ARITH_F16X2 && h->has_weights) return ensure_f16x2_image(h);
+    return SYN_OK;
+}
+
+int syn_get_network_arithmetic(syn_engine* h, int* arithmetic, syn_f16x2_plan* plan) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (arithmetic) *arithmetic = h->net_arith;
+    if (plan) {
+        std::memset(plan, 0, sizeof(*plan));
+        if (h->has_weights && h->net_kind == 0 && !h->host_blob.empty()) {
+            F16Image im;
+            if (build_f16x2_image(h->host_blob.data(), im)) {
+                plan->valid = 1;
+                for (int l = 0; l < 5; l++) { plan->activation_exp[l] = im.s[l]; plan->weight_exp[l] = im.t[l]; plan->bound[l] = im.bound[l]; }
+                plan->out_exp = im.out_exp;
+            }
+        }
+    }
     return SYN_OK;
 }
 
@@ -789,6 +887,9 @@ int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats) {
     if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));  // a new network: empty cache
     h->has_weights = true;
     h->net_kind = 1;
+    h->host_blob.clear();
+    h->img16_current = false;
+    h->net_arith = SYN_NET_ARITH_F32;   // (Connect4ConvNet has the f32 arithmetic only)
     return SYN_OK;
 }
 
@@ -817,6 +918,26 @@ static hipError_t launch_policy_eval(syn_engine* h, hipStream_t st, const uint64
         hipLaunchKernelGGL(k, dim3(grid), dim3(NT), (LDS), st, h->d_wimg, reinterpret_cast<const unsigned long long*>(d_my),    \
                            reinterpret_cast<const unsigned long long*>(d_op), n, d_logits, d_value);                           \
     }
+    if (h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F16X2) {
+        // Connect4Net in the f16x2 arithmetic: the throughput kernel at every size (its tile is 3x shorter than the f32 one's)
+#define SYN_LAUNCH_EVAL16(NT, SLOT)                                                                                            \
+    {                                                                                                                          \
+        auto k = policy_eval_f16x2_kernel<NT>;                                                                                 \
+        if (!h->eval_attr_set[SLOT].load(std::memory_order_acquire)) {                                                         \
+            if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,         \
+                                         (int)(F16Geom::IMG_WORDS * 4))) != hipSuccess)                                        \
+                return e;                                                                                                      \
+            h->eval_attr_set[SLOT].store(true, std::memory_order_release);                                                     \
+        }                                                                                                                      \
+        int grid = (ntiles + NT / 64 - 1) / (NT / 64);                                                                         \
+        if (grid > h->num_cus) grid = h->num_cus;                                                                              \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(NT), (size_t)F16Geom::IMG_WORDS * 4, st, h->d_wimg16,                           \
+                           reinterpret_cast<const unsigned long long*>(d_my), reinterpret_cast<const unsigned long long*>(d_op), n, \
+                           d_logits, d_value);                                                                                 \
+    }
+        if (ntiles >= h->num_cus * 16 * 4) SYN_LAUNCH_EVAL16(1024, 3) else SYN_LAUNCH_EVAL16(512, 4)
+#undef SYN_LAUNCH_EVAL16
+    } else
     if (h->net_kind == 0 && (size_t)n <= EVAL_TILE_MAX) {
         // at most a tile per CU: the latency kernel (eval_small.cuh), one workgroup per tile, no weight staging
         hipLaunchKernelGGL(policy_eval_tile_kernel, dim3((unsigned)ntiles), dim3(256), EVAL_TILE_LDS, st, h->d_wimg,
@@ -952,7 +1073,7 @@ int syn_eval_ctx_submit(syn_eval_ctx* c, const uint64_t* my_bb, const uint64_t* 
     // with one DMA (syn_policy_eval_batch, measured)
     c->out_in_place = nb <= h->eval_zero_copy_out;
     float* o_logits = c->out_in_place ? s_logits : static_cast<float*>(c->d_out);
-    c->polled = c->out_in_place && h->net_kind == 0 && nb <= h->eval_poll_max && !c->poll_broken;
+    c->polled = c->out_in_place && h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F32 && nb <= h->eval_poll_max && !c->poll_broken;
     if (c->polled) {
         // the latency kernels: their last workgroup stores this call's number into pinned memory, syn_eval_ctx_wait polls it
         c->seq += 1u;
@@ -1207,11 +1328,12 @@ static bool valid_root(uint64_t my, uint64_t op) {
 
 static int common_params(syn_engine* h, EngineParams& P, int explores, bool need_weights = true) {
     if (need_weights && !h->has_weights) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+    if (need_weights && h->net_arith == SYN_NET_ARITH_F16X2) { int rc16 = ensure_f16x2_image(h); if (rc16 != SYN_OK) return rc16; }
     if (explores < 0) return fail(h, SYN_ERR_INVALID_ARGUMENT, "explores must be >= 0");
     if (explores > h->max_explores)
         return fail(h, SYN_ERR_CAPACITY, "explores %d exceeds the engine's max_explores %d", explores, h->max_explores);
     std::memset(&P, 0, sizeof(P));
-    P.wimg = h->d_wimg;
+    P.wimg = (h->net_arith == SYN_NET_ARITH_F16X2 && h->net_kind == 0) ? reinterpret_cast<const float*>(h->d_wimg16) : h->d_wimg;
     P.stat = h->d_stat;
     P.edge = h->d_edge;
     P.cap = h->cap;
@@ -2219,14 +2341,22 @@ int syn_trainer_publish_weights(syn_engine* h) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         h->has_weights = true;
         h->net_kind = 1;
+        h->host_blob.clear();
+        h->img16_current = false;
+        h->net_arith = SYN_NET_ARITH_F32;
         return SYN_OK;
     }
     // the trainer keeps its weights in the inference fragment order as well (train_mfma.cuh): publishing is one device copy
     HIP_TRY(h, hipMemcpyAsync(h->d_wimg, h->d_twimg, (size_t)MlpGeom::IMG_FLOATS * 4, hipMemcpyDeviceToDevice, h->stream));
     if (h->d_cache) HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));  // new network: empty PolicyWithCache
+    // the f16x2 image is built on the host from the canonical parameters: keep a copy of what was published
+    h->host_blob.resize((size_t)MlpGeom::NUM_PARAMS);
+    HIP_TRY(h, hipMemcpyAsync(h->host_blob.data(), h->d_tw, (size_t)MlpGeom::NUM_PARAMS * 4, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->has_weights = true;
     h->net_kind = 0;
+    h->img16_current = false;
+    if (h->net_arith == SYN_NET_ARITH_F16X2) return ensure_f16x2_image(h);
     return SYN_OK;
 }
 

@@ -12,6 +12,7 @@
 #pragma once
 #include "mcts.cuh"
 #include "mlp.cuh"
+#include "f16x2_tile.cuh"
 
 namespace syn {
 
@@ -799,6 +800,47 @@ __global__ __launch_bounds__(NT) void policy_eval_kernel(const float* __restrict
         uint64_t hi, lo;
         feature_boards(my, op, hi, lo);
         f32x4 o = mlp_tile16(wimg, bimg, lane, FT, hi, lo);
+        if (valid) {
+            if (q < 2) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) logits[(size_t)pos * 9 + q * 4 + r] = o[r];
+            } else if (q == 2) {
+                logits[(size_t)pos * 9 + 8] = o[0];
+                float v0 = o[1], v1 = o[2], v2 = o[3];
+                value_softmax(v0, v1, v2);
+                value[(size_t)pos * 3 + 0] = v0;
+                value[(size_t)pos * 3 + 1] = v1;
+                value[(size_t)pos * 3 + 2] = v2;
+            }
+        }
+    }
+}
+
+// The same in the f16x2 arithmetic (f16x2_tile.cuh): g_img = the F16Geom image.
+template <int NT>
+__global__ __launch_bounds__(NT) void policy_eval_f16x2_kernel(const uint32_t* __restrict__ g_img,
+                                                               const unsigned long long* __restrict__ my_bb,
+                                                               const unsigned long long* __restrict__ op_bb, int n,
+                                                               float* __restrict__ logits, float* __restrict__ value) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem16[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < F16Geom::IMG_WORDS / 4; i += NT) reinterpret_cast<uint4*>(smem16)[i] = reinterpret_cast<const uint4*>(g_img)[i];
+    __syncthreads();
+    const int ntiles = (n + 15) >> 4;
+    const int j = lane & 15, q = lane >> 4;
+    for (int tile = blockIdx.x * (NT / 64) + wave; tile < ntiles; tile += gridDim.x * (NT / 64)) {
+        uint32_t img_off = 0;   // opaque per iteration: the image reads stay LDS reads next to their MFMAs
+        asm volatile("" : "+v"(img_off));
+        const uint32_t* img = smem16 + img_off;
+        int pos = tile * 16 + j;
+        bool valid = pos < n;
+        uint64_t my = valid ? my_bb[pos] : 0ull, op = valid ? op_bb[pos] : 0ull;
+        uint64_t hi, lo;
+        feature_boards(my, op, hi, lo);
+        f32x4 o = f16x2_tile16<3>(img, lane, hi, lo);
+        const float os = reinterpret_cast<const float*>(img + F16Geom::SCALE_WORD0)[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] *= os;
         if (valid) {
             if (q < 2) {
 #pragma unroll

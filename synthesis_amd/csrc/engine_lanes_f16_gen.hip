@@ -1,0 +1,15 @@
+// synthesis_amd — translation unit of the library: the lane-per-tree kernels (lane_kernel.cuh) evaluating Connect4Net in the f16x2
+// arithmetic (POLICY 3) for the runtime-switched configurations (Uct, ParentQ, Dirichlet / Equal noise, solver switches off ...).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/synthesis_amd.h"
+#include "lane_kernel.cuh"
+#include "lane_instances.h"
+
+namespace syn {
+#define SYN_X(MODE, COUNT, FAST, NW, PROF, POLICY) template __global__ void selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF, POLICY>(EngineParams);
+SYN_LANES_F16_GEN_LIST(SYN_X)
+#undef SYN_X
+}  // namespace syn

@@ -31,3 +31,23 @@
     X(MODE_SELFPLAY, false, 2, 8, true, 0) X(MODE_SELFPLAY, false, 2, 16, true, 0)                               \
     X(MODE_SELFPLAY, false, 2, 12, false, 0) X(MODE_SELFPLAY, true, 2, 12, false, 0) X(MODE_SEARCH, false, 2, 12, false, 0) \
     X(MODE_SELFPLAY, false, 2, 12, true, 0)
+// Connect4Net in the f16x2 arithmetic (POLICY 3, f16x2_tile.cuh): every configuration family at every wave count
+// (engine_lanes_f16.hip)
+#define SYN_LANES_F16_LIST(X)                                                                                    \
+    X(MODE_SELFPLAY, false, true, 4, false, 3) X(MODE_SELFPLAY, false, true, 8, false, 3)                        \
+    X(MODE_SELFPLAY, false, true, 12, false, 3) X(MODE_SELFPLAY, false, true, 16, false, 3)                      \
+    X(MODE_SELFPLAY, true, true, 4, false, 3) X(MODE_SELFPLAY, true, true, 8, false, 3)                          \
+    X(MODE_SELFPLAY, true, true, 12, false, 3) X(MODE_SELFPLAY, true, true, 16, false, 3)                        \
+    X(MODE_SEARCH, false, true, 4, false, 3) X(MODE_SEARCH, false, true, 8, false, 3)                            \
+    X(MODE_SEARCH, false, true, 12, false, 3) X(MODE_SEARCH, false, true, 16, false, 3)                          \
+    X(MODE_SELFPLAY, false, true, 12, true, 3) X(MODE_SELFPLAY, false, true, 16, true, 3)                        \
+    X(MODE_SELFPLAY, false, 2, 4, false, 3) X(MODE_SELFPLAY, false, 2, 8, false, 3)                              \
+    X(MODE_SELFPLAY, false, 2, 12, false, 3) X(MODE_SELFPLAY, false, 2, 16, false, 3)                            \
+    X(MODE_SELFPLAY, true, 2, 4, false, 3) X(MODE_SELFPLAY, true, 2, 8, false, 3)                                \
+    X(MODE_SELFPLAY, true, 2, 12, false, 3) X(MODE_SELFPLAY, true, 2, 16, false, 3)                              \
+    X(MODE_SEARCH, false, 2, 4, false, 3) X(MODE_SEARCH, false, 2, 8, false, 3)                                  \
+    X(MODE_SEARCH, false, 2, 12, false, 3) X(MODE_SEARCH, false, 2, 16, false, 3)
+#define SYN_LANES_F16_GEN_LIST(X)                                                                                \
+    X(MODE_SELFPLAY, false, false, 4, false, 3) X(MODE_SELFPLAY, false, false, 8, false, 3)                      \
+    X(MODE_SELFPLAY, true, false, 4, false, 3) X(MODE_SELFPLAY, true, false, 8, false, 3)                        \
+    X(MODE_SEARCH, false, false, 4, false, 3) X(MODE_SEARCH, false, false, 8, false, 3)

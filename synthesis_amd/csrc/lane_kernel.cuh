@@ -23,6 +23,7 @@
 #include "engine_kernels.cuh"
 #include "noise.cuh"
 #include "convnet.cuh"
+#include "f16x2_tile.cuh"
 
 namespace syn {
 
@@ -1381,7 +1382,8 @@ SYN_DEV void lane_rollout(uint64_t my, uint64_t op, unsigned long long seed, int
 // ---------------------------------------------------------------------------------------------- the kernel
 template <int NW>
 struct LaneLds {
-    static constexpr size_t IDX_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;  // 123,264 B weight + bias image
+    // weight + bias image: 123,264 B (Connect4Net f32, mlp.cuh) or 124,320 B (Connect4Net as f16 pairs, f16x2_tile.cuh)
+    static constexpr size_t IDX_OFF = (size_t)MlpGeom::IMG_FLOATS * 4 > (size_t)F16Geom::IMG_WORDS * 4 ? (size_t)MlpGeom::IMG_FLOATS * 4 : (size_t)F16Geom::IMG_WORDS * 4;
     static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;        // + 64 B compaction index per wave
     static constexpr size_t PARK_OFF = FT_OFF + 64;                    // + the four feature shift tables (16 B each)
     static constexpr size_t BYTES = PARK_OFF + (size_t)NW * 64 * 20;   // + 5 parked dwords per lane (root boards, turn|rng)
@@ -1395,6 +1397,7 @@ SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
 
 // POLICY: 0 = Connect4Net on the matrix cores, 1 = RolloutPolicy (policies/rollout.rs; searches only),
 //         2 = Connect4ConvNet on the matrix cores (convnet.cuh: its image takes the first 66 KB of the Connect4Net image's LDS)
+//         3 = Connect4Net in the f16x2 arithmetic (f16x2_tile.cuh: two-term f16 split on v_mfma_f32_16x16x32_f16; P.wimg is that image)
 template <int MODE, bool COUNT, int FAST, int NW, bool PROF = false, int POLICY = 0>
 __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1407,6 +1410,11 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
 
     if (POLICY == 0) stage_weight_image(wimg, P.wimg, tid, NT);
     if (POLICY == 2) stage_conv_image(wimg, P.wimg, tid, NT);
+    if (POLICY == 3) {
+        const uint4* src = reinterpret_cast<const uint4*>(P.wimg);
+        uint4* dst = reinterpret_cast<uint4*>(smem_raw);
+        for (int i = tid; i < F16Geom::IMG_WORDS / 4; i += NT) dst[i] = src[i];
+    }
     // RolloutPolicy needs no weights: the image's LDS holds the waves' ChaCha12 block rings instead (12 KB per wave)
     RolloutRing ring;
     ring.lds = reinterpret_cast<uint32_t*>(smem_raw) + (size_t)wave * (3 * 16 * 64) + lane;
@@ -1535,6 +1543,17 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
                 uint32_t img_off = 0;  // opaque per tile: the image reads stay LDS reads next to their MFMAs
                 asm volatile("" : "+v"(img_off));
                 o = conv_tile16(wimg + img_off, lane, tmy, top);
+            } else if (POLICY == 3) {
+                uint64_t hi, lo;
+                feature_boards(Wk.my, Wk.op, hi, lo);
+                const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
+                uint32_t img_off = 0;  // opaque per tile: the image reads stay LDS reads next to their MFMAs
+                asm volatile("" : "+v"(img_off));
+                const uint32_t* img16 = reinterpret_cast<const uint32_t*>(smem_raw) + img_off;
+                o = f16x2_tile16<3>(img16, lane, thi, tlo);
+                const float os = reinterpret_cast<const float*>(img16 + F16Geom::SCALE_WORD0)[4];   // exact power of two
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] *= os;
             } else {
                 uint64_t hi, lo;
                 feature_boards(Wk.my, Wk.op, hi, lo);

@@ -42,6 +42,11 @@ class CSearchResult(C.Structure):  # struct syn_search_result
     ]
 
 
+class CF16x2Plan(C.Structure):  # struct syn_f16x2_plan
+    _fields_ = [("valid", C.c_int), ("activation_exp", C.c_int * 5), ("weight_exp", C.c_int * 5), ("out_exp", C.c_int),
+                ("bound", C.c_double * 5)]
+
+
 class CTrainConfig(C.Structure):  # struct syn_train_config
     _fields_ = [("weight_decay", C.c_float), ("policy_weight", C.c_float), ("value_weight", C.c_float),
                 ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float)]
@@ -96,6 +101,8 @@ def load_library():
     lib.syn_engine_destroy.argtypes = [C.c_void_p]
     lib.syn_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.syn_load_weights_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.syn_set_network_arithmetic.argtypes = [C.c_void_p, C.c_int]
+    lib.syn_get_network_arithmetic.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(CF16x2Plan)]
     lib.syn_policy_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.syn_policy_eval_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_int]
@@ -265,6 +272,23 @@ class Engine:
         """Connect4ConvNet (Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12>; include/synthesis_amd.h) becomes the engine's policy."""
         blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
         self._check(self._lib.syn_load_weights_conv(self._h, _p(blob), blob.size))
+
+    # ---- the arithmetic Connect4Net is evaluated in (include/synthesis_amd.h: SYN_NET_ARITH_*)
+    def set_network_arithmetic(self, arithmetic):
+        """"f32" (default: v_mfma_f32_16x16x4_f32, the oracle's ACC_FMA) or "f16x2" (two-term f16 split on v_mfma_f32_16x16x32_f16, the
+        oracle's ACC_F16X2); holds for policy_eval, evaluation contexts, mcts_search and selfplay until changed."""
+        code = {"f32": 0, "f16x2": 1}.get(arithmetic, arithmetic)
+        self._check(self._lib.syn_set_network_arithmetic(self._h, int(code)))
+
+    def network_arithmetic(self):
+        """(name, plan): plan = None or a dict of the f16x2 scales of the current Connect4Net."""
+        a = C.c_int()
+        pl = CF16x2Plan()
+        self._check(self._lib.syn_get_network_arithmetic(self._h, C.byref(a), C.byref(pl)))
+        plan = None
+        if pl.valid:
+            plan = dict(activation_exp=list(pl.activation_exp), weight_exp=list(pl.weight_exp), out_exp=pl.out_exp, bound=list(pl.bound))
+        return ("f16x2" if a.value == 1 else "f32"), plan
 
     # ---- Policy::eval, batched (policies.rs:47-59)
     def policy_eval(self, my_bb, op_bb):
