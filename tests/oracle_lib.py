@@ -71,6 +71,7 @@ def _p(a):
 class Oracle:
     ACC_SLIMNN = 0
     ACC_FMA = 1
+    ACC_F16X2 = 2   # the engine's SYN_NET_ARITH_F16X2 arithmetic (oracle/nn_f16x2.hpp)
 
     def __init__(self, lib):
         self.lib = lib
