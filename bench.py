@@ -38,6 +38,8 @@ if ROOT not in sys.path:
 FLOP_PER_EVAL = 60288           # 2 * (63*128 + 128*96 + 96*64 + 64*48 + 48*12)  
 PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/F16 dense matrix peak (~2.5 PF; the 5 PF headline figure includes 2:1 sparsity)
+F16X2_FLOP_PER_EVAL = 184320    # the f16x2 tile as executed: 180 v_mfma_f32_16x16x32_f16 x 16,384 FLOP per 16 positions (3 products, inputs padded to 32s)
 
 
 def make_weights(seed=20211003):
@@ -353,6 +355,45 @@ def main():
                 "mfma_frac": (ct["policy_evals"] / 32768.0) * (n_games / dt4) * FLOP_PER_EVAL / 1e12 / PEAK_F32_MFMA_TFLOPS,
                 "launch_shape": shape4, "roofline": near, "roofline_other": other}
 
+    def f16x2_leg(eng, n_games, first):
+        """Connect4Net in the f16x2 arithmetic (SYN_NET_ARITH_F16X2: every operand a pair of f16 numbers, products on
+        v_mfma_f32_16x16x32_f16; include/synthesis_amd.h): the headline workload, one launch of n_games games, then the trained checkpoint.
+        The arithmetic is not the headline's (23-bit operands instead of 24, results equal to the oracle's ACC_F16X2 and as close to f64 as
+        f32 is: profiles/r05_f16_split.txt), so this is a leg of its own and never `value`. Three roofs: the f16 matrix peak against the
+        MFMAs it executes (3 products x zero-padded inputs: 184,320 FLOP per evaluation), the f32 matrix peak against the 60,288 FLOP the
+        network needs (what the f32 kernel is priced by), and HBM against the tree traffic."""
+        eng.set_network_arithmetic("f16x2")
+        res = {}
+        for name, w in (("random_init", blob), ("trained_checkpoint", trained_blob)):
+            if w is None:
+                continue
+            eng.load_weights(w)
+            eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=first, outputs=False)
+            t1 = time.perf_counter()
+            rt = eng.selfplay(cfg, base_seed=0, n_games=n_games, first_game=first + args.concurrent, outputs=False)
+            dt = time.perf_counter() - t1
+            shape = list(eng.last_launch_shape())
+            ct = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=first + args.concurrent, outputs=False, counters=True)["counters"]
+            key = "f16x2_traffic_bytes_per_launch" if name == "random_init" else "f16x2_trained_traffic_bytes_per_launch"
+            near, other = leg_rooflines(ct, 32768, n_games, rt["kernel_ms"], key, FLOP_PER_EVAL)
+            evals = ct["policy_evals"] * (n_games / 32768.0)
+            secs = rt["kernel_ms"] * 1e-3
+            res[name] = {"games_per_s": n_games / dt, "games": n_games, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
+                         "leaf_evals_per_s": evals / dt, "select_levels_per_explore": ct["select_levels"] / max(1, ct["explores"]),
+                         "launch_shape": shape, "roofline": near, "roofline_other": other,
+                         "roofline_f16_mfma": {"bound": "mfma", "achieved": evals * F16X2_FLOP_PER_EVAL / secs / 1e12, "peak": PEAK_F16_MFMA_TFLOPS,
+                                               "unit": "TFLOP/s", "frac": evals * F16X2_FLOP_PER_EVAL / secs / 1e12 / PEAK_F16_MFMA_TFLOPS,
+                                               "flop_per_leaf_eval_executed": F16X2_FLOP_PER_EVAL, "kernel_ms_avg": rt["kernel_ms"]}}
+            first += args.concurrent + n_games
+        eng.set_network_arithmetic("f32")
+        eng.load_weights(blob)
+        out16 = res.get("random_init", {})
+        out16["dtype"] = "f16x2 (operands: pairs of f16, 22-23 significand bits; accumulation f32)"
+        out16["parity"] = "searches and games bit-identical to the oracle run in ACC_F16X2 (tests/test_gpu_f16x2.py); network within 1e-5 / 3 of slimnn order"
+        if "trained_checkpoint" in res:
+            out16["trained_checkpoint"] = res["trained_checkpoint"]
+        return out16
+
     def conv_leg(eng, n_games, first):
         """the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same engine, same
         MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)"""
@@ -379,6 +420,7 @@ def main():
         if trained_blob is not None:
             out["with_trained_weights"] = trained_leg(eng, gh, 0)
         out["with_conv_policy"] = conv_leg(eng, gh, 4 * gh)
+        out["with_f16x2_network"] = f16x2_leg(eng, gh, 8 * gh)
         eng.close()
         if rank == 0:
             print(json.dumps(out), flush=True)
@@ -523,6 +565,9 @@ def main():
             out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
         next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
         extras = world == 1 and not args.no_extras
+        if extras and fits("with_f16x2_network", 5.5 * t_q + 12):
+            out["with_f16x2_network"] = f16x2_leg(eng, gh, next_first)
+            next_first += 2 * (args.concurrent + gh)
         if extras and trained_blob is not None and fits("with_trained_weights", 3.6 * t_q + 8):
             out["with_trained_weights"] = trained_leg(eng, gh, next_first)
             out["with_trained_weights"]["random_init_for_comparison"] = {"select_levels_per_explore": c["select_levels"] / max(1, c["explores"]),

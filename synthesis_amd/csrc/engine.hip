@@ -487,7 +487,9 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         // configuration — run 12 waves of 168 registers (17 spilled) on at most 768 trees per CU rather than 16 x 128 (55 spilled):
         // measured 90.5k against 84.8k games/s with the cache, 61.2k against 55.8k with the trained checkpoint and the cache,
         // 51.2k against 47.7k for the reference configuration; without the cache the two shapes are equal (70.6k / 71.2k).
-        if (!conv && nw == 16 && (P.cache != nullptr || cfg_family(P.mcts) == 2) && (fast || cfg_family(P.mcts) == 2) &&
+        // The f16x2 arithmetic makes every regime tree-bound (its network tile is a quarter of the f32 one): 102k games/s at 16 x 1,024
+        // against 111k at 12 x 768 (random-init), 65.0k against 72.4k (trained checkpoint).
+        if (!conv && nw == 16 && (P.cache != nullptr || cfg_family(P.mcts) == 2 || f16x2) && (fast || cfg_family(P.mcts) == 2) &&
             debug_env("SYN_LANES") == nullptr) {
             nw = 12;
             if (want_slots > h->num_cus * 768) want_slots = h->num_cus * 768;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer tool: throughput of the lane-per-tree / producer-consumer kernels. Args: conc:nw[:games[:policy_cache_log2]] ...
+"""Developer tool (a first argument "f16x2" selects the f16x2 network arithmetic): throughput of the lane-per-tree / producer-consumer kernels. Args: conc:nw[:games[:policy_cache_log2]] ...
 (nw = waves per workgroup of the lane kernel, 0 = the engine's own choice, negative = producer/consumer kernel with -nw
 virtual waves per tree wave, 208 / 212 = the two-trees-per-lane kernel with 8 / 12 waves). A first argument "reference" runs the
 reference's own self-play configuration (trained checkpoint + Fpu::Func(Normal(1.0, 0.1)); give a policy_cache_log2 too). A first argument "conv" runs Connect4ConvNet (convnet.cuh) instead of Connect4Net; "eval" appended
@@ -14,6 +14,8 @@ sys.path.insert(0, ROOT)
 import synthesis_amd as sa
 from bench import make_conv_weights, make_weights
 argv = sys.argv[1:]
+f16x2 = bool(argv) and argv[0] == "f16x2"      # Connect4Net in the f16x2 arithmetic (syn_set_network_arithmetic)
+if f16x2: argv = argv[1:]
 conv = bool(argv) and argv[0] == "conv"
 if conv: argv = argv[1:]
 reference = bool(argv) and argv[0] == "reference"
@@ -39,6 +41,7 @@ for c in combos:
     elif nw < 0: os.environ["SYN_PC"] = str(-nw)
     eng = sa.Engine(concurrent_games=conc, max_explores=800, policy_cache_log2=clog)
     (eng.load_weights_conv if conv else eng.load_weights)(blob)
+    if f16x2: eng.set_network_arithmetic("f16x2")
     eng.selfplay(cfg, 0, 256, outputs=False)
     t0 = time.perf_counter()
     r = eng.selfplay(cfg, 0, n, first_game=conc, outputs=False)
@@ -50,6 +53,7 @@ for c in combos:
 if do_eval:
     eng = sa.Engine(concurrent_games=256, max_explores=16)
     (eng.load_weights_conv if conv else eng.load_weights)(blob)
+    if f16x2: eng.set_network_arithmetic("f16x2")
     rng = np.random.default_rng(0)
     n = 1 << 22
     my = rng.integers(0, 1 << 62, n, dtype=np.uint64); op = rng.integers(0, 1 << 62, n, dtype=np.uint64) & ~my
