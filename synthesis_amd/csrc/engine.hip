@@ -31,7 +31,7 @@
 #include "train_conv.cuh"
 #include "train_conv_mfma.cuh"
 #include "lane_instances.h"
-#include "mail_kernel.cuh"
+#include "free_kernel.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <cmath>
@@ -76,15 +76,15 @@ SYN_LANES_REF_LIST(SYN_X)
 SYN_LANES_F16_LIST(SYN_X)
 SYN_LANES_F16_GEN_LIST(SYN_X)
 #undef SYN_X
-// ... and the one-tree-per-wave mailbox kernels (mail_kernel.cuh) in engine_mail.hip
-#define SYN_MAIL(MODE, COUNT)                                                                      \
-    extern template __global__ void selfplay_kernel_mail<MODE, COUNT, true, false>(EngineParams);  \
-    extern template __global__ void selfplay_kernel_mail<MODE, COUNT, false, false>(EngineParams);
-SYN_MAIL(MODE_SEARCH, false)
-SYN_MAIL(MODE_SELFPLAY, false)
-SYN_MAIL(MODE_SELFPLAY, true)
-#undef SYN_MAIL
-extern template __global__ void selfplay_kernel_mail<MODE_SELFPLAY, false, true, true>(EngineParams);
+// ... and the free-running four-trees-per-wave kernels (free_kernel.cuh) in engine_free.hip
+#define SYN_FREE(MODE, COUNT)                                                                      \
+    extern template __global__ void selfplay_kernel_free<MODE, COUNT, true, false>(EngineParams);  \
+    extern template __global__ void selfplay_kernel_free<MODE, COUNT, false, false>(EngineParams);
+SYN_FREE(MODE_SEARCH, false)
+SYN_FREE(MODE_SELFPLAY, false)
+SYN_FREE(MODE_SELFPLAY, true)
+#undef SYN_FREE
+extern template __global__ void selfplay_kernel_free<MODE_SELFPLAY, false, true, true>(EngineParams);
 }  // namespace syn
 
 static_assert(sizeof(DevSearchResult) == sizeof(syn_search_result), "search result layout must match the C ABI");
@@ -407,30 +407,27 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             return hipGetLastError();
         }
     }
-    // At most 16 trees per CU in the f16x2 arithmetic: one tree per wave, leaves through an LDS mailbox (mail_kernel.cuh). The draws of
-    // Fpu::Func / PolicyNoise::Dirichlet live in the lane-per-tree kernels only. SYN_DEBUG=1 SYN_MAIL=0 switches it off (the lane
-    // kernel at 4 waves then plays these games), SYN_MAIL_THRESH=<n> makes a waiting wave hold its tile until n leaves are posted.
+    // At most 16 trees per CU in the f16x2 arithmetic: four free-running waves of four trees, each evaluating its own leaves in a tile
+    // of its own (free_kernel.cuh). The draws of Fpu::Func / PolicyNoise::Dirichlet live in the lane-per-tree kernels only.
+    // SYN_DEBUG=1 SYN_FREE=0 switches it off (the lane kernel at 4 waves then plays these games).
     if (h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F16X2 && P.wimg == reinterpret_cast<const float*>(h->d_wimg16) &&
         want_slots <= 16 * h->num_cus && P.mcts.fpu != 2 && P.mcts.noise != 2 && debug_env("SYN_LANES") == nullptr &&
-        !(debug_env("SYN_MAIL") && std::atoi(debug_env("SYN_MAIL")) == 0)) {
+        !(debug_env("SYN_FREE") && std::atoi(debug_env("SYN_FREE")) == 0)) {
         const int mgrid = (want_slots + 15) / 16;
-        EngineParams PM = P;
-        PM.lane_thresh = 1;
-        if (const char* ev = debug_env("SYN_MAIL_THRESH")) PM.lane_thresh = std::atoi(ev);
-#define SYN_LAUNCH_M(FAST, PROFV)                                                                                  \
+#define SYN_LAUNCH_FR(FAST, PROFV)                                                                                 \
     {                                                                                                              \
-        auto k = selfplay_kernel_mail<MODE, COUNT, FAST, PROFV>;                                                   \
+        auto k = selfplay_kernel_free<MODE, COUNT, FAST, PROFV>;                                                   \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)MailLds::BYTES);       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)FreeLds::BYTES);       \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL(k, dim3(mgrid), dim3(1024), MailLds::BYTES, h->stream, PM);                             \
+        hipLaunchKernelGGL(k, dim3(mgrid), dim3(256), FreeLds::BYTES, h->stream, P);                               \
     }
-        constexpr bool PROFM = PROF && MODE == MODE_SELFPLAY && !COUNT;
-        if (fast) SYN_LAUNCH_M(true, PROFM) else SYN_LAUNCH_M(false, false)
-#undef SYN_LAUNCH_M
-        h->last_shape = 7; h->last_grid = mgrid; h->last_threads = 1024;
+        constexpr bool PROFFR = PROF && MODE == MODE_SELFPLAY && !COUNT;
+        if (fast) SYN_LAUNCH_FR(true, PROFFR) else SYN_LAUNCH_FR(false, false)
+#undef SYN_LAUNCH_FR
+        h->last_shape = 7; h->last_grid = mgrid; h->last_threads = 256;
         if (out_grid) *out_grid = mgrid;
-        if (out_nt) *out_nt = 1024;
+        if (out_nt) *out_nt = 256;
         return hipGetLastError();
     }
     // Two trees per lane (lane2_kernel.cuh): 8 waves per workgroup, 1,024 trees per CU. SYN_DEBUG=1 SYN_LANES2=8 forces it,
@@ -1649,21 +1646,20 @@ int syn_selfplay_run(syn_engine* h, const syn_rollout_config* cfg, uint64_t base
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     if (prof) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (h->last_shape == 7) {  // mailbox kernel: per wave [A, wait, serve, C, iterations, tiles, leaves] (mail_kernel.cuh)
-            const int nwv = pgrid * 16;
-            std::vector<unsigned long long> hp((size_t)nwv * MP_FIELDS);
+        if (h->last_shape == 7) {  // free-running rows: per wave [A, B, C, iterations, tiles, leaves] (free_kernel.cuh)
+            const int nwv = pgrid * 4;
+            std::vector<unsigned long long> hp((size_t)nwv * FP_FIELDS);
             HIP_TRY(h, hipMemcpy(hp.data(), d_prof, hp.size() * 8, hipMemcpyDeviceToHost));
             HIP_TRY(h, hipFree(d_prof));
             d_prof = nullptr;
-            double s7[MP_FIELDS] = {0};
+            double s7[FP_FIELDS] = {0};
             for (int w = 0; w < nwv; w++)
-                for (int j = 0; j < MP_FIELDS; j++) s7[j] += (double)hp[(size_t)w * MP_FIELDS + j];
-            const double it7 = s7[MP_ITERS] + 1e-9;
-            fprintf(stderr, "[syn profile mail] grid=%d waves=%d explores/wave=%.0f | cycles per explore and tree: A=%.0f wait=%.0f serve=%.0f C=%.0f "
-                            "total=%.0f | tiles per explore=%.3f, leaves per tile=%.2f, cycles per tile=%.0f\n",
-                    pgrid, nwv, it7 / nwv, s7[MP_A] / it7, s7[MP_WAIT] / it7, s7[MP_SERVE] / it7, s7[MP_C] / it7,
-                    (s7[MP_A] + s7[MP_WAIT] + s7[MP_SERVE] + s7[MP_C]) / it7, s7[MP_TILES] / it7, s7[MP_LEAVES] / (s7[MP_TILES] + 1e-9),
-                    s7[MP_SERVE] / (s7[MP_TILES] + 1e-9));
+                for (int j = 0; j < FP_FIELDS; j++) s7[j] += (double)hp[(size_t)w * FP_FIELDS + j];
+            const double it7 = s7[FP_ITERS] + 1e-9;
+            fprintf(stderr, "[syn profile free] grid=%d waves=%d rounds/wave=%.0f | cycles per round (one explore on each of a wave's four trees): "
+                            "A=%.0f B=%.0f C=%.0f total=%.0f | tiles per round=%.3f, leaves per tile=%.2f, cycles per tile=%.0f\n",
+                    pgrid, nwv, it7 / nwv, s7[FP_A] / it7, s7[FP_B] / it7, s7[FP_C] / it7, (s7[FP_A] + s7[FP_B] + s7[FP_C]) / it7,
+                    s7[FP_TILES] / it7, s7[FP_LEAVES] / (s7[FP_TILES] + 1e-9), s7[FP_B] / (s7[FP_TILES] + 1e-9));
         } else
         if (h->last_shape == 5) {  // producer/consumer kernel: per wave [role, ...] (pc_kernel.cuh)
             const int nwv = pgrid * 16;

@@ -113,7 +113,7 @@ def test_f16x2_search_and_selfplay_match_the_oracle(engine, oracle, blob):
     got = engine.mcts_search(sa.parity_mcts_config(), my[:24], op[:24], 800)
     ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my[:24], op[:24], 800, nn_mode=oracle.ACC_F16X2)
     assert_search_equal(got, ref, "explores=800")
-    assert engine.last_launch_shape()[0] == 7   # <= 16 trees per CU: one tree per wave, LDS mailbox (mail_kernel.cuh)
+    assert engine.last_launch_shape()[0] == 7   # <= 16 trees per CU: free-running waves (free_kernel.cuh)
     # the root's priors are the stand-alone kernel's softmax inputs: fused == stand-alone, bit for bit
     l, _ = engine.policy_eval(my[:24], op[:24])
     for i in range(24):
@@ -131,9 +131,9 @@ def test_f16x2_search_and_selfplay_match_the_oracle(engine, oracle, blob):
     assert engine.last_launch_shape()[0] == 7
 
 
-def test_f16x2_mailbox_kernel_at_4096_games(oracle, trained, monkeypatch):
-    """BASELINE configs[1]'s size: 4,096 concurrent games = 16 trees per CU, the mailbox kernel on every CU at once (256 workgroups of 16
-    waves), trained checkpoint, a runtime-switched configuration and a quorum threshold as well: the oracle's games."""
+def test_f16x2_free_running_kernel_at_4096_games(oracle, trained):
+    """BASELINE configs[1]'s size: 4,096 concurrent games = 16 trees per CU — four free-running waves of four trees on every CU
+    (free_kernel.cuh), trained checkpoint (deep trees, uneven descents), a runtime-switched configuration as well: the oracle's games."""
     import synthesis_amd as sa
     from tests.oracle_lib import parity_mcts_config, parity_rollout_config
 
@@ -141,19 +141,17 @@ def test_f16x2_mailbox_kernel_at_4096_games(oracle, trained, monkeypatch):
     try:
         eng.load_weights(trained)
         eng.set_network_arithmetic("f16x2")
-        got = eng.selfplay(sa.parity_rollout_config(100), base_seed=17, n_games=6000)
-        assert eng.last_launch_shape() == (7, 256, 1024)
-        ref = oracle.c4_selfplay(parity_rollout_config(100), trained, 17, 6000, threads=8, nn_mode=oracle.ACC_F16X2)
-        assert_selfplay_equal(got, ref, "4096 concurrent")
-        my, op = random_positions(oracle, 300, seed=5)
+        got = eng.selfplay(sa.parity_rollout_config(60), base_seed=17, n_games=5000)
+        assert eng.last_launch_shape() == (7, 256, 256)
+        ref = oracle.c4_selfplay(parity_rollout_config(60), trained, 17, 700, threads=8, nn_mode=oracle.ACC_F16X2)
+        assert_selfplay_equal({k: got[k][:700] for k in SELFPLAY_KEYS}, ref, "4096 concurrent, games 0..699")
+        ref = oracle.c4_selfplay(parity_rollout_config(60), trained, 17, 200, first_game=4700, threads=8, nn_mode=oracle.ACC_F16X2)
+        assert_selfplay_equal({k: got[k][4700:4900] for k in SELFPLAY_KEYS}, ref, "4096 concurrent, refilled slots")
+        my, op = random_positions(oracle, 120, seed=5)
         got = eng.mcts_search(sa.MCTSConfig(exploration=sa.Exploration.Uct, c=1.5, fpu=sa.Fpu.ParentQ, select_solved_nodes=False), my, op, 150)
         ref = oracle.c4_mcts_search(parity_mcts_config(exploration=0, c=1.5, fpu=1, select_solved_nodes=0), trained, my, op, 150, nn_mode=oracle.ACC_F16X2)
         assert_search_equal(got, ref, "general configuration")
         assert eng.last_launch_shape()[0] == 7
-        monkeypatch.setenv("SYN_DEBUG", "1")
-        monkeypatch.setenv("SYN_MAIL_THRESH", "6")
-        got = eng.selfplay(sa.parity_rollout_config(100), base_seed=17, n_games=600)
-        assert_selfplay_equal(got, {k: ref[k][:600] for k in SELFPLAY_KEYS}, "quorum of 6")
     finally:
         eng.close()
 
