@@ -114,9 +114,12 @@ SYN_DEV void f16x2_split_block(f32x4_ v, float c, uint32_t& h01, uint32_t& h23, 
 
 // ---- the tile, software-pipelined in 32 groups --------------------------------------------------------------------------------------
 // A group = (layer, a part of at most two output blocks, one 32-input block): 3 products x nb MFMAs on nb independent accumulators.
-// While a group's MFMAs run, the weight fragments of the next group are on their way from LDS (double buffer) and the activations of
-// the part that finished in the PREVIOUS group are rescaled / split for the next layer (their consumers are at least two groups
-// away: the first 32-input block of a layer reads output blocks 0-1 = part 0 of the layer before). `sched_barrier`s pin that order.
+// While a group's MFMAs run, the weight fragments of the next group are on their way from LDS (double buffer), and the activations
+// of output blocks that finished EARLIER are rescaled / split for the next layer, one block (16 vector instructions) per group, in
+// five stages placed behind successive MFMAs: every stage's inputs are a whole MFMA old, and the two or three vector instructions per
+// MFMA fit the half of its 16 cycles in which the instruction leaves the vector issue port free (MI355X guide: an MFMA of this shape
+// holds the port for 8 of its 16 cycles). `sched_barrier`s pin that order. The schedule (which block is split in which group) is
+// fixed by f16_split_of_group(): a block is split after its part has finished and before the first group that reads it.
 struct F16Group { int layer, nob, ob0, nb, kb, nkb; };
 constexpr F16Group f16_group(int gi) {
     if (gi < 8) return {0, 8, (gi / 2) * 2, 2, gi % 2, 2};                      // L1: 4 parts x 2 input blocks
@@ -127,103 +130,153 @@ constexpr F16Group f16_group(int gi) {
     return {4, 1, 0, 1, gi - 30, 2};                                            // L5: 1 block x 2
 }
 constexpr int F16_GROUPS = 32;
+// output blocks split in group gi: count n and (layer, first block); blocks are first, first + 1, ...
+struct F16Split { int n, layer, blk; };
+constexpr F16Split f16_split_of_group(int gi) {
+    if (gi >= 2 && gi <= 9) return {1, 0, gi - 2};       // L1 blocks 0-7 (parts finish in groups 1, 3, 5, 7; L2 reads from group 8 on)
+    if (gi == 12 || gi == 13) return {1, 1, gi - 12};    // L2 blocks 0-1 (finish in 11)
+    if (gi == 16 || gi == 17) return {1, 1, gi - 14};    // L2 blocks 2-3 (finish in 15)
+    if (gi == 20 || gi == 21) return {1, 1, gi - 16};    // L2 blocks 4-5 (finish in 19; L3's third input block is read in 22)
+    if (gi == 23 || gi == 24) return {1, 2, gi - 23};    // L3 blocks 0-1 (finish in 22)
+    if (gi == 26) return {2, 2, 2};                      // L3 blocks 2-3 (finish in 25; L4's second input block is read in 27)
+    if (gi == 28 || gi == 29) return {1, 3, gi - 28};    // L4 blocks 0-1 (finish in 27)
+    if (gi == 30) return {1, 3, 2};                      // L4 block 2 (finishes in 29; L5's second input block is read in 31)
+    return {0, 0, 0};
+}
 
+template <int PF>
 struct F16Regs {
-    u32x4 ah[2][2], al[2][2];      // weight fragments (hi, lo): double buffer x up to 2 blocks
-    f32x4_ bb[2];                  // biases of the part that starts with the next group
+    u32x4 ah[PF + 1][2], al[PF + 1][2];   // weight fragments (hi, lo) of up to 2 blocks: the group in flight + PF groups ahead
+    f32x4_ bb[PF + 1][2];          // biases of a part's first group, fetched with its fragments
     f32x4_ acc[2];                 // accumulators of the current part
-    f32x4_ pend[2];                // accumulators of the part that finished in the previous group
+    f32x4_ pend[4];                // finished accumulators waiting for their split: block b of a layer sits in pend[b & 3]
+    f32x4_ sp[2];                  // the split in flight (up to two blocks): scaled / clamped values, then residuals
+    uint32_t sh[2][2];             // ... and their hi halves
+    float cs[4];                   // the four rescale factors (wave-uniform: scalar registers)
     u32x4 x1h[2], x1l[2], x2h[4], x2l[4], x3h[3], x3l[3], x4h[2], x4l[2], x5h[2], x5l[2];   // B operands per layer (hi, lo) per input block
 };
 
-template <int GI>
-SYN_DEV void f16_prefetch(const uint32_t* __restrict__ img, int lane, F16Regs& R) {
+template <int GI, int PF>
+SYN_DEV void f16_prefetch(const uint32_t* __restrict__ img, int lane, F16Regs<PF>& R) {
     if constexpr (GI < F16_GROUPS) {
         constexpr F16Group G = f16_group(GI);
         const u32x4* whi = reinterpret_cast<const u32x4*>(img + F16Geom::H_OFF[G.layer] / 2) + lane;
         const u32x4* wlo = reinterpret_cast<const u32x4*>(img + F16Geom::PART_WORDS + F16Geom::H_OFF[G.layer] / 2) + lane;
 #pragma unroll
         for (int ob = 0; ob < G.nb; ob++) {
-            R.ah[GI & 1][ob] = whi[(G.kb * G.nob + G.ob0 + ob) * 64];
-            R.al[GI & 1][ob] = wlo[(G.kb * G.nob + G.ob0 + ob) * 64];
+            R.ah[GI % (PF + 1)][ob] = whi[(G.kb * G.nob + G.ob0 + ob) * 64];
+            R.al[GI % (PF + 1)][ob] = wlo[(G.kb * G.nob + G.ob0 + ob) * 64];
         }
         if constexpr (G.kb == 0) {
             const float* bimg = reinterpret_cast<const float*>(img + F16Geom::BIAS_WORD0);
             const int q = lane >> 4;
 #pragma unroll
             for (int ob = 0; ob < G.nb; ob++)
-                R.bb[ob] = *reinterpret_cast<const f32x4_*>(bimg + F16Geom::B_OFF[G.layer] + ((G.ob0 + ob) * 4 + q) * 4);
+                R.bb[GI % (PF + 1)][ob] = *reinterpret_cast<const f32x4_*>(bimg + F16Geom::B_OFF[G.layer] + ((G.ob0 + ob) * 4 + q) * 4);
         }
     }
 }
 
-// the part that finished in group GI - 1 (if any) becomes B operands of the next layer
-template <int GI>
-SYN_DEV void f16_deferred_split(const uint32_t* __restrict__ img, F16Regs& R) {
-    if constexpr (GI >= 1 && GI <= F16_GROUPS) {
-        constexpr F16Group P = f16_group(GI - 1);
-        if constexpr (P.kb == P.nkb - 1 && P.layer < 4) {
-            const float c = reinterpret_cast<const float*>(img + F16Geom::SCALE_WORD0)[P.layer];
+// stage ST (0..4) of the splits scheduled in group GI (f16x2_split_block cut into its five dependent steps)
+template <int GI, int ST, int PF>
+SYN_DEV void f16_split_stage(F16Regs<PF>& R) {
+    constexpr F16Split S = f16_split_of_group(GI);
+    if constexpr (S.n > 0) {
 #pragma unroll
-            for (int ob = 0; ob < P.nb; ob++) {
-                uint32_t h01, h23, l01, l23;
-                f16x2_split_block(R.pend[ob], c, h01, h23, l01, l23);
-                constexpr int dummy = 0; (void)dummy;
-                const int blk = P.ob0 + ob, kb = blk >> 1, at = 2 * (blk & 1);
-                u32x4* xh = P.layer == 0 ? R.x2h : P.layer == 1 ? R.x3h : P.layer == 2 ? R.x4h : R.x5h;
-                u32x4* xl = P.layer == 0 ? R.x2l : P.layer == 1 ? R.x3l : P.layer == 2 ? R.x4l : R.x5l;
-                xh[kb][at] = h01; xh[kb][at + 1] = h23;
+        for (int i = 0; i < S.n; i++) {
+            const int blk = S.blk + i;
+            if constexpr (ST == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) R.sp[i][r] = R.pend[blk & 3][r] * R.cs[S.layer];
+            } else if constexpr (ST == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) R.sp[i][r] = __builtin_amdgcn_fmed3f(R.sp[i][r], 0.0f, F16Geom::ACT_MAX);
+            } else if constexpr (ST == 2) {
+                R.sh[i][0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{R.sp[i][0], R.sp[i][1]}, f16x2));
+                R.sh[i][1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{R.sp[i][2], R.sp[i][3]}, f16x2));
+            } else if constexpr (ST == 3) {
+                R.sp[i][0] = f16x2_residual<0>(R.sh[i][0], R.sp[i][0]);
+                R.sp[i][1] = f16x2_residual<1>(R.sh[i][0], R.sp[i][1]);
+                R.sp[i][2] = f16x2_residual<0>(R.sh[i][1], R.sp[i][2]);
+                R.sp[i][3] = f16x2_residual<1>(R.sh[i][1], R.sp[i][3]);
+            } else {
+                const uint32_t l01 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{R.sp[i][0], R.sp[i][1]}, f16x2));
+                const uint32_t l23 = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_{R.sp[i][2], R.sp[i][3]}, f16x2));
+                const int kb = blk >> 1, at = 2 * (blk & 1);
+                u32x4* xh = S.layer == 0 ? R.x2h : S.layer == 1 ? R.x3h : S.layer == 2 ? R.x4h : R.x5h;
+                u32x4* xl = S.layer == 0 ? R.x2l : S.layer == 1 ? R.x3l : S.layer == 2 ? R.x4l : R.x5l;
+                xh[kb][at] = R.sh[i][0]; xh[kb][at + 1] = R.sh[i][1];
                 xl[kb][at] = l01; xl[kb][at + 1] = l23;
             }
         }
     }
 }
 
-template <int GI, int NPROD>
-SYN_DEV void f16_group_run(const uint32_t* __restrict__ img, int lane, F16Regs& R) {
+template <int GI, int NPROD, int PF>
+SYN_DEV void f16_group_run(const uint32_t* __restrict__ img, int lane, F16Regs<PF>& R) {
     constexpr F16Group G = f16_group(GI);
-    f16_prefetch<GI + 1>(img, lane, R);
+    f16_prefetch<GI + PF, PF>(img, lane, R);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G.kb == 0) {
 #pragma unroll
-        for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = R.bb[ob];
+        for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = R.bb[GI % (PF + 1)][ob];
     }
     const u32x4* xh = G.layer == 0 ? R.x1h : G.layer == 1 ? R.x2h : G.layer == 2 ? R.x3h : G.layer == 3 ? R.x4h : R.x5h;
     const u32x4* xl = G.layer == 0 ? R.x1l : G.layer == 1 ? R.x2l : G.layer == 2 ? R.x3l : G.layer == 3 ? R.x4l : R.x5l;
     const f16x8 bh = as_f16x8(xh[G.kb]), bl = as_f16x8(xl[G.kb]);
+    // MFMA m of the group: product m / nb (hi.hi, hi.lo, lo.hi[, lo.lo]) on accumulator m % nb; the five split stages follow MFMAs
+    // 0 .. 4 of a six-MFMA group (two stages per MFMA in the three-MFMA groups of the last layers)
+    constexpr int NM = NPROD * G.nb;
+    constexpr int PER = NM >= 5 ? 1 : 2;
 #pragma unroll
-    for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(R.ah[GI & 1][ob]), bh, R.acc[ob], 0, 0, 0);
-#pragma unroll
-    for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(R.ah[GI & 1][ob]), bl, R.acc[ob], 0, 0, 0);
-#pragma unroll
-    for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(R.al[GI & 1][ob]), bh, R.acc[ob], 0, 0, 0);
-    if constexpr (NPROD == 4) {
-#pragma unroll
-        for (int ob = 0; ob < G.nb; ob++) R.acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16x8(R.al[GI & 1][ob]), bl, R.acc[ob], 0, 0, 0);
+    for (int m = 0; m < NM; m++) {
+        const int prod = m / G.nb, ob = m % G.nb;
+        const f16x8 a = as_f16x8(prod == 0 || prod == 1 ? R.ah[GI % (PF + 1)][ob] : R.al[GI % (PF + 1)][ob]);
+        const f16x8 x = (prod == 0 || prod == 2) ? bh : bl;
+        R.acc[ob] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, x, R.acc[ob], 0, 0, 0);
+        if (PER == 1) {
+            if (m == 0) f16_split_stage<GI, 0, PF>(R);
+            if (m == 1) f16_split_stage<GI, 1, PF>(R);
+            if (m == 2) f16_split_stage<GI, 2, PF>(R);
+            if (m == 3) f16_split_stage<GI, 3, PF>(R);
+            if (m == 4) f16_split_stage<GI, 4, PF>(R);
+        } else {
+            if (m == 0) { f16_split_stage<GI, 0, PF>(R); f16_split_stage<GI, 1, PF>(R); }
+            if (m == 1) { f16_split_stage<GI, 2, PF>(R); f16_split_stage<GI, 3, PF>(R); }
+            if (m == 2) f16_split_stage<GI, 4, PF>(R);
+        }
+        if (m + 1 < NM) __builtin_amdgcn_sched_barrier(0);
     }
-    f16_deferred_split<GI>(img, R);
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (G.kb == G.nkb - 1 && G.layer < 4) {
 #pragma unroll
-        for (int ob = 0; ob < G.nb; ob++) R.pend[ob] = R.acc[ob];
+        for (int ob = 0; ob < G.nb; ob++) R.pend[(G.ob0 + ob) & 3] = R.acc[ob];
     }
-    if constexpr (GI + 1 < F16_GROUPS) f16_group_run<GI + 1, NPROD>(img, lane, R);
+    if constexpr (GI + 1 < F16_GROUPS) f16_group_run<GI + 1, NPROD, PF>(img, lane, R);
 }
 
 // Evaluates the network for the 16 positions of this wave's tile. Lane l = (j = l&15, q = l>>4) passes the feature boards of
 // position j (mlp.cuh feature_boards). Returns the last layer's D registers: lane (j,q) register r = raw output 4q + r of
 // position j DIVIDED by the image's out scale (multiply by the f32 at word SCALE_WORD0 + 4: an exact power of two).
-template <int NPROD>
+// PF = how many groups ahead the weight fragments are requested: 1 under the 128-register budget of the 16-wave shapes (other waves
+// cover the LDS latency), 2 for a wave that is alone on its SIMD (free_kernel.cuh: +16 registers, -10 % cycles per tile).
+template <int NPROD, int PF = 1>
 SYN_DEV f32x4_ f16x2_tile16(const uint32_t* __restrict__ img, int lane, uint64_t hi, uint64_t lo) {
-    F16Regs R;
-    f16_prefetch<0>(img, lane, R);
+    F16Regs<PF> R;
+    {   // read once, ahead of everything: a later LDS read of them would wait for the weight fragments in flight behind it
+        const f32x4_ c4 = *reinterpret_cast<const f32x4_*>(img + F16Geom::SCALE_WORD0);
+#pragma unroll
+        for (int l = 0; l < 4; l++) R.cs[l] = bits_f32((uint32_t)__builtin_amdgcn_readfirstlane((int)f32_bits(c4[l])));
+    }
+    f16_prefetch<0, PF>(img, lane, R);
+    if constexpr (PF >= 2) f16_prefetch<1, PF>(img, lane, R);
     uint32_t H, NL;
     f16_feature_fields(hi, lo, lane >> 4, H, NL);
     f16_feature_block<0>(H, NL, R.x1h[0], R.x1l[0]);
     f16_feature_block<1>(H, NL, R.x1h[1], R.x1l[1]);
     // the unused upper half of an odd layer's last input block (L5 reads output blocks 0-2 of L4): zeros against zero weights
     R.x5h[1][2] = 0; R.x5h[1][3] = 0; R.x5l[1][2] = 0; R.x5l[1][3] = 0;
-    f16_group_run<0, NPROD>(img, lane, R);
+    f16_group_run<0, NPROD, PF>(img, lane, R);
     return R.acc[0];
 }
 

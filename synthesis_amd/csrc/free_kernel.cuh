@@ -93,10 +93,11 @@ __global__ __launch_bounds__(256, 1) void selfplay_kernel_free(EngineParams P) {
 #pragma unroll
             for (int r = 0; r < 4; r++) o[r] *= os;
             const int j = lane & 15, q = lane >> 4;
-            if (q == 2) {
+            {   // (whole wave: the packed form tests its range with a ballot; only the q == 2 lanes keep the result)
                 float v0 = o[1], v1 = o[2], v2 = o[3];
-                value_softmax(v0, v1, v2);
-                o[1] = v0; o[2] = v1; o[3] = v2;
+                if (q != 2) { v0 = 0.0f; v1 = 0.0f; v2 = 0.0f; }
+                value_softmax_packed(v0, v1, v2);
+                if (q == 2) { o[1] = v0; o[2] = v1; o[3] = v2; }
             }
             if (q < 3 && j < 4) *reinterpret_cast<f32x4*>(outbuf + (wave * 4 + j) * 16 + q * 4) = o;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its LDS operations complete in order)

@@ -347,6 +347,29 @@ SYN_DEV void value_softmax(float& v0, float& v1, float& v2) {
     v2 = e2 / total;
 }
 
+// value_softmax with its three exponentials and divisions in the packed forms of device_common.cuh (det_expf2_in_range,
+// div2_by_shared: the same operations per component, the same bits — lane_kernel.cuh's lane_softmaxes does its value part this way)
+// whenever no lane of the wave is outside their exact range; otherwise the plain form. Must be called by whole waves.
+SYN_DEV void value_softmax_packed(float& v0, float& v1, float& v2) {
+    float m = v0;
+    m = v1 > m ? v1 : m;
+    m = v2 > m ? v2 : m;
+    const float d0 = v0 - m, d1 = v1 - m, d2 = v2 - m;
+    const bool in_range = d0 >= -41.0f && d1 >= -41.0f && d2 >= -41.0f;   // (NaN fails)
+    if (__ballot(!in_range) == 0ull) {
+        const f32x2 ea = det_expf2_in_range(f32x2{d0, d1}), eb = det_expf2_in_range(f32x2{d2, d2});
+        float total = 0.0f;
+        total += ea[0];
+        total += ea[1];
+        total += eb[0];
+        const float r = rcp_refined_safe_range(total);   // 1 <= total <= 3, every e >= exp(-41) > 2^-60
+        const f32x2 qa = div2_by_shared(ea, total, r), qb = div2_by_shared(eb, total, r);
+        v0 = qa[0]; v1 = qa[1]; v2 = qb[0];
+    } else {
+        value_softmax(v0, v1, v2);
+    }
+}
+
 // Copies the prebuilt weight image (global, fragment order) into LDS. All threads of the block participate.
 SYN_DEV void stage_weight_image(float* __restrict__ lds_img, const float* __restrict__ g_img, int tid, int nthreads) {
     const f32x4* src = reinterpret_cast<const f32x4*>(g_img);

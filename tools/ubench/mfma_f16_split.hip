@@ -373,6 +373,32 @@ __global__ __launch_bounds__(1024) void f16_tiles_kernel(const uint32_t* __restr
     unsigned long long t1 = __builtin_readcyclecounter();
     if (lane == 0) { cyc[(blockIdx.x * nw + wave) * 2] = t1 - t0; cyc[(blockIdx.x * nw + wave) * 2 + 1] = done; }
 }
+// the tile with its weight fragments requested two groups ahead (f16x2_tile16<3, 2>: for a wave alone on its SIMD) under the register budget of a 256-thread workgroup
+__global__ __launch_bounds__(256, 1) void f16_tiles_wide_kernel(const uint32_t* __restrict__ g_img, const uint64_t* __restrict__ my, const uint64_t* __restrict__ op,
+                                                                int ntiles, float* __restrict__ out, unsigned long long* __restrict__ cyc, float out_scale) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_img[];
+    for (int i = threadIdx.x; i < F16Geom::IMG_WORDS / 4; i += blockDim.x)
+        reinterpret_cast<uint4*>(lds_img)[i] = reinterpret_cast<const uint4*>(g_img)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    int done = 0;
+    for (int t = blockIdx.x * nw + wave; t < ntiles; t += gridDim.x * nw, done++) {
+        const size_t p = (size_t)t * 16 + (lane & 15);
+        uint64_t hi, lo;
+        feature_boards(my[p], op[p], hi, lo);
+        uint32_t img_off = 0;
+        asm volatile("" : "+v"(img_off));
+        f32x4 o = f16x2_tile16<3, 2>(lds_img + img_off, lane, hi, lo);
+        const int q = lane >> 4;
+        if (q < 3) {
+            f32x4 w; for (int r = 0; r < 4; r++) w[r] = o[r] * out_scale;
+            *reinterpret_cast<f32x4*>(out + p * 12 + 4 * q) = w;
+        }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane == 0) { cyc[(blockIdx.x * nw + wave) * 2] = t1 - t0; cyc[(blockIdx.x * nw + wave) * 2 + 1] = done; }
+}
 template <int VARIANT>   // 0 = mlp_tile16_pipe, 1 = mlp_tile16
 __global__ __launch_bounds__(1024) void f32_tiles_kernel(const float* __restrict__ g_img, const uint64_t* __restrict__ my, const uint64_t* __restrict__ op,
                                                          int ntiles, float* __restrict__ out, unsigned long long* __restrict__ cyc) {
@@ -501,7 +527,7 @@ int main(int argc, char** argv) {
     (void)!system(("mkdir -p " + outdir).c_str());
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
     printf("device: %s, %d CUs\n", prop.name, prop.multiProcessorCount);
-    run_probe(outdir);
+    if (!(argc > 3 && !strcmp(argv[3], "tilesonly"))) run_probe(outdir);
     if (argc > 3 && !strcmp(argv[3], "probeonly")) return 0;
 
     const size_t NP = 1 << 20;
@@ -513,6 +539,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d_my, my.data(), NP * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(d_op, op.data(), NP * 8, hipMemcpyHostToDevice));
     CK(hipFuncSetAttribute((const void*)f16_tiles_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, F16Geom::IMG_WORDS * 4));
     CK(hipFuncSetAttribute((const void*)f16_tiles_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, F16Geom::IMG_WORDS * 4));
+    CK(hipFuncSetAttribute((const void*)f16_tiles_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, F16Geom::IMG_WORDS * 4));
     CK(hipFuncSetAttribute((const void*)f32_tiles_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom::IMG_FLOATS * 4));
     CK(hipFuncSetAttribute((const void*)f32_tiles_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MlpGeom::IMG_FLOATS * 4));
     const int ntiles = (int)(NP / 16), CUS = prop.multiProcessorCount;
@@ -597,6 +624,11 @@ int main(int argc, char** argv) {
             };
             timed("f32 pipe tile (today)", [&] { hipLaunchKernelGGL(f32_tiles_kernel<0>, dim3(CUS), dim3(64 * nw), MlpGeom::IMG_FLOATS * 4, 0, d_img32, d_my, d_op, ntiles, d_out, d_cyc); });
             timed("f16x2, 3 products", [&] { hipLaunchKernelGGL(f16_tiles_kernel<3>, dim3(CUS), dim3(64 * nw), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale); });
+            if (nw <= 4) {
+                timed("f16x2, prefetch 2 groups", [&] { hipLaunchKernelGGL(f16_tiles_wide_kernel, dim3(CUS), dim3(64 * nw), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale); });
+                CK(hipMemcpy(tmp.data(), d_out, NP * 48, hipMemcpyDeviceToHost));
+                printf("        prefetch-2 tile bit-identical to the prefetch-1 tile: %s\n", memcmp(tmp.data(), out3.data(), NP * 48) ? "NO" : "yes");
+            }
             timed("f16x2, 4 products", [&] { hipLaunchKernelGGL(f16_tiles_kernel<4>, dim3(CUS), dim3(64 * nw), F16Geom::IMG_WORDS * 4, 0, d_img, d_my, d_op, ntiles, d_out, d_cyc, oscale); });
         }
     }
