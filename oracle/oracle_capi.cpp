@@ -129,6 +129,21 @@ void orc_c4conv_eval(const float* blob, const uint64_t* my_bb, const uint64_t* o
         }
     }
 }
+// one v_mfma_f32_16x16x32_f16 output per (a[32], b[32], c): the accumulation model of nn_f16x2.hpp (test replay of device vectors)
+void orc_mfma_f16_k32(const uint16_t* a, const uint16_t* b, const float* c, int n, float* out) {
+    for (int i = 0; i < n; i++) out[i] = mfma_f16_k32(c[i], a + (size_t)i * 32, b + (size_t)i * 32);
+}
+void orc_f16_round_trip(const float* x, int n, uint16_t* bits, float* back) {
+    for (int i = 0; i < n; i++) { bits[i] = f16_bits_rne(x[i]); back[i] = f16_value(bits[i]); }
+}
+// the f16x2 plan of a Connect4Net blob: exponents [s0..s4, t0..t4, cexp0..3, out_exp] and the five bounds; returns 1 if the blob has one
+int orc_f16x2_plan(const float* blob, int* exps15, double* bounds5) {
+    F16x2Net net(blob);
+    for (int l = 0; l < 5; l++) { exps15[l] = net.s[l]; exps15[5 + l] = net.t[l]; bounds5[l] = net.bound[l]; }
+    for (int l = 0; l < 4; l++) exps15[10 + l] = net.cexp[l];
+    exps15[14] = net.out_exp;
+    return net.ok ? 1 : 0;
+}
 void orc_c4net_forward_raw(const float* blob, const float* x63, int n, float* out12, int mode) {
     Connect4Net net;
     net.blob = blob;

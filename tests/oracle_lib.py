@@ -192,6 +192,26 @@ class Oracle:
         return logits, value
 
     # ---- Connect4ConvNet (oracle/nn.hpp)
+    def mfma_f16_k32(self, a_bits, b_bits, c):
+        """One v_mfma_f32_16x16x32_f16 output per row: a_bits, b_bits [n][32] uint16 (f16 bit patterns, the instruction's k order), c [n]."""
+        a = np.ascontiguousarray(a_bits, np.uint16); b = np.ascontiguousarray(b_bits, np.uint16); c = np.ascontiguousarray(c, np.float32)
+        out = np.zeros(c.size, np.float32)
+        self.lib.orc_mfma_f16_k32(_p(a), _p(b), _p(c), int(c.size), _p(out))
+        return out
+
+    def f16_round_trip(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        bits = np.zeros(x.size, np.uint16); back = np.zeros(x.size, np.float32)
+        self.lib.orc_f16_round_trip(_p(x), int(x.size), _p(bits), _p(back))
+        return bits, back
+
+    def f16x2_plan(self, blob):
+        blob = np.ascontiguousarray(blob, np.float32)
+        e = np.zeros(15, np.int32); bnd = np.zeros(5, np.float64)
+        ok = self.lib.orc_f16x2_plan(_p(blob), _p(e), _p(bnd))
+        return dict(ok=bool(ok), activation_exp=e[:5].tolist(), weight_exp=e[5:10].tolist(), rescale_exp=e[10:14].tolist(), out_exp=int(e[14]),
+                    bound=bnd.tolist())
+
     def c4conv_eval(self, blob, my_bb, op_bb, mode=0, raw=False):
         blob = np.ascontiguousarray(blob, np.float32)
         assert blob.size == self.lib.orc_c4conv_num_params()

@@ -1,0 +1,106 @@
+"""CPU tests of the oracle's ACC_F16X2 mode (oracle/nn_f16x2.hpp): the restatement of the HIP engine's SYN_NET_ARITH_F16X2 arithmetic.
+
+What pins it WITHOUT a GPU: vectors an MI355X produced, committed as fixtures —
+  * tests/golden/mfma_f16_probe.npz: 18,560 dot products through one v_mfma_f32_16x16x32_f16 (designed probes + random regimes;
+    tests/golden/make_mfma_f16_golden.py) — the accumulation model must reproduce every bit;
+  * tests/golden/c4net_f16x2_device.npz: the engine's logits / outcome probabilities for 512 positions under both committed checkpoints
+    (tests/golden/make_f16x2_device_golden.py) — the whole restated network must reproduce every bit, and the plan's exponents.
+And what holds it to the reference's function (study-connect4/src/policies.rs:28-59, slimnn/src/linear.rs:17-25): north_star's 1e-5 against
+the slimnn-order evaluation and the torch-f64 goldens, with a 3x margin, on the random-init network.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_parity import random_positions
+
+
+@pytest.fixture(scope="module")
+def blob(golden_dir):
+    return np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+
+
+@pytest.fixture(scope="module")
+def trained(golden_dir):
+    return np.load(os.path.join(golden_dir, "c4net_trained_f32.npy"))
+
+
+def test_f16_conversions_are_ieee_round_to_nearest_even(oracle):
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.standard_normal(200000).astype(np.float32) * np.float32(2.0) ** rs.randint(-30, 20, 200000).astype(np.float32),
+                        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, 2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25, 6.1e-5, -6.0e-8], np.float32),
+                        np.arange(0, 65536, dtype=np.uint16).view(np.float16).astype(np.float32)[np.isfinite(np.arange(0, 65536, dtype=np.uint16).view(np.float16))]])
+    bits, back = oracle.f16_round_trip(x)
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16)
+    assert np.array_equal(bits, ref.view(np.uint16))
+    assert np.array_equal(back.view(np.uint32), ref.astype(np.float32).view(np.uint32))
+
+
+def test_mfma_accumulation_model_replays_device_vectors(oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "mfma_f16_probe.npz"))
+    out = oracle.mfma_f16_k32(g["a_bits"], g["b_bits"], g["c"])
+    bad = np.flatnonzero(out.view(np.uint32) != g["d_device"].view(np.uint32))
+    assert bad.size == 0, (bad[:5], out[bad[:5]], g["d_device"][bad[:5]])
+    assert len(out) >= 18000
+    # hand-checkable corners of the model: a tie goes to even, eight products are summed before they meet the accumulator, a product
+    # more than 24 binary orders under the largest one of its pass is lost, the four passes round separately
+    one, h = 0x3C00, 0x3800   # 1.0, 0.5
+
+    def run(c, terms):
+        a = np.zeros((1, 32), np.uint16); b = np.zeros((1, 32), np.uint16)
+        for k, x, y in terms:
+            a[0, k] = x; b[0, k] = y
+        return float(oracle.mfma_f16_k32(a, b, np.array([c], np.float32))[0])
+    assert run(2.0 ** 24, [(0, one, one)]) == 2.0 ** 24
+    assert run(2.0 ** 24, [(0, one, one), (1, one, one)]) == 2.0 ** 24 + 2
+    assert run(2.0 ** 24, [(0, one, one), (8, one, one)]) == 2.0 ** 24          # different passes: two separate ties
+    assert run(0.0, [(0, 0x7800, 0x7800), (1, 0xF800, 0x7800), (2, 0x2800, 0x2800)]) == 0.0   # 2^30 - 2^30 + 2^-10: the small one is cut
+    assert run(0.0, [(0, 0x7800, 0x7800), (8, 0xF800, 0x7800), (16, 0x2800, 0x2800)]) == 2.0 ** -10
+
+
+def test_f16x2_network_matches_device_bits_and_plan(oracle, golden_dir, blob, trained):
+    g = np.load(os.path.join(golden_dir, "c4net_f16x2_device.npz"))
+    for name, w in (("c4net_blob_f32", blob), ("c4net_trained_f32", trained)):
+        l, v = oracle.c4net_eval(w, g["my_bb"], g["op_bb"], mode=oracle.ACC_F16X2)
+        assert np.array_equal(l.view(np.uint32), g[name + "_logits"].view(np.uint32)), name
+        assert np.array_equal(v.view(np.uint32), g[name + "_value"].view(np.uint32)), name
+        plan = oracle.f16x2_plan(w)
+        assert plan["ok"] and plan["activation_exp"] + plan["weight_exp"] + [plan["out_exp"]] == g[name + "_plan"].tolist()
+        # the plan keeps every activation the bound admits inside the f16 range
+        for l_i in range(4):
+            assert plan["bound"][l_i] * 2.0 ** plan["activation_exp"][l_i + 1] <= 2.0 ** 15
+
+
+def test_f16x2_network_is_the_reference_function_within_tolerance(oracle, golden_dir, blob, trained):
+    my, op = random_positions(oracle, 3000, seed=77)
+    l, v = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_F16X2)
+    sl, sv = oracle.c4net_eval(blob, my, op, mode=oracle.ACC_SLIMNN)
+    assert np.abs(l - sl).max() < 1e-5 / 3 and np.abs(v - sv).max() < 1e-5 / 3
+    g = json.load(open(os.path.join(golden_dir, "c4net_torch_goldens.json")))
+    gl, gv = oracle.c4net_eval(blob, g["my_bb"], g["op_bb"], mode=oracle.ACC_F16X2)
+    assert np.abs(gl - np.array(g["logits_f64"])).max() < 1e-5 / 3 and np.abs(gv - np.array(g["value_f64"])).max() < 1e-5 / 3
+    # a trained network's logits are two orders of magnitude larger: relative to their size the arithmetic is as close to the slimnn
+    # order as the f32 fused-multiply-add order is (both sit at f32 rounding noise), the probabilities stay inside 1e-5
+    tl, tv = oracle.c4net_eval(trained, my, op, mode=oracle.ACC_F16X2)
+    fl, fv = oracle.c4net_eval(trained, my, op, mode=oracle.ACC_FMA)
+    sl, sv = oracle.c4net_eval(trained, my, op, mode=oracle.ACC_SLIMNN)
+    scale = float(np.abs(sl).max())
+    assert scale > 50 and np.abs(tl - sl).max() / scale < 2e-6 and np.abs(tv - sv).max() < 1e-5
+    assert np.abs(tl - sl).max() < 4.0 * np.abs(fl - sl).max()
+    # non-finite parameters have no plan
+    bad = blob.copy(); bad[100] = np.nan
+    assert not oracle.f16x2_plan(bad)["ok"]
+
+
+def test_f16x2_search_runs_and_differs_from_f32_only_by_rounding(oracle, blob):
+    """The oracle's MCTS driven by ACC_F16X2: same code path as every other mode; priors within rounding of the ACC_FMA priors."""
+    from tests.oracle_lib import parity_mcts_config
+
+    my, op = random_positions(oracle, 8, seed=5)
+    a = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 60, nn_mode=oracle.ACC_F16X2)
+    b = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 60, nn_mode=oracle.ACC_FMA)
+    assert np.abs(a["child_P"] - b["child_P"]).max() < 1e-6
+    assert a["num_nodes"].shape == b["num_nodes"].shape

@@ -2,7 +2,7 @@
 
 Each case is one dot product  c + sum_k a[k] b[k]  placed on the diagonal of a 16x16 tile (row i of A, column i of B, C[i][i]); 16 cases
 per tile.  Writes tools/ubench/probe_in.bin (travels to the GPU box) and tools/ubench/probe_cases.json (case descriptions for the
-offline analysis, tools/ubench/f16_probe_fit.py).
+offline analysis).  Argument: main (default) | zeros | binades — the three probe sets behind tests/golden/mfma_f16_probe.npz.
 """
 import json
 import os
@@ -37,6 +37,7 @@ def split_exp(total):
     return ea, eb
 
 
+WHICH = sys.argv[1] if len(sys.argv) > 1 else "main"   # main | zeros | binades
 cases = []
 
 
@@ -51,64 +52,103 @@ def prod(k, sign, total_exp, ma=0, mb=0):
     return (k, f16(sign, ea, ma), f16(0, eb, mb))
 
 
-BIG = 30
-# A: product against product inside one pass
-for (kb, ks, kc) in ((0, 1, 2), (0, 7, 3), (2, 3, 0), (0, 4, 1), (5, 0, 6)):
-    for n in range(0, 59):
-        for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF)):
+def main_set():
+    BIG = 30
+    # A: product against product inside one pass
+    for (kb, ks, kc) in ((0, 1, 2), (0, 7, 3), (2, 3, 0), (0, 4, 1), (5, 0, 6)):
+        for n in range(0, 59):
+            for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF)):
+                for sg in (0, 1):
+                    add("A", 0.0, [prod(kb, 0, BIG), prod(kc, 1, BIG), prod(ks, sg, BIG - n, ma, mb)], n=n, ma=ma, mb=mb, sign=sg, pos=(kb, ks, kc))
+    # B: accumulator cancels against a product, small product survives
+    for cs in (0, 1):
+        for n in range(0, 59):
+            for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF)):
+                for sg in (0, 1):
+                    add("B", (-1.0 if cs else 1.0) * 2.0 ** BIG, [prod(0, 1 - cs, BIG), prod(1, sg, BIG - n, ma, mb)], n=n, ma=ma, mb=mb, sign=sg, csign=cs)
+    # C: two products cancel, small accumulator survives
+    for n in range(0, 64):
+        for m24 in (0x800000, 0x800001, 0xFFFFFF, 0xC00001):
             for sg in (0, 1):
-                add("A", 0.0, [prod(kb, 0, BIG), prod(kc, 1, BIG), prod(ks, sg, BIG - n, ma, mb)], n=n, ma=ma, mb=mb, sign=sg, pos=(kb, ks, kc))
-# B: accumulator cancels against a product, small product survives
-for cs in (0, 1):
-    for n in range(0, 59):
-        for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF)):
+                c = (-1.0 if sg else 1.0) * m24 * 2.0 ** (BIG - n - 23)
+                add("C", c, [prod(0, 0, BIG), prod(1, 1, BIG)], n=n, m24=m24, sign=sg)
+    # D: a tie at the accumulator's half ulp plus something small
+    for ks in (1, 7):
+        for n in range(25, 72):
             for sg in (0, 1):
-                add("B", (-1.0 if cs else 1.0) * 2.0 ** BIG, [prod(0, 1 - cs, BIG), prod(1, sg, BIG - n, ma, mb)], n=n, ma=ma, mb=mb, sign=sg, csign=cs)
-# C: two products cancel, small accumulator survives
-for n in range(0, 64):
-    for m24 in (0x800000, 0x800001, 0xFFFFFF, 0xC00001):
-        for sg in (0, 1):
-            c = (-1.0 if sg else 1.0) * m24 * 2.0 ** (BIG - n - 23)
-            add("C", c, [prod(0, 0, BIG), prod(1, 1, BIG)], n=n, m24=m24, sign=sg)
-# D: a tie at the accumulator's half ulp plus something small
-for ks in (1, 7):
-    for n in range(25, 72):
-        for sg in (0, 1):
-            add("D", 2.0 ** BIG, [prod(0, 0, BIG - 24), prod(ks, sg, BIG - n)], n=n, sign=sg, ks=ks)
-# E: one big product and m small ones
-for small in (24, 25, 26, 27):
-    for m in range(1, 8):
-        for k0 in (0, 7):
-            ks = [k for k in range(8) if k != k0][:m]
-            add("E", 0.0, [prod(k0, 0, 0)] + [prod(k, 0, -small) for k in ks], m=m, small=small, k0=k0)
-            add("E", 0.0, [prod(k0, 0, 0)] + [prod(k, 1, -small) for k in ks], m=-m, small=small, k0=k0)
-# F: two products (and optionally an accumulator) with an exponent gap
-for g in range(0, 34):
-    for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF), (0x155, 0x2AA)):
-        for sg in (0, 1):
-            add("F", 0.0, [prod(0, 0, 10, 0x3FF, 0x3FF), prod(1, sg, 10 - g, ma, mb)], g=g, ma=ma, mb=mb, sign=sg)
-            add("F2", 3.0 * 2.0 ** 8, [prod(0, 0, 10, 0x3FF, 0x3FF), prod(1, sg, 10 - g, ma, mb)], g=g, ma=ma, mb=mb, sign=sg)
-# G: random single-pass cases (k < 8 only), with and without an accumulator, several exponent spreads
-rs = np.random.RandomState(5)
-for spread in (2, 6, 12, 20, 30):
-    for i in range(1200):
+                add("D", 2.0 ** BIG, [prod(0, 0, BIG - 24), prod(ks, sg, BIG - n)], n=n, sign=sg, ks=ks)
+    # E: one big product and m small ones
+    for small in (24, 25, 26, 27):
+        for m in range(1, 8):
+            for k0 in (0, 7):
+                ks = [k for k in range(8) if k != k0][:m]
+                add("E", 0.0, [prod(k0, 0, 0)] + [prod(k, 0, -small) for k in ks], m=m, small=small, k0=k0)
+                add("E", 0.0, [prod(k0, 0, 0)] + [prod(k, 1, -small) for k in ks], m=-m, small=small, k0=k0)
+    # F: two products (and optionally an accumulator) with an exponent gap
+    for g in range(0, 34):
+        for (ma, mb) in ((0, 0), (1, 1), (0x3FF, 0x3FF), (0x155, 0x2AA)):
+            for sg in (0, 1):
+                add("F", 0.0, [prod(0, 0, 10, 0x3FF, 0x3FF), prod(1, sg, 10 - g, ma, mb)], g=g, ma=ma, mb=mb, sign=sg)
+                add("F2", 3.0 * 2.0 ** 8, [prod(0, 0, 10, 0x3FF, 0x3FF), prod(1, sg, 10 - g, ma, mb)], g=g, ma=ma, mb=mb, sign=sg)
+    # G: random single-pass cases (k < 8 only), with and without an accumulator, several exponent spreads
+    rs = np.random.RandomState(5)
+    for spread in (2, 6, 12, 20, 30):
+        for i in range(1200):
+            terms = []
+            for k in range(8):
+                ea = int(rs.randint(-spread // 2, spread // 2 + 1)); eb = int(rs.randint(-spread // 2, spread // 2 + 1))
+                terms.append((k, f16(int(rs.randint(2)), max(-14, min(15, ea)), int(rs.randint(1024))), f16(0, max(-14, min(15, eb)), int(rs.randint(1024)))))
+            if i % 3 == 0:
+                c = 0.0
+            else:
+                c = float(np.float32((1 + rs.randint(1 << 23) / float(1 << 23)) * 2.0 ** int(rs.randint(-spread, spread + 1)) * (1 if rs.randint(2) else -1)))
+            add("G", c, terms, spread=spread)
+    # H: random full 32-term cases with moderate spread (validates the four-pass chaining of a single-pass model)
+    for i in range(2000):
         terms = []
-        for k in range(8):
-            ea = int(rs.randint(-spread // 2, spread // 2 + 1)); eb = int(rs.randint(-spread // 2, spread // 2 + 1))
-            terms.append((k, f16(int(rs.randint(2)), max(-14, min(15, ea)), int(rs.randint(1024))), f16(0, max(-14, min(15, eb)), int(rs.randint(1024)))))
-        if i % 3 == 0:
-            c = 0.0
-        else:
-            c = float(np.float32((1 + rs.randint(1 << 23) / float(1 << 23)) * 2.0 ** int(rs.randint(-spread, spread + 1)) * (1 if rs.randint(2) else -1)))
-        add("G", c, terms, spread=spread)
-# H: random full 32-term cases with moderate spread (validates the four-pass chaining of a single-pass model)
-for i in range(2000):
-    terms = []
-    for k in range(32):
-        terms.append((k, f16(int(rs.randint(2)), int(rs.randint(-6, 7)), int(rs.randint(1024))), f16(0, int(rs.randint(-6, 7)), int(rs.randint(1024)))))
-    c = float(np.float32((1 + rs.randint(1 << 23) / float(1 << 23)) * 2.0 ** int(rs.randint(-12, 13)) * (1 if rs.randint(2) else -1)))
-    add("H", c, terms)
+        for k in range(32):
+            terms.append((k, f16(int(rs.randint(2)), int(rs.randint(-6, 7)), int(rs.randint(1024))), f16(0, int(rs.randint(-6, 7)), int(rs.randint(1024)))))
+        c = float(np.float32((1 + rs.randint(1 << 23) / float(1 << 23)) * 2.0 ** int(rs.randint(-12, 13)) * (1 if rs.randint(2) else -1)))
+        add("H", c, terms)
 
+
+
+def zero_set():
+    """does a product with a ZERO factor take part in the alignment? (zero x 2^e beside a small product with a long significand)"""
+    for zero in (0x0000, 0x8000):
+        for side in (0, 1):
+            for e in range(-14, 16):
+                z = (zero, f16(0, e, 0x155)) if side == 0 else (f16(0, e, 0x155), zero)
+                add("Z0", 0.0, [(0,) + z, (1, f16(0, -10, 1), f16(0, -10, 1))], e=e, zero=zero, side=side)
+                add("Z1", 1.0, [(0,) + z, (1, f16(0, -12, 0), f16(0, -12, 0)), (2, f16(0, -14, 1), f16(0, -14, 1))], e=e, zero=zero, side=side)
+
+
+def binade_set():
+    """where is the sum cut when it drops / keeps / gains a binade against the accumulator? (a tie at the result's half ulp +- 2^-j)"""
+    def pw(sign, e, mant=0):
+        ea = max(-14, min(15, e // 2))
+        return f16(sign, ea, mant), f16(0, e - ea, 0)
+    for E in (30, 20):
+        u = E - 23
+        for k, name in ((2, "dropEven"), (1, "dropOdd")):
+            m, e = (0x100, 1) if k == 2 else (0x200, 0)
+            for j in range(14):
+                for ds in (0, 1):
+                    add(name, 2.0 ** E, [(0,) + pw(1, e + u - 1, m), (1,) + pw(ds, u - 7 - j)], E=E, j=j, dsign=ds)
+        for k, name in ((0, "sameEven"), (1, "sameOdd")):
+            m, e = (0x000, -1) if k == 0 else (0x200, 0)
+            for j in range(14):
+                for ds in (0, 1):
+                    add(name, 2.0 ** E, [(0,) + pw(0, e + u, m), (1,) + pw(ds, u - 7 - j)], E=E, j=j, dsign=ds)
+        for k, name in ((0, "growEven"), (1, "growOdd")):
+            c = 2.0 ** (E + 1) - 2 * 2.0 ** u
+            m, e = (0x200, 1) if k == 0 else (0x100, 2)
+            for j in range(14):
+                for ds in (0, 1):
+                    add(name, c, [(0,) + pw(0, e + u, m), (1,) + pw(ds, u - 7 - j)], E=E, j=j, dsign=ds)
+
+
+{"main": main_set, "zeros": zero_set, "binades": binade_set}[WHICH]()
 ntiles = (len(cases) + 15) // 16
 A = np.zeros((ntiles, 16, 32), np.uint16); B = np.zeros((ntiles, 32, 16), np.uint16); C = np.zeros((ntiles, 16, 16), np.float32)
 for idx, cs in enumerate(cases):
