@@ -156,7 +156,11 @@ int syn_get_network_arithmetic(syn_engine* h, int* arithmetic, syn_f16x2_plan* p
 /* Replaces: Policy::eval (study-connect4/src/policies.rs:47-59) for n states at once. State i is the position with
  * bitboards (my_bb[i], op_bb[i]) in the layout of connect4.rs:3-13 (my_bb = side to move). Outputs: logits[n*9] raw
  * policy logits, value[n*3] = softmax over [lose, draw, win]. Up to 32,768 positions the call runs on the engine's own
- * evaluation context (below): 14 us for n <= 16, 27 us for 4,096; beyond, pageable transfers around the throughput kernel. */
+ * evaluation context (below): 14 us for n <= 16, 27 us for 4,096; beyond, pageable transfers around the throughput kernel.
+ * Side effects differ by size: a batch of up to 32,768 positions runs on that context's own non-blocking stream — it does NOT wait
+ * for work queued on the engine stream (e.g. a preceding syn_policy_eval_batch_device(..., sync = 0)) and syn_last_timing reports 0
+ * for it; larger batches run on the engine stream, drain it and are timed. Not re-entrant: the engine's context is one per engine
+ * (two threads evaluating at once take one syn_eval_ctx each). */
 int syn_policy_eval_batch(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, int n, float* logits,
                           float* value);
 /* Same with all four pointers resident in device memory (no PCIe in the call); asynchronous on the engine stream

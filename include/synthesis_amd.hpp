@@ -230,8 +230,10 @@ public:
         for (size_t i = 0; i < games.size(); i++) { my[i] = games[i].my_bb(); op[i] = games[i].op_bb(); }
         logits.resize(games.size());
         value.resize(games.size());
-        e_.check(syn_policy_eval_batch(e_.handle(), my.data(), op.data(), (int)games.size(),
-                                       games.empty() ? nullptr : logits[0].data(), games.empty() ? nullptr : value[0].data()));
+        if (games.empty()) return;
+        // on this object's own context (stream, staging, error slot): two HipPolicy objects of one Engine may batch from two threads
+        const int rc = syn_eval_ctx_eval(ctx_, my.data(), op.data(), (int)games.size(), logits[0].data(), value[0].data());
+        if (rc != SYN_OK) throw Error(rc, syn_eval_ctx_last_error(ctx_));
     }
 
 private:

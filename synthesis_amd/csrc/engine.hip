@@ -34,7 +34,9 @@
 #include "free_kernel.cuh"
 
 #include <hipcub/hipcub.hpp>
+#include <chrono>
 #include <cmath>
+#include <thread>
 
 using namespace syn;
 
@@ -1012,6 +1014,17 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint
 // ---- evaluation contexts: one worker's policy (alpha_zero.rs:192-198 gives every worker thread of gather_experience its own) ----
 // A context owns a stream, pinned staging and device scratch, and reads the engine's weight image; contexts of one engine run
 // side by side from different host threads. Errors stay in the context (the engine's error slot belongs to the engine's thread).
+// one polite spin-wait step on the host CPU
+static inline void spin_pause() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 struct syn_eval_ctx {
     syn_engine* h = nullptr;
     hipStream_t stream = nullptr;
@@ -1131,14 +1144,19 @@ int syn_eval_ctx_wait(syn_eval_ctx* c, float* logits, float* value) {
     if (!logits || !value) return ctx_fail(c, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_eval_ctx_wait");
     const size_t nb = (size_t)c->pending;
     c->pending = 0;
+    // (under CombiningPolicy the wait runs on whichever worker thread finishes the batch: that thread may never have selected the device)
+    CTX_TRY(c, hipSetDevice(c->h->device));
     bool done = false;
     if (c->polled) {
-        // ~2 ms of polling (a call is tens of microseconds); a kernel that does not report falls through to the stream, where a
-        // fault shows as an error
+        // at most ~300 us of polling (a call is tens of microseconds; behind a long self-play launch the kernel is far away and a
+        // burning core buys nothing); a kernel that has not reported by then falls through to the stream, where a fault shows as an error
         const volatile unsigned* flag = c->h_flag;
-        for (int spin = 0; spin < 200000 && !done; spin++) {
+        const auto t_poll = std::chrono::steady_clock::now();
+        for (int spin = 0; !done; spin++) {
             done = *flag == c->seq;
-            if (!done) __builtin_ia32_pause();
+            if (done) break;
+            spin_pause();
+            if ((spin & 255) == 255 && std::chrono::steady_clock::now() - t_poll > std::chrono::microseconds(300)) break;
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     }
@@ -1149,7 +1167,7 @@ int syn_eval_ctx_wait(syn_eval_ctx* c, float* logits, float* value) {
             // (the workgroup counter was disturbed). Not an error for the caller: note it, put the counter back and let this context
             // wait on its stream from now on.
             unsigned done_word = 0xFFFFFFFFu;
-            hipMemcpy(&done_word, c->d_done, 4, hipMemcpyDeviceToHost);
+            if (hipMemcpy(&done_word, c->d_done, 4, hipMemcpyDeviceToHost) != hipSuccess) done_word = 0xFFFFFFFFu;   // (diagnostic only)
             char msg[256];
             std::snprintf(msg, sizeof msg, "note: an evaluation kernel finished without reporting completion (n %zu, call %u, word in pinned "
                           "memory %u, workgroups counted %u); this context now waits on its stream", nb, c->seq,

@@ -183,7 +183,7 @@ class EvalContext:
         self._lib = engine._lib
         self._c = C.c_void_p()
         engine._check(self._lib.syn_eval_ctx_create(engine._h, C.byref(self._c)))
-        self._n = 0
+        self._n = None
 
     def _check(self, rc):
         if rc != 0:
@@ -194,12 +194,16 @@ class EvalContext:
         op = np.ascontiguousarray(op_bb, dtype=np.uint64).ravel()
         if my.size != op.size:
             raise ValueError("my_bb and op_bb must have the same length")
-        self._check(self._lib.syn_eval_ctx_submit(self._c, _p(my), _p(op), int(my.size)))
+        self._check(self._lib.syn_eval_ctx_submit(self._c, _p(my), _p(op), int(my.size)))   # (a refused submit leaves a batch in flight as it was)
         self._n = int(my.size)
 
     def wait(self):
-        logits = np.zeros((self._n, 9), np.float32)
-        value = np.zeros((self._n, 3), np.float32)
+        """Results of the submitted batch. Raises when nothing was submitted (or the submission failed): there is nothing to wait for."""
+        if self._n is None:
+            raise SynthesisAmdError(-1, "EvalContext.wait(): no batch has been submitted")
+        n, self._n = self._n, None
+        logits = np.zeros((n, 9), np.float32)
+        value = np.zeros((n, 3), np.float32)
         self._check(self._lib.syn_eval_ctx_wait(self._c, _p(logits), _p(value)))
         return logits, value
 

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <thread>
 
 #include "synthesis_amd.hpp"
 
@@ -50,6 +51,25 @@ int main(int argc, char** argv) {
         std::vector<std::array<float, 3>> bv;
         policy.eval_batch(line, bl, bv);
         for (size_t i = 0; i < line.size(); i++) put("batch_logits", bl[i].data(), 9);
+        {   // two workers, one HipPolicy each (alpha_zero.rs:192-198), batching at the same time: each on its own context
+            int wrong[2] = {0, 0};
+            auto work = [&](int w) {
+                try {
+                    HipPolicy mine(engine);
+                    std::vector<std::array<float, 9>> l2;
+                    std::vector<std::array<float, 3>> v2;
+                    for (int it = 0; it < 300; it++) {
+                        std::vector<Connect4> part(line.begin() + (it + w) % 3, line.end());
+                        mine.eval_batch(part, l2, v2);
+                        for (size_t i = 0; i < part.size(); i++)
+                            if (std::memcmp(l2[i].data(), bl[i + (it + w) % 3].data(), 36) || std::memcmp(v2[i].data(), bv[i + (it + w) % 3].data(), 12)) wrong[w]++;
+                    }
+                } catch (const Error& e) { wrong[w] = -1000 - e.code; }
+            };
+            std::thread t0(work, 0), t1(work, 1);
+            t0.join(); t1.join();
+            std::printf("two_policies_batching %d %d\n", wrong[0], wrong[1]);
+        }
 
         // run_n_games -> ReplayBuffer
         RolloutConfig cfg;

@@ -18,7 +18,7 @@ def harness(tmp_path_factory, golden_dir):
     lib = os.path.join(ROOT, "synthesis_amd")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "host_harness.cpp"), "-o", exe, "-L" + lib,
-                           "-lsynthesis_amd", "-Wl,-rpath," + lib])
+                           "-lsynthesis_amd", "-Wl,-rpath," + lib, "-pthread"])
     blob = str(d / "blob.f32")
     np.load(os.path.join(golden_dir, "c4net_blob_f32.npy")).astype("<f4").tofile(blob)
     return exe, blob
@@ -52,6 +52,7 @@ def test_cpp_host_matches_oracle(harness, oracle, golden_dir):
     for l in lines:
         by.setdefault(l[0], []).append(l[1:])
 
+    assert by["two_policies_batching"] == [["0", "0"]]   # two HipPolicy objects of one Engine, eval_batch from two threads at once
     # Policy::eval (batch of one and batched) + Game::features + Game::player on the scripted line 4 4 3 5 2 4 0 8 8
     moves = [4, 4, 3, 5, 2, 4, 0, 8, 8]
     assert len(by["pos"]) == len(moves) + 1

@@ -188,9 +188,13 @@ def test_policy_eval_transfer_paths_and_contexts(engine, oracle, blob):
     with pytest.raises(sa.SynthesisAmdError) as e:
         c0.eval(my[:3], op[:3])
     assert e.value.code == -4 and "syn_load_weights" in str(e.value)
+    with pytest.raises(sa.SynthesisAmdError):
+        c0.wait()   # the submission failed: there is no batch to wait for (and no zeros posing as results)
     bare.load_weights(blob)
     l, v = c0.eval(my[:3], op[:3])
     assert np.array_equal(l, fl[:3]) and np.array_equal(v, fv[:3])
+    with pytest.raises(sa.SynthesisAmdError):
+        c0.wait()   # ... nor a second time for a batch already collected
     bare.close()   # (closes its contexts first)
     errors = []
 
