@@ -140,3 +140,174 @@ def parse_export_text(text: str) -> np.ndarray:
         parts.append(string_to_tensor(strings[2 * i], o * k))
         parts.append(string_to_tensor(strings[2 * i + 1], o))
     return np.concatenate(parts).astype(np.float32)
+
+
+# ---- the `.ot` VarStore container (synthesis/src/alpha_zero.rs:37,97 `vs.save(model_i.ot)`, reloaded at :194) --------------------
+# tch's VarStore::save hands the named variables to libtorch's torch::serialize::OutputArchive: a zip archive (stored, not deflated)
+# with one top-level directory holding `data.pkl` — a protocol-2 pickle of a `__torch__.Module` object whose state maps variable names
+# (`l_1.weight` ... `l_5.bias`, study-connect4/src/policies.rs:20-24) to tensors rebuilt from `data/<key>` (raw little-endian storages)
+# — plus `code/__torch__.py` (the parameter declarations), `constants.pkl`, `version`. Read here with `zipfile` and an unpickler that
+# admits exactly the globals such an archive needs: no torch at run time, nothing executable is ever looked up.
+# No `.ot` written by the reference itself exists in this build (no Rust toolchain): the layout is pinned by archives the image's
+# libtorch writes through that same OutputArchive (tests/golden/make_ot_golden.py).
+import collections
+import io
+import pickle
+import struct
+import zipfile
+
+_STORAGE_DTYPES = {"FloatStorage": np.dtype("<f4"), "DoubleStorage": np.dtype("<f8"), "HalfStorage": np.dtype("<f2"),
+                   "LongStorage": np.dtype("<i8"), "IntStorage": np.dtype("<i4")}
+
+
+class _StorageType:
+    def __init__(self, name):
+        self.dtype = _STORAGE_DTYPES[name]
+
+
+class _JitObject:
+    """stand-in for the archive's `__torch__.Module`: keeps the state dictionary BUILD hands it"""
+    def __init__(self, *a):
+        self.state = {}
+
+    def __setstate__(self, state):
+        self.state = state
+
+
+def _rebuild_tensor_v2(storage, offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
+    size, stride = tuple(size), tuple(stride)
+    if len(size) == 0:
+        return storage[offset:offset + 1].reshape(()).copy()
+    return np.lib.stride_tricks.as_strided(storage[offset:], shape=size, strides=tuple(s * storage.itemsize for s in stride)).copy()
+
+
+class _OtUnpickler(pickle.Unpickler):
+    def __init__(self, data, read_record):
+        super().__init__(io.BytesIO(data))
+        self._read_record = read_record
+
+    def find_class(self, module, name):
+        if module == "__torch__" or module.startswith("__torch__."):
+            return _JitObject
+        if module == "torch._utils" and name == "_rebuild_tensor_v2":
+            return _rebuild_tensor_v2
+        if module == "torch._utils" and name == "_rebuild_parameter":
+            return lambda data, requires_grad=True, backward_hooks=None: data
+        if module == "torch" and name in _STORAGE_DTYPES:
+            return _StorageType(name)
+        if module == "collections" and name == "OrderedDict":
+            return collections.OrderedDict
+        raise pickle.UnpicklingError(f"a VarStore archive has no business with {module}.{name}")
+
+    def persistent_load(self, pid):
+        if not (isinstance(pid, tuple) and len(pid) >= 5 and pid[0] == "storage" and isinstance(pid[1], _StorageType)):
+            raise pickle.UnpicklingError(f"unexpected persistent id {pid!r}")
+        raw = self._read_record("data/" + str(pid[2]))
+        arr = np.frombuffer(raw, dtype=pid[1].dtype)
+        if arr.size < int(pid[4]):
+            raise ValueError(f"storage {pid[2]} holds {arr.size} elements, the archive says {pid[4]}")
+        return arr
+
+
+def load_ot_tensors(path):
+    """name -> ndarray for every variable of a VarStore archive (`.ot`)."""
+    with zipfile.ZipFile(path) as z:
+        pkl = [n for n in z.namelist() if n.endswith("/data.pkl") and n.count("/") == 1]
+        if len(pkl) != 1:
+            raise ValueError(f"{path}: not a libtorch archive (no single <root>/data.pkl)")
+        root = pkl[0][: -len("data.pkl")]
+        order = (z.read(root + "byteorder").decode().strip() if root + "byteorder" in z.namelist() else "little")
+        if order != "little":
+            raise ValueError(f"{path}: {order}-endian archives are not supported")
+        obj = _OtUnpickler(z.read(pkl[0]), lambda rec: z.read(root + rec)).load()
+    state = obj.state if isinstance(obj, _JitObject) else obj
+    if not isinstance(state, dict):
+        raise ValueError(f"{path}: the archive's root object carries no variables")
+    return {str(k): np.asarray(v) for k, v in state.items() if isinstance(v, np.ndarray)}
+
+
+def load_ot(path):
+    """The flat f32 blob (`l_1.weight, l_1.bias, ... l_5.bias`; syn_load_weights' order) of a Connect4Net VarStore archive."""
+    t = load_ot_tensors(path)
+    parts = []
+    for l in range(5):
+        w, b = t.get(f"l_{l + 1}.weight"), t.get(f"l_{l + 1}.bias")
+        if w is None or b is None:
+            raise ValueError(f"{path}: no l_{l + 1}.weight / l_{l + 1}.bias (variables: {sorted(t)})")
+        if w.shape != (DIMS[l + 1], DIMS[l]) or b.shape != (DIMS[l + 1],):
+            raise ValueError(f"{path}: l_{l + 1} has shapes {w.shape} / {b.shape}, Connect4Net needs {(DIMS[l + 1], DIMS[l])} / {(DIMS[l + 1],)}")
+        parts += [w.astype(np.float32).ravel(), b.astype(np.float32).ravel()]
+    return np.concatenate(parts)
+
+
+def _pickle_varstore(named):
+    """data.pkl of an OutputArchive holding the f32 tensors `named` [(name, array)]: the opcode stream libtorch's pickler emits"""
+    out = bytearray(b"\x80\x02c__torch__\nModule\nq\x00)\x81}(")
+    memo = 1
+
+    def put():
+        nonlocal memo
+        memo += 1
+        return b"q" + bytes([memo - 1]) if memo - 1 < 256 else b"r" + struct.pack("<I", memo - 1)
+
+    def uni(sv):
+        b = sv.encode()
+        return b"X" + struct.pack("<I", len(b)) + b
+
+    def integer(v):
+        return b"K" + bytes([v]) if 0 <= v < 256 else (b"M" + struct.pack("<H", v) if v < 65536 else b"J" + struct.pack("<i", v))
+
+    first = True
+    for key, (name, arr) in enumerate(named):
+        out += uni(name) + put()
+        if first:
+            out += b"ctorch._utils\n_rebuild_tensor_v2\n" + put()
+            rebuild = memo - 1
+        else:
+            out += b"h" + bytes([rebuild])
+        out += b"(("
+        if first:
+            out += uni("storage") + put(); m_storage = memo - 1
+            out += b"ctorch\nFloatStorage\n" + put(); m_float = memo - 1
+        else:
+            out += b"h" + bytes([m_storage]) + b"h" + bytes([m_float])
+        out += uni(str(key)) + put()
+        if first:
+            out += uni("cpu") + put(); m_cpu = memo - 1
+        else:
+            out += b"h" + bytes([m_cpu])
+        out += integer(arr.size) + b"tQ" + put() + integer(0)
+        out += b"(" + b"".join(integer(d) for d in arr.shape) + b"t"
+        strides = [int(np.prod(arr.shape[i + 1:])) for i in range(arr.ndim)]
+        out += b"(" + b"".join(integer(d) for d in strides) + b"t" + b"\x89"
+        if first:
+            out += b"ccollections\nOrderedDict\n" + put(); m_od = memo - 1
+        else:
+            out += b"h" + bytes([m_od])
+        out += b")RtR" + put()
+        first = False
+    out += b"ub" + put() + b"."
+    return bytes(out)
+
+
+def save_ot(blob, path, root="archive"):
+    """Writes the flat Connect4Net blob as a VarStore archive `vs.load(path)` / torch.jit.load read: the inverse of load_ot."""
+    blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+    if blob.size != NUM_PARAMS:
+        raise ValueError(f"Connect4Net has {NUM_PARAMS} parameters, got {blob.size}")
+    named, off = [], 0
+    for l in range(5):
+        w = blob[off:off + DIMS[l] * DIMS[l + 1]].reshape(DIMS[l + 1], DIMS[l]); off += w.size
+        b = blob[off:off + DIMS[l + 1]]; off += b.size
+        named += [(f"l_{l + 1}.weight", w), (f"l_{l + 1}.bias", b)]
+    names = "".join(f'"{n}", ' for n, _ in named)
+    code = ("class Module(Module):\n  __parameters__ = [" + names + "]\n  __buffers__ = []\n  __annotations__ = []\n" +
+            "".join(f'  __annotations__["{n}"] = Tensor\n' for n, _ in named))
+    with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as z:
+        for key, (_, arr) in enumerate(named):
+            z.writestr(f"{root}/data/{key}", np.ascontiguousarray(arr, "<f4").tobytes())
+        z.writestr(f"{root}/data.pkl", _pickle_varstore(named))
+        z.writestr(f"{root}/code/__torch__.py", code)
+        z.writestr(f"{root}/constants.pkl", b"\x80\x02).")
+        z.writestr(f"{root}/version", b"3\n")
+        z.writestr(f"{root}/byteorder", b"little")

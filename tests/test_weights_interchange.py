@@ -76,14 +76,50 @@ def test_export_text_layout_and_round_trip(golden_dir):
         W.parse_export_text("const PARAMETERS: [&'static str; 2] = [\n\"\",\n\"\",\n];\n")
 
 
+def test_ot_varstore_archive_round_trips(golden_dir, tmp_path):
+    """`vs.save("models/model_i.ot")` / `vs.load(...)` (synthesis/src/alpha_zero.rs:37,97,194; names policies.rs:20-24): the archive
+    libtorch's OutputArchive writes for the committed blob (tests/golden/c4net_blob.ot, made by tests/golden/make_ot_golden.py with the
+    image's libtorch — NO reference-produced .ot exists to pin the reader, the reference cannot be built here) reads back bit for bit,
+    without torch; and what save_ot writes is an archive torch's own loader (the one InputArchive / vs.load uses) accepts."""
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    got = W.load_ot(os.path.join(golden_dir, "c4net_blob.ot"))
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), blob.view(np.uint32))
+    t = W.load_ot_tensors(os.path.join(golden_dir, "c4net_blob.ot"))
+    assert sorted(t) == sorted(f"l_{l}.{k}" for l in range(1, 6) for k in ("weight", "bias")) and t["l_2.weight"].shape == (96, 128)
+    mine = str(tmp_path / "mine.ot")
+    W.save_ot(blob * np.float32(0.5), mine)
+    assert np.array_equal(W.load_ot(mine), blob * np.float32(0.5))
+    import torch
+
+    m = torch.jit.load(mine)   # (test-time cross-check only: the product path never imports torch for this)
+    sd = dict(m.named_parameters())
+    assert np.array_equal(sd["l_5.bias"].numpy(), (blob * np.float32(0.5))[-12:]) and tuple(sd["l_1.weight"].shape) == (128, 63)
+    # what is not a Connect4Net VarStore says so
+    import zipfile
+
+    bad = str(tmp_path / "bad.ot")
+    with zipfile.ZipFile(bad, "w") as z:
+        z.writestr("x/data.pkl", b"\x80\x02cos\nsystem\nq\x00.")
+    with pytest.raises(Exception) as e:
+        W.load_ot(bad)
+    assert "no business" in str(e.value)
+    with pytest.raises(ValueError):
+        W.save_ot(blob[:-1], mine)
+
+
 @pytest.mark.gpu
-def test_engine_runs_on_an_exported_checkpoint(golden_dir, oracle):
-    """A PARAMETERS file as the reference's export binary writes it (bf16) drives the engine: the network outputs equal
-    the oracle's on the bf16-rounded weights."""
+@pytest.mark.parametrize("container", ["export-bf16", "ot"])
+def test_engine_runs_on_an_exported_checkpoint(golden_dir, oracle, container):
+    """A PARAMETERS file as the reference's export binary writes it (bf16), or a VarStore archive (.ot, f32: lossless), drives the engine:
+    the network outputs equal the oracle's on the loaded weights."""
     import synthesis_amd as sa
 
     blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
-    loaded = W.parse_export_text(W.export_text(blob, "bf16"))
+    if container == "ot":
+        loaded = W.load_ot(os.path.join(golden_dir, "c4net_blob.ot"))
+        assert np.array_equal(loaded, blob)
+    else:
+        loaded = W.parse_export_text(W.export_text(blob, "bf16"))
     eng = sa.Engine(concurrent_games=64, max_explores=64)
     eng.load_weights(loaded)
     from tests.test_gpu_parity import random_positions
