@@ -501,6 +501,29 @@ def main():
                             "collectives": "one fixed-layout tensor gather of the new positions to rank 0 + one %d-byte weight broadcast per iteration (%s)"
                                            % (blob.size * 4, args.dist_backend if world > 1 else "none: one rank"),
                             "note": "the 1 -> 8 GPU curve of this loop has not been measured on an 8-GPU node (one GPU per box here)"}
+                # What the loop does at 8 ranks, from THIS run's phase times (alpha_zero.rs:45-100 has ONE learner: every added rank adds
+                # its games AND its share of rank 0's serial work): play is per rank (weak scaling); the gather moves 72 B per position
+                # from 7 peers to rank 0 (xGMI: one ~153 GB/s link per peer, in parallel) and rank 0 unpacks 8 x as many positions
+                # (priced at 5 GB/s of host copies, this run's pack / unpack rate); de-duplication and the epochs grow with the
+                # positions (x 8); the 122 KB broadcast does not grow.
+                sec = r4["seconds"]
+                pos = float(r4.get("steps_in_buffer") or 0) / max(1, min(2, len(recs))) if world == 1 else None
+                if world == 1 and pos:
+                    per_rank_bytes = 72.0 * pos
+                    g8 = per_rank_bytes / 153e9 + 8 * per_rank_bytes / 5e9
+                    tot8 = sec["selfplay"] + g8 + 8 * sec["dedup"] + 8 * sec["train"] + sec["broadcast"]
+                    ceiling = r4["games"] / max(1e-9, sec["dedup"] + sec["train"])
+                    loop_rec["projected_8_ranks"] = {
+                        "seconds": {"selfplay": sec["selfplay"], "gather": round(g8, 4), "dedup": round(8 * sec["dedup"], 4),
+                                    "train": round(8 * sec["train"], 4), "broadcast": sec["broadcast"], "total": round(tot8, 4)},
+                        "games_per_s_of_the_whole_iteration": 8 * r4["games"] / tot8,
+                        "speedup_over_one_rank": (8 * r4["games"] / tot8) / (r4["games"] / max(1e-9, sec["total"])),
+                        "amdahl_ceiling_games_per_s": ceiling,
+                        "model": "play x1 (weak scaling), gather = 72 B x positions over one xGMI link per peer + 8 x the host unpack, dedup x8, "
+                                 "train x8 (one learner, alpha_zero.rs:45-100), broadcast x1; NOT measured on 8 GPUs",
+                        "reading": "the loop is serial in the learner: past ~%.1f ranks the seven other GPUs wait for rank 0; the data-parallel "
+                                   "learner (DataParallelLearner: one fused all-reduce per step) is the shape that scales the training half"
+                                   % max(1.0, (sec["selfplay"] + sec["dedup"] + sec["train"]) / max(1e-9, sec["dedup"] + sec["train"]))}
         except Exception as ex:   # never lose the bench line over the learner leg
             loop_rec = {"error": repr(ex)}
 

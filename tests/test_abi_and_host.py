@@ -253,6 +253,40 @@ def test_learning_loop_collectives_under_gloo(tmp_path):
     assert one["buffer"][2] < one["buffer"][1] + sum(7 + g % 5 for g in range(202, 303))
 
 
+def test_eight_ranks_under_gloo(tmp_path):
+    """The shape an 8-GPU node runs (BASELINE configs[3] / [4]) with world_size 8 on CPU (gloo): dist_util.step_game_range + the
+    barrier / MAX / SUM reduction of bench.py, and LearningLoop's fixed-layout gather with UNEVEN per-rank position counts (101 games
+    over 8 ranks: five ranks play 13, three play 12; plies differ per game), the replay bookkeeping on rank 0 and the weight broadcast —
+    the trained weights equal the single-rank run's bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    port = _free_port()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+         "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=600).decode()
+    line = [l for l in out.splitlines() if l.startswith("RESULT")][0].split()
+    assert float(line[1]) == 8.0 and int(line[2]) == 8 * 500              # MAX of (1..8), SUM of the per-rank game counts
+    assert int(line[3]) == sum((2 * 8 + r) * 500 for r in range(8))       # SUM of the eight shard offsets of step 2
+    loop = tmp_path / "loop_worker.py"
+    loop.write_text(LOOP_WORKER)
+    port = _free_port()
+    env.update(MASTER_PORT=port)
+    out = subprocess.check_output(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+         "127.0.0.1", "--master-port", port, str(loop), ROOT], env=env, stderr=subprocess.STDOUT, timeout=600).decode()
+    eight = sorted((json.loads(l.split(" ", 1)[1]) for l in out.splitlines() if l.startswith("LOOP")), key=lambda d: d["rank"])
+    one = json.loads([l for l in subprocess.check_output([sys.executable, str(loop), ROOT], env=env, stderr=subprocess.STDOUT,
+                                                          timeout=300).decode().splitlines() if l.startswith("LOOP")][0].split(" ", 1)[1])
+    assert len(eight) == 8 and all(d["world"] == 8 for d in eight)
+    assert [d["games"][0] for d in eight] == [13, 13, 13, 13, 13, 12, 12, 12]
+    assert all(d["w0"] == one["w0"] and d["wsum"] == one["wsum"] for d in eight)
+    assert all(d["loaded"] == eight[0]["loaded"] and len(d["loaded"]) == 4 for d in eight)
+    assert eight[0]["unique"] == one["unique"] and eight[0]["steps"] == one["steps"] and eight[0]["buffer"] == one["buffer"]
+    assert all(d["unique"] == [None] * 3 for d in eight[1:])
+
+
 def test_bench_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher (how the driver runs it) must start two ranks itself: the parent never
     touches the GPU, the ranks rendezvous over 127.0.0.1 and rank 0 reports world size 2 (launch plumbing only, no GPU)."""
