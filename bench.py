@@ -668,7 +668,22 @@ def main():
             r2 = e2.selfplay(cfg, base_seed=1, n_games=16384, first_game=4096, outputs=False)
             dt = time.perf_counter() - t1
             out["at_4096_concurrent_games"] = {"games_per_s": 16384 / dt, "kernel_ms": r2["kernel_ms"],
-                                               "games": 16384, "plies_per_game": float(r2["plies"].mean())}
+                                               "games": 16384, "plies_per_game": float(r2["plies"].mean()),
+                                               "launch_shape": list(e2.last_launch_shape())}
+            # the same 16,384 games in the f16x2 network arithmetic: four free-running waves of four trees per CU, every wave evaluating
+            # its own leaves (free_kernel.cuh) instead of 16 trees in lock step behind one f32 tile split over four waves
+            try:
+                e2.set_network_arithmetic("f16x2")
+                e2.selfplay(cfg, base_seed=1, n_games=4096, outputs=False)
+                t1 = time.perf_counter()
+                r2h = e2.selfplay(cfg, base_seed=1, n_games=16384, first_game=4096, outputs=False)
+                dth = time.perf_counter() - t1
+                out["at_4096_concurrent_games"]["with_f16x2_network"] = {
+                    "games_per_s": 16384 / dth, "kernel_ms": r2h["kernel_ms"], "games": 16384, "plies_per_game": float(r2h["plies"].mean()),
+                    "launch_shape": list(e2.last_launch_shape()), "dtype": "f16x2 (see with_f16x2_network)"}
+                e2.set_network_arithmetic("f32")
+            except Exception as ex:  # noqa: BLE001
+                out["at_4096_concurrent_games"]["with_f16x2_network"] = {"error": str(ex)[:200]}
             # configs[1] as worded — host trees, batched Policy::eval launches (include/synthesis_amd_lockstep.hpp behind
             # syn_mcts_search_lockstep: one worker thread per usable CPU, each with two halves of its trees taking turns, the workers'
             # leaves combined into one launch on one evaluation context) — beside the fused search on the same 4,096 roots (mid-game

@@ -524,7 +524,9 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         // 51.2k against 47.7k for the reference configuration; without the cache the two shapes are equal (70.6k / 71.2k).
         // The f16x2 arithmetic makes every regime tree-bound (its network tile is a quarter of the f32 one): 102k games/s at 16 x 1,024
         // against 111k at 12 x 768 (random-init), 65.0k against 72.4k (trained checkpoint).
-        if (!conv && nw == 16 && (P.cache != nullptr || cfg_family(P.mcts) == 2 || f16x2) && (fast || cfg_family(P.mcts) == 2) &&
+        // Round 5: the headline (parity family, f32, no cache) takes the same shape — it measures the same or better there (75.9k against
+        // 74.6k at 1,048,576 games, 77.5k against 76.9k at a full step) and 12 x 164 registers spill nothing where 16 x 128 spills 35.
+        if (!conv && nw == 16 && (fast || cfg_family(P.mcts) == 2) &&
             debug_env("SYN_LANES") == nullptr) {
             nw = 12;
             if (want_slots > h->num_cus * 768) want_slots = h->num_cus * 768;
