@@ -17,7 +17,7 @@ CONV_NUM_PARAMS = 12412  # Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear
 # every symbol include/synthesis_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
-    "syn_load_weights_conv",
+    "syn_load_weights_conv", "syn_set_network_arithmetic", "syn_get_network_arithmetic",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_eval_ctx_create", "syn_eval_ctx_submit", "syn_eval_ctx_wait",
     "syn_eval_ctx_eval", "syn_eval_ctx_last_error", "syn_eval_ctx_destroy", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_selfplay_run_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
