@@ -78,7 +78,7 @@ def algorithmic_bytes(c):
 
 
 SELFPLAY_KERNEL_SOURCES = ("device_common.cuh", "mcts.cuh", "mlp.cuh", "engine_kernels.cuh", "lane_kernel.cuh", "pc_kernel.cuh",
-                           "noise.cuh", "zig_tables.cuh", "convnet.cuh")
+                           "noise.cuh", "zig_tables.cuh", "convnet.cuh", "f16x2_tile.cuh", "free_kernel.cuh")
 
 
 def kernel_source_hash():

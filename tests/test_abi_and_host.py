@@ -239,7 +239,7 @@ def test_learning_loop_collectives_under_gloo(tmp_path):
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
          "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
-    two = sorted((json.loads(l.split(" ", 1)[1]) for l in out.splitlines() if l.startswith("LOOP")), key=lambda d: d["rank"])
+    two = sorted((json.loads(m) for m in re.findall(r"LOOP (\{[^{}]*\})", out)), key=lambda d: d["rank"])
     one = json.loads([l for l in subprocess.check_output([sys.executable, str(script), ROOT], env=env, stderr=subprocess.STDOUT,
                                                           timeout=300).decode().splitlines() if l.startswith("LOOP")][0].split(" ", 1)[1])
     assert len(two) == 2 and two[0]["world"] == 2 and one["world"] == 1
@@ -276,7 +276,8 @@ def test_eight_ranks_under_gloo(tmp_path):
     out = subprocess.check_output(
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
          "127.0.0.1", "--master-port", port, str(loop), ROOT], env=env, stderr=subprocess.STDOUT, timeout=600).decode()
-    eight = sorted((json.loads(l.split(" ", 1)[1]) for l in out.splitlines() if l.startswith("LOOP")), key=lambda d: d["rank"])
+    # (eight ranks share one pipe: two records can land on one line, so they are cut out by pattern — a record holds no nested braces)
+    eight = sorted((json.loads(m) for m in re.findall(r"LOOP (\{[^{}]*\})", out)), key=lambda d: d["rank"])
     one = json.loads([l for l in subprocess.check_output([sys.executable, str(loop), ROOT], env=env, stderr=subprocess.STDOUT,
                                                           timeout=300).decode().splitlines() if l.startswith("LOOP")][0].split(" ", 1)[1])
     assert len(eight) == 8 and all(d["world"] == 8 for d in eight)

@@ -5,7 +5,7 @@
 # discussion quotes; distilled into gpurun_out/profiles_<tag>/ for copying into profiles/ (tracked).
 #   usage: tools/collect_profiles.sh r03 [fast]      ("fast": skip the SQ / TA / L2 passes)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 MODE=${2:-full}     # full | fast (no SQ / TA / L2 passes) | trace (only the kernel trace: refreshes <tag>_kernel_stats.csv)
 R=$PWD
 OUT=$R/gpurun_out/profiles_$TAG

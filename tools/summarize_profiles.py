@@ -39,6 +39,20 @@ def per_launch(name, pick, largest=True):
     return {k: sum(v) / len(v) for k, v in res.items()}, len(acc)
 
 
+def nth_timed_launch(name, pick, nth):
+    """counter -> value of the nth (in dispatch order) TIMED launch among the dispatches `pick` accepts: a leg's timed launch plays four
+    times the games of its warm-up launch, so the timed ones are the dispatches whose counters reach half of the largest one's."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows(name):
+        if pick(r["Kernel_Name"]):
+            acc[int(r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    if not acc:
+        return {}
+    top = max(sum(d.values()) for d in acc.values())
+    big = [dict(acc[k]) for k in sorted(acc) if sum(acc[k].values()) >= 0.5 * top]
+    return big[nth] if nth < len(big) else {}
+
+
 # the un-instrumented (COUNT = false) self-play launches: the parity configuration takes the FAST instantiation, the reference's
 # Fpu::Func configuration the general one (template arguments <MODE, COUNT, FAST, ...>)
 import re  # noqa: E402
@@ -46,8 +60,11 @@ timed = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (true|1),", 
 # the extra legs of `bench.py --only-extra-legs`, told apart by their instantiation <MODE, COUNT, FAST, waves, PROF, POLICY>: PolicyWithCache
 # = the parity family on 12 waves, the trained network = the parity family on 16 waves, the conv network = POLICY 2, the reference's
 # Fpu::Func configuration = family 2 (the runtime-switched instantiation before round 4)
+# (round 5: Connect4Net's parity family runs 12 waves in every leg, so the PolicyWithCache leg and the trained-network leg are the FIRST and
+#  the SECOND timed launch of that instantiation in the command's order; POLICY 3 = the f16x2 arithmetic: random-init, then trained)
 leg_cache = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 12, (false|0), 0>", n) is not None
-leg_trained = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 16, (false|0), 0>", n) is not None
+leg_trained = leg_cache
+leg_f16 = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 12, (false|0), 3>", n) is not None
 leg_conv = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 16, (false|0), 2>", n) is not None
 timed_general = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (false|0|2),", n) is not None
 line = None
@@ -60,10 +77,12 @@ if os.path.exists(f"{out}/{tag}_cache_lines_under_profiler.jsonl"):
         cache_line = json.loads(l)
 f, nf = per_launch("pmc_fetch", timed)
 w, nw = per_launch("pmc_write", timed)
-cf, _ = per_launch("pmc_cfetch", leg_cache)
-cw, _ = per_launch("pmc_cwrite", leg_cache)
-tf, _ = per_launch("pmc_cfetch", leg_trained)
-tw, _ = per_launch("pmc_cwrite", leg_trained)
+cf = nth_timed_launch("pmc_cfetch", leg_cache, 0)
+cw = nth_timed_launch("pmc_cwrite", leg_cache, 0)
+tf = nth_timed_launch("pmc_cfetch", leg_trained, 1)
+tw = nth_timed_launch("pmc_cwrite", leg_trained, 1)
+hf, hw = nth_timed_launch("pmc_cfetch", leg_f16, 0), nth_timed_launch("pmc_cwrite", leg_f16, 0)
+htf, htw = nth_timed_launch("pmc_cfetch", leg_f16, 1), nth_timed_launch("pmc_cwrite", leg_f16, 1)
 vf, _ = per_launch("pmc_cfetch", leg_conv)
 vw, _ = per_launch("pmc_cwrite", leg_conv)
 rf, _ = per_launch("pmc_cfetch", timed_general)
@@ -95,11 +114,17 @@ summary = {
     "trained_traffic_bytes_per_launch": traffic(tf, tw),
     "conv_FETCH_SIZE_kb_per_launch": vf.get("FETCH_SIZE"), "conv_WRITE_SIZE_kb_per_launch": vw.get("WRITE_SIZE"),
     "conv_traffic_bytes_per_launch": traffic(vf, vw),
+    "f16x2_FETCH_SIZE_kb_per_launch": hf.get("FETCH_SIZE"), "f16x2_WRITE_SIZE_kb_per_launch": hw.get("WRITE_SIZE"),
+    "f16x2_traffic_bytes_per_launch": traffic(hf, hw),
+    "f16x2_trained_FETCH_SIZE_kb_per_launch": htf.get("FETCH_SIZE"), "f16x2_trained_WRITE_SIZE_kb_per_launch": htw.get("WRITE_SIZE"),
+    "f16x2_trained_traffic_bytes_per_launch": traffic(htf, htw),
     "extra_leg_games": {
         "cache_traffic_bytes_per_launch": (cache_line or {}).get("with_policy_cache", {}).get("games"),
         "reference_traffic_bytes_per_launch": (cache_line or {}).get("reference_selfplay_config", {}).get("games"),
         "trained_traffic_bytes_per_launch": (cache_line or {}).get("with_trained_weights", {}).get("games"),
         "conv_traffic_bytes_per_launch": (cache_line or {}).get("with_conv_policy", {}).get("games"),
+        "f16x2_traffic_bytes_per_launch": (cache_line or {}).get("with_f16x2_network", {}).get("games"),
+        "f16x2_trained_traffic_bytes_per_launch": (cache_line or {}).get("with_f16x2_network", {}).get("trained_checkpoint", {}).get("games"),
     },
 }
 json.dump(summary, open(f"{out}/{tag}_pmc.json", "w"), indent=1)
@@ -129,10 +154,14 @@ for name in ("pmc_sq1", "pmc_sq2", "pmc_ta", "pmc_l2"):
     sq.update(per_launch(name, timed)[0])
 if sq:
     d["counters_per_launch"] = sq
-    d["derived"] = derive(sq, 4)
-csq = {}
+    d["derived"] = derive(sq, 3)   # (round 5: 12 waves per CU = 3 per SIMD)
+csq, hsq = {}, {}
 for name in ("pmc_csq1", "pmc_csq2", "pmc_cl2"):
-    csq.update(per_launch(name, leg_cache)[0])
+    csq.update(nth_timed_launch(name, leg_cache, 0))
+    hsq.update(nth_timed_launch(name, leg_f16, 0))
+if hsq:
+    d["f16x2_leg"] = {"command": "python3 bench.py --only-extra-legs (the first timed launch of the 12-wave POLICY-3 instantiation: random-init network)",
+                      "counters_per_launch": hsq, "derived": derive(hsq, 3)}
 if csq:
     d["policy_cache_leg"] = {"command": "python3 bench.py --only-extra-legs (the largest 12-wave parity-family dispatch of each pass)",
                              "counters_per_launch": csq, "derived": derive(csq, 3)}
