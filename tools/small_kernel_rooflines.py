@@ -2,7 +2,7 @@
 """Developer tool (GPU): achieved HBM rate of the stand-alone streaming kernels — features_kernel, linear_kernel, conv2d_kernel,
 activation_kernel, policy_eval_kernel — and the search rate of frozen_search_kernel, each against its roof. The layer entry points
 take host pointers, so the kernel time is taken from HIP events inside the library (syn_last_timing) and the bytes are the
-algorithmic ones (inputs read once + outputs written once). Writes one JSON object (profiles/r02_small_kernels.json)."""
+algorithmic ones (inputs read once + outputs written once). Writes one JSON object (profiles/rNN_small_kernels.json)."""
 import json
 import os
 import sys
@@ -41,6 +41,18 @@ eng.policy_eval(my, op)
 ms = eng.last_kernel_ms()
 line("policy_eval_kernel (compute-bound: f32 MFMA)", n * 64, ms, {"positions": n, "tflops": n * 60288 / (ms * 1e-3) / 1e12,
                                                                     "mfma_frac": n * 60288 / (ms * 1e-3) / 1e12 / 157.3})
+# the same network in the f16x2 arithmetic (f16x2_tile.cuh): priced against the f16 matrix peak by the MFMAs it executes (184,320 FLOP
+# per evaluation: three products, inputs padded to 32s) and, for comparison with the line above, against the f32 peak by the 60,288 FLOP
+# the network needs
+eng.set_network_arithmetic("f16x2")
+eng.policy_eval(my[:65536], op[:65536]); eng.policy_eval(my, op)
+ms = eng.last_kernel_ms()
+line("policy_eval_f16x2_kernel (compute-bound: f16 MFMA)", n * 64, ms, {"positions": n, "g_evals_per_s": n / (ms * 1e-3) / 1e9,
+                                                                          "tflops_executed": n * 184320 / (ms * 1e-3) / 1e12,
+                                                                          "f16_mfma_frac": n * 184320 / (ms * 1e-3) / 1e12 / 2500.0,
+                                                                          "f32_equivalent_tflops": n * 60288 / (ms * 1e-3) / 1e12,
+                                                                          "f32_equivalent_frac_of_157.3": n * 60288 / (ms * 1e-3) / 1e12 / 157.3})
+eng.set_network_arithmetic("f32")
 # the conv policy/value network's stand-alone evaluation (convnet.cuh), on its own engine (it replaces the engine's network)
 from bench import CONV_FLOP_PER_EVAL, make_conv_weights  # noqa: E402
 ce = sa.Engine(concurrent_games=256, max_explores=16)
@@ -81,4 +93,4 @@ out["frozen_search_kernel"] = {"searches": m, "explores_each": 800, "kernel_ms":
                                "explores_per_s": m * 800 / (ms * 1e-3), "bound": "latency (dependent pointer chase + playouts)"}
 print("frozen_search_kernel", json.dumps(out["frozen_search_kernel"]), flush=True)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r02_small_kernels.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "small_kernels.json"), "w"), indent=1)
