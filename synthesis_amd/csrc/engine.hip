@@ -545,9 +545,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             }
             EngineParams PL = P;
             PL.path = h->d_path;
-            PL.lane_thresh = 48;
+            // a round ends once this many lanes of a wave stand on a leaf: 48 with the f32 tile; with the f16x2 tile (a quarter of the cost) waiting
+            // for all 64 measures +1-2 % (same box: 107.5k -> 108.7k games/s random-init, 65.3k -> 66.7k trained; 32: 100.5k / 60.8k)
+            PL.lane_thresh = f16x2 ? 64 : 48;
             if (const char* ev = debug_env("SYN_LANE_THRESH")) PL.lane_thresh = std::atoi(ev);
-            if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = 48;
+            if (PL.lane_thresh < 16 || PL.lane_thresh > 64) PL.lane_thresh = f16x2 ? 64 : 48;
             PL.lane_thresh &= ~15;  // whole tiles
             PL.debug_stub = 0;
             if (PROF) { if (const char* ev = debug_env("SYN_ABLATE")) PL.debug_stub = std::atoi(ev); }
