@@ -413,7 +413,8 @@ int syn_last_cache_stats(const syn_engine* h, uint64_t* hits, uint64_t* misses);
  * DESIGN.md §6.1): *shape = 1 row-per-tree kernel with the weights in registers (16 trees per workgroup), 2 = the same
  * with two workgroups per CU, 3 = quad-async row kernel (several 16-tree quads per workgroup), 4 = lane-per-tree kernel
  * (one tree per lane), 5 = the evaluator baseline's lane-per-tree kernel / the producer-consumer debug shape, 6 = the lane-per-tree kernel
- * with two trees per lane; grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
+ * with two trees per lane, 7 = the free-running row kernel of the f16x2 arithmetic (at most 16 trees per CU: four waves of four trees, every
+ * wave evaluating its own leaves); grid / threads = workgroups and threads per workgroup. Diagnostics and tests only. */
 int syn_last_launch_shape(const syn_engine* h, int* shape, int* grid, int* threads);
 
 /* A self-play launch plays its whole batch inside ONE kernel (seconds to tens of seconds). These two entry points may be called
