@@ -65,7 +65,6 @@ SYN_CONV_LANES(MODE_SELFPLAY, true)
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 12, 2>(EngineParams);  \
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 12, 2>(EngineParams);
 extern template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>(EngineParams);
-extern template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 3>(EngineParams);
 SYN_LANES2(MODE_SEARCH, false)
 SYN_LANES2(MODE_SELFPLAY, false)
 SYN_LANES2(MODE_SELFPLAY, true)
@@ -463,22 +462,13 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     {                                                                                                              \
         auto k = selfplay_kernel_lanes2<MODE, COUNT, FAST, NW, POL>;                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lane2Lds<NW, POL>::BYTES);  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lane2Lds<NW>::BYTES);  \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), (Lane2Lds<NW, POL>::BYTES), h->stream, PL);                     \
+        hipLaunchKernelGGL(k, dim3(lgrid), dim3(64 * NW), Lane2Lds<NW>::BYTES, h->stream, PL);                     \
     }
             if (nw2 == 12) {
                 if (h->net_kind == 1) { if (fast) SYN_LAUNCH_L2(12, true, 2) else SYN_LAUNCH_L2(12, false, 2) }
                 else { if (fast) SYN_LAUNCH_L2(12, true, 0) else SYN_LAUNCH_L2(12, false, 0) }
-            }
-            else if (h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F16X2) {
-                // (debug shape, f16x2: the parity family's self-play kernel only — one measurement, profiles/NOTES.md round 5)
-                if (MODE == MODE_SELFPLAY && !COUNT && fast) {
-                    auto k = selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 3>;
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Lane2Lds<8, 3>::BYTES);
-                    if (e != hipSuccess) return e;
-                    hipLaunchKernelGGL(k, dim3(lgrid), dim3(512), (Lane2Lds<8, 3>::BYTES), h->stream, PL);
-                } else return hipErrorInvalidValue;
             }
             else if (h->net_kind == 1) { if (fast) SYN_LAUNCH_L2(8, true, 2) else SYN_LAUNCH_L2(8, false, 2) }
             else if (MODE == MODE_SELFPLAY && !COUNT && fast && debug_env("SYN_L2_TILE")) {

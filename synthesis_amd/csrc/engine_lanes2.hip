@@ -19,7 +19,6 @@ namespace syn {
     template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 12, 2>(EngineParams);  \
     template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 12, 2>(EngineParams);
 template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 0, 1>(EngineParams);
-template __global__ void selfplay_kernel_lanes2<MODE_SELFPLAY, false, true, 8, 3>(EngineParams);   // the f16x2 arithmetic: one re-measurement (round 5)
 SYN_LANES2(MODE_SEARCH, false)
 SYN_LANES2(MODE_SELFPLAY, false)
 SYN_LANES2(MODE_SELFPLAY, true)

@@ -22,10 +22,9 @@
 
 namespace syn {
 
-template <int NW, int POLICY = 0>
+template <int NW>
 struct Lane2Lds {
-    // the weight + bias image: 123,264 B (Connect4Net f32 / Connect4ConvNet) or 124,320 B (Connect4Net f16x2: fits at 8 waves only)
-    static constexpr size_t OUT_OFF = POLICY == 3 ? (size_t)F16Geom::IMG_WORDS * 4 : (size_t)MlpGeom::IMG_FLOATS * 4;
+    static constexpr size_t OUT_OFF = (size_t)MlpGeom::IMG_FLOATS * 4;     // 123,264 B weight + bias image
     // + 768 B result patch per wave (16 positions x 12 outputs); its first 64 bytes double as the wave's compaction index (rank ->
     //   lane), which every lane reads into a register before the first tile's results overwrite it
     static constexpr size_t FT_OFF = OUT_OFF + (size_t)NW * 768;
@@ -67,24 +66,19 @@ template <int MODE, bool COUNT, bool FAST, int NW, int POLICY = 0, int TILE = 0>
 __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     constexpr int NT = 64 * NW;
-    static_assert(POLICY == 0 || POLICY == 2 || POLICY == 3, "network policies only");
+    static_assert(POLICY == 0 || POLICY == 2, "network policies only");
     float* wimg = reinterpret_cast<float*>(smem_raw);
     const float* bimg = wimg + MlpGeom::W_FLOATS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    float* outw = reinterpret_cast<float*>(smem_raw + Lane2Lds<NW, POLICY>::OUT_OFF) + wave * 192;
+    float* outw = reinterpret_cast<float*>(smem_raw + Lane2Lds<NW>::OUT_OFF) + wave * 192;
 
     if (POLICY == 0) stage_weight_image(wimg, P.wimg, tid, NT);
     if (POLICY == 2) stage_conv_image(wimg, P.wimg, tid, NT);
-    if (POLICY == 3) {
-        const uint4* src = reinterpret_cast<const uint4*>(P.wimg);
-        uint4* dst = reinterpret_cast<uint4*>(smem_raw);
-        for (int i = tid; i < F16Geom::IMG_WORDS / 4; i += NT) dst[i] = src[i];
-    }
     if (tid < 4) {
         const FeatureTable f = make_feature_table(tid);
-        *reinterpret_cast<uint4*>(smem_raw + Lane2Lds<NW, POLICY>::FT_OFF + tid * 16) = make_uint4(f.t[0], f.t[1], f.t[2], f.t[3]);
+        *reinterpret_cast<uint4*>(smem_raw + Lane2Lds<NW>::FT_OFF + tid * 16) = make_uint4(f.t[0], f.t[1], f.t[2], f.t[3]);
     }
 
     uint32_t ctr[COUNT ? CTR_COUNT : 1];
@@ -96,7 +90,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
     const size_t slab_bytes = (size_t)P.cap * 32u;
     unsigned char* const slab0 = reinterpret_cast<unsigned char*>(P.stat) + slot * 2u * slab_bytes;
     uint4* const pl0 = P.path + ((size_t)blockIdx.x * NW + (size_t)wave) * (2u * PATH_ENTRIES) + (size_t)lane;
-    uint32_t* const pk0 = reinterpret_cast<uint32_t*>(smem_raw + Lane2Lds<NW, POLICY>::PARK_OFF) + tid;
+    uint32_t* const pk0 = reinterpret_cast<uint32_t*>(smem_raw + Lane2Lds<NW>::PARK_OFF) + tid;
     const uint32_t bcap = P.cap / 4u;  // 128-byte blocks in a slab
 
     // Cold per-context state lives in LDS between the ends of searches (5 dwords: the root position and the game's turn / RNG
@@ -276,21 +270,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes2(EngineParam
                 uint32_t img_off = 0;  // opaque per tile: the image reads stay LDS reads next to their MFMAs
                 asm volatile("" : "+v"(img_off));
                 o = conv_tile16(wimg + img_off, lane, tmy, top);
-            } else if (POLICY == 3) {
-                uint64_t hi, lo;
-                feature_boards(C.my, C.op, hi, lo);
-                const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
-                uint32_t img_off = 0;
-                asm volatile("" : "+v"(img_off));
-                const uint32_t* img16 = reinterpret_cast<const uint32_t*>(smem_raw) + img_off;
-                o = f16x2_tile16<3>(img16, lane, thi, tlo);
-                const float os = reinterpret_cast<const float*>(img16 + F16Geom::SCALE_WORD0)[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) o[r] *= os;
             } else {
                 uint64_t hi, lo;
                 feature_boards(C.my, C.op, hi, lo);
-                const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + Lane2Lds<NW, POLICY>::FT_OFF + (lane >> 4) * 16);
+                const uint4 ftw = *reinterpret_cast<const uint4*>(smem_raw + Lane2Lds<NW>::FT_OFF + (lane >> 4) * 16);
                 FeatureTable FT;
                 FT.t[0] = ftw.x; FT.t[1] = ftw.y; FT.t[2] = ftw.z; FT.t[3] = ftw.w;
                 const uint64_t thi = shfl_u64(hi, src), tlo = shfl_u64(lo, src);
