@@ -227,6 +227,22 @@ def test_f16x2_arithmetic_switches_cleanly(oracle, blob):
         bad = blob.copy(); bad[5] = np.inf
         with pytest.raises(sa.SynthesisAmdError):
             eng.load_weights(bad)
+        # the learner's hand-off (syn_trainer_publish_weights: model_{i+1}.ot of alpha_zero.rs:97,194) arrives in the chosen arithmetic:
+        # a few optimiser steps, publish, and the engine evaluates the TRAINED parameters as the oracle's ACC_F16X2 does
+        eng.load_weights(blob)
+        eng.trainer_init(blob)
+        rs = np.random.RandomState(4)
+        tpi = rs.dirichlet(np.ones(9), 32).astype(np.float32); tv = rs.dirichlet(np.ones(3), 32).astype(np.float32)
+        for _ in range(5):
+            eng.train_step(my, op, tpi, tv, 1e-2)
+        eng.trainer_publish_weights()
+        trained_now = eng.trainer_state()["weights"]
+        assert np.abs(trained_now - blob).max() > 1e-3
+        l, v = eng.policy_eval(my, op)
+        rl, rv = oracle.c4net_eval(trained_now, my, op, mode=oracle.ACC_F16X2)
+        assert np.array_equal(l, rl) and np.array_equal(v, rv)
+        got = eng.mcts_search(sa.parity_mcts_config(), my[:8], op[:8], 100)
+        assert_search_equal(got, oracle.c4_mcts_search(parity_mcts_config(), trained_now, my[:8], op[:8], 100, nn_mode=oracle.ACC_F16X2), "published")
     finally:
         eng.close()
     big = sa.Engine(concurrent_games=16, max_explores=8000, device=0)
