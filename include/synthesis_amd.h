@@ -150,6 +150,9 @@ typedef struct syn_f16x2_plan {
     double bound[5];
 } syn_f16x2_plan;
 int syn_get_network_arithmetic(syn_engine* h, int* arithmetic, syn_f16x2_plan* plan);
+/* The same plan for a parameter blob without an engine (pure host code, no GPU needed): what syn_set_network_arithmetic would choose for
+ * these parameters. SYN_OK with plan->valid = 0 when the blob has no plan (non-finite parameters). */
+int syn_f16x2_plan_of_blob(const float* blob, size_t n_floats, syn_f16x2_plan* plan);
 
 /* ---- leaf evaluation ------------------------------------------------------------------------------------------- */
 

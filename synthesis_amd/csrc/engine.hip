@@ -912,6 +912,18 @@ int syn_get_network_arithmetic(syn_engine* h, int* arithmetic, syn_f16x2_plan* p
     return SYN_OK;
 }
 
+int syn_f16x2_plan_of_blob(const float* blob, size_t n_floats, syn_f16x2_plan* plan) {
+    if (!blob || !plan || n_floats != (size_t)MlpGeom::NUM_PARAMS) return SYN_ERR_INVALID_ARGUMENT;
+    std::memset(plan, 0, sizeof(*plan));
+    F16Image im;
+    if (build_f16x2_image(blob, im)) {
+        plan->valid = 1;
+        for (int l = 0; l < 5; l++) { plan->activation_exp[l] = im.s[l]; plan->weight_exp[l] = im.t[l]; plan->bound[l] = im.bound[l]; }
+        plan->out_exp = im.out_exp;
+    }
+    return SYN_OK;
+}
+
 int syn_load_weights_conv(syn_engine* h, const float* blob, size_t n_floats) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;
     if (!blob) return fail(h, SYN_ERR_INVALID_ARGUMENT, "blob is NULL");

@@ -17,7 +17,7 @@ CONV_NUM_PARAMS = 12412  # Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear
 # every symbol include/synthesis_amd.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "syn_default_rollout_config", "syn_engine_create", "syn_engine_destroy", "syn_last_error", "syn_load_weights",
-    "syn_load_weights_conv", "syn_set_network_arithmetic", "syn_get_network_arithmetic",
+    "syn_load_weights_conv", "syn_set_network_arithmetic", "syn_get_network_arithmetic", "syn_f16x2_plan_of_blob",
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_eval_ctx_create", "syn_eval_ctx_submit", "syn_eval_ctx_wait",
     "syn_eval_ctx_eval", "syn_eval_ctx_last_error", "syn_eval_ctx_destroy", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_selfplay_run_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
@@ -103,6 +103,7 @@ def load_library():
     lib.syn_load_weights_conv.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.syn_set_network_arithmetic.argtypes = [C.c_void_p, C.c_int]
     lib.syn_get_network_arithmetic.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(CF16x2Plan)]
+    lib.syn_f16x2_plan_of_blob.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(CF16x2Plan)]
     lib.syn_policy_eval_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.syn_policy_eval_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                                  C.c_int]
@@ -163,6 +164,20 @@ def load_library():
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def f16x2_plan_of_blob(blob):
+    """The f16x2 plan (power-of-two scales) syn_set_network_arithmetic would choose for a Connect4Net blob — host code only, no GPU.
+    None when the blob has no plan (non-finite parameters)."""
+    lib = load_library()
+    blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+    pl = CF16x2Plan()
+    rc = lib.syn_f16x2_plan_of_blob(_p(blob), blob.size, C.byref(pl))
+    if rc != 0:
+        raise SynthesisAmdError(rc, "syn_f16x2_plan_of_blob: bad arguments")
+    if not pl.valid:
+        return None
+    return dict(activation_exp=list(pl.activation_exp), weight_exp=list(pl.weight_exp), out_exp=pl.out_exp, bound=list(pl.bound))
 
 
 def shard_games(n_games, rank, world_size):

@@ -104,3 +104,19 @@ def test_f16x2_search_runs_and_differs_from_f32_only_by_rounding(oracle, blob):
     b = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 60, nn_mode=oracle.ACC_FMA)
     assert np.abs(a["child_P"] - b["child_P"]).max() < 1e-6
     assert a["num_nodes"].shape == b["num_nodes"].shape
+
+
+def test_product_library_chooses_the_oracles_plan(oracle, blob, trained):
+    """The product's host-side plan (syn_f16x2_plan_of_blob: the code behind syn_set_network_arithmetic, no GPU involved) and the oracle's
+    independent restatement of it agree exponent for exponent and bound for bound on both checkpoints and on rescaled ones; a blob with a
+    non-finite parameter has no plan on either side."""
+    from synthesis_amd.engine import f16x2_plan_of_blob
+
+    for w in (blob, trained, (blob * np.float32(37.5)).astype(np.float32), (trained * np.float32(2.0 ** -9)).astype(np.float32)):
+        a, b = f16x2_plan_of_blob(w), oracle.f16x2_plan(w)
+        assert a is not None and b["ok"]
+        assert a["activation_exp"] == b["activation_exp"] and a["weight_exp"] == b["weight_exp"] and a["out_exp"] == b["out_exp"]
+        assert a["bound"] == b["bound"]
+    bad = blob.copy(); bad[7] = np.inf
+    assert f16x2_plan_of_blob(bad) is None and not oracle.f16x2_plan(bad)["ok"]
+
