@@ -97,8 +97,16 @@ class LearningLoop:
         self.dist.all_gather(counts, cnt)     # (also where a rank waits for the slowest rank's self-play to end)
         counts = [int(c.item()) for c in counts]
         self._last_gather_wait = time.perf_counter() - t_w
-        cap = max(max(counts), 1)
-        buf = np.empty(cap * self._POS_BYTES, np.uint8)
+        # every rank sends the same, slowly changing size: the largest count rounded up to 32,768 positions, so that the pack buffer and
+        # rank 0's receive buffers live across iterations (first-touch page faults of fresh 10 MB buffers were most of this phase)
+        cap = (max(max(counts), 1) + 32767) // 32768 * 32768
+        if getattr(self, "_gcap", 0) != cap:
+            self._gcap = cap
+            self._gbuf = np.zeros(cap * self._POS_BYTES, np.uint8)
+            self._gdev = t.empty(cap * self._POS_BYTES, dtype=t.uint8, device=dev) if on_gpu else None
+            like = self._gdev if on_gpu else t.from_numpy(self._gbuf)
+            self._gparts = [t.zeros_like(like) for _ in range(self.world)] if self.rank == 0 else None
+        buf = self._gbuf
         off = 0
         for name, dt, width in self._FIELDS:
             sec = buf[off: off + cap * np.dtype(dt).itemsize * width].view(dt)
@@ -106,8 +114,9 @@ class LearningLoop:
             off += cap * np.dtype(dt).itemsize * width
         mine = t.from_numpy(buf)
         if on_gpu:
-            mine = mine.to(dev)
-        parts = [t.empty_like(mine) for _ in range(self.world)] if self.rank == 0 else None
+            self._gdev.copy_(mine)
+            mine = self._gdev
+        parts = self._gparts
         self.dist.gather(mine, parts, dst=0)
         if self.rank != 0:
             return new

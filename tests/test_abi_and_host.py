@@ -175,7 +175,7 @@ def test_multi_rank_reduce_under_gloo(tmp_path):
 
 
 LOOP_WORKER = r'''
-import sys, json
+import os, sys, json
 sys.path.insert(0, sys.argv[1])
 import numpy as np
 import torch  # noqa
@@ -220,7 +220,8 @@ recs = [loop.iteration(None, 101, 150, 2, 32) for _ in range(3)]
 out = dict(rank=rank, world=world, w0=float(loop.weights[0]), wsum=float(loop.weights.astype(np.float64).sum()), loaded=eng.loaded,
            games=[r["games_this_rank"] for r in recs], unique=[r.get("unique") for r in recs], steps=[r.get("optimiser_steps") for r in recs],
            lr=[r["lr"] for r in recs], buffer=[r.get("steps_in_buffer") for r in recs])
-print("LOOP", json.dumps(out), flush=True)
+# one write per record (ranks share the pipe: print() issues the text and the newline separately, and records got cut into each other)
+os.write(1, ("LOOP " + json.dumps(out) + "\n").encode())
 if dist is not None:
     dist.barrier(); dist.destroy_process_group()
 '''
