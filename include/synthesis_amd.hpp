@@ -7,6 +7,7 @@
 //   synthesis::Connect4                              study-connect4/src/connect4.rs:108-258 (Game<9>: new, player, is_over,
 //                                                    reward, iter_actions, step, features)
 //   synthesis::Policy<G, N>::eval                    synthesis/src/policies/traits.rs:4-6
+//   synthesis::PolicyWithCache / OwnedPolicyWithCache policies/cache.rs:5-59 (host map in front of any Policy)
 //   synthesis::HipPolicy                             the `impl Policy<Connect4, 9>` a maintainer adds;
 //                                                    eval = batch of one, eval_batch = the throughput form
 //   synthesis::ReplayBuffer                          synthesis/src/data.rs:107-235 (new_game, add, extend,
@@ -25,6 +26,7 @@
 #include <limits>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -179,6 +181,54 @@ template <class G, int N>
 struct Policy {  // policies/traits.rs:4-6
     virtual ~Policy() = default;
     virtual std::pair<std::array<float, N>, std::array<float, 3>> eval(const G& game) = 0;
+};
+
+// ---- PolicyWithCache / OwnedPolicyWithCache (policies/cache.rs:5-59) ------------------------------------------------------
+// `HashMap<G, ([f32; N], [f32; 3])>` in front of a policy: a position seen before is answered from the map, a new one goes to the
+// policy and is remembered. G needs operator== and a hash (default std::hash<G>; Connect4's is below). PolicyWithCache borrows the
+// policy (the reference's `&'a mut P`: run_game wraps its worker's policy for the length of one game), OwnedPolicyWithCache holds it.
+// (On the device the same thing is Engine's policy_cache_log2: a lock-free table shared by all trees of a launch.)
+struct Connect4Hash {
+    size_t operator()(const Connect4& g) const {
+        uint64_t x = g.my_bb() * 0x9E3779B97F4A7C15ull ^ (g.op_bb() + 0x7F4A7C15F39CC060ull);
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+        return (size_t)x;
+    }
+};
+template <class G> struct DefaultGameHash { using type = std::hash<G>; };
+template <> struct DefaultGameHash<Connect4> { using type = Connect4Hash; };
+
+template <class G, int N, class Hash = typename DefaultGameHash<G>::type>
+class PolicyWithCache : public Policy<G, N> {
+public:
+    using Answer = std::pair<std::array<float, N>, std::array<float, 3>>;
+    PolicyWithCache(size_t capacity, Policy<G, N>& policy) : policy(policy) { cache.reserve(capacity); }   // with_capacity
+    Answer eval(const G& game) override {
+        const auto it = cache.find(game);
+        if (it != cache.end()) return it->second;
+        const Answer pi_v = policy.eval(game);
+        cache.emplace(game, pi_v);
+        return pi_v;
+    }
+    Policy<G, N>& policy;
+    std::unordered_map<G, Answer, Hash> cache;
+};
+
+template <class G, int N, class P, class Hash = typename DefaultGameHash<G>::type>
+class OwnedPolicyWithCache : public Policy<G, N> {
+public:
+    using Answer = std::pair<std::array<float, N>, std::array<float, 3>>;
+    template <class... Args>
+    explicit OwnedPolicyWithCache(size_t capacity, Args&&... policy_args) : policy(std::forward<Args>(policy_args)...) { cache.reserve(capacity); }
+    Answer eval(const G& game) override {
+        const auto it = cache.find(game);
+        if (it != cache.end()) return it->second;
+        const Answer pi_v = policy.eval(game);
+        cache.emplace(game, pi_v);
+        return pi_v;
+    }
+    P policy;
+    std::unordered_map<G, Answer, Hash> cache;
 };
 
 // One engine handle = one GPU + one stream + a device node pool (the reference's "one policy per worker thread").

@@ -19,6 +19,7 @@
 //                                           fill_state_info / store_rewards (alpha_zero.rs:229-338), one StdRng per game
 //   synthesis::lockstep_*_sharded           the same with one policy per host thread (gather_experience's worker model)
 //   synthesis::CombiningPolicy<G, N>        one (GPU) policy shared by the workers of a sharded driver: their batches go out combined
+//   synthesis::BatchPolicyWithCache         policies/cache.rs:5-59 in front of a BatchPolicy (Owned...: holding it)
 //   synthesis::HipBatchPolicy               BatchPolicy<Connect4, 9> over an evaluation context of the engine (syn_eval_ctx_*)
 //
 // Numerics: the f32 expression order of mcts.rs, exp / ln through the same deterministic restatements the device and the oracle
@@ -39,6 +40,7 @@
 #include <mutex>
 #include <numeric>
 #include <thread>
+#include <unordered_map>
 
 #include "synthesis_amd.hpp"
 #include "synthesis_amd_zig_tables.hpp"
@@ -1284,6 +1286,84 @@ private:
     std::vector<const G*> all_games_;
     std::vector<float> all_logits_, all_value_;
     size_t calls_ = 0;
+};
+
+// policies/cache.rs:5-59 for a batch policy. A batch is answered position by position in batch order, as the reference's sequential
+// eval calls would be: a position in the map (or seen EARLIER IN THE SAME BATCH — by then the reference would have inserted it) is
+// a hit; the first occurrences of the others go to the inner policy as ONE batch and are remembered. A deterministic policy gives
+// the same answers with or without the wrapper, so trees do not change — only the number of positions the policy sees.
+// One wrapper per worker (it is not thread-safe, like the reference's HashMap); `Policy` is BatchPolicy<G, N>& to borrow
+// (PolicyWithCache) or a BatchPolicy type to own (OwnedPolicyWithCache, constructed from the arguments after the capacity).
+template <class G, int N, class Hash = typename DefaultGameHash<G>::type>
+class BatchPolicyWithCache : public BatchPolicy<G, N> {
+public:
+    BatchPolicyWithCache(size_t capacity, BatchPolicy<G, N>& policy) : policy_(policy) { cache_.reserve(capacity); }   // with_capacity
+    void eval_batch(const std::vector<const G*>& games, float* logits, float* value) override {
+        const size_t n = games.size();
+        miss_games_.clear();
+        from_.assign(n, nullptr);
+        miss_slot_.assign(n, (size_t)-1);
+        pending_.clear();
+        for (size_t i = 0; i < n; i++) {
+            const auto it = cache_.find(*games[i]);
+            if (it != cache_.end()) {
+                from_[i] = &it->second;   // (unordered_map: references stay valid across the inserts below)
+                hits_++;
+                continue;
+            }
+            const auto ins = pending_.emplace(*games[i], miss_games_.size());
+            if (ins.second) miss_games_.push_back(games[i]);
+            else hits_++;   // same position earlier in this batch
+            miss_slot_[i] = ins.first->second;
+        }
+        if (!miss_games_.empty()) {
+            miss_logits_.resize(miss_games_.size() * (size_t)N);
+            miss_value_.resize(miss_games_.size() * 3);
+            policy_.eval_batch(miss_games_, miss_logits_.data(), miss_value_.data());
+            misses_ += miss_games_.size();
+            for (size_t k = 0; k < miss_games_.size(); k++) {
+                Answer a;
+                std::memcpy(a.logits, &miss_logits_[k * (size_t)N], sizeof(a.logits));
+                std::memcpy(a.value, &miss_value_[k * 3], sizeof(a.value));
+                cache_.emplace(*miss_games_[k], a);
+            }
+        }
+        for (size_t i = 0; i < n; i++) {
+            const float* lg = from_[i] ? from_[i]->logits : &miss_logits_[miss_slot_[i] * (size_t)N];
+            const float* vv = from_[i] ? from_[i]->value : &miss_value_[miss_slot_[i] * 3];
+            std::memcpy(logits + i * (size_t)N, lg, (size_t)N * sizeof(float));
+            std::memcpy(value + i * 3, vv, 3 * sizeof(float));
+        }
+    }
+    size_t hits() const { return hits_; }
+    size_t misses() const { return misses_; }     // positions the inner policy was asked for
+    size_t size() const { return cache_.size(); }
+    void clear() { cache_.clear(); }
+
+private:
+    struct Answer { float logits[N]; float value[3]; };
+    BatchPolicy<G, N>& policy_;
+    std::unordered_map<G, Answer, Hash> cache_;
+    std::unordered_map<G, size_t, Hash> pending_;
+    std::vector<const G*> miss_games_;
+    std::vector<const Answer*> from_;
+    std::vector<size_t> miss_slot_;
+    std::vector<float> miss_logits_, miss_value_;
+    size_t hits_ = 0, misses_ = 0;
+};
+template <class G, int N, class P, class Hash = typename DefaultGameHash<G>::type>
+class OwnedBatchPolicyWithCache : public BatchPolicy<G, N> {
+public:
+    template <class... Args>
+    explicit OwnedBatchPolicyWithCache(size_t capacity, Args&&... policy_args)
+        : policy(std::forward<Args>(policy_args)...), cached_(capacity, policy) {}
+    void eval_batch(const std::vector<const G*>& games, float* logits, float* value) override { cached_.eval_batch(games, logits, value); }
+    size_t hits() const { return cached_.hits(); }
+    size_t misses() const { return cached_.misses(); }
+    P policy;
+
+private:
+    BatchPolicyWithCache<G, N, Hash> cached_;
 };
 
 // BatchPolicy<Connect4, 9> on the GPU: one worker's policy = one evaluation context of the engine (syn_eval_ctx: its own stream

@@ -47,10 +47,12 @@ struct AsyncOraclePolicy : OraclePolicy {
 struct Policies {
     std::vector<std::unique_ptr<OraclePolicy>> owned;
     std::unique_ptr<CombiningPolicy<Connect4, 9>> combined;
+    std::vector<std::unique_ptr<BatchPolicyWithCache<Connect4, 9>>> cached;   // LS_CACHE = 1: policies/cache.rs in front of each
     std::vector<BatchPolicy<Connect4, 9>*> list;
     Policies(size_t n, const float* blob) {
         const char* a = std::getenv("LS_ASYNC");
         const char* c = std::getenv("LS_COMBINE");
+        const char* k = std::getenv("LS_CACHE");
         const bool combine = c && c[0] == '1';
         for (size_t i = 0; i < (combine ? 1 : n); i++) {
             owned.emplace_back(a && a[0] == '1' ? new AsyncOraclePolicy : new OraclePolicy);
@@ -61,8 +63,17 @@ struct Policies {
             combined.reset(new CombiningPolicy<Connect4, 9>(*owned[0], n));
             list = combined->workers();
         }
+        if (k && k[0] == '1') {
+            for (auto& p : list) {
+                cached.emplace_back(new BatchPolicyWithCache<Connect4, 9>(1024, *p));
+                p = cached.back().get();
+            }
+        }
     }
     size_t calls() const { size_t c = 0; for (const auto& p : owned) c += p->calls; return c; }
+    size_t positions() const { size_t c = 0; for (const auto& p : owned) c += p->positions; return c; }
+    size_t hits() const { size_t c = 0; for (const auto& p : cached) c += p->hits(); return c; }
+    size_t misses() const { size_t c = 0; for (const auto& p : cached) c += p->misses(); return c; }
 };
 
 // Take 1, 2 or 3 stones; whoever takes the last stone wins. Game<3>.
@@ -112,7 +123,49 @@ struct UniformThrowingPolicy : BatchPolicy<ThrowingNim, 3> {
     }
 };
 
+// policies/cache.rs for single positions: a policy that counts its calls, behind the borrowing and the owning wrapper
+struct CountingNimPolicy : Policy<Nim, 3> {
+    size_t calls = 0;
+    std::pair<std::array<float, 3>, std::array<float, 3>> eval(const Nim& g) override {
+        calls++;
+        return {{(float)g.stones, 0.5f, -1.0f}, {0.25f, 0.5f, 0.25f}};
+    }
+};
+struct NimHash { size_t operator()(const Nim& g) const { return (size_t)g.stones * 2u + (size_t)g.to_move; } };
+inline bool operator==(const Nim& a, const Nim& b) { return a.stones == b.stones && a.to_move == b.to_move; }
+
 int main(int argc, char** argv) {
+    if (argc >= 2 && std::string(argv[1]) == "cachepolicy") {
+        CountingNimPolicy inner;
+        PolicyWithCache<Nim, 3, NimHash> borrowed(16, inner);
+        OwnedPolicyWithCache<Nim, 3, CountingNimPolicy, NimHash> owned(16);
+        int wrong = 0;
+        for (int round = 0; round < 3; round++)
+            for (int st = 1; st <= 10; st++) {
+                Nim g; g.stones = st; g.to_move = (st & 1) ? Nim::First : Nim::Second;
+                const auto a = borrowed.eval(g), b = owned.eval(g);
+                wrong += a.first[0] != (float)st || b.first[0] != (float)st || a.second[1] != 0.5f || b.second[1] != 0.5f;
+            }
+        Nim other; other.stones = 3; other.to_move = Nim::Second;   // same stones as an entry, other side to move: a different key
+        borrowed.eval(other);
+        std::printf("borrowed calls %zu entries %zu owned calls %zu entries %zu wrong %d\n", inner.calls, borrowed.cache.size(),
+                    owned.policy.calls, owned.cache.size(), wrong);
+        // Connect4's default hash: two positions with the stones swapped are different keys
+        struct C4Count : Policy<Connect4, 9> {
+            size_t calls = 0;
+            std::pair<std::array<float, 9>, std::array<float, 3>> eval(const Connect4& g) override {
+                calls++;
+                std::pair<std::array<float, 9>, std::array<float, 3>> o{};
+                o.first[0] = (float)(g.my_bb() & 0xFFFF);
+                return o;
+            }
+        } c4;
+        PolicyWithCache<Connect4, 9> c4c(8, c4);
+        const Connect4 a = Connect4::from_bitboards(1, 128), b = Connect4::from_bitboards(128, 1);
+        for (int i = 0; i < 4; i++) { c4c.eval(a); c4c.eval(b); }
+        std::printf("connect4 calls %zu entries %zu first %g %g\n", c4.calls, c4c.cache.size(), c4c.eval(a).first[0], c4c.eval(b).first[0]);
+        return 0;
+    }
     if (argc >= 2 && std::string(argv[1]) == "nimthrow") {
         // 256 trees on 4 threads; the roots with 8..10 stones reach the forbidden position in their first expansion
         UniformThrowingPolicy policy;
@@ -319,6 +372,7 @@ int main(int argc, char** argv) {
     }
     std::ofstream of(argv[7], std::ios::binary);
     of.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * sizeof(syn_search_result)));
-    std::printf("rounds %zu evals %zu calls %zu\n", rounds, evals, policies.calls());
+    std::printf("rounds %zu evals %zu calls %zu positions %zu hits %zu misses %zu\n", rounds, evals, policies.calls(), policies.positions(),
+                policies.hits(), policies.misses());
     return 0;
 }

@@ -74,7 +74,7 @@ def test_lockstep_trees_equal_the_sequential_oracle(harness, oracle, golden_dir)
         got = records(out, len(my))
         ref = oracle.c4_mcts_search(parity_mcts_config(**VARIANTS[variant]), blob, my, op, explores, nn_mode=oracle.ACC_FMA)
         assert_search_equal(got, ref, f"lockstep variant {variant} explores {explores}")
-        rounds, evals, calls = [int(x) for x in p.stdout.split()[1::2]]
+        rounds, evals, calls = [int(x) for x in p.stdout.split()[1:6:2]]
         # one batched call per round, and rounds are bounded by the deepest tree: construction + explores — per group of trees that
         # shares its calls: all of them on a pool, two halves taking turns on one thread, two halves per shard
         groups = 1 if threads > 1 else 2 * abs(max(threads, -4))
@@ -153,6 +153,36 @@ def test_lockstep_selfplay_equals_the_sequential_oracle(harness, oracle, golden_
         assert_games_equal(got, ref, f"lockstep self-play variant {variant}")
         rounds, evals, calls = [int(x) for x in p.stdout.split()[1::2]]
         assert (calls <= rounds if env.get("LS_COMBINE") else calls == rounds) and evals <= int(ref["plies"].sum()) * (explores + 1)
+
+
+def test_policy_cache_wrappers_change_nothing_but_the_policys_work(harness, oracle):
+    """policies/cache.rs:5-59 on the host: BatchPolicyWithCache in front of the batch policy of every worker leaves every tree as it
+    was (same records, byte for byte) while the inner policy sees fewer positions — each position once per worker — and the
+    single-position PolicyWithCache / OwnedPolicyWithCache call their policy once per distinct key (the side to move is part of it)."""
+    exe, blobf, d = harness
+    my, op = random_positions(oracle, 24, seed=77, max_moves=40)
+    my = np.concatenate([my, my[:8]]); op = np.concatenate([op, op[:8]])      # repeated roots: the same positions come up again
+    roots = str(d / "roots_cache.u64")
+    np.concatenate([my, op]).astype("<u8").tofile(roots)
+    outs = {}
+    for cache in ("0", "1"):
+        for threads in ("1", "-2"):
+            out = str(d / f"cache_{cache}_{threads}.bin")
+            txt = subprocess.check_output([exe, "c4", blobf, roots, "150", "0", threads, out], env=dict(os.environ, LS_CACHE=cache)).decode()
+            f = dict(zip(txt.split()[0::2], map(int, txt.split()[1::2])))
+            outs[cache, threads] = (open(out, "rb").read(), f)
+    for threads in ("1", "-2"):
+        plain, cached = outs["0", threads], outs["1", threads]
+        assert plain[0] == cached[0]
+        assert plain[1]["positions"] == plain[1]["evals"] and plain[1]["hits"] == 0
+        assert cached[1]["evals"] == plain[1]["evals"]                       # the trees ask the same questions
+        assert cached[1]["hits"] + cached[1]["misses"] == cached[1]["evals"] and cached[1]["positions"] == cached[1]["misses"]
+        assert cached[1]["hits"] > 0                                         # transpositions
+        if threads == "1":   # one worker, one map: the eight repeated roots alone are a quarter of the work
+            assert cached[1]["hits"] > 0.2 * cached[1]["evals"]
+    txt = subprocess.check_output([exe, "cachepolicy"]).decode().splitlines()
+    assert txt[0] == "borrowed calls 11 entries 11 owned calls 10 entries 10 wrong 0"
+    assert txt[1] == "connect4 calls 2 entries 2 first 1 128"
 
 
 def test_lockstep_driver_is_generic_over_the_game(harness):
