@@ -45,9 +45,12 @@ class LearningLoop:
     blob         initial parameters — identical on every rank (P::new(&vs), alpha_zero.rs:31)
     precision    "f32" | "bf16" (Connect4ConvNet's learner only: syn_trainer_set_precision)
     dist         torch.distributed (initialised) or None for one rank
+    logs_dir     None, or where the learner's rank writes what the reference writes per iteration (alpha_zero.rs:37,97-100):
+                 models/model_{i}.ot (Connect4Net: a VarStore archive `vs.load` reads; Connect4ConvNet: the flat blob as .npy) and
+                 latest_states.npy [n, 1, 7, 9] / latest_pis.npy [n, 9] / latest_vs.npy [n, 3] of the de-duplicated buffer
     """
 
-    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, precision="f32", **hyper):
+    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, precision="f32", logs_dir=None, **hyper):
         import torch
 
         self._torch = torch
@@ -76,6 +79,21 @@ class LearningLoop:
                       v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
         self.games_played = 0
         self.iterations_done = 0
+        self.logs_dir = logs_dir if self.rank == 0 else None
+        if self.logs_dir:
+            self._save_model(0)
+
+    def _save_model(self, i):
+        import os
+
+        from .weights import save_ot
+
+        d = os.path.join(self.logs_dir, "models")
+        os.makedirs(d, exist_ok=True)
+        if self.net == "mlp":
+            save_ot(self.weights, os.path.join(d, f"model_{i}.ot"))
+        else:
+            np.save(os.path.join(d, f"model_{i}.npy"), self.weights)
 
     # one replay position on the wire: my_bb, op_bb (u64), gid (i64), pi[9], v[3] (f32) = 72 bytes, no pickling. A rank's buffer is
     # five contiguous sections [my | op | gid | pi | v] of `cap` positions each (five block copies to pack, views to unpack).
@@ -176,6 +194,14 @@ class LearningLoop:
             t_train = time.perf_counter() - t3
             self.weights = self.engine.trainer_state()["weights"]
             rec.update(steps_in_buffer=int(self.R["my"].size), unique=n_unique, optimiser_steps=steps, epoch_losses=epoch_losses)
+            if self.logs_dir:   # alpha_zero.rs:97-100
+                import os
+
+                self._save_model(it + 1)
+                np.save(os.path.join(self.logs_dir, "latest_states.npy"),
+                        np.asarray(self.engine.features(D["my_bb"], D["op_bb"]), np.float32).reshape(-1, 1, 7, 9))
+                np.save(os.path.join(self.logs_dir, "latest_pis.npy"), np.asarray(D["pis"], np.float32).reshape(-1, 9))
+                np.save(os.path.join(self.logs_dir, "latest_vs.npy"), np.asarray(D["vs"], np.float32).reshape(-1, 3))
         # ---- model_{i+1} (alpha_zero.rs:97,194): the trained parameters become every rank's self-play network
         t4 = time.perf_counter()
         if self.dist is not None:

@@ -211,11 +211,13 @@ class StandInEngine:
         return np.ones((steps, 2), np.float32)
     def trainer_state(self): return dict(weights=self.tw.copy(), step=self.steps)
     def trainer_publish_weights(self): self.load_weights(self.tw)
+    def features(self, my, op): return np.zeros((np.asarray(my).size, 63), np.float32)
 
 rank, local_rank, world = dist_util.rank_info()
 dist = dist_util.init_process_group("gloo") if world > 1 else None
 eng = StandInEngine()
-loop = LearningLoop(eng, "mlp", np.full(NUM_PARAMS, 0.5, np.float32), dist=dist, seed=3, lr_schedule=[(1, 1e-3), (2, 5e-4)])
+loop = LearningLoop(eng, "mlp", np.full(NUM_PARAMS, 0.5, np.float32), dist=dist, seed=3, lr_schedule=[(1, 1e-3), (2, 5e-4)],
+                    logs_dir=sys.argv[2] if len(sys.argv) > 2 else None)
 recs = [loop.iteration(None, 101, 150, 2, 32) for _ in range(3)]
 out = dict(rank=rank, world=world, w0=float(loop.weights[0]), wsum=float(loop.weights.astype(np.float64).sum()), loaded=eng.loaded,
            games=[r["games_this_rank"] for r in recs], unique=[r.get("unique") for r in recs], steps=[r.get("optimiser_steps") for r in recs],
@@ -241,9 +243,18 @@ def test_learning_loop_collectives_under_gloo(tmp_path):
         [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
          "127.0.0.1", "--master-port", port, str(script), ROOT], env=env, stderr=subprocess.STDOUT, timeout=300).decode()
     two = sorted((json.loads(m) for m in re.findall(r"LOOP (\{[^{}]*\})", out)), key=lambda d: d["rank"])
-    one = json.loads([l for l in subprocess.check_output([sys.executable, str(script), ROOT], env=env, stderr=subprocess.STDOUT,
+    logs = tmp_path / "logs"
+    one = json.loads([l for l in subprocess.check_output([sys.executable, str(script), ROOT, str(logs)], env=env, stderr=subprocess.STDOUT,
                                                           timeout=300).decode().splitlines() if l.startswith("LOOP")][0].split(" ", 1)[1])
     assert len(two) == 2 and two[0]["world"] == 2 and one["world"] == 1
+    # what the reference writes per iteration (alpha_zero.rs:37,97-100): model_0.ot .. model_3.ot and the latest de-duplicated tensors
+    from synthesis_amd.weights import load_ot
+    assert sorted(os.listdir(logs / "models")) == [f"model_{i}.ot" for i in range(4)]
+    assert float(load_ot(str(logs / "models" / "model_0.ot"))[0]) == 0.5
+    last = load_ot(str(logs / "models" / "model_3.ot"))
+    assert float(last[0]) == one["w0"] and float(last.astype(np.float64).sum()) == one["wsum"]
+    st, pis, vs = (np.load(logs / f"latest_{k}.npy") for k in ("states", "pis", "vs"))
+    assert st.shape == (one["unique"][2], 1, 7, 9) and pis.shape == (one["unique"][2], 9) and vs.shape == (one["unique"][2], 3)
     assert two[0]["games"] == [51, 51, 51] and two[1]["games"] == [50, 50, 50] and one["games"] == [101, 101, 101]
     assert two[0]["w0"] == two[1]["w0"] == one["w0"] and two[0]["wsum"] == two[1]["wsum"] == one["wsum"]
     assert two[0]["loaded"] == two[1]["loaded"] and len(two[1]["loaded"]) == 4   # the initial network + one broadcast per iteration
