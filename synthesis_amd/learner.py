@@ -45,12 +45,15 @@ class LearningLoop:
     blob         initial parameters — identical on every rank (P::new(&vs), alpha_zero.rs:31)
     precision    "f32" | "bf16" (Connect4ConvNet's learner only: syn_trainer_set_precision)
     dist         torch.distributed (initialised) or None for one rank
+    sampler      "numpy" (default: numpy's PCG64 permutation seeded by (seed, iteration, epoch)) | "torch": BatchRandSampler's own
+                 `Tensor::randperm(n, INT64_CPU)` (data.rs:29) — libtorch's CPU randperm from ONE generator seeded with `seed` and
+                 advanced epoch after epoch, i.e. the stream a reference run started with `tch::manual_seed(seed)` draws from
     logs_dir     None, or where the learner's rank writes what the reference writes per iteration (alpha_zero.rs:37,97-100):
                  models/model_{i}.ot (Connect4Net: a VarStore archive `vs.load` reads; Connect4ConvNet: the flat blob as .npy) and
                  latest_states.npy [n, 1, 7, 9] / latest_pis.npy [n, 9] / latest_vs.npy [n, 3] of the de-duplicated buffer
     """
 
-    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, precision="f32", logs_dir=None, **hyper):
+    def __init__(self, engine, net, blob, dist=None, device=0, lr_schedule=((1, 1e-3),), seed=0, precision="f32", logs_dir=None, sampler="numpy", **hyper):
         import torch
 
         self._torch = torch
@@ -79,6 +82,10 @@ class LearningLoop:
                       v=np.zeros((0, 3), np.float32), gid=np.zeros(0, np.int64))
         self.games_played = 0
         self.iterations_done = 0
+        if sampler not in ("numpy", "torch"):
+            raise ValueError(f"sampler must be 'numpy' or 'torch', got {sampler!r}")
+        self.sampler = sampler
+        self._torch_gen = torch.Generator().manual_seed(self.seed) if sampler == "torch" else None
         self.logs_dir = logs_dir if self.rank == 0 else None
         if self.logs_dir:
             self._save_model(0)
@@ -186,7 +193,10 @@ class LearningLoop:
             steps, epoch_losses = 0, []
             n_steps = n_unique // batch_size   # drop_last = true (data.rs:41-62)
             for ep in range(epochs):
-                perm = np.random.default_rng([self.seed, it, ep]).permutation(n_unique)   # BatchRandSampler's randperm
+                if self.sampler == "torch":   # BatchRandSampler::new (data.rs:29)
+                    perm = self._torch.randperm(n_unique, generator=self._torch_gen, dtype=self._torch.int64).numpy()
+                else:
+                    perm = np.random.default_rng([self.seed, it, ep]).permutation(n_unique)
                 if n_steps:
                     sl = self.engine.train_epoch(perm[: n_steps * batch_size], batch_size, lr)
                     epoch_losses.append((sl.astype(np.float64).sum(axis=0) * batch_size / n_unique).tolist())

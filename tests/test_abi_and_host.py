@@ -265,6 +265,33 @@ def test_learning_loop_collectives_under_gloo(tmp_path):
     assert one["buffer"][2] < one["buffer"][1] + sum(7 + g % 5 for g in range(202, 303))
 
 
+def test_learning_loop_torch_sampler_is_libtorchs_randperm_stream():
+    """sampler="torch": the epochs' orders are BatchRandSampler's own `Tensor::randperm(n, INT64_CPU)` (data.rs:29) — successive
+    draws of ONE libtorch CPU generator seeded once, as in a reference run after tch::manual_seed — cut to whole batches
+    (drop_last = true, data.rs:41-62). The stand-in engine of the collective tests records what the learner is handed."""
+    import torch
+
+    from synthesis_amd.engine import NUM_PARAMS
+    from synthesis_amd.learner import LearningLoop
+
+    ns = {"np": np}
+    exec("class StandInEngine:" + LOOP_WORKER.split("class StandInEngine:")[1].split("rank, local_rank, world")[0], ns)
+    perms = []
+
+    class Recording(ns["StandInEngine"]):
+        def train_epoch(self, perm, batch, lr):
+            perms.append(np.array(perm))
+            return super().train_epoch(perm, batch, lr)
+
+    loop = LearningLoop(Recording(), "mlp", np.full(NUM_PARAMS, 0.5, np.float32), seed=11, sampler="torch")
+    recs = [loop.iteration(None, 101, 150, 2, 32) for _ in range(2)]
+    g = torch.Generator().manual_seed(11)
+    want = [torch.randperm(r["unique"], generator=g).numpy()[: r["unique"] // 32 * 32] for r in recs for _ in range(2)]
+    assert len(perms) == 4 and all(np.array_equal(a, b) for a, b in zip(perms, want))
+    with pytest.raises(ValueError):
+        LearningLoop(Recording(), "mlp", np.full(NUM_PARAMS, 0.5, np.float32), sampler="mt19937")
+
+
 def test_eight_ranks_under_gloo(tmp_path):
     """The shape an 8-GPU node runs (BASELINE configs[3] / [4]) with world_size 8 on CPU (gloo): dist_util.step_game_range + the
     barrier / MAX / SUM reduction of bench.py, and LearningLoop's fixed-layout gather with UNEVEN per-rank position counts (101 games
