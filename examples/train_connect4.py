@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) | gloo (every rank on GPU 0: tests)")
     ap.add_argument("--reference-fpu", action="store_true", help="self-play with Fpu::Func(|| Normal(1.0, 0.1)) (main.rs:43-47)")
     ap.add_argument("--dump-weights", default="", help="write the final weights of every rank to <prefix>.rank<r>.npy")
+    ap.add_argument("--sampler", default="numpy", choices=["numpy", "torch"], help="order of an epoch's batches: numpy's PCG64 or "
+                    "libtorch's randperm stream (what the reference's BatchRandSampler draws, data.rs:29); learning loop only")
     ap.add_argument("--logs", default="", help="directory for what the reference writes per iteration (alpha_zero.rs:37,97-100): "
                     "models/model_{i}.ot and latest_{states,pis,vs}.npy (the learning loop's rank 0)")
     ap.add_argument("--net", default="mlp", choices=["mlp", "conv"], help="mlp = the reference's Connect4Net; conv = Connect4ConvNet "
@@ -105,7 +107,7 @@ def main():
         games_played = 0
     else:
         loop = LearningLoop(eng, args.net, blob, dist=dist, device=local_rank, lr_schedule=lr_schedule, seed=args.seed,
-                            precision=args.precision, logs_dir=args.logs or None, **hyper)
+                            precision=args.precision, logs_dir=args.logs or None, sampler=args.sampler, **hyper)
     log = []
     eval_eng = None
     for it in range(args.iterations):
