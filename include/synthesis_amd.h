@@ -443,9 +443,14 @@ int syn_debug_stdrng_u32(syn_engine* h, uint64_t seed, int n, uint32_t* out);
 int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
                    float* out_sqrt_a);
 
-/* fast[i] = the packed division of the lane / producer-consumer kernels' descent (device_common.cuh div2_safe_range) on
- * a[i] / b[i]; full[i] = the device's IEEE division. Equal bit for bit for a = 0 or 2^-60 <= a <= 2^60 and 1 <= b <= 2^16. */
+/* fast[i] = the packed division of the lane / producer-consumer kernels' descent (device_common.cuh div2_by_small_int) on
+ * a[i] / b[i]; full[i] = the device's IEEE division. Equal bit for bit for a = 0 or 2^-60 <= a <= 2^60 and INTEGER 1 <= b <= 2^16. */
 int syn_debug_fast_div(syn_engine* h, const float* a, const float* b, int n, float* out_fast, float* out_full);
+/* Enumeration behind the descent's shortened sequences: every f32 significand (2^23) at three exponents against every integer
+ * divisor b_lo .. b_hi, and every significand at four exponents under the square root. mismatches3[0] = quotients where
+ * div2_by_small_int differs from the IEEE division, [1] = the same for div2_safe_range, [2] = square roots where sqrt_normal_range
+ * differs from sqrtf. All three must be 0. */
+int syn_debug_small_int_math(syn_engine* h, int b_lo, int b_hi, unsigned long long* mismatches3);
 
 /* PMC calibration probe (tools/calibrate_pmc.py): gathers n_spans 288-byte sibling spans of 32-byte node records at
  * record offsets d_span_off[i] from d_base (device pointers), optionally rewriting 16 bytes per touched record. */

@@ -220,6 +220,29 @@ SYN_DEV f32x2 div2_by_shared(f32x2 a, float b, float y) {
     r = __builtin_elementwise_fma(nb, q, a);
     return __builtin_elementwise_fma(r, yy, q);
 }
+// a / b for INTEGER divisors 1 <= b <= 2^16 (explore_value's 1 + n): the same sequence with ONE residual correction. After the Newton
+// step y is within an ulp of 1 / b, q0 = RN(a y) within 3 ulp of a / b, its residual exact, and q1 = RN(q0 + r y) rounds a / b perturbed
+// by less than 2^-21 ulp — a quotient by a 16-bit divisor is never closer than 2^-17 ulp to a rounding boundary, so q1 is the IEEE
+// quotient and div2_safe_range's second correction returns it unchanged.
+SYN_DEV f32x2 div2_by_small_int(f32x2 a, f32x2 b) {
+    f32x2 y = f32x2{__builtin_amdgcn_rcpf(b[0]), __builtin_amdgcn_rcpf(b[1])};
+    const f32x2 e = __builtin_elementwise_fma(-b, y, f32x2{1.0f, 1.0f});
+    y = __builtin_elementwise_fma(e, y, y);
+    const f32x2 q = a * y;
+    const f32x2 r = __builtin_elementwise_fma(-b, q, a);
+    return __builtin_elementwise_fma(r, y, q);
+}
+// sqrtf(x) for 2^-60 <= x <= 2^60 (a visit count): the hardware's own correctly rounded sequence (v_sqrt_f32, then the two
+// neighbours tested with exact residuals) without the scaling it wraps around denormal inputs.
+SYN_DEV float sqrt_normal_range(float x) {
+    const float y = __builtin_amdgcn_sqrtf(x);
+    const float yd = bits_f32(f32_bits(y) - 1u), yu = bits_f32(f32_bits(y) + 1u);
+    const float rd = __builtin_fmaf(-yd, y, x);
+    const float ru = __builtin_fmaf(-yu, y, x);
+    float r = rd <= 0.0f ? yd : y;
+    r = ru > 0.0f ? yu : r;
+    return r;
+}
 // smallest non-zero prior the packed division accepts; records of smaller (or non-finite) priors carry a flag (sign bit)
 constexpr float PRIOR_SAFE_MIN = 0x1p-40f;
 

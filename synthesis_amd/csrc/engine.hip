@@ -2616,6 +2616,21 @@ int syn_debug_fast_div(syn_engine* h, const float* a, const float* b, int n, flo
     return SYN_OK;
 }
 
+int syn_debug_small_int_math(syn_engine* h, int b_lo, int b_hi, unsigned long long* mismatches3) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!mismatches3 || b_lo < 1 || b_hi < b_lo || b_hi > 65536) return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments");
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_scratch(h, 256);
+    if (rc != SYN_OK) return rc;
+    unsigned long long* dm = static_cast<unsigned long long*>(h->d_scratch);
+    HIP_TRY(h, hipMemsetAsync(dm, 0, 24, h->stream));
+    hipLaunchKernelGGL(debug_small_int_math_kernel, dim3((1u << 23) / 256), dim3(256), 0, h->stream, b_lo, b_hi, dm);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(mismatches3, dm, 24, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+
 int syn_debug_math(syn_engine* h, const float* a, const float* b, int n, float* out_exp_a, float* out_div,
                    float* out_sqrt_a) {
     if (!h) return SYN_ERR_INVALID_ARGUMENT;

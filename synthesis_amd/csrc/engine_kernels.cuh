@@ -998,10 +998,39 @@ __global__ void debug_fast_div_kernel(const float* a, const float* b, int n, flo
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
         const int j = i ^ 1;  // partner element: both halves of the packed instructions carry live data
-        const f32x2 q = div2_safe_range(f32x2{a[i], a[j < n ? j : i]}, f32x2{b[i], b[j < n ? j : i]});
+        const f32x2 q = div2_by_small_int(f32x2{a[i], a[j < n ? j : i]}, f32x2{b[i], b[j < n ? j : i]});   // (the descent's form)
         fast[i] = q[0];
         full[i] = a[i] / b[i];
     }
+}
+// Enumeration behind the descent's two shortened sequences (device_common.cuh): thread t takes the significand t (2^23 of them).
+// mism[0] += quotients a / b, a = 1.m x {2^-60, 1, 2^59}, b = b_lo .. b_hi (integers), where div2_by_small_int differs from the IEEE
+// division; mism[1] += the same for div2_safe_range; mism[2] += square roots of 1.m x {1, 2, 2^-60, 2^59} where sqrt_normal_range
+// differs from sqrtf.
+__global__ void debug_small_int_math_kernel(int b_lo, int b_hi, unsigned long long* mism) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= (1u << 23)) return;
+    const float scale[3] = {0x1p-60f, 1.0f, 0x1p59f};
+    uint32_t bad_small = 0, bad_safe = 0, bad_sqrt = 0;
+    for (int e = 0; e < 3; e++) {
+        const float a = bits_f32(0x3F800000u | m) * scale[e];   // (exact: a power of two)
+        for (int b = b_lo; b <= b_hi; b += 2) {
+            const float b0 = (float)b, b1 = (float)(b + 1 <= b_hi ? b + 1 : b);
+            const f32x2 q = div2_by_small_int(f32x2{a, a}, f32x2{b0, b1});
+            const f32x2 q2 = div2_safe_range(f32x2{a, a}, f32x2{b0, b1});
+            const float r0 = a / b0, r1 = a / b1;
+            bad_small += (f32_bits(q[0]) != f32_bits(r0)) + (f32_bits(q[1]) != f32_bits(r1));
+            bad_safe += (f32_bits(q2[0]) != f32_bits(r0)) + (f32_bits(q2[1]) != f32_bits(r1));
+        }
+    }
+    const float sq[4] = {1.0f, 2.0f, 0x1p-60f, 0x1p59f};
+    for (int e = 0; e < 4; e++) {
+        const float x = bits_f32(0x3F800000u | m) * sq[e];
+        bad_sqrt += f32_bits(sqrt_normal_range(x)) != f32_bits(sqrtf(x));
+    }
+    if (bad_small) atomicAdd(&mism[0], (unsigned long long)bad_small);
+    if (bad_safe) atomicAdd(&mism[1], (unsigned long long)bad_safe);
+    if (bad_sqrt) atomicAdd(&mism[2], (unsigned long long)bad_sqrt);
 }
 __global__ void debug_math_kernel(const float* a, const float* b, int n, float* e, float* d, float* s) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

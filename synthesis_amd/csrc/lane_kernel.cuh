@@ -277,7 +277,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
     unsigned long long lp_t1 = 0ull;
     if (lp) { lp_wait_vm(lp); lp_t1 = lp_now(); lp_add(lp, LP_A_WAIT, lp_t1 - lp_t0); }
     const float q_fpu = cfg.fpu_const() ? cfg.fpu_value() : -bits_f32(C.qt);  // parent.q() = -(stored q)
-    const float visits = cfg.puct() ? sqrtf(C.pN) : sqrtf(cfg.cc() * det_logf(C.pN));
+    const float visits = cfg.puct() ? (cfg_.fast_div != 0 ? sqrt_normal_range(C.pN) : sqrtf(C.pN)) : sqrtf(cfg.cc() * det_logf(C.pN));
     // select_best_child: sequential scan, `Some(v) > best` (strict: first maximum wins, NaN never replaces). Slots past
     // the last child hold -inf / prior 0 (st_rec_none), so all nine are scored without a count check.
     // what an unexpanded, unsolved child scores under a non-constant FPU: the parent's q (Fpu::ParentQ), or one
@@ -317,7 +317,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
                 const uint32_t j = i + 1 < 9 ? i + 1 : i;
                 f32x2 a = f32x2{cfg.cc(), cfg.cc()} * f32x2{bits_f32(d[3 * i + 1]), bits_f32(d[3 * j + 1])};
                 a = a * f32x2{visits, visits};
-                uu[i >> 1] = div2_safe_range(a, f32x2{1.0f, 1.0f} + f32x2{nf_N(d[3 * i + 2]), nf_N(d[3 * j + 2])});
+                uu[i >> 1] = div2_by_small_int(a, f32x2{1.0f, 1.0f} + f32x2{nf_N(d[3 * i + 2]), nf_N(d[3 * j + 2])});
             }
         } else {
 #pragma unroll
@@ -792,17 +792,17 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 w_old = hdr.w;
                 uint32_t key = outcome_key(pm_solved(meta), pm_kind(meta), pe.w);
                 if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
+                uint32_t unsolved = 0u;   // (slots past the last child hold st_rec_none: not solved, masked by the count below)
 #pragma unroll
                 for (uint32_t i = 0; i < 9; i++) {
-                    if (i < nc) {
-                        const uint32_t nf = d[3 * i + 2];
-                        all_solved = all_solved && nf_solved(nf);
-                        // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
-                        const uint32_t ck = nf_kind(nf);
-                        const uint32_t rk = nf_solved(nf) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
-                        key = rk > key ? rk : key;
-                    }
+                    const uint32_t nf = d[3 * i + 2];
+                    unsolved |= nf_solved(nf) ? 0u : (1u << i);
+                    // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
+                    const uint32_t ck = nf_kind(nf);
+                    const uint32_t rk = nf_solved(nf) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
+                    key = rk > key ? rk : key;
                 }
+                all_solved = (unsolved & ((1u << nc) - 1u)) == 0u;
                 outcome_from_key(key, bsome, bkind, bturns);
             }
             first = false;

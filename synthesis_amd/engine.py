@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "syn_policy_eval_batch", "syn_policy_eval_batch_device", "syn_eval_ctx_create", "syn_eval_ctx_submit", "syn_eval_ctx_wait",
     "syn_eval_ctx_eval", "syn_eval_ctx_last_error", "syn_eval_ctx_destroy", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_selfplay_run_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
-    "syn_debug_math", "syn_debug_fast_div", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
+    "syn_debug_math", "syn_debug_fast_div", "syn_debug_small_int_math", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
     "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
 
@@ -140,6 +140,7 @@ def load_library():
     lib.syn_last_cache_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.syn_debug_stdrng_u32.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     lib.syn_debug_fast_div.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.syn_debug_small_int_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.syn_debug_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.syn_default_rollout_config.argtypes = [C.POINTER(CRolloutConfig)]
     lib.syn_debug_calibrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -616,6 +617,12 @@ class Engine:
         f = np.zeros_like(a); d = np.zeros_like(a)
         self._check(self._lib.syn_debug_fast_div(self._h, _p(a), _p(b), int(a.size), _p(f), _p(d)))
         return f, d
+
+    def debug_small_int_math(self, b_lo, b_hi):
+        """(mismatches of div2_by_small_int, of div2_safe_range, of sqrt_normal_range) over every significand: see synthesis_amd.h"""
+        out = np.zeros(3, np.uint64)
+        self._check(self._lib.syn_debug_small_int_math(self._h, int(b_lo), int(b_hi), _p(out)))
+        return tuple(int(x) for x in out)
 
     def debug_math(self, a, b):
         a = np.ascontiguousarray(a, np.float32).ravel()

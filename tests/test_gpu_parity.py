@@ -85,8 +85,19 @@ def test_slimnn_activation_layers_match_oracle(engine, oracle):
         engine.activation(7, rows)
 
 
+def test_descent_division_and_square_root_are_ieee_exact_by_enumeration(engine):
+    """The two shortened sequences of the descent (device_common.cuh) against the device's IEEE operations over EVERY f32
+    significand: div2_by_small_int (one residual correction) for every integer divisor 1 .. 8,192 — beyond any 1 + n a tree can hold
+    (max_explores <= 7,280) — at three exponents (2.1e11 quotients), plus divisors up to 2^16 in blocks; div2_safe_range (two
+    corrections: the softmax sums' form) on the same operands; sqrt_normal_range at both exponent parities and near the ends of its
+    range (3.4e7 roots). Not one bit differs."""
+    assert engine.debug_small_int_math(1, 8192) == (0, 0, 0)
+    for lo in (8193, 20000, 32768, 65000):
+        assert engine.debug_small_int_math(lo, lo + 535) == (0, 0, 0)
+
+
 def test_packed_division_is_ieee_exact_on_its_range(engine):
-    """device_common.cuh div2_safe_range (two quotients per v_pk_fma stream, used by the descent's explore_value): equal to the
+    """device_common.cuh div2_by_small_int (two quotients per v_pk_fma stream, used by the descent's explore_value): equal to the
     IEEE quotient bit for bit for a = 0 or 2^-60 <= a <= 2^60 and integer-valued 1 <= b <= 2^16 — the only range it is used on
     (numerator c * prior * sqrt(N), denominator 1 + n; priors below 2^-40 are flagged and take the full division)."""
     rng = np.random.RandomState(7)
