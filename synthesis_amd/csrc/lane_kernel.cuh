@@ -792,17 +792,21 @@ SYN_DEV void lane_backprop(const DevMctsCfg& cfg_, LaneTree& T, int depth, float
                 w_old = hdr.w;
                 uint32_t key = outcome_key(pm_solved(meta), pm_kind(meta), pe.w);
                 if (COUNT) ctr[CTR_SOLVER_CHILDREN] += nc;
-                uint32_t unsolved = 0u;   // (slots past the last child hold st_rec_none: not solved, masked by the count below)
+                // (selects, not nine branches: a slot past the last child contributes nothing — a terminal node's block, read here as
+                //  the leaf by the kernels without LEAF_KNOWN, has no initialised slots at all)
+                const uint32_t live = (1u << nc) - 1u;
+                uint32_t unsolved = 0u;
 #pragma unroll
                 for (uint32_t i = 0; i < 9; i++) {
                     const uint32_t nf = d[3 * i + 2];
-                    unsolved |= nf_solved(nf) ? 0u : (1u << i);
+                    const bool sol = nf_solved(nf) && ((live >> i) & 1u) != 0u;
+                    unsolved |= sol ? 0u : (1u << i);
                     // solution.map(reversed) (game.rs:29-35): Win<->Lose, Draw stays, turns + 1
                     const uint32_t ck = nf_kind(nf);
-                    const uint32_t rk = nf_solved(nf) ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
+                    const uint32_t rk = sol ? outcome_key(true, ck == 1u ? 1u : 2u - ck, d[3 * i] + 1u) : 0u;
                     key = rk > key ? rk : key;
                 }
-                all_solved = (unsolved & ((1u << nc) - 1u)) == 0u;
+                all_solved = (unsolved & live) == 0u;
                 outcome_from_key(key, bsome, bkind, bturns);
             }
             first = false;
