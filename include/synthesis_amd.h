@@ -43,11 +43,17 @@ typedef enum syn_status {
 enum { SYN_EXPLORATION_UCT = 0, SYN_EXPLORATION_POLYNOMIAL_UCT = 1 };
 /* config.rs:15-19 ActionSelection */
 enum { SYN_ACTION_Q = 0, SYN_ACTION_NUM_VISITS = 1 };
-/* config.rs:21-26 Fpu. Func(fn()->f32) is a host closure and cannot cross a C ABI; the closure the reference itself uses —
- * Normal::new(mean, std).sample(&mut thread_rng()) (study-connect4/src/main.rs:43-47) — runs on the device as
- * SYN_FPU_NORMAL {fpu_value = mean, fpu_std = std}: one draw per unexpanded child per select_best_child scan
- * (mcts.rs:351-356), from a per-tree StdRng stream instead of thread_rng (reproducible; csrc/noise.cuh). */
-enum { SYN_FPU_CONST = 0, SYN_FPU_PARENT_Q = 1, SYN_FPU_NORMAL = 2 };
+/* config.rs:21-26 Fpu. Func(fn() -> f32) is a plain function pointer (config.rs:25), called once per unexpanded child per
+ * select_best_child scan (mcts.rs:351-356):
+ *   SYN_FPU_FUNC {fpu_fn}: that pointer as `float (*)(void)`. A host function — it is called by the HOST trees of
+ *     syn_mcts_search_lockstep / syn_selfplay_run_lockstep (from their worker threads, as the reference calls it from its
+ *     workers: it must be thread-safe, like the reference's thread_rng closure); the device entry points (syn_mcts_search,
+ *     syn_selfplay_run, ...) refuse it with SYN_ERR_UNSUPPORTED — a kernel cannot call into the host.
+ *   SYN_FPU_NORMAL {fpu_value = mean, fpu_std = std}: the closure the reference itself configures —
+ *     Normal::new(mean, std).sample(&mut thread_rng()) (study-connect4/src/main.rs:43-47) — as a function the device can
+ *     compute too: the draw comes from a per-tree counter-based stream instead of thread_rng (reproducible; csrc/noise.cuh),
+ *     identical on the device and on the host trees. */
+enum { SYN_FPU_CONST = 0, SYN_FPU_PARENT_Q = 1, SYN_FPU_NORMAL = 2, SYN_FPU_FUNC = 3 };
 /* config.rs:39-44 PolicyNoise. Dirichlet{alpha, weight} (mcts.rs:241-256) samples rand_distr's Dirichlet on the device from
  * the tree's own stream (csrc/noise.cuh). */
 enum { SYN_NOISE_NONE = 0, SYN_NOISE_EQUAL = 1, SYN_NOISE_DIRICHLET = 2 };
@@ -70,6 +76,7 @@ typedef struct syn_mcts_config {
     float noise_alpha;                /* Dirichlet{alpha,..} */
     float noise_weight;               /* Equal{weight} / Dirichlet{..,weight} */
     float fpu_std;                    /* standard deviation of SYN_FPU_NORMAL (>= 0) */
+    float (*fpu_fn)(void);            /* SYN_FPU_FUNC: Fpu::Func's fn() -> f32 (config.rs:25); NULL otherwise */
 } syn_mcts_config;
 
 /* config.rs:46-56 RolloutConfig (num_workers has no meaning here: concurrency is syn_engine_config.concurrent_games) */
@@ -247,7 +254,7 @@ int syn_mcts_search_rollout(syn_engine* h, const syn_mcts_config* cfg, uint64_t 
  * advances the other — and the batches the workers hand in are combined into one launch on one evaluation context
  * (syn_eval_ctx_*). This is the driver a caller with a different Game impl instantiates; for Connect4 the fused syn_mcts_search
  * is the fast path and this entry point exists to hold the driver to it: results are identical, field for field. host_threads:
- * 0 = what the process may use (hardware concurrency cut to a cgroup CPU quota), at most 32. cfg: every configuration syn_mcts_search takes — SYN_FPU_NORMAL and SYN_NOISE_DIRICHLET
+ * 0 = what the process may use (hardware concurrency cut to a cgroup CPU quota), at most 32. cfg: every configuration syn_mcts_search takes and SYN_FPU_FUNC (a host function pointer: this is where it can be called) — SYN_FPU_NORMAL and SYN_NOISE_DIRICHLET
  * draw what syn_mcts_search draws (root i: tree stream (i, turn 0)). stats may be NULL. */
 typedef struct syn_lockstep_stats {
     uint64_t rounds;               /* evaluation launches (combined batches) */
@@ -264,7 +271,7 @@ int syn_mcts_search_lockstep(syn_engine* h, const syn_mcts_config* cfg, const ui
  * run_game / sample_action / fill_state_info / store_rewards (alpha_zero.rs:229-338) on the host with game g's own
  * StdRng::seed_from_u64(base_seed + g) (include/synthesis_amd_lockstep.hpp::lockstep_selfplay_sharded).
  * Arguments and outputs are syn_selfplay_run's; the games are identical to that call's, move for move and float for float.
- * host_threads as above; SYN_FPU_NORMAL (the reference's own self-play configuration) and SYN_NOISE_DIRICHLET included — the
+ * host_threads as above; SYN_FPU_FUNC, SYN_FPU_NORMAL (the reference's own self-play configuration) and SYN_NOISE_DIRICHLET included — the
  * host trees take the draws of syn_selfplay_run's trees; stats may be NULL. */
 int syn_selfplay_run_lockstep(syn_engine* h, const syn_rollout_config* cfg, uint64_t base_seed, uint64_t first_game, int n_games,
                               int host_threads, int32_t* plies, uint64_t* states_bb, float* pis, float* vs, uint8_t* actions,
@@ -365,6 +372,14 @@ int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, 
 int syn_train_gradients_device(syn_engine* h, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,
                                const float* d_target_v, int batch, float* d_grads, float* losses);
 int syn_train_apply_device(syn_engine* h, const float* d_grads, float lr, float grad_scale);
+/* The stream-ordered form of the same two calls (one optimiser step of alpha_zero.rs:76-92 split around the RCCL all-reduce, no host
+ * in between): both enqueue on `stream` (a hipStream_t of the engine's device: the stream the batch was prepared on and the all-reduce
+ * runs on; NULL = the engine's own) and return without synchronising. d_losses: DEVICE pointer to 2 floats {pi-loss sum, v-loss sum}
+ * of this rank's minibatch (may be NULL) — typically the two words behind the 30,492 gradients, so they ride in the same message.
+ * While a caller drives the trainer this way it keeps the engine's other trainer entry points (which use the engine's stream) idle. */
+int syn_train_gradients_enqueue(syn_engine* h, void* stream, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,
+                                const float* d_target_v, int batch, float* d_grads, float* d_losses);
+int syn_train_apply_enqueue(syn_engine* h, void* stream, const float* d_grads, float lr, float grad_scale);
 /* Arithmetic of the Connect4ConvNet learner's gradient step (forward, dZ, backward; BASELINE configs[4] words the on-node training
  * step "bf16 conv"): SYN_TRAIN_F32 (default after every syn_trainer_init*) = f32 matrix cores, bit-identical to the oracle;
  * SYN_TRAIN_BF16 = every matrix operand rounded to bf16 and multiplied on the bf16 matrix cores with f32 accumulation — master

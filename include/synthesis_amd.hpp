@@ -42,7 +42,8 @@ struct Error : std::runtime_error {
 // ---- config.rs ------------------------------------------------------------------------------------------------------
 enum class Exploration { Uct = SYN_EXPLORATION_UCT, PolynomialUct = SYN_EXPLORATION_POLYNOMIAL_UCT };
 enum class ActionSelection { Q = SYN_ACTION_Q, NumVisits = SYN_ACTION_NUM_VISITS };
-enum class Fpu { Const = SYN_FPU_CONST, ParentQ = SYN_FPU_PARENT_Q, Normal = SYN_FPU_NORMAL /* Func(|| Normal(mean, std)) */ };
+enum class Fpu { Const = SYN_FPU_CONST, ParentQ = SYN_FPU_PARENT_Q, Normal = SYN_FPU_NORMAL /* Func(|| Normal(mean, std)) */,
+                 Func = SYN_FPU_FUNC /* Func(fn() -> f32), config.rs:25: host trees only */ };
 enum class PolicyNoise { None = SYN_NOISE_NONE, Equal = SYN_NOISE_EQUAL, Dirichlet = SYN_NOISE_DIRICHLET };
 enum class ValueTarget { Z = SYN_VALUE_Z, Q = SYN_VALUE_Q, QZaverage = SYN_VALUE_QZ_AVERAGE, QtoZ = SYN_VALUE_Q_TO_Z };
 
@@ -59,13 +60,14 @@ struct MCTSConfig {  // defaults: policy_mcts_cfg of study-connect4/src/main.rs:
     float noise_alpha = 0.0f;
     float noise_weight = 0.0f;
     float fpu_std = 0.0f;  // Fpu::Normal: Func(|| Normal::new(fpu_value, fpu_std).sample(..)), study-connect4/src/main.rs:43-47
+    float (*fpu_fn)() = nullptr;  // Fpu::Func(fn() -> f32) (config.rs:25), called at mcts.rs:354 by the host trees (thread-safe, as in the reference)
 
     syn_mcts_config to_c() const {
         syn_mcts_config m{};
         m.exploration = (int32_t)exploration; m.c = c; m.solve = solve; m.correct_values_on_solve = correct_values_on_solve;
         m.select_solved_nodes = select_solved_nodes; m.auto_extend = auto_extend; m.fpu = (int32_t)fpu;
         m.fpu_value = fpu_value; m.root_policy_noise = (int32_t)root_policy_noise; m.noise_alpha = noise_alpha;
-        m.noise_weight = noise_weight; m.fpu_std = fpu_std;
+        m.noise_weight = noise_weight; m.fpu_std = fpu_std; m.fpu_fn = fpu_fn;
         return m;
     }
 };

@@ -756,6 +756,7 @@ private:
         if (child.num_children == 0) {
             if (cfg_.fpu == Fpu::Const) return cfg_.fpu_value;
             if (cfg_.fpu == Fpu::ParentQ) return parent.q();
+            if (cfg_.fpu == Fpu::Func) return cfg_.fpu_fn();  // Fpu::Func(fpu_fn) => fpu_fn() (mcts.rs:354): the caller's function, its own state
             drew = true;  // Fpu::Func(|| Normal(mean, std)) (main.rs:43-47)
             return detail::noise_fpu_normal(noise_seed_, fpu_scans_, slot, cfg_.fpu_value, cfg_.fpu_std);
         }

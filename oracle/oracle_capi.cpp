@@ -181,7 +181,7 @@ struct orc_mcts_config {
     int exploration;  // 0 Uct, 1 PolynomialUct
     float c;
     int solve, correct_values_on_solve, select_solved_nodes, auto_extend;
-    int fpu;  // 0 Const, 1 ParentQ, 2 Func = Normal(fpu_value, fpu_std)
+    int fpu;  // 0 Const, 1 ParentQ, 2 Func = Normal(fpu_value, fpu_std), 3 Func(fn) with the function orc_set_fpu_fn installed
     float fpu_value;
     int noise;  // 0 None, 1 Equal, 2 Dirichlet
     float noise_alpha, noise_weight;
@@ -195,6 +195,10 @@ struct orc_rollout_config {
     orc_mcts_config mcts;
 };
 
+// Fpu::Func(fn() -> f32) (config.rs:25): the function a test installs for configurations with fpu = 3
+static float (*g_fpu_fn)() = nullptr;
+extern "C" void orc_set_fpu_fn(float (*fn)()) { g_fpu_fn = fn; }
+
 static MCTSConfig to_cfg(const orc_mcts_config& c) {
     MCTSConfig m;
     m.exploration = c.exploration;
@@ -203,7 +207,8 @@ static MCTSConfig to_cfg(const orc_mcts_config& c) {
     m.correct_values_on_solve = c.correct_values_on_solve != 0;
     m.select_solved_nodes = c.select_solved_nodes != 0;
     m.auto_extend = c.auto_extend != 0;
-    m.fpu = c.fpu;
+    m.fpu = c.fpu == 3 ? (int)FPU_FUNC : c.fpu;
+    m.fpu_fn = c.fpu == 3 ? g_fpu_fn : nullptr;
     m.fpu_value = c.fpu_value;
     m.noise = c.noise;
     m.noise_alpha = c.noise_alpha;

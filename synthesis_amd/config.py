@@ -23,7 +23,8 @@ class ActionSelection(enum.IntEnum):      # config.rs:15-19
 class Fpu(enum.IntEnum):                  # config.rs:21-26
     Const = 0
     ParentQ = 1
-    Func = 2
+    Func = 2        # SYN_FPU_NORMAL: Func(|| Normal(fpu_value, fpu_std)), the closure study-connect4/src/main.rs:43-47 configures
+    FuncPtr = 3     # SYN_FPU_FUNC: Func(fpu_fn), any fn() -> f32 (config.rs:25) — called by the host trees only
 
 
 class PolicyNoise(enum.IntEnum):          # config.rs:39-44
@@ -39,6 +40,9 @@ class ValueTarget(enum.IntEnum):          # config.rs:1-7
     QtoZ = 3
 
 
+FPU_FN = C.CFUNCTYPE(C.c_float)           # float (*fpu_fn)(void): Fpu::Func's fn() -> f32 (config.rs:25)
+
+
 class CMctsConfig(C.Structure):           # struct syn_mcts_config
     _fields_ = [
         ("exploration", C.c_int32), ("c", C.c_float),
@@ -47,6 +51,7 @@ class CMctsConfig(C.Structure):           # struct syn_mcts_config
         ("fpu", C.c_int32), ("fpu_value", C.c_float),
         ("root_policy_noise", C.c_int32), ("noise_alpha", C.c_float), ("noise_weight", C.c_float),
         ("fpu_std", C.c_float),
+        ("fpu_fn", FPU_FN),
     ]
 
 
@@ -80,11 +85,17 @@ class MCTSConfig:                         # config.rs:28-37
     noise_alpha: float = 0.0
     noise_weight: float = 0.0
     fpu_std: float = 0.0              # Fpu.Func = Normal(fpu_value, fpu_std)
+    fpu_fn: object = None             # Fpu.FuncPtr: a Python callable () -> float or a ctypes FPU_FN (kept alive by this object)
 
     def to_c(self) -> CMctsConfig:
+        fn = self.fpu_fn
+        if fn is not None and not isinstance(fn, FPU_FN):
+            fn = FPU_FN(fn)
+            self._fpu_fn_c = fn       # the callback object must outlive every call that holds its address
         return CMctsConfig(int(self.exploration), float(self.c), int(self.solve), int(self.correct_values_on_solve),
                            int(self.select_solved_nodes), int(self.auto_extend), int(self.fpu), float(self.fpu_value),
-                           int(self.root_policy_noise), float(self.noise_alpha), float(self.noise_weight), float(self.fpu_std))
+                           int(self.root_policy_noise), float(self.noise_alpha), float(self.noise_weight), float(self.fpu_std),
+                           fn if fn is not None else FPU_FN())
 
 
 @dataclass

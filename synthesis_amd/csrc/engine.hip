@@ -20,8 +20,10 @@
 #include "engine_kernels.cuh"
 #include "eval_small.cuh"
 #include "lane_kernel.cuh"
+#ifdef SYN_DEBUG_SHAPES   // measured dead ends kept as parity-tested debug shapes: `make DEBUG_SHAPES=1` (default: not in the library)
 #include "lane2_kernel.cuh"
 #include "pc_kernel.cuh"
+#endif
 #include "frozen_kernel.cuh"
 #include "train_kernels.cuh"
 #include "train_mfma.cuh"
@@ -54,7 +56,8 @@ SYN_CONV_LANES(MODE_SEARCH, false)
 SYN_CONV_LANES(MODE_SELFPLAY, false)
 SYN_CONV_LANES(MODE_SELFPLAY, true)
 #undef SYN_CONV_LANES
-// ... and the two-trees-per-lane kernels in engine_lanes2.hip (a third one)
+// ... and (DEBUG_SHAPES=1 builds only) the two-trees-per-lane kernels in engine_lanes2.hip
+#ifdef SYN_DEBUG_SHAPES
 #define SYN_LANES2(MODE, COUNT)                                                                      \
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, true, 8, 0>(EngineParams);   \
     extern template __global__ void selfplay_kernel_lanes2<MODE, COUNT, false, 8, 0>(EngineParams);  \
@@ -69,6 +72,7 @@ SYN_LANES2(MODE_SEARCH, false)
 SYN_LANES2(MODE_SELFPLAY, false)
 SYN_LANES2(MODE_SELFPLAY, true)
 #undef SYN_LANES2
+#endif
 // ... and the Connect4Net / RolloutPolicy lane-per-tree kernels in engine_lanes_fast.hip and engine_lanes_gen.hip
 #define SYN_X(MODE, COUNT, FAST, NW, PROF, POLICY) \
     extern template __global__ void selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF, POLICY>(EngineParams);
@@ -203,6 +207,10 @@ static int fail(syn_engine* h, int code, const char* fmt, ...) {
 // for the library's host-only translation units (lockstep_capi.cpp)
 extern "C" int syn_internal_fail(syn_engine* h, int code, const char* msg) { return fail(h, code, "%s", msg); }
 extern "C" int syn_internal_concurrent_games(const syn_engine* h) { return h ? h->slots : 0; }
+#ifdef SYN_DEBUG_SHAPES
+// present only in `make DEBUG_SHAPES=1` builds: the tests of the two debug launch shapes skip when it is absent
+extern "C" int syn_internal_debug_shapes(void) { return 1; }
+#endif
 
 #define HIP_TRY(h, call)                                                                          \
     do {                                                                                          \
@@ -298,9 +306,12 @@ static int convert_mcts(syn_engine* h, const syn_mcts_config* c, DevMctsCfg& d) 
     if (!c) return fail(h, SYN_ERR_INVALID_ARGUMENT, "mcts config is NULL");
     if (c->exploration != SYN_EXPLORATION_UCT && c->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration %d", c->exploration);
+    if (c->fpu == SYN_FPU_FUNC)
+        return fail(h, SYN_ERR_UNSUPPORTED, "SYN_FPU_FUNC (Fpu::Func(fn() -> f32), config.rs:25) is a host function: a device kernel cannot call it. "
+                                            "It runs on the host trees (syn_mcts_search_lockstep / syn_selfplay_run_lockstep); on the device, "
+                                            "SYN_FPU_NORMAL is the reference's own Normal(mean, std) closure");
     if (c->fpu != SYN_FPU_CONST && c->fpu != SYN_FPU_PARENT_Q && c->fpu != SYN_FPU_NORMAL)
-        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu %d (an arbitrary Fpu::Func closure cannot cross the C ABI; "
-                                                 "SYN_FPU_NORMAL is the reference's own Normal(mean, std) closure)", c->fpu);
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu %d", c->fpu);
     if (c->fpu == SYN_FPU_NORMAL && !(c->fpu_std >= 0.0f && c->fpu_std < 1e30f && c->fpu_value == c->fpu_value))
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_FPU_NORMAL needs a finite mean and a standard deviation >= 0 (Normal::new)");
     if (c->root_policy_noise != SYN_NOISE_NONE && c->root_policy_noise != SYN_NOISE_EQUAL && c->root_policy_noise != SYN_NOISE_DIRICHLET)
@@ -357,6 +368,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // slower than the symmetric lane kernel (the f32 MFMA shares the SIMD's FP32 datapath with the VALU, so
     // dedicating waves to the matrix pipe frees nothing), so it is never chosen automatically:
     // SYN_DEBUG=1 SYN_PC=<NV 1..3> selects it (parity tests, profiling).
+#ifdef SYN_DEBUG_SHAPES
     {
         int nv = 0;
         if (const char* ev = debug_env("SYN_PC")) nv = std::atoi(ev);
@@ -409,6 +421,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             return hipGetLastError();
         }
     }
+#endif
     // At most 16 trees per CU in the f16x2 arithmetic: four free-running waves of four trees, each evaluating its own leaves in a tile
     // of its own (free_kernel.cuh). The draws of Fpu::Func / PolicyNoise::Dirichlet live in the lane-per-tree kernels only.
     // SYN_DEBUG=1 SYN_FREE=0 switches it off (the lane kernel at 4 waves then plays these games).
@@ -432,6 +445,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         if (out_nt) *out_nt = 256;
         return hipGetLastError();
     }
+#ifdef SYN_DEBUG_SHAPES
     // Two trees per lane (lane2_kernel.cuh): 8 waves per workgroup, 1,024 trees per CU. SYN_DEBUG=1 SYN_LANES2=8 forces it,
     // SYN_LANES2=0 switches it off.
     {
@@ -485,6 +499,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             return hipGetLastError();
         }
     }
+#endif
     {
         int nw = 0;
         // 4 waves per workgroup up to 256 trees per CU, 8 up to 512, 12 up to 768, 16 (hand-pipelined network tile that fits
@@ -835,8 +850,21 @@ int syn_engine_destroy(syn_engine* h) {
     return SYN_OK;
 }
 
-// The f16x2 image of the engine's Connect4Net (f16x2_tile.cuh: build_f16x2_image from the host copy of the parameters), built on
-// first use after the parameters changed.
+// The f16x2 image of the engine's Connect4Net (f16x2_tile.cuh: build_f16x2_image). State is committed only after the image exists:
+// a blob without an f16x2 plan (non-finite values, scales outside the window) leaves the engine exactly as it was — arithmetic,
+// parameters, both images and the policy cache — so nothing can evaluate a stale or missing image afterwards.
+static int upload_f16x2_image(syn_engine* h, const F16Image& im) {
+    HIP_TRY(h, hipSetDevice(h->device));   // (reached through common_params before the entry point's own hipSetDevice)
+    if (!h->d_wimg16) HIP_TRY(h, hipMalloc(&h->d_wimg16, (size_t)F16Geom::IMG_WORDS * 4));
+    HIP_TRY(h, hipMemcpyAsync(h->d_wimg16, im.words.data(), (size_t)F16Geom::IMG_WORDS * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return SYN_OK;
+}
+static int no_f16x2_plan(syn_engine* h) {
+    return fail(h, SYN_ERR_UNSUPPORTED, "these parameters have no f16x2 plan (non-finite values or scales outside the f32-safe window); "
+                                        "the engine keeps its previous network and arithmetic");
+}
+// (re)builds the image from the engine's own copy of the parameters when it is not current (after syn_trainer_publish_weights)
 static int ensure_f16x2_image(syn_engine* h) {
     if (h->img16_current) return SYN_OK;
     if (h->net_kind != 0 || h->host_blob.size() != (size_t)MlpGeom::NUM_PARAMS)
@@ -844,10 +872,16 @@ static int ensure_f16x2_image(syn_engine* h) {
     F16Image im;
     if (!build_f16x2_image(h->host_blob.data(), im))
         return fail(h, SYN_ERR_UNSUPPORTED, "these parameters have no f16x2 plan (non-finite values or scales outside the f32-safe window)");
-    if (!h->d_wimg16) HIP_TRY(h, hipMalloc(&h->d_wimg16, (size_t)F16Geom::IMG_WORDS * 4));
-    HIP_TRY(h, hipMemcpyAsync(h->d_wimg16, im.words.data(), (size_t)F16Geom::IMG_WORDS * 4, hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const int rc = upload_f16x2_image(h, im);
+    if (rc != SYN_OK) return rc;
     h->img16_current = true;
+    return SYN_OK;
+}
+// every path that evaluates Connect4Net in the f16x2 arithmetic checks this first
+static int require_f16x2_image(syn_engine* h) {
+    if (h->net_arith != SYN_NET_ARITH_F16X2 || h->net_kind != 0) return SYN_OK;
+    if (!h->img16_current || !h->d_wimg16)
+        return fail(h, SYN_ERR_UNSUPPORTED, "the engine is in the f16x2 arithmetic but holds no f16x2 image of its parameters");
     return SYN_OK;
 }
 
@@ -857,8 +891,16 @@ int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
     if (n_floats != (size_t)MlpGeom::NUM_PARAMS)
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "Connect4Net has %d parameters, got %zu", MlpGeom::NUM_PARAMS, n_floats);
     HIP_TRY(h, hipSetDevice(h->device));
+    F16Image im16;
+    const bool want16 = h->net_arith == SYN_NET_ARITH_F16X2;
+    if (want16 && !build_f16x2_image(blob, im16)) return no_f16x2_plan(h);   // (before anything of the engine changes)
     std::vector<float> img;
     build_weight_image(blob, img);
+    if (want16) {
+        h->img16_current = false;
+        const int rc = upload_f16x2_image(h, im16);
+        if (rc != SYN_OK) return rc;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_wimg, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     // PolicyWithCache entries belong to the network that produced them (the reference builds a fresh cache per
@@ -867,8 +909,7 @@ int syn_load_weights(syn_engine* h, const float* blob, size_t n_floats) {
     h->has_weights = true;
     h->net_kind = 0;
     h->host_blob.assign(blob, blob + n_floats);
-    h->img16_current = false;
-    if (h->net_arith == SYN_NET_ARITH_F16X2) return ensure_f16x2_image(h);
+    h->img16_current = want16;
     return SYN_OK;
 }
 
@@ -885,13 +926,22 @@ int syn_set_network_arithmetic(syn_engine* h, int arithmetic) {
             return fail(h, SYN_ERR_UNSUPPORTED, "the f16x2 arithmetic exists for Connect4Net only (the engine holds Connect4ConvNet)");
     }
     HIP_TRY(h, hipSetDevice(h->device));
+    if (arithmetic == SYN_NET_ARITH_F16X2 && h->has_weights && !h->img16_current) {
+        // the image first; the switch is committed only when it exists
+        if (h->net_kind != 0 || h->host_blob.size() != (size_t)MlpGeom::NUM_PARAMS)
+            return fail(h, SYN_ERR_UNSUPPORTED, "the f16x2 arithmetic exists for Connect4Net only");
+        F16Image im;
+        if (!build_f16x2_image(h->host_blob.data(), im)) return no_f16x2_plan(h);
+        const int rc = upload_f16x2_image(h, im);
+        if (rc != SYN_OK) return rc;
+        h->img16_current = true;
+    }
     h->net_arith = arithmetic;
     // PolicyWithCache entries belong to the arithmetic that produced them: the two differ in the last bits
     if (h->d_cache) {
         HIP_TRY(h, hipMemsetAsync(h->d_cache, 0, (size_t)64 << h->cache_log2, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
-    if (arithmetic == SYN_NET_ARITH_F16X2 && h->has_weights) return ensure_f16x2_image(h);
     return SYN_OK;
 }
 
@@ -1017,6 +1067,7 @@ int syn_policy_eval_batch_device(syn_engine* h, const uint64_t* d_my, const uint
     if (n == 0) return SYN_OK;
     HIP_TRY(h, hipSetDevice(h->device));
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    { const int rc16 = require_f16x2_image(h); if (rc16 != SYN_OK) return rc16; }
     HIP_TRY(h, launch_policy_eval(h, h->stream, d_my, d_op, n, d_logits, d_value));
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->last_launches = 1;
@@ -1114,6 +1165,8 @@ int syn_eval_ctx_submit(syn_eval_ctx* c, const uint64_t* my_bb, const uint64_t* 
     if (c->pending != 0) return ctx_fail(c, SYN_ERR_INVALID_ARGUMENT, "syn_eval_ctx_submit: the previous batch has not been waited for");
     syn_engine* h = c->h;
     if (!h->has_weights) return ctx_fail(c, SYN_ERR_NO_WEIGHTS, "call syn_load_weights first");
+    if (h->net_arith == SYN_NET_ARITH_F16X2 && h->net_kind == 0 && (!h->img16_current || !h->d_wimg16))
+        return ctx_fail(c, SYN_ERR_UNSUPPORTED, "the engine is in the f16x2 arithmetic but holds no f16x2 image of its parameters");
     if (n == 0) return SYN_OK;
     CTX_TRY(c, hipSetDevice(h->device));
     const size_t nb = (size_t)n;
@@ -2019,7 +2072,8 @@ int syn_trainer_set_precision(syn_engine* h, int precision) {
 
 static int launch_grads(syn_engine* h, const unsigned long long* d_my, const unsigned long long* d_op,
                         const float* d_tpi, const float* d_tv, int batch, float* d_grads, float* d_losses = nullptr,
-                        const int* d_idx = nullptr) {
+                        const int* d_idx = nullptr, hipStream_t on = nullptr) {
+    const hipStream_t st = on ? on : h->stream;   // (the *_enqueue entry points run the step on the caller's stream)
     if (h->trainer_kind == 1) {
         // Connect4ConvNet (train_conv_mfma.cuh): one workgroup, the minibatch's activations resident in LDS, every chain on the
         // f32 matrix cores
@@ -2029,7 +2083,7 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
         const size_t clds = (size_t)ConvMfmaGeom::LDS_FLOATS * 4;
         auto kg = h->train_bf16 ? train_conv_grad_kernel_mfma<true> : train_conv_grad_kernel_mfma<false>;
         HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void*>(kg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)clds));
-        hipLaunchKernelGGL(kg, dim3(1), dim3(CONV_TRAIN_THREADS), clds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
+        hipLaunchKernelGGL(kg, dim3(1), dim3(CONV_TRAIN_THREADS), clds, st, h->d_tw, d_my, d_op, d_tpi, d_tv, batch,
                            h->train_hp, d_grads, d_losses ? d_losses : h->d_tloss, d_idx);
         HIP_TRY(h, hipGetLastError());
         return SYN_OK;
@@ -2047,18 +2101,18 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
     unsigned long long* d_prof = nullptr;
     if (prof) {
         HIP_TRY(h, hipMalloc(&d_prof, 4096));
-        HIP_TRY(h, hipMemsetAsync(d_prof, 0, 4096, h->stream));
+        HIP_TRY(h, hipMemsetAsync(d_prof, 0, 4096, st));
     }
     if (valu)
-        hipLaunchKernelGGL(train_grad_kernel, dim3(1), dim3(1024), lds, h->stream, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
+        hipLaunchKernelGGL(train_grad_kernel, dim3(1), dim3(1024), lds, st, h->d_tw, d_my, d_op, d_tpi, d_tv, batch, h->train_hp,
                            d_grads, d_losses ? d_losses : h->d_tloss, d_idx, d_prof);
     else
-        hipLaunchKernelGGL(train_grad_kernel_mfma, dim3(1), dim3(1024), lds, h->stream, h->d_tw, h->d_twimg, h->d_ttimg, d_my, d_op,
+        hipLaunchKernelGGL(train_grad_kernel_mfma, dim3(1), dim3(1024), lds, st, h->d_tw, h->d_twimg, h->d_ttimg, d_my, d_op,
                            d_tpi, d_tv, batch, h->train_hp, d_grads, d_losses ? d_losses : h->d_tloss, d_idx, d_prof);
     HIP_TRY(h, hipGetLastError());
     if (prof) {
         unsigned long long t[8] = {0};
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        HIP_TRY(h, hipStreamSynchronize(st));
         HIP_TRY(h, hipMemcpy(t, d_prof, sizeof(t), hipMemcpyDeviceToHost));
         HIP_TRY(h, hipFree(d_prof));
         fprintf(stderr, "[syn train profile] cycles: features %llu forward %llu heads %llu backward %llu param-grads %llu\n",
@@ -2067,7 +2121,8 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
     return SYN_OK;
 }
 
-static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad_scale) {
+static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad_scale, hipStream_t on = nullptr) {
+    const hipStream_t st = on ? on : h->stream;
     h->train_step += 1;
     const double bc1 = 1.0 - std::pow((double)h->train_hp.beta1, (double)h->train_step);
     const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, (double)h->train_step);
@@ -2075,13 +2130,13 @@ static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad
     const float inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
     if (h->trainer_kind == 1) {
         const int nc = ConvGeom::NUM_PARAMS;
-        hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads, nc,
+        hipLaunchKernelGGL(adam_kernel, dim3((nc + 255) / 256), dim3(256), 0, st, h->d_tw, h->d_tm, h->d_tv, d_grads, nc,
                            h->train_hp, step_size, inv_sqrt_bc2, grad_scale);
         HIP_TRY(h, hipGetLastError());
         return SYN_OK;
     }
     const int n = TrainGeom::NUM_PARAMS;
-    hipLaunchKernelGGL(adam_image_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_tw, h->d_tm, h->d_tv, d_grads,
+    hipLaunchKernelGGL(adam_image_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->d_tw, h->d_tm, h->d_tv, d_grads,
                        n, h->train_hp, step_size, inv_sqrt_bc2, grad_scale, h->d_twimg, h->d_ttimg);
     HIP_TRY(h, hipGetLastError());
     return SYN_OK;
@@ -2111,6 +2166,28 @@ int syn_train_apply_device(syn_engine* h, const float* d_grads, float lr, float 
     if (rc != SYN_OK) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return SYN_OK;
+}
+
+// The same two halves of a data-parallel step WITHOUT the host in between: both are enqueued on the caller's stream (the stream the
+// batch was prepared on and the all-reduce runs on), nothing is synchronised, the two loss sums go to device memory — a step is
+// gradients -> all-reduce -> Adam in one stream order. The caller keeps other trainer calls of this engine off other streams meanwhile.
+int syn_train_gradients_enqueue(syn_engine* h, void* stream, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,
+                                const float* d_target_v, int batch, float* d_grads, float* d_losses) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (batch < 1 || !d_my_bb || !d_op_bb || !d_target_pi || !d_target_v || !d_grads)
+        return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_train_gradients_enqueue");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_grads(h, reinterpret_cast<const unsigned long long*>(d_my_bb), reinterpret_cast<const unsigned long long*>(d_op_bb),
+                        d_target_pi, d_target_v, batch, d_grads, d_losses, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int syn_train_apply_enqueue(syn_engine* h, void* stream, const float* d_grads, float lr, float grad_scale) {
+    if (!h) return SYN_ERR_INVALID_ARGUMENT;
+    if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
+    if (!d_grads) return fail(h, SYN_ERR_INVALID_ARGUMENT, "d_grads is NULL");
+    HIP_TRY(h, hipSetDevice(h->device));
+    return launch_adam(h, d_grads, lr, grad_scale, static_cast<hipStream_t>(stream));
 }
 
 int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,

@@ -54,8 +54,10 @@ int host_mcts_config(syn_engine* h, const syn_mcts_config* cfg, synthesis::MCTSC
     using namespace synthesis;
     if (cfg->exploration != SYN_EXPLORATION_UCT && cfg->exploration != SYN_EXPLORATION_POLYNOMIAL_UCT)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown exploration");
-    if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q && cfg->fpu != SYN_FPU_NORMAL)
+    if (cfg->fpu != SYN_FPU_CONST && cfg->fpu != SYN_FPU_PARENT_Q && cfg->fpu != SYN_FPU_NORMAL && cfg->fpu != SYN_FPU_FUNC)
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "unknown fpu");
+    if (cfg->fpu == SYN_FPU_FUNC && cfg->fpu_fn == nullptr)
+        return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_FPU_FUNC needs fpu_fn (Fpu::Func(fn() -> f32), config.rs:25)");
     if (cfg->fpu == SYN_FPU_NORMAL && !(cfg->fpu_std >= 0.0f && cfg->fpu_std < 1e30f && cfg->fpu_value == cfg->fpu_value))
         return syn_internal_fail(h, SYN_ERR_INVALID_ARGUMENT, "SYN_FPU_NORMAL needs a finite mean and 0 <= std < 1e30");
     if (cfg->root_policy_noise != SYN_NOISE_NONE && cfg->root_policy_noise != SYN_NOISE_EQUAL && cfg->root_policy_noise != SYN_NOISE_DIRICHLET)
@@ -76,6 +78,7 @@ int host_mcts_config(syn_engine* h, const syn_mcts_config* cfg, synthesis::MCTSC
     m.noise_alpha = cfg->noise_alpha;
     m.noise_weight = cfg->noise_weight;
     m.fpu_std = cfg->fpu_std;
+    m.fpu_fn = cfg->fpu == SYN_FPU_FUNC ? cfg->fpu_fn : nullptr;
     return SYN_OK;
 }
 }  // namespace

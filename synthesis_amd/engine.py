@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "syn_eval_ctx_eval", "syn_eval_ctx_last_error", "syn_eval_ctx_destroy", "syn_features_batch", "syn_linear_forward",
     "syn_conv2d_forward", "syn_activation_forward", "syn_mcts_search", "syn_mcts_search_rollout", "syn_mcts_search_lockstep", "syn_selfplay_run_lockstep", "syn_frozen_search_rollout", "syn_selfplay_run", "syn_progress", "syn_cancel", "syn_trainer_set_precision", "syn_last_timing", "syn_last_launch_shape", "syn_last_cache_stats", "syn_debug_stdrng_u32",
     "syn_debug_math", "syn_debug_fast_div", "syn_debug_small_int_math", "syn_debug_calibrate", "syn_trainer_init", "syn_trainer_init_conv", "syn_train_step", "syn_train_gradients_device",
-    "syn_train_apply_device", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
+    "syn_train_apply_device", "syn_train_gradients_enqueue", "syn_train_apply_enqueue", "syn_trainer_get_state", "syn_trainer_publish_weights", "syn_replay_deduplicate", "syn_train_set_data", "syn_train_epoch",
 ]
 
 
@@ -151,6 +151,9 @@ def load_library():
     lib.syn_train_gradients_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                                C.c_void_p, C.c_void_p]
     lib.syn_train_apply_device.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float]
+    lib.syn_train_gradients_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                                C.c_void_p, C.c_void_p]
+    lib.syn_train_apply_enqueue.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]
     lib.syn_trainer_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong),
                                           C.c_void_p]
     lib.syn_trainer_publish_weights.argtypes = [C.c_void_p]
@@ -564,6 +567,15 @@ class Engine:
 
     def train_apply_device(self, d_grads, lr, grad_scale=1.0):
         self._check(self._lib.syn_train_apply_device(self._h, C.c_void_p(d_grads), float(lr), float(grad_scale)))
+
+    def train_gradients_enqueue(self, stream, d_my, d_op, d_tpi, d_tv, batch, d_grads, d_losses=0):
+        """syn_train_gradients_enqueue: the gradient kernel on `stream` (a raw hipStream_t, e.g. torch.cuda.current_stream().cuda_stream),
+        loss sums to the device words at d_losses; nothing is synchronised."""
+        self._check(self._lib.syn_train_gradients_enqueue(self._h, C.c_void_p(stream), C.c_void_p(d_my), C.c_void_p(d_op), C.c_void_p(d_tpi),
+                                                          C.c_void_p(d_tv), int(batch), C.c_void_p(d_grads), C.c_void_p(d_losses)))
+
+    def train_apply_enqueue(self, stream, d_grads, lr, grad_scale=1.0):
+        self._check(self._lib.syn_train_apply_enqueue(self._h, C.c_void_p(stream), C.c_void_p(d_grads), float(lr), float(grad_scale)))
 
     def trainer_state(self):
         blob = np.zeros(getattr(self, "_trainer_params", NUM_PARAMS), np.float32)

@@ -47,7 +47,9 @@ class LearningLoop:
     dist         torch.distributed (initialised) or None for one rank
     sampler      "numpy" (default: numpy's PCG64 permutation seeded by (seed, iteration, epoch)) | "torch": BatchRandSampler's own
                  `Tensor::randperm(n, INT64_CPU)` (data.rs:29) — libtorch's CPU randperm from ONE generator seeded with `seed` and
-                 advanced epoch after epoch, i.e. the stream a reference run started with `tch::manual_seed(seed)` draws from
+                 advanced epoch after epoch: the reference's algorithm and generator TYPE, not its stream — in a reference run
+                 `tch::manual_seed(seed)` (alpha_zero.rs:28) is followed by `P::new(&vs)` (:31), whose parameter initialisation draws
+                 from that same global generator before the first randperm, so the permutations of a Rust run differ
     logs_dir     None, or where the learner's rank writes what the reference writes per iteration (alpha_zero.rs:37,97-100):
                  models/model_{i}.ot (Connect4Net: a VarStore archive `vs.load` reads; Connect4ConvNet: the flat blob as .npy) and
                  latest_states.npy [n, 1, 7, 9] / latest_pis.npy [n, 9] / latest_vs.npy [n, 3] of the de-duplicated buffer
@@ -233,13 +235,15 @@ class LearningLoop:
 class DataParallelLearner:
     """Gradient all-reduce per optimiser step (see the module docstring). Every rank holds identical weights and Adam moments."""
 
-    def __init__(self, engine, blob, dist=None, device=0, net="mlp", **hyper):
+    def __init__(self, engine, blob, dist=None, device=0, net="mlp", collective_at_world_1=False, **hyper):
+        """collective_at_world_1: keep the all-reduce in the step when the group has one rank (bench.py's `data_parallel_world1`:
+        the literal gradients -> RCCL all-reduce -> Adam path of BASELINE configs[4] on a one-GPU box)."""
         import torch
 
         self._torch = torch
         self.engine = engine
         self.net = net
-        self.dist = dist if (dist is not None and dist.is_initialized() and dist.get_world_size() > 1) else None
+        self.dist = dist if (dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or collective_at_world_1)) else None
         self.world = self.dist.get_world_size() if self.dist else 1
         self.device = torch.device(f"cuda:{device}")
         self.n_params = CONV_NUM_PARAMS if net == "conv" else NUM_PARAMS
@@ -277,25 +281,28 @@ class DataParallelLearner:
         tpi = t.from_numpy(np.ascontiguousarray(target_pi, dtype=np.float32)).to(self.device)
         tv = t.from_numpy(np.ascontiguousarray(target_v, dtype=np.float32)).to(self.device)
         self._step_device(my, op, tpi, tv, lr)
-        return (self.buf[self.n_params:] / self.world).cpu().numpy()
+        return (self.buf[self.n_params:] / self.world).cpu().numpy()   # (the read-back waits for the step)
 
     def _step_device(self, my, op, tpi, tv, lr):
+        """gradients -> all-reduce -> Adam in ONE stream order (torch's current stream, which is also where the batch was gathered and
+        where RCCL orders its collective): the gradient kernel writes its two loss sums behind the gradients, so they ride in the
+        same 122 KB message; no host wait, no host-to-device copy, no synchronisation per step (13 us of compute per step would
+        otherwise sit behind four of them). Under a host-staged backend (gloo: CPU tests, dry runs) the message crosses the host."""
         t = self._torch
-        t.cuda.current_stream(self.device).synchronize()  # the engine runs on its own stream: the batch must be there
-        losses = self.engine.train_gradients_device(my.data_ptr(), op.data_ptr(), tpi.data_ptr(), tv.data_ptr(),
-                                                    int(my.numel()), self.buf.data_ptr())  # returns after the kernel
-        self.buf[self.n_params:] = t.from_numpy(losses)   # the two loss sums ride in the same message as the gradients
+        st = t.cuda.current_stream(self.device).cuda_stream
+        self.engine.train_gradients_enqueue(st, my.data_ptr(), op.data_ptr(), tpi.data_ptr(), tv.data_ptr(), int(my.numel()),
+                                            self.buf.data_ptr(), self.buf.data_ptr() + 4 * self.n_params)
         if self.dist is not None:
             if self._staged:
-                self._host.copy_(self.buf)
+                self._host.copy_(self.buf)      # (stream-ordered copy to pinned memory, then the host waits for it)
+                t.cuda.current_stream(self.device).synchronize()
                 self.dist.all_reduce(self._host)
-                self.buf.copy_(self._host)
+                self.buf.copy_(self._host, non_blocking=True)
             else:
-                self.dist.all_reduce(self.buf)  # RCCL over xGMI: one 122 KB message (latency-bound)
-            t.cuda.current_stream(self.device).synchronize()
+                self.dist.all_reduce(self.buf)  # RCCL over xGMI: one 122 KB message (latency-bound), ordered behind the kernel
         self._loss_sum += self.buf[self.n_params:].double() / self.world
         self._steps += 1
-        self.engine.train_apply_device(self.buf.data_ptr(), lr, grad_scale=1.0 / self.world)
+        self.engine.train_apply_enqueue(st, self.buf.data_ptr(), lr, grad_scale=1.0 / self.world)
 
     def take_losses(self):
         """(sum of the per-step global (pi_loss, v_loss), steps) since the last call — one read-back per epoch instead of per step."""
@@ -306,7 +313,9 @@ class DataParallelLearner:
 
     def publish(self):
         """The trained network becomes the engine's self-play network (model_{i+1}.ot of alpha_zero.rs:97)."""
+        self._torch.cuda.current_stream(self.device).synchronize()   # the steps ran on torch's stream, the hand-off runs on the engine's
         self.engine.trainer_publish_weights()
 
     def state(self):
+        self._torch.cuda.current_stream(self.device).synchronize()
         return self.engine.trainer_state()

@@ -175,9 +175,17 @@ class _JitObject:
 
 
 def _rebuild_tensor_v2(storage, offset, size, stride, requires_grad=False, backward_hooks=None, metadata=None):
-    size, stride = tuple(size), tuple(stride)
+    size, stride = tuple(int(v) for v in size), tuple(int(v) for v in stride)
+    offset = int(offset)
+    # the numbers come from the archive's pickle: every element the view can reach must lie inside the storage
+    if len(size) != len(stride) or offset < 0 or any(v < 0 for v in size) or any(v < 0 for v in stride):
+        raise ValueError(f"tensor with offset {offset}, size {size}, stride {stride}: not a view of its storage")
+    if all(v > 0 for v in size) and offset + sum((n - 1) * st for n, st in zip(size, stride)) >= storage.size:
+        raise ValueError(f"tensor with offset {offset}, size {size}, stride {stride} reaches past its storage of {storage.size} elements")
     if len(size) == 0:
         return storage[offset:offset + 1].reshape(()).copy()
+    if any(v == 0 for v in size):
+        return np.zeros(size, storage.dtype)
     return np.lib.stride_tricks.as_strided(storage[offset:], shape=size, strides=tuple(s * storage.itemsize for s in stride)).copy()
 
 
@@ -223,7 +231,9 @@ def load_ot_tensors(path):
     state = obj.state if isinstance(obj, _JitObject) else obj
     if not isinstance(state, dict):
         raise ValueError(f"{path}: the archive's root object carries no variables")
-    return {str(k): np.asarray(v) for k, v in state.items() if isinstance(v, np.ndarray)}
+    # tch writes a VarStore through Tensor::save_multi, which stores every name with '.' replaced by '|' (a TorchScript attribute
+    # name cannot hold a dot) and maps it back in load_multi: `l_1|weight` on disk is the variable `l_1.weight`
+    return {str(k).replace("|", "."): np.asarray(v) for k, v in state.items() if isinstance(v, np.ndarray)}
 
 
 def load_ot(path):
@@ -290,8 +300,12 @@ def _pickle_varstore(named):
     return bytes(out)
 
 
-def save_ot(blob, path, root="archive"):
-    """Writes the flat Connect4Net blob as a VarStore archive `vs.load(path)` / torch.jit.load read: the inverse of load_ot."""
+def save_ot(blob, path, root="archive", names="tch"):
+    """Writes the flat Connect4Net blob as a VarStore archive `vs.load(path)` / torch.jit.load read: the inverse of load_ot.
+    names="tch": the on-disk names `vs.save` produces (`l_1|weight`: tch's save_multi replaces '.' by '|', load_multi maps it
+    back); names="dotted": `l_1.weight`, what a bare OutputArchive::write(name, ...) stores."""
+    if names not in ("tch", "dotted"):
+        raise ValueError("names must be 'tch' or 'dotted'")
     blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
     if blob.size != NUM_PARAMS:
         raise ValueError(f"Connect4Net has {NUM_PARAMS} parameters, got {blob.size}")
@@ -299,7 +313,8 @@ def save_ot(blob, path, root="archive"):
     for l in range(5):
         w = blob[off:off + DIMS[l] * DIMS[l + 1]].reshape(DIMS[l + 1], DIMS[l]); off += w.size
         b = blob[off:off + DIMS[l + 1]]; off += b.size
-        named += [(f"l_{l + 1}.weight", w), (f"l_{l + 1}.bias", b)]
+        sep = "|" if names == "tch" else "."
+        named += [(f"l_{l + 1}{sep}weight", w), (f"l_{l + 1}{sep}bias", b)]
     names = "".join(f'"{n}", ' for n, _ in named)
     code = ("class Module(Module):\n  __parameters__ = [" + names + "]\n  __buffers__ = []\n  __annotations__ = []\n" +
             "".join(f'  __annotations__["{n}"] = Tensor\n' for n, _ in named))

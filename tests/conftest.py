@@ -42,3 +42,17 @@ def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(("127.0.0.1", 0))
         return sk.getsockname()[1]
+
+
+def debug_shapes_built():
+    """True when the library was built with `make DEBUG_SHAPES=1` (two-trees-per-lane and producer/consumer kernels: measured dead
+    ends, forced-only launch shapes). The default library ships without them and their parity tests skip."""
+    from synthesis_amd.engine import load_library
+
+    return hasattr(load_library(), "syn_internal_debug_shapes")
+
+
+@pytest.fixture
+def debug_shapes():
+    if not debug_shapes_built():
+        pytest.skip("library built without DEBUG_SHAPES=1: the lane2 / producer-consumer debug kernels are not in it")

@@ -134,6 +134,14 @@ struct CountingNimPolicy : Policy<Nim, 3> {
 struct NimHash { size_t operator()(const Nim& g) const { return (size_t)g.stones * 2u + (size_t)g.to_move; } };
 inline bool operator==(const Nim& a, const Nim& b) { return a.stones == b.stones && a.to_move == b.to_move; }
 
+// the counter-based Fpu::Func of variant 10 (tests/test_lockstep.py computes the same numbers): call k returns
+// 0.5 + (k * 2654435761 mod 2^32 >> 16) / 65536, exact in f32
+static uint32_t g_fpu_calls = 0;
+static float counter_fpu() {
+    const uint32_t h = (g_fpu_calls++) * 2654435761u;
+    return 0.5f + (float)(h >> 16) * (1.0f / 65536.0f);
+}
+
 int main(int argc, char** argv) {
     if (argc >= 2 && std::string(argv[1]) == "cachepolicy") {
         CountingNimPolicy inner;
@@ -338,6 +346,9 @@ int main(int argc, char** argv) {
     if (variant == 8) { cfg.root_policy_noise = PolicyNoise::Dirichlet; cfg.noise_alpha = 1.0f; cfg.noise_weight = 0.5f;
                         cfg.fpu = Fpu::Normal; cfg.fpu_value = 1.0f; cfg.fpu_std = 0.1f; }
     if (variant == 9) { cfg.root_policy_noise = PolicyNoise::Dirichlet; cfg.noise_alpha = 2.5f; cfg.noise_weight = 0.25f; cfg.auto_extend = false; }
+    // Fpu::Func(fn() -> f32) (config.rs:25, called at mcts.rs:354): a function with a state of its own. Its values depend on the order
+    // of its calls, so the test searches ONE root on one thread and compares with the sequential oracle calling the same function.
+    if (variant == 10) { cfg.fpu = Fpu::Func; cfg.fpu_fn = counter_fpu; g_fpu_calls = 0; }
     std::vector<Connect4> roots;
     for (size_t i = 0; i < n; i++) roots.push_back(Connect4::from_bitboards(bb[i], bb[n + i]));
     Policies policies(threads < 0 ? (size_t)-threads : 1, blob.data());
@@ -372,7 +383,7 @@ int main(int argc, char** argv) {
     }
     std::ofstream of(argv[7], std::ios::binary);
     of.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * sizeof(syn_search_result)));
-    std::printf("rounds %zu evals %zu calls %zu positions %zu hits %zu misses %zu\n", rounds, evals, policies.calls(), policies.positions(),
-                policies.hits(), policies.misses());
+    std::printf("rounds %zu evals %zu calls %zu positions %zu hits %zu misses %zu fpu_calls %u\n", rounds, evals, policies.calls(), policies.positions(),
+                policies.hits(), policies.misses(), g_fpu_calls);
     return 0;
 }

@@ -32,3 +32,7 @@ for l in range(5):
     tensors += [torch.from_numpy(w.copy()), torch.from_numpy(b.copy())]
 ext.save_ot(names, tensors, os.path.join(HERE, "c4net_blob.ot"))
 print("written", os.path.getsize(os.path.join(HERE, "c4net_blob.ot")), "bytes")
+# The names as tch's VarStore::save hands them to that call: Tensor::save_multi replaces every '.' by '|' before at_save_multi
+# (a TorchScript attribute name cannot hold a dot; Tensor::load_multi maps it back) — the on-disk form of a reference `model_i.ot`.
+ext.save_ot([n.replace(".", "|") for n in names], tensors, os.path.join(HERE, "c4net_blob_tch_names.ot"))
+print("written", os.path.getsize(os.path.join(HERE, "c4net_blob_tch_names.ot")), "bytes")

@@ -81,6 +81,13 @@ class Oracle:
         lib.orc_c4conv_num_params.restype = C.c_size_t
         lib.orc_outcome_value.restype = C.c_float
 
+    # ---- Fpu::Func(fn() -> f32) (config.rs:25): the function configurations with fpu = 3 call (None uninstalls it)
+    FPU_FN = C.CFUNCTYPE(C.c_float)
+
+    def set_fpu_fn(self, fn):
+        self._fpu_fn = None if fn is None else (fn if isinstance(fn, self.FPU_FN) else self.FPU_FN(fn))   # keeps the callback alive
+        self.lib.orc_set_fpu_fn(self._fpu_fn if self._fpu_fn is not None else self.FPU_FN())
+
     # ---- outcome
     def outcome_cmp(self, a, b):
         """a, b: None or (kind, turns) with kind in 'Lose','Draw','Win'."""

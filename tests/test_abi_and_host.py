@@ -52,7 +52,8 @@ def test_struct_layouts_match_header():
     def fields(struct):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), h, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-        return [m.group(1) for m in re.finditer(r"\b([a-z_A-Z0-9]+)(?:\[\d+\])*;", body)]
+        # (a data member `type name[n];` or a function pointer `type (*name)(void);`)
+        return [m.group(1) or m.group(2) for m in re.finditer(r"\b([a-z_A-Z0-9]+)(?:\[\d+\])*;|\(\*([a-z_A-Z0-9]+)\)\([a-z ]*\);", body)]
 
     assert fields("syn_mcts_config") == [f[0] for f in CMctsConfig._fields_]
     assert fields("syn_rollout_config") == [f[0] for f in CRolloutConfig._fields_]
@@ -60,7 +61,7 @@ def test_struct_layouts_match_header():
     assert fields("syn_search_result") == [f[0] for f in CSearchResult._fields_]
     assert fields("syn_counters") == [f[0] for f in CCounters._fields_]
     assert fields("syn_train_config") == [f[0] for f in CTrainConfig._fields_] and C.sizeof(CTrainConfig) == 24
-    assert C.sizeof(CMctsConfig) == 48 and C.sizeof(CRolloutConfig) == 36 + 48
+    assert C.sizeof(CMctsConfig) == 56 and C.sizeof(CRolloutConfig) == 40 + 56   # (fpu_fn is a pointer: 8-byte alignment)
     assert C.sizeof(CSearchResult) == 4 * (9 + 27 + 9 + 27 + 1 + 3 + 3 + 1 + 1 + 9 + 3)
     assert C.sizeof(CCounters) == 96
 
@@ -77,6 +78,9 @@ def test_default_config_is_the_reference_parity_config():
     for name, _ in CRolloutConfig._fields_:
         if name == "mcts_cfg":
             for n2, _ in type(c.mcts_cfg)._fields_:
+                if n2 == "fpu_fn":   # a function pointer: NULL on both sides (ctypes wraps each read in a fresh object)
+                    assert not c.mcts_cfg.fpu_fn and not p.mcts_cfg.fpu_fn
+                    continue
                 assert getattr(c.mcts_cfg, n2) == getattr(p.mcts_cfg, n2), n2
         else:
             assert getattr(c, name) == getattr(p, name), name
@@ -290,6 +294,40 @@ def test_learning_loop_torch_sampler_is_libtorchs_randperm_stream():
     assert len(perms) == 4 and all(np.array_equal(a, b) for a, b in zip(perms, want))
     with pytest.raises(ValueError):
         LearningLoop(Recording(), "mlp", np.full(NUM_PARAMS, 0.5, np.float32), sampler="mt19937")
+
+
+def test_every_device_entry_point_selects_its_engines_device():
+    """One process may hold engines on several GPUs (one handle per host thread and GPU: SURVEY §8b), so an entry point that touches the
+    device must first make the handle's device current. Read off the source: every `syn_*` function defined in csrc/engine.hip either
+    calls hipSetDevice(h->device) itself, or reaches the device only through a callee that does, or makes no HIP call at all."""
+    src = open(os.path.join(ROOT, "synthesis_amd", "csrc", "engine.hip")).read()
+    bodies = {}
+    for m in re.finditer(r"^(?:static\s+)?(?:int|const char\*|void|hipError_t)\s+([a-z0-9_]+)\s*\([^)]*\)\s*\{", src, re.M):
+        depth, j = 1, m.end()
+        while depth:
+            depth += {"{": 1, "}": -1}.get(src[j], 0)
+            j += 1
+        bodies[m.group(1)] = src[m.end():j]
+    abi = sorted(n for n in bodies if n.startswith("syn_") and not n.startswith("syn_internal"))
+    assert len(abi) >= 45
+    # entry points without a hipSetDevice of their own, and why that is right
+    delegated = {
+        "syn_mcts_search": "mcts_search_impl", "syn_mcts_search_rollout": "mcts_search_impl",   # the shared body selects the device
+        "syn_eval_ctx_eval": "syn_eval_ctx_submit",                                                # submit + wait, both select it
+    }
+    host_only = {"syn_default_rollout_config", "syn_last_error", "syn_get_network_arithmetic", "syn_f16x2_plan_of_blob",
+                 "syn_eval_ctx_last_error", "syn_trainer_set_precision", "syn_last_timing", "syn_last_cache_stats", "syn_last_launch_shape"}
+    for name in abi:
+        body = bodies[name]
+        if "hipSetDevice(h->device)" in body or "hipSetDevice(device)" in body or "hipSetDevice(c->h->device)" in body:
+            continue
+        if name in delegated:
+            assert delegated[name] in body and "hipSetDevice(h->device)" in bodies[delegated[name]], name
+            continue
+        assert name in host_only, f"{name} makes device calls without selecting the engine's device"
+        assert not re.search(r"\bhip[A-Z][A-Za-z]+\(", body), f"{name} is listed as host-only but calls HIP"
+    # helpers that allocate or copy and can be reached before the entry point's own hipSetDevice
+    assert "hipSetDevice(h->device)" in bodies["upload_f16x2_image"]
 
 
 def test_eight_ranks_under_gloo(tmp_path):

@@ -30,22 +30,40 @@ def blob(golden_dir):
 # (round 5: Connect4Net's compile-time-folded families run 12 waves on at most 768 trees per CU whatever the pool holds — the headline
 #  engine of 262,144 slots plays on 196,608 of them; the conv network keeps 16 waves)
 @pytest.mark.parametrize("net,conc,expect", [("mlp", 262144, (4, 256, 768)), ("mlp", 196608, (4, 256, 768)),
-                                             ("conv", 262144, (4, 256, 1024))])
-def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, net, conc, expect):
-    """The configuration bench.py times, at its own size and with the launch shape the engine picks by itself: Connect4Net (the
-    headline) and the conv policy/value network (the `with_conv_policy` leg; layers slimnn/src/conv.rs:45-85, linear.rs:17-25)."""
+                                             ("conv", 262144, (4, 256, 1024)),
+                                             # every other leg bench.py times on the headline engine, at its own shape (round 6):
+                                             ("mlp-f16x2", 262144, (4, 256, 768)), ("mlp-trained", 262144, (4, 256, 768)),
+                                             ("mlp-f16x2-trained", 262144, (4, 256, 768))])
+def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, golden_dir, monkeypatch, net, conc, expect):
+    """The configurations bench.py times, at their own size and with the launch shape the engine picks by itself: Connect4Net (the
+    headline; `with_trained_weights`: the trained checkpoint), the same two in the f16x2 arithmetic (`with_f16x2_network`: POLICY 3 of
+    the lane-per-tree kernel against the oracle's ACC_F16X2) and the conv policy/value network (the `with_conv_policy` leg; layers
+    slimnn/src/conv.rs:45-85, linear.rs:17-25)."""
     import synthesis_amd as sa
     from tests.oracle_lib import parity_rollout_config
     from tests.test_gpu_parity import assert_selfplay_equal
 
-    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_LANES2", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE", "SYN_PC"):
+    for k in ("SYN_DEBUG", "SYN_LANES", "SYN_LANES2", "SYN_QUADS", "SYN_LANE_THRESH", "SYN_PROFILE", "SYN_PC", "SYN_FREE", "SYN_POOL"):
         monkeypatch.delenv(k, raising=False)
+    f16x2, trained = "f16x2" in net, "trained" in net
+    onet = "conv" if net == "conv" else "mlp"
     if net == "conv":
         from tests.test_gpu_convnet import conv_blob
         weights = conv_blob()
+    elif trained:
+        weights = np.load(os.path.join(golden_dir, "c4net_trained_f32.npy"))
     else:
         weights = blob
-    load = (lambda e: e.load_weights_conv(weights)) if net == "conv" else (lambda e: e.load_weights(weights))
+    nn_mode = oracle.ACC_F16X2 if f16x2 else oracle.ACC_FMA
+
+    def load(e):
+        if net == "conv":
+            e.load_weights_conv(weights)
+        else:
+            if f16x2:
+                e.set_network_arithmetic("f16x2")
+            e.load_weights(weights)
+
     n_games, seed = conc + 12288, 20260
     cfg = sa.parity_rollout_config(800)
     big = sa.Engine(concurrent_games=conc, max_explores=800, device=0)
@@ -58,18 +76,18 @@ def test_bench_shape_matches_oracle_and_small_engine(blob, oracle, monkeypatch, 
 
     # (1) game for game against the oracle: blocks of games from the first wave, the last slots of the pool (highest
     # slab offsets: > 40 GB into the pool) and the refill tail
-    for first in (0, 65536 + 5, conc - 8, conc, n_games - 8):
-        ref = oracle.c4_selfplay(parity_rollout_config(800), weights, seed, 8, first_game=first, threads=8, nn_mode=oracle.ACC_FMA,
-                                 net=net)
+    played = grid * threads    # tree slots the launch plays on
+    for first in (0, 65536 + 5, played - 4, conc - 8, conc, n_games - 8):
+        ref = oracle.c4_selfplay(parity_rollout_config(800), weights, seed, 8, first_game=first, threads=8, nn_mode=nn_mode, net=onet)
         sub = {k: got[k][first:first + 8] for k in ("plies", "states_bb", "pis", "vs", "actions", "root_nodes", "final_kind")}
         assert_selfplay_equal(sub, ref, f"bench shape ({net}), games {first}..{first + 7}")
 
-    # (2) every game against a 4,096-slot engine (Connect4Net: row-per-tree kernel, another node layout; conv: the 4-wave
-    # lane-per-tree shape): same lengths, same last positions and same final results
+    # (2) every game against a 4,096-slot engine (Connect4Net f32: row-per-tree kernel, another node layout; f16x2: the free-running
+    # four-trees-per-wave kernel; conv: the 4-wave lane-per-tree shape): same lengths, same last positions and same final results
     small = sa.Engine(concurrent_games=4096, max_explores=800, device=0)
     load(small)
     ref = small.selfplay(cfg, base_seed=seed, n_games=n_games)
-    assert small.last_launch_shape()[0] in ((1, 2) if net == "mlp" else (4,))
+    assert small.last_launch_shape()[0] in ((4,) if net == "conv" else (7,) if f16x2 else (1, 2))
     small.close()
     assert np.array_equal(got["plies"], ref["plies"])
     assert np.array_equal(got["final_kind"], ref["final_kind"])
@@ -179,6 +197,39 @@ def test_bench_two_ranks_on_one_gpu():
     assert ll["ranks"] == 2 and ll["games_per_iteration"] == 16384 and ll["optimiser_steps"] > 0 and ll["seconds"]["broadcast"] >= 0
     assert abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 16384) < 1.0   # value = games of BOTH ranks / time
     assert 7 <= line["plies_per_game"] <= 63
+
+
+def test_rccl_process_group_at_world_size_1():
+    """What of the N > 1 plumbing a one-GPU box can run over RCCL itself (backend "nccl"): bench.py's process group with a device id,
+    barrier, the MAX / SUM reductions of dist_util.reduce_scalars on the device, an all-reduce of the learner's 30,492-float gradient
+    message, teardown (tools/check_rccl_world1.py, in a child process: a process group belongs to a process)."""
+    from tests.conftest import free_port
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_rccl_world1.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "rccl world-1 ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+
+
+def test_engine_on_a_device_that_is_not_there_fails_loudly(blob):
+    """One rank per GPU: a rank whose GPU is not visible must fail at syn_engine_create with SYN_ERR_NO_DEVICE and a message that
+    names the device — never fall back to GPU 0 (two ranks would silently share a GPU and the scaling curve would lie)."""
+    import torch
+
+    import synthesis_amd as sa
+
+    n = torch.cuda.device_count()
+    for dev in (n, n + 6, -1):
+        with pytest.raises(sa.SynthesisAmdError) as e:
+            sa.Engine(concurrent_games=64, max_explores=16, device=dev)
+        assert e.value.code == -2 and f"device {dev}" in str(e.value) and f"{n} visible" in str(e.value)
+    # the last visible device is a valid home for an engine, and an engine says which device it lives on
+    eng = sa.Engine(concurrent_games=64, max_explores=16, device=n - 1)
+    assert eng.device == n - 1
+    eng.load_weights(blob)
+    l, v = eng.policy_eval(np.zeros(1, np.uint64), np.zeros(1, np.uint64))
+    assert np.isfinite(l).all() and abs(float(v.sum()) - 1.0) < 1e-5
+    eng.close()
 
 
 def test_progress_and_cancel_from_another_thread(blob, oracle):

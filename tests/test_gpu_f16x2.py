@@ -227,6 +227,26 @@ def test_f16x2_arithmetic_switches_cleanly(oracle, blob):
         bad = blob.copy(); bad[5] = np.inf
         with pytest.raises(sa.SynthesisAmdError):
             eng.load_weights(bad)
+        # ... and a refused load changes nothing: the engine still holds blob2 in the f16x2 arithmetic, for policy_eval, an
+        # evaluation context and the searches alike (nothing may run on a stale or missing image)
+        assert eng.network_arithmetic()[0] == "f16x2"
+        l, v = eng.policy_eval(my, op)
+        assert np.array_equal(l, rl) and np.array_equal(v, rv)
+        ctx = eng.eval_context()
+        cl, cv = ctx.eval(my, op)
+        ctx.close()
+        assert np.array_equal(cl, rl) and np.array_equal(cv, rv)
+        got = eng.mcts_search(sa.parity_mcts_config(), my[:8], op[:8], 60)
+        assert_search_equal(got, oracle.c4_mcts_search(parity_mcts_config(), blob2, my[:8], op[:8], 60, nn_mode=oracle.ACC_F16X2), "after a refused load")
+        # the same from the f32 side: the switch itself is refused for parameters without a plan and the engine stays in f32
+        eng.set_network_arithmetic("f32")
+        wide = blob.copy(); wide[7] = np.float32(3e38)
+        eng.load_weights(wide)
+        with pytest.raises(sa.SynthesisAmdError):
+            eng.set_network_arithmetic("f16x2")
+        assert eng.network_arithmetic()[0] == "f32"
+        eng.load_weights(blob2)
+        eng.set_network_arithmetic("f16x2")
         # the learner's hand-off (syn_trainer_publish_weights: model_{i+1}.ot of alpha_zero.rs:97,194) arrives in the chosen arithmetic:
         # a few optimiser steps, publish, and the engine evaluates the TRAINED parameters as the oracle's ACC_F16X2 does
         eng.load_weights(blob)

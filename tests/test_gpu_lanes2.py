@@ -1,4 +1,5 @@
-"""GPU parity of the two-trees-per-lane kernel (synthesis_amd/csrc/lane2_kernel.cuh), the launch shape of the headline benchmark.
+"""GPU parity of the two-trees-per-lane kernel (synthesis_amd/csrc/lane2_kernel.cuh), a debug launch shape
+(`make DEBUG_SHAPES=1`; the tests skip on the default library).
 
 It is the lane-per-tree kernel's algorithm — synthesis/src/mcts.rs:310-488 (explore / select_best_child / visit / backprop) and
 synthesis/src/alpha_zero.rs:229-338 (run_game ...) — with a different schedule: every lane owns two trees and descends one while
@@ -24,7 +25,7 @@ def blob(golden_dir):
 
 
 @pytest.fixture(params=[8, 12])
-def lanes2(monkeypatch, request):
+def lanes2(monkeypatch, request, debug_shapes):
     monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
     monkeypatch.setenv("SYN_LANES2", str(request.param))
     return request.param

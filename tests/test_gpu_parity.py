@@ -360,6 +360,9 @@ def test_trained_checkpoint_deep_trees_match_oracle(golden_dir, oracle, monkeypa
     if shape != "rows":
         monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
         if shape == "pc2":
+            from tests.conftest import debug_shapes_built
+            if not debug_shapes_built():
+                pytest.skip("library built without DEBUG_SHAPES=1")
             monkeypatch.setenv("SYN_PC", "2")
         else:
             monkeypatch.setenv("SYN_LANES", shape[5:])
@@ -655,7 +658,7 @@ def test_lane_per_tree_kernel_matches_oracle(blob, oracle, monkeypatch, waves):
 
 
 @pytest.mark.parametrize("nv", [1, 2, 3])
-def test_producer_consumer_kernel_matches_oracle(blob, oracle, monkeypatch, nv):
+def test_producer_consumer_kernel_matches_oracle(blob, oracle, monkeypatch, nv, debug_shapes):
     """The producer/consumer debug shape (pc_kernel.cuh: 12 tree waves time-slicing `nv` virtual waves of 64 trees each, 4 matrix
     waves fed through an LDS ring, per-tree state parked in global memory between visits) is never chosen automatically
     (measured no faster than the symmetric kernel); force it on a small engine (partial virtual waves, idle tree waves) and hold it to the same
@@ -707,7 +710,7 @@ def test_producer_consumer_kernel_matches_oracle(blob, oracle, monkeypatch, nv):
     eng.close()
 
 
-def test_producer_consumer_kernel_with_policy_cache(blob, oracle, monkeypatch):
+def test_producer_consumer_kernel_with_policy_cache(blob, oracle, monkeypatch, debug_shapes):
     """PolicyWithCache on the producer/consumer kernel (hits skip the ring; their outputs wait in the virtual wave's own
     buffer): results are the oracle's bit for bit, with a tiny contended table and with one that hits."""
     import synthesis_amd as sa

@@ -279,6 +279,32 @@ def test_data_parallel_learner_two_ranks(oracle, blob, gold, tmp_path):
     assert np.abs(r0["weights"] - wf).max() < 1e-5
 
 
+def test_data_parallel_step_through_rccl_at_world_size_1(oracle, blob, gold, tmp_path):
+    """BASELINE configs[4]'s literal step — gradients -> RCCL all-reduce -> Adam, enqueued on one stream with no host wait in between
+    (syn_train_gradients_enqueue / syn_train_apply_enqueue, DataParallelLearner._step_device) — on the process group a one-GPU box can
+    build: backend nccl (= RCCL), world size 1. The message really crosses RCCL (30,494 floats: gradients + the two loss sums); the
+    result equals the oracle's full-batch steps bit for bit."""
+    import subprocess
+    import sys
+
+    from tests.conftest import free_port
+    from tests.oracle_lib import default_train_hyper
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DP_BACKEND="nccl")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "tests", "dp_learner_worker.py"), str(tmp_path)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    r0 = np.load(tmp_path / "rank0.npz")
+    assert int(r0["step"]) == 4
+    hp = default_train_hyper()
+    X = np.stack([oracle.c4_features(gold["my_bb"][s], gold["op_bb"][s]) for s in range(4)])
+    wf, mf, vf, _, lf = oracle.train_steps(blob, hp, X, gold["target_pi"][:4], gold["target_v"][:4], gold["lrs"][:4])
+    assert np.array_equal(r0["weights"], wf) and np.array_equal(r0["m"], mf) and np.array_equal(r0["v"], vf)
+    assert np.array_equal(r0["losses"], lf)
+
+
 @pytest.mark.parametrize("net,mode", [("mlp", "loop"), ("conv", "loop"), ("mlp", "data-parallel"), ("conv", "data-parallel")])
 def test_training_example_keeps_two_ranks_identical(tmp_path, net, mode):
     """examples/train_connect4.py with two ranks (gloo, both on GPU 0), both networks, both readings of BASELINE configs[4].

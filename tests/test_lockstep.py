@@ -81,6 +81,46 @@ def test_lockstep_trees_equal_the_sequential_oracle(harness, oracle, golden_dir)
         assert calls <= rounds <= groups * (explores + 1) and evals <= len(my) * (explores + 1)
 
 
+def counter_fpu_fn():
+    """The counter-based Fpu::Func of the harness's variant 10 (tests/cpp/lockstep_harness.cpp::counter_fpu): call k returns
+    0.5 + (k * 2654435761 mod 2^32 >> 16) / 65536. Returns (callable, calls) — calls[0] counts."""
+    calls = [0]
+
+    def fn():
+        h = (calls[0] * 2654435761) & 0xFFFFFFFF
+        calls[0] += 1
+        return 0.5 + (h >> 16) / 65536.0
+
+    return fn, calls
+
+
+def test_fpu_func_pointer_on_the_host_trees_equals_the_oracle(harness, oracle, golden_dir):
+    """Fpu::Func(fn() -> f32) as the reference types it (config.rs:25; called once per unexpanded child per scan, mcts.rs:351-356) on
+    the host trees: a function with state (a counter) gives a tree the same numbers as the sequential oracle gives it when both call
+    it in the same order — one root, one thread, the same explores; the call counts agree as well."""
+    from tests.oracle_lib import parity_mcts_config
+
+    exe, blobf, d = harness
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    my, op = random_positions(oracle, 6, seed=77, max_moves=30)
+    my[0] = 0; op[0] = 0
+    for i in range(len(my)):
+        roots = str(d / f"root_fn{i}.u64")
+        np.array([my[i], op[i]]).astype("<u8").tofile(roots)
+        out = str(d / f"out_fn{i}.bin")
+        p = subprocess.run([exe, "c4", blobf, roots, "200", "10", "1", out], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        got = records(out, 1)
+        fn, calls = counter_fpu_fn()
+        oracle.set_fpu_fn(fn)
+        try:
+            ref = oracle.c4_mcts_search(parity_mcts_config(fpu=3), blob, my[i:i + 1], op[i:i + 1], 200, nn_mode=oracle.ACC_FMA)
+        finally:
+            oracle.set_fpu_fn(None)
+        assert_search_equal(got, ref, f"Fpu::Func(fn) root {i}")
+        assert int(p.stdout.split()[-1]) == calls[0] > 0
+
+
 SELFPLAY_DTYPE = np.dtype([("bb", np.uint64, (2,)), ("pi", np.float32, (9,)), ("v", np.float32, (3,)), ("action", np.uint32),
                            ("root_nodes", np.uint32)])
 GAME_DTYPE = np.dtype([("plies", np.int32), ("final_kind", np.int32), ("pos", SELFPLAY_DTYPE, (63,))])
@@ -286,6 +326,34 @@ def test_lockstep_search_on_the_gpu_equals_the_fused_search(oracle, golden_dir):
     with pytest.raises(sa.SynthesisAmdError) as e:
         eng.mcts_search_lockstep(sa.MCTSConfig(root_policy_noise=sa.PolicyNoise.Dirichlet, noise_alpha=0.0, noise_weight=0.25), my[:4], op[:4], 8)
     assert e.value.code == -1
+    # Fpu::Func(fn() -> f32) as the reference types it (config.rs:25): a function pointer in syn_mcts_config, called by the host trees
+    # (mcts.rs:354). One root on one thread calls a counter-based function in the oracle's order: same tree, same number of calls.
+    for i in (0, 5, 17):
+        fn, calls = counter_fpu_fn()
+        got = eng.mcts_search_lockstep(sa.MCTSConfig(fpu=sa.Fpu.FuncPtr, fpu_fn=fn), my[i:i + 1], op[i:i + 1], 150, host_threads=1)
+        got.pop("stats")
+        ofn, ocalls = counter_fpu_fn()
+        oracle.set_fpu_fn(ofn)
+        try:
+            ref = oracle.c4_mcts_search(parity_mcts_config(fpu=3), blob, my[i:i + 1], op[i:i + 1], 150, nn_mode=oracle.ACC_FMA)
+        finally:
+            oracle.set_fpu_fn(None)
+        assert_search_equal(got, ref, f"Fpu::Func(fn) through the C ABI, root {i}")
+        assert calls[0] == ocalls[0] > 0
+    # ... a function without state (any fn() -> f32) serves every tree of a many-thread search: Func(|| 1.0) is Fpu::Const(1.0)
+    got = eng.mcts_search_lockstep(sa.MCTSConfig(fpu=sa.Fpu.FuncPtr, fpu_fn=lambda: 1.0), my[:512], op[:512], 40)
+    got.pop("stats")
+    assert_search_equal(got, eng.mcts_search(sa.parity_mcts_config(), my[:512], op[:512], 40), "Func(|| 1.0) == Const(1.0)")
+    # the pointer is required, and a device kernel cannot call into the host: the fused entry points say so
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.mcts_search_lockstep(sa.MCTSConfig(fpu=sa.Fpu.FuncPtr), my[:4], op[:4], 8)
+    assert e.value.code == -1 and "fpu_fn" in str(e.value)
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.mcts_search(sa.MCTSConfig(fpu=sa.Fpu.FuncPtr, fpu_fn=lambda: 1.0), my[:4], op[:4], 8)
+    assert e.value.code == -5 and "host function" in str(e.value)
+    with pytest.raises(sa.SynthesisAmdError) as e:
+        eng.selfplay(sa.parity_rollout_config(8, mcts_cfg=sa.MCTSConfig(fpu=sa.Fpu.FuncPtr, fpu_fn=lambda: 1.0)), base_seed=1, n_games=2)
+    assert e.value.code == -5
     eng.close()
 
 

@@ -86,17 +86,34 @@ def test_ot_varstore_archive_round_trips(golden_dir, tmp_path):
     assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), blob.view(np.uint32))
     t = W.load_ot_tensors(os.path.join(golden_dir, "c4net_blob.ot"))
     assert sorted(t) == sorted(f"l_{l}.{k}" for l in range(1, 6) for k in ("weight", "bias")) and t["l_2.weight"].shape == (96, 128)
-    mine = str(tmp_path / "mine.ot")
-    W.save_ot(blob * np.float32(0.5), mine)
-    assert np.array_equal(W.load_ot(mine), blob * np.float32(0.5))
-    import torch
-
-    m = torch.jit.load(mine)   # (test-time cross-check only: the product path never imports torch for this)
-    sd = dict(m.named_parameters())
-    assert np.array_equal(sd["l_5.bias"].numpy(), (blob * np.float32(0.5))[-12:]) and tuple(sd["l_1.weight"].shape) == (128, 63)
-    # what is not a Connect4Net VarStore says so
+    # the on-disk names of a reference checkpoint: tch's VarStore::save goes through Tensor::save_multi, which stores `l_1|weight`
+    # ('.' -> '|', mapped back by load_multi). The same libtorch writer with those names (c4net_blob_tch_names.ot) reads the same.
+    tch = os.path.join(golden_dir, "c4net_blob_tch_names.ot")
     import zipfile
 
+    with zipfile.ZipFile(tch) as z:
+        pkl = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    assert b"l_1|weight" in pkl and b"l_1.weight" not in pkl
+    got = W.load_ot(tch)
+    assert np.array_equal(got.view(np.uint32), blob.view(np.uint32))
+    assert sorted(W.load_ot_tensors(tch)) == sorted(t)
+    import torch
+
+    for names, sep in (("tch", "|"), ("dotted", ".")):
+        mine = str(tmp_path / f"mine_{names}.ot")
+        W.save_ot(blob * np.float32(0.5), mine, names=names)
+        assert np.array_equal(W.load_ot(mine), blob * np.float32(0.5))
+        with zipfile.ZipFile(mine) as z:
+            assert f"l_3{sep}bias".encode() in z.read("archive/data.pkl")
+        m = torch.jit.load(mine)   # (test-time cross-check only: the product path never imports torch for this)
+        sd = dict(m.named_parameters())
+        assert np.array_equal(sd[f"l_5{sep}bias"].numpy(), (blob * np.float32(0.5))[-12:]) and tuple(sd[f"l_1{sep}weight"].shape) == (128, 63)
+    # a view that reaches past its storage is refused before any memory is touched
+    with pytest.raises(ValueError, match="past its storage"):
+        W._rebuild_tensor_v2(np.zeros(8, np.float32), 4, (2, 3), (3, 1))
+    with pytest.raises(ValueError, match="not a view"):
+        W._rebuild_tensor_v2(np.zeros(8, np.float32), -1, (2,), (1,))
+    # what is not a Connect4Net VarStore says so
     bad = str(tmp_path / "bad.ot")
     with zipfile.ZipFile(bad, "w") as z:
         z.writestr("x/data.pkl", b"\x80\x02cos\nsystem\nq\x00.")
