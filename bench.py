@@ -11,7 +11,7 @@
 
 Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7 Connect4, 800 explores per move,
            deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
-           SoA MCTS node pool) at 262,144 concurrent games per GPU (1,024 per CU: the 16-wave lane-per-tree kernel);
+           SoA MCTS node pool) at 196,608 concurrent games per GPU (768 per CU: the 12-wave lane-per-tree kernel);
            configs[1]'s 4096 concurrent games is measured in the same run and reported under "at_4096_concurrent_games".
 Step     : one pass of the hot path over one batch = GAMES_PER_STEP (2,097,152 = 8 per tree slot) self-play games per GPU played to completion by
            ONE launch of the fused kernel (finished games hand their tree slot to the next game index, so the slots stay busy).
@@ -152,6 +152,23 @@ def cpu_baseline(blob, explores, sample_games, threads):
     }
 
 
+def cpu_baseline_single_thread(blob, explores, games=16):
+    """BASELINE configs[0]: the reference's CPU path on ONE thread (study-connect4/src/main.rs:85-86 pins libtorch to one thread; one
+    worker of gather_experience) — a few games of the same workload without and with PolicyWithCache (alpha_zero.rs:196-198)."""
+    from tests import oracle_lib
+
+    oracle = oracle_lib.load()
+    cfg = oracle_lib.parity_rollout_config(explores)
+    out = {"cores": 1, "kind": "port", "games": games, "unit": "games/s"}
+    for name, cache in (("policy_cache_off", False), ("policy_cache_on", True)):
+        r = oracle.c4_selfplay(cfg, blob, base_seed=0, n_games=games, threads=1, use_cache=cache, nn_mode=oracle.ACC_SLIMNN, outputs=False)
+        c = r["counters"]
+        out[name] = {"value": games / r["seconds"], "seconds": r["seconds"], "leaf_evals_per_s": c["policy_evals"] / r["seconds"],
+                     "explores_per_s": c["explores"] / r["seconds"]}
+    out["sample"] = f"{games} games of the same workload ({explores}-explore self-play, parity config, slimnn accumulation order) on one host thread, twice"
+    return out
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU, RANK = LOCAL_RANK = 0..N-1) as
     children of this process, which has not touched the GPU and will not. Returns the worst exit status."""
@@ -185,12 +202,24 @@ def spawn_ranks(n, argv):
 
 def main():
     t_run0 = time.perf_counter()
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to stdout when a communicator is created
+    # (every N > 1 run; the learner's world-size-1 leg at N = 1). File descriptor 1 points at stderr for the whole run and the line
+    # goes to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        real_stdout.write(json.dumps(obj) + "\n")
+        real_stdout.flush()
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--concurrent", type=int, default=262144,
-                    help="concurrent games (tree slots) per GPU; BASELINE configs[1] names 4096, reported as extra")
+    ap.add_argument("--concurrent", type=int, default=196608,
+                    help="concurrent games (tree slots) per GPU: 768 per CU = 12 waves of 64 trees, what the headline launch plays on "
+                         "(rounds 1-5 created 262,144 slots and played on 196,608 of them); BASELINE configs[1] names 4096, reported as extra")
     ap.add_argument("--games-per-step", type=int, default=2097152, help="self-play games per GPU per step (8 per tree slot)")
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
@@ -233,7 +262,7 @@ def main():
         dist_util.barrier(dist)
         _, (ranks, lsum) = dist_util.reduce_scalars(dist, "cpu", 0.0, [1, local_rank])
         if rank == 0:
-            print(json.dumps({"check_launch": True, "n_gpus": world, "ranks_joined": ranks, "local_rank_sum": lsum}), flush=True)
+            emit({"check_launch": True, "n_gpus": world, "ranks_joined": ranks, "local_rank_sum": lsum})
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -378,6 +407,13 @@ def main():
         f32-equivalent rate (the 60,288 FLOP the network needs, the figure the f32 kernel is priced by)."""
         eng.set_network_arithmetic("f16x2")
         res = {}
+        try:
+            return _f16x2_leg_body(eng, n_games, first, res)
+        finally:   # whatever happened, the shared engine goes back to the headline's arithmetic and weights for the legs that follow
+            eng.set_network_arithmetic("f32")
+            eng.load_weights(blob)
+
+    def _f16x2_leg_body(eng, n_games, first, res):
         for name, w in (("random_init", blob), ("trained_checkpoint", trained_blob)):
             if w is None:
                 continue
@@ -406,8 +442,6 @@ def main():
                          "f32_equivalent": {"tflops_at_60288_flop_per_eval": f32eq["achieved"], "frac_of_the_f32_matrix_peak": f32eq["frac"],
                                             "note": "what the f32 kernel is priced by; the f16x2 kernel does not run on that pipe"}}
             first += args.concurrent + n_games
-        eng.set_network_arithmetic("f32")
-        eng.load_weights(blob)
         out16 = res.get("random_init", {})
         out16["dtype"] = "f16x2 (operands: pairs of f16, 22-23 significand bits; accumulation f32)"
         out16["parity"] = "searches and games bit-identical to the oracle run in ACC_F16X2 (tests/test_gpu_f16x2.py); network within 1e-5 / 3 of slimnn order"
@@ -415,9 +449,17 @@ def main():
             out16["trained_checkpoint"] = res["trained_checkpoint"]
         return out16
 
-    def conv_leg(eng, n_games, first):
-        """the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same engine, same
-        MCTS configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476)"""
+    def conv_leg(_eng, n_games, first):
+        """the conv policy/value network of north_star (Connect4ConvNet, convnet.cuh) behind the same Policy::eval: same MCTS
+        configuration, fixed-seed init; its matrix-core tile is 567 MFMAs per 16 positions (Connect4Net: 476). An engine of its own at
+        the size this network's launch shape wants (16 waves x 1,024 trees per CU = 262,144 slots; 12 x 768 measures 48.7k against 62.7k)."""
+        eng = sa.Engine(concurrent_games=max(args.concurrent, 262144), max_explores=args.explores, device=local_rank)
+        try:
+            return _conv_leg_body(eng, n_games, first)
+        finally:
+            eng.close()
+
+    def _conv_leg_body(eng, n_games, first):
         eng.load_weights_conv(make_conv_weights())
         eng.selfplay(cfg, base_seed=0, n_games=args.concurrent, first_game=first, outputs=False)
         t1 = time.perf_counter()
@@ -427,8 +469,7 @@ def main():
         cc = eng.selfplay(cfg, base_seed=0, n_games=32768, first_game=first + args.concurrent, outputs=False, counters=True)["counters"]
         evals_per_s = (cc["policy_evals"] / 32768.0) * (n_games / dt5)
         near, other = leg_rooflines(cc, 32768, n_games, rt["kernel_ms"], "conv_traffic_bytes_per_launch", CONV_FLOP_PER_EVAL)
-        eng.load_weights(blob)
-        return {"network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
+        return {"concurrent_games": conv_shape[1] * conv_shape[2], "network": "Connect4ConvNet: Conv2d<2,16,3,pad 1> + ReLU + Linear<1008,12> (12,412 parameters), fixed-seed init",
                 "games_per_s": n_games / dt5, "games": n_games, "kernel_ms": rt["kernel_ms"], "plies_per_game": float(rt["plies"].mean()),
                 "leaf_evals_per_s": evals_per_s, "select_levels_per_explore": cc["select_levels"] / max(1, cc["explores"]),
                 "flop_per_eval": CONV_FLOP_PER_EVAL,
@@ -444,7 +485,7 @@ def main():
         out["with_f16x2_network"] = f16x2_leg(eng, gh, 8 * gh)
         eng.close()
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         return
 
     eng = sa.Engine(concurrent_games=args.concurrent, max_explores=args.explores, device=local_rank)
@@ -482,11 +523,11 @@ def main():
     if args.skip_counted:
         # tools/collect_profiles.sh's counter passes only need the launches themselves: no instrumented re-run, no roofline objects
         if rank == 0:
-            print(json.dumps({"metric": "self-play games/sec, 9x7 Connect4", "value": gps * world * args.steps / elapsed, "unit": "games/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-                              "kernel_ms_avg": float(np.mean(kernel_ms)), "roofline": None, "profile_pass": True,
-                              "config": {"games_per_step_per_gpu": gps, "concurrent_games_per_gpu": args.concurrent,
-                                         "explores_per_move": args.explores}}), flush=True)
+            emit({"metric": "self-play games/sec, 9x7 Connect4", "value": gps * world * args.steps / elapsed, "unit": "games/s",
+                  "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                  "kernel_ms_avg": float(np.mean(kernel_ms)), "roofline": None, "profile_pass": True,
+                  "config": {"games_per_step_per_gpu": gps, "concurrent_games_per_gpu": args.concurrent,
+                             "explores_per_move": args.explores}})
         eng.close()
         if dist is not None:
             dist.barrier()
@@ -499,6 +540,8 @@ def main():
                    4: "selfplay_kernel_lanes", 5: "selfplay_kernel_pc", 6: "selfplay_kernel_lanes2"}.get(shape, "?") + f" <<<{sgrid}, {sthreads}>>>"
     last_ms = kernel_ms[-1]
     avg_ms = float(np.mean(kernel_ms))
+    # concurrent games = trees the launch plays on: one per lane of the lane-per-tree kernels, 16 per workgroup of the row kernels
+    played_slots = min(args.concurrent, sgrid * sthreads if shape in (4, 6, 8) else sgrid * 16 * (sthreads // 256) if shape in (1, 2, 3, 7) else args.concurrent)
 
     # ---- BASELINE configs[4] (self-play on every GPU + the training step): three iterations of the learning loop in the shape that
     #      scales (synthesis_amd.learner.LearningLoop: every rank plays 8,192 games at 200 explores, rank 0 gathers, de-duplicates and
@@ -575,10 +618,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"9x7 Connect4 self-play, 1 MI355X per rank, GPU-resident SoA MCTS node pool "
-                                   f"(BASELINE configs[2]) + fused f32-MFMA Connect4Net leaf inference, {args.concurrent} "
+                                   f"(BASELINE configs[2]) + fused f32-MFMA Connect4Net leaf inference, {played_slots} "
                                    f"concurrent games per GPU, {args.explores} explores/move, parity MCTS config; "
                                    f"fixed-seed random-init weights",
-                       "games_per_step_per_gpu": gps, "concurrent_games_per_gpu": args.concurrent,
+                       # trees the launch plays on (grid x threads of the lane-per-tree kernel: one tree per lane) and the slots the
+                       # engine was created with — equal by default; a larger engine only holds idle slabs
+                       "games_per_step_per_gpu": gps, "concurrent_games_per_gpu": played_slots, "tree_slots_allocated": args.concurrent,
                        "explores_per_move": args.explores, "parallelism": f"games sharded over {world} GPU(s), no collective"},
             "leaf_evals_per_s": games_per_s * evals_per_game, "explores_per_s": games_per_s * explores_per_game,
             "plies_per_game": plies / total_games,
@@ -608,10 +653,17 @@ def main():
             sample = args.cpu_sample_games or 64 * threads  # ~15-20 s of wall time
             out["cpu_baseline"] = cpu_baseline(blob, args.explores, sample, threads)
             out["cpu_baseline"]["host"] = {"logical_cpus": os.cpu_count(), "cgroup_cpu_quota": quota, "usable_cpus": budget}
+            try:
+                out["cpu_baseline"]["single_thread"] = cpu_baseline_single_thread(blob, args.explores)   # BASELINE configs[0]
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_baseline"]["single_thread"] = {"error": str(ex)[:200]}
         next_first = (args.warmup + args.steps) * gps   # game indices never reused by a later leg
         extras = world == 1 and not args.no_extras
         if extras and fits("with_f16x2_network", 5.5 * t_q + 12):
-            out["with_f16x2_network"] = f16x2_leg(eng, gh, next_first)
+            try:
+                out["with_f16x2_network"] = f16x2_leg(eng, gh, next_first)
+            except Exception as ex:  # noqa: BLE001 (never lose the bench line over an extra leg)
+                out["with_f16x2_network"] = {"error": str(ex)[:200]}
             next_first += 2 * (args.concurrent + gh)
         if extras and trained_blob is not None and fits("with_trained_weights", 3.6 * t_q + 8):
             out["with_trained_weights"] = trained_leg(eng, gh, next_first)
@@ -774,13 +826,45 @@ def main():
                     e3.train_epoch(perm[: n_steps * 32], 32, 1e-3)
                     dt6 = time.perf_counter() - t1
                     learner[name] = {"steps": n_steps, "steps_per_s": n_steps / dt6, "us_per_step": dt6 / n_steps * 1e6}
+                # BASELINE configs[4]'s literal step — gradients -> RCCL all-reduce -> Adam — through DataParallelLearner on the process
+                # group a one-GPU box can build (backend nccl, world size 1): the 122 KB message really goes through RCCL; steps/s
+                # of the whole stream-ordered step incl. the device-side minibatch gather (the epoch kernels above have no collective)
+                try:
+                    import socket
+
+                    from synthesis_amd.learner import DataParallelLearner
+
+                    own = None
+                    if dist is None and args.dist_backend == "nccl":
+                        with socket.socket() as sk:
+                            sk.bind(("127.0.0.1", 0))
+                            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+                        os.environ.update(MASTER_ADDR="127.0.0.1", RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+                        own = dist_util.init_process_group("nccl", local_rank)
+                    dp = DataParallelLearner(e3, blob, dist=own if own is not None else dist, device=local_rank, collective_at_world_1=True)
+                    dp.set_data(d3["my_bb"], d3["op_bb"], d3["pis"], d3["vs"])
+                    dp.epoch(perm[: 64 * 32], 32, 1e-3)
+                    torch.cuda.synchronize(local_rank)
+                    t1 = time.perf_counter()
+                    nst = dp.epoch(perm[: min(st3, 2000) * 32], 32, 1e-3)
+                    torch.cuda.synchronize(local_rank)
+                    dt7 = time.perf_counter() - t1
+                    learner["data_parallel_world1"] = {"steps": nst, "steps_per_s": nst / dt7, "us_per_step": dt7 / nst * 1e6, "network": "connect4net",
+                                                       "collective": "all_reduce of 30,494 f32 (gradients + 2 loss sums) per step, backend %s, world size 1"
+                                                                     % (args.dist_backend if (own is not None or dist is not None) else "none"),
+                                                       "path": "device gather of the minibatch -> syn_train_gradients_enqueue -> all_reduce -> "
+                                                               "syn_train_apply_enqueue on one stream, no host synchronisation per step"}
+                    if own is not None:
+                        own.destroy_process_group()
+                except Exception as ex:  # noqa: BLE001
+                    learner["data_parallel_world1"] = {"error": repr(ex)[:300]}
                 out["learner"] = learner
                 e3.close()
             except Exception as ex:  # the learner is not the benchmarked path: never lose the bench line over it
                 out["learner"] = {"error": repr(ex)}
         if skipped:
             out["skipped_for_time_budget"] = {"legs": skipped, "budget_s": args.time_budget_s}
-        print(json.dumps(out), flush=True)
+        emit(out)
 
     try:
         eng.close()

@@ -374,7 +374,7 @@ int syn_train_gradients_device(syn_engine* h, const uint64_t* d_my_bb, const uin
 int syn_train_apply_device(syn_engine* h, const float* d_grads, float lr, float grad_scale);
 /* The stream-ordered form of the same two calls (one optimiser step of alpha_zero.rs:76-92 split around the RCCL all-reduce, no host
  * in between): both enqueue on `stream` (a hipStream_t of the engine's device: the stream the batch was prepared on and the all-reduce
- * runs on; NULL = the engine's own) and return without synchronising. d_losses: DEVICE pointer to 2 floats {pi-loss sum, v-loss sum}
+ * runs on; NULL is the device's null stream — PyTorch's default stream — not the engine's own) and return without synchronising. d_losses: DEVICE pointer to 2 floats {pi-loss sum, v-loss sum}
  * of this rank's minibatch (may be NULL) — typically the two words behind the 30,492 gradients, so they ride in the same message.
  * While a caller drives the trainer this way it keeps the engine's other trainer entry points (which use the engine's stream) idle. */
 int syn_train_gradients_enqueue(syn_engine* h, void* stream, const uint64_t* d_my_bb, const uint64_t* d_op_bb, const float* d_target_pi,

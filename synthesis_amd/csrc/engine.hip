@@ -34,6 +34,7 @@
 #include "train_conv_mfma.cuh"
 #include "lane_instances.h"
 #include "free_kernel.cuh"
+#include "pool_kernel.cuh"
 
 #include <hipcub/hipcub.hpp>
 #include <chrono>
@@ -82,6 +83,11 @@ SYN_LANES_REF_LIST(SYN_X)
 SYN_LANES_F16_LIST(SYN_X)
 SYN_LANES_F16_GEN_LIST(SYN_X)
 #undef SYN_X
+// ... and the pool kernels (pool_kernel.cuh) in engine_pool.hip / engine_pool_f16.hip
+#define SYN_X(MODE, COUNT, FAST, NW, POLICY) extern template __global__ void selfplay_kernel_pool<MODE, COUNT, FAST, NW, POLICY>(EngineParams);
+SYN_POOL_F32_LIST(SYN_X)
+SYN_POOL_F16_LIST(SYN_X)
+#undef SYN_X
 // ... and the free-running four-trees-per-wave kernels (free_kernel.cuh) in engine_free.hip
 #define SYN_FREE(MODE, COUNT)                                                                      \
     extern template __global__ void selfplay_kernel_free<MODE, COUNT, true, false>(EngineParams);  \
@@ -123,6 +129,8 @@ struct syn_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int slots = 0;
     int last_shape = 0, last_grid = 0, last_threads = 0;
+    int pool_trees = 0;  // > 64: the pool kernel (pool_kernel.cuh) with that many trees per wave plays the folded Connect4Net families at headline size
+    int last_pool_trees = 0;
     int pool_slots = 0;  // tree slabs actually allocated (slots rounded up to the largest workgroup + slack)
     int max_explores = 0;
     uint32_t cap = 0;
@@ -500,6 +508,71 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         }
     }
 #endif
+    // The pool kernel (pool_kernel.cuh): a wave's 64 lanes work on a pool of M trees (64 < M <= 128) — a lane whose descent arrives
+    // binds the next READY tree in the same iteration, a round fires on 64 leaves — for the two compile-time-folded configuration
+    // families of Connect4Net (f32 and f16x2). 12 waves x M trees per CU. SYN_DEBUG=1 SYN_POOL=<M> forces it (0 = never).
+    {
+        int pm = h->pool_trees;
+        if (const char* ev = debug_env("SYN_POOL")) pm = std::atoi(ev);
+        // 1 = as many trees per wave as the engine's slots give 12 waves on every CU (at most 128)
+        if (pm == 1) pm = (want_slots + h->num_cus * 12 - 1) / (h->num_cus * 12) > PoolGeom::M_MAX ? PoolGeom::M_MAX
+                                                                                                   : (want_slots + h->num_cus * 12 - 1) / (h->num_cus * 12);
+        const int fam = cfg_family(P.mcts);
+        const bool f16 = h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F16X2 && P.wimg == reinterpret_cast<const float*>(h->d_wimg16);
+        const bool lanes_forced = debug_env("SYN_LANES") != nullptr || debug_env("SYN_QUADS") != nullptr;
+        if (pm > 64 && pm <= PoolGeom::M_MAX && (fam == 1 || fam == 2) && h->net_kind == 0 && h->cap <= LANE_MAX_CAP && !PROF && !lanes_forced &&
+            (debug_env("SYN_POOL") != nullptr || want_slots >= h->num_cus * 768)) {
+            constexpr int nw = 12;
+            const int per_wg = nw * pm;
+            int pgrid = (want_slots + per_wg - 1) / per_wg;
+            if (pgrid > h->num_cus) pgrid = h->num_cus;   // one workgroup per CU: a larger engine only holds idle slabs
+            if (pgrid < 1) pgrid = 1;
+            const size_t nwv = (size_t)pgrid * nw;
+            const size_t need_path = nwv * 2 * PATH_ENTRIES * sizeof(uint4);
+            if (need_path > h->path_bytes) {
+                if (h->d_path) (void)hipFree(h->d_path);
+                h->d_path = nullptr;
+                h->path_bytes = 0;
+                hipError_t pe = hipMalloc(&h->d_path, need_path);
+                if (pe != hipSuccess) return pe;
+                h->path_bytes = need_path;
+            }
+            const size_t need_vw = nwv * PoolGeom::WAVE_BYTES;
+            if (need_vw > h->vw_bytes) {
+                if (h->d_vw) (void)hipFree(h->d_vw);
+                h->d_vw = nullptr;
+                h->vw_bytes = 0;
+                hipError_t pe = hipMalloc(&h->d_vw, need_vw);
+                if (pe != hipSuccess) return pe;
+                h->vw_bytes = need_vw;
+            }
+            EngineParams PL = P;
+            PL.path = h->d_path;
+            PL.vw_buf = h->d_vw;
+            PL.nv = pm;
+            PL.lane_thresh = 24;   // Fpu::Func: waiting lanes that trigger a scan iteration
+            if (const char* ev = debug_env("SYN_POOL_SCAN")) PL.lane_thresh = std::atoi(ev);
+            if (PL.lane_thresh < 1 || PL.lane_thresh > 64) PL.lane_thresh = 24;
+#define SYN_LAUNCH_P(FASTV, POL)                                                                                   \
+    {                                                                                                              \
+        auto k = selfplay_kernel_pool<MODE, COUNT, FASTV, 12, POL>;                                                \
+        using PLds = PoolLds<12, FASTV>;                                                                           \
+        const size_t plds = PLds::BYTES;                                                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                 \
+        if (e != hipSuccess) return e;                                                                             \
+        hipLaunchKernelGGL(k, dim3(pgrid), dim3(64 * 12), plds, h->stream, PL);                                    \
+    }
+            if (f16) { if (fam == 1) SYN_LAUNCH_P(1, 3) else SYN_LAUNCH_P(2, 3) }
+            else { if (fam == 1) SYN_LAUNCH_P(1, 0) else SYN_LAUNCH_P(2, 0) }
+#undef SYN_LAUNCH_P
+            h->last_shape = 8; h->last_grid = pgrid; h->last_threads = 64 * nw;
+            h->last_pool_trees = pm;
+            if (out_grid) *out_grid = pgrid;
+            if (out_nt) *out_nt = 64 * nw;
+            return hipGetLastError();
+        }
+    }
     {
         int nw = 0;
         // 4 waves per workgroup up to 256 trees per CU, 8 up to 512, 12 up to 768, 16 (hand-pipelined network tile that fits
@@ -2072,8 +2145,9 @@ int syn_trainer_set_precision(syn_engine* h, int precision) {
 
 static int launch_grads(syn_engine* h, const unsigned long long* d_my, const unsigned long long* d_op,
                         const float* d_tpi, const float* d_tv, int batch, float* d_grads, float* d_losses = nullptr,
-                        const int* d_idx = nullptr, hipStream_t on = nullptr) {
-    const hipStream_t st = on ? on : h->stream;   // (the *_enqueue entry points run the step on the caller's stream)
+                        const int* d_idx = nullptr, bool on_callers_stream = false, hipStream_t callers = nullptr) {
+    // (the *_enqueue entry points run the step on the caller's stream — which may be the null stream: torch's default)
+    const hipStream_t st = on_callers_stream ? callers : h->stream;
     if (h->trainer_kind == 1) {
         // Connect4ConvNet (train_conv_mfma.cuh): one workgroup, the minibatch's activations resident in LDS, every chain on the
         // f32 matrix cores
@@ -2121,8 +2195,9 @@ static int launch_grads(syn_engine* h, const unsigned long long* d_my, const uns
     return SYN_OK;
 }
 
-static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad_scale, hipStream_t on = nullptr) {
-    const hipStream_t st = on ? on : h->stream;
+static int launch_adam(syn_engine* h, const float* d_grads, float lr, float grad_scale, bool on_callers_stream = false,
+                       hipStream_t callers = nullptr) {
+    const hipStream_t st = on_callers_stream ? callers : h->stream;
     h->train_step += 1;
     const double bc1 = 1.0 - std::pow((double)h->train_hp.beta1, (double)h->train_step);
     const double bc2 = 1.0 - std::pow((double)h->train_hp.beta2, (double)h->train_step);
@@ -2179,7 +2254,7 @@ int syn_train_gradients_enqueue(syn_engine* h, void* stream, const uint64_t* d_m
         return fail(h, SYN_ERR_INVALID_ARGUMENT, "bad arguments to syn_train_gradients_enqueue");
     HIP_TRY(h, hipSetDevice(h->device));
     return launch_grads(h, reinterpret_cast<const unsigned long long*>(d_my_bb), reinterpret_cast<const unsigned long long*>(d_op_bb),
-                        d_target_pi, d_target_v, batch, d_grads, d_losses, nullptr, static_cast<hipStream_t>(stream));
+                        d_target_pi, d_target_v, batch, d_grads, d_losses, nullptr, true, static_cast<hipStream_t>(stream));
 }
 
 int syn_train_apply_enqueue(syn_engine* h, void* stream, const float* d_grads, float lr, float grad_scale) {
@@ -2187,7 +2262,7 @@ int syn_train_apply_enqueue(syn_engine* h, void* stream, const float* d_grads, f
     if (!h->has_trainer) return fail(h, SYN_ERR_NO_WEIGHTS, "call syn_trainer_init first");
     if (!d_grads) return fail(h, SYN_ERR_INVALID_ARGUMENT, "d_grads is NULL");
     HIP_TRY(h, hipSetDevice(h->device));
-    return launch_adam(h, d_grads, lr, grad_scale, static_cast<hipStream_t>(stream));
+    return launch_adam(h, d_grads, lr, grad_scale, true, static_cast<hipStream_t>(stream));
 }
 
 int syn_train_step(syn_engine* h, const uint64_t* my_bb, const uint64_t* op_bb, const float* target_pi,

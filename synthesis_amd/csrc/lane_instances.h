@@ -51,3 +51,11 @@
     X(MODE_SELFPLAY, false, false, 4, false, 3) X(MODE_SELFPLAY, false, false, 8, false, 3)                      \
     X(MODE_SELFPLAY, true, false, 4, false, 3) X(MODE_SELFPLAY, true, false, 8, false, 3)                        \
     X(MODE_SEARCH, false, false, 4, false, 3) X(MODE_SEARCH, false, false, 8, false, 3)
+// The pool kernel (pool_kernel.cuh: trees unbound from the lanes for the descent), Connect4Net f32 (POLICY 0: engine_pool.hip) and f16x2
+// (POLICY 3: engine_pool_f16.hip), the two compile-time-folded families, 12 waves:  X(MODE, COUNT, FAST, NW, POLICY)
+#define SYN_POOL_F32_LIST(X)                                                                                     \
+    X(MODE_SELFPLAY, false, 1, 12, 0) X(MODE_SELFPLAY, true, 1, 12, 0) X(MODE_SEARCH, false, 1, 12, 0)           \
+    X(MODE_SELFPLAY, false, 2, 12, 0) X(MODE_SELFPLAY, true, 2, 12, 0) X(MODE_SEARCH, false, 2, 12, 0)
+#define SYN_POOL_F16_LIST(X)                                                                                     \
+    X(MODE_SELFPLAY, false, 1, 12, 3) X(MODE_SELFPLAY, true, 1, 12, 3) X(MODE_SEARCH, false, 1, 12, 3)           \
+    X(MODE_SELFPLAY, false, 2, 12, 3) X(MODE_SELFPLAY, true, 2, 12, 3) X(MODE_SEARCH, false, 2, 12, 3)

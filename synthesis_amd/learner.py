@@ -271,6 +271,19 @@ class DataParallelLearner:
         my, op, tpi, tv = (a.index_select(0, ix).contiguous() for a in self._data)
         self._step_device(my, op, tpi, tv, lr)
 
+    def epoch(self, order, batch, lr):
+        """len(order) // batch optimiser steps over the uploaded data set in the given order (THIS rank's shard of every global batch):
+        the order is uploaded once, every step gathers its minibatch on the device and runs gradients -> all-reduce -> Adam in stream
+        order; the host only enqueues. Returns the number of steps."""
+        t = self._torch
+        od = t.as_tensor(np.ascontiguousarray(order, dtype=np.int64), device=self.device)
+        n = int(od.numel()) // int(batch)
+        for s in range(n):
+            ix = od[s * batch:(s + 1) * batch]
+            my, op, tpi, tv = (a.index_select(0, ix) for a in self._data)
+            self._step_device(my, op, tpi, tv, lr)
+        return n
+
     def step(self, my_bb, op_bb, target_pi, target_v, lr):
         """One optimiser step; the arguments are THIS rank's shard of the batch (host arrays). Returns the (pi_loss, v_loss) of
         the global batch (mean over ranks of the per-shard means) — which costs a device synchronisation; `step_indices` +

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Developer tool (a first argument "f16x2" selects the f16x2 network arithmetic): throughput of the lane-per-tree / producer-consumer kernels. Args: conc:nw[:games[:policy_cache_log2]] ...
 (nw = waves per workgroup of the lane kernel, 0 = the engine's own choice, negative = producer/consumer kernel with -nw
-virtual waves per tree wave, 208 / 212 = the two-trees-per-lane kernel with 8 / 12 waves). A first argument "reference" runs the
+virtual waves per tree wave, 208 / 212 = the two-trees-per-lane kernel with 8 / 12 waves, 365 .. 428 = the pool kernel with
+nw - 300 trees per wave, 300 = the pool kernel switched off). A first argument "reference" runs the
 reference's own self-play configuration (trained checkpoint + Fpu::Func(Normal(1.0, 0.1)); give a policy_cache_log2 too). A first argument "conv" runs Connect4ConvNet (convnet.cuh) instead of Connect4Net; "eval" appended
 measures the stand-alone batched Policy::eval of the chosen network on 4M positions as well."""
 import os
@@ -35,8 +36,10 @@ for c in combos:
     conc, nw = c[0], c[1]
     n = c[2] if len(c) > 2 else 2 * conc
     clog = c[3] if len(c) > 3 else 0
-    os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None); os.environ.pop("SYN_LANES2", None)
-    if nw in (208, 212): os.environ["SYN_LANES2"] = str(nw - 200)
+    os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None); os.environ.pop("SYN_LANES2", None); os.environ.pop("SYN_POOL", None)
+    if 365 <= nw <= 428: os.environ["SYN_POOL"] = str(nw - 300)   # the pool kernel with nw - 300 trees per wave (pool_kernel.cuh)
+    elif nw == 300: os.environ["SYN_POOL"] = "0"                   # ... switched off (the lane kernel the engine would pick without it)
+    elif nw in (208, 212): os.environ["SYN_LANES2"] = str(nw - 200)
     elif nw > 0: os.environ["SYN_LANES"] = str(nw); os.environ["SYN_PC"] = "0"
     elif nw < 0: os.environ["SYN_PC"] = str(-nw)
     eng = sa.Engine(concurrent_games=conc, max_explores=800, policy_cache_log2=clog)
