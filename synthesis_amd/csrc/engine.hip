@@ -435,7 +435,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // SYN_DEBUG=1 SYN_FREE=0 switches it off (the lane kernel at 4 waves then plays these games).
     if (h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F16X2 && P.wimg == reinterpret_cast<const float*>(h->d_wimg16) &&
         want_slots <= 16 * h->num_cus && P.mcts.fpu != 2 && P.mcts.noise != 2 && debug_env("SYN_LANES") == nullptr &&
-        !(debug_env("SYN_FREE") && std::atoi(debug_env("SYN_FREE")) == 0)) {
+        !(debug_env("SYN_FREE") && std::atoi(debug_env("SYN_FREE")) == 0) && !(debug_env("SYN_POOL") && std::atoi(debug_env("SYN_POOL")) > 64)) {
         const int mgrid = (want_slots + 15) / 16;
 #define SYN_LAUNCH_FR(FAST, PROFV)                                                                                 \
     {                                                                                                              \
@@ -522,7 +522,8 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         const bool lanes_forced = debug_env("SYN_LANES") != nullptr || debug_env("SYN_QUADS") != nullptr;
         if (pm > 64 && pm <= PoolGeom::M_MAX && (fam == 1 || fam == 2) && h->net_kind == 0 && h->cap <= LANE_MAX_CAP && !PROF && !lanes_forced &&
             (debug_env("SYN_POOL") != nullptr || want_slots >= h->num_cus * 768)) {
-            constexpr int nw = 12;
+            int nw = 12;   // waves per workgroup: 12 (three per SIMD, 168 registers) or 8 (two per SIMD, 256 registers)
+            if (const char* ev = debug_env("SYN_POOL_NW")) nw = std::atoi(ev) == 8 ? 8 : 12;
             const int per_wg = nw * pm;
             int pgrid = (want_slots + per_wg - 1) / per_wg;
             if (pgrid > h->num_cus) pgrid = h->num_cus;   // one workgroup per CU: a larger engine only holds idle slabs
@@ -553,19 +554,24 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             PL.lane_thresh = 24;   // Fpu::Func: waiting lanes that trigger a scan iteration
             if (const char* ev = debug_env("SYN_POOL_SCAN")) PL.lane_thresh = std::atoi(ev);
             if (PL.lane_thresh < 1 || PL.lane_thresh > 64) PL.lane_thresh = 24;
-#define SYN_LAUNCH_P(FASTV, POL)                                                                                   \
+            PL.debug_prio = 64;    // leaves that fire a round
+            if (const char* ev = debug_env("SYN_POOL_FIRE")) PL.debug_prio = std::atoi(ev);
+            if (PL.debug_prio < 16 || PL.debug_prio > 64) PL.debug_prio = 64;
+#define SYN_LAUNCH_P(FASTV, POL) { if (nw == 8) SYN_LAUNCH_PN(FASTV, POL, 8) else SYN_LAUNCH_PN(FASTV, POL, 12) }
+#define SYN_LAUNCH_PN(FASTV, POL, NWV)                                                                             \
     {                                                                                                              \
-        auto k = selfplay_kernel_pool<MODE, COUNT, FASTV, 12, POL>;                                                \
-        using PLds = PoolLds<12, FASTV>;                                                                           \
+        auto k = selfplay_kernel_pool<MODE, COUNT, FASTV, NWV, POL>;                                               \
+        using PLds = PoolLds<NWV, FASTV>;                                                                          \
         const size_t plds = PLds::BYTES;                                                                           \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),                                       \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds);                 \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL(k, dim3(pgrid), dim3(64 * 12), plds, h->stream, PL);                                    \
+        hipLaunchKernelGGL(k, dim3(pgrid), dim3(64 * NWV), plds, h->stream, PL);                                   \
     }
             if (f16) { if (fam == 1) SYN_LAUNCH_P(1, 3) else SYN_LAUNCH_P(2, 3) }
             else { if (fam == 1) SYN_LAUNCH_P(1, 0) else SYN_LAUNCH_P(2, 0) }
 #undef SYN_LAUNCH_P
+#undef SYN_LAUNCH_PN
             h->last_shape = 8; h->last_grid = pgrid; h->last_threads = 64 * nw;
             h->last_pool_trees = pm;
             if (out_grid) *out_grid = pgrid;

@@ -55,7 +55,11 @@
 // (POLICY 3: engine_pool_f16.hip), the two compile-time-folded families, 12 waves:  X(MODE, COUNT, FAST, NW, POLICY)
 #define SYN_POOL_F32_LIST(X)                                                                                     \
     X(MODE_SELFPLAY, false, 1, 12, 0) X(MODE_SELFPLAY, true, 1, 12, 0) X(MODE_SEARCH, false, 1, 12, 0)           \
-    X(MODE_SELFPLAY, false, 2, 12, 0) X(MODE_SELFPLAY, true, 2, 12, 0) X(MODE_SEARCH, false, 2, 12, 0)
+    X(MODE_SELFPLAY, false, 2, 12, 0) X(MODE_SELFPLAY, true, 2, 12, 0) X(MODE_SEARCH, false, 2, 12, 0)           \
+    X(MODE_SELFPLAY, false, 1, 8, 0) X(MODE_SELFPLAY, true, 1, 8, 0) X(MODE_SEARCH, false, 1, 8, 0)              \
+    X(MODE_SELFPLAY, false, 2, 8, 0) X(MODE_SELFPLAY, true, 2, 8, 0) X(MODE_SEARCH, false, 2, 8, 0)
 #define SYN_POOL_F16_LIST(X)                                                                                     \
     X(MODE_SELFPLAY, false, 1, 12, 3) X(MODE_SELFPLAY, true, 1, 12, 3) X(MODE_SEARCH, false, 1, 12, 3)           \
-    X(MODE_SELFPLAY, false, 2, 12, 3) X(MODE_SELFPLAY, true, 2, 12, 3) X(MODE_SEARCH, false, 2, 12, 3)
+    X(MODE_SELFPLAY, false, 2, 12, 3) X(MODE_SELFPLAY, true, 2, 12, 3) X(MODE_SEARCH, false, 2, 12, 3)           \
+    X(MODE_SELFPLAY, false, 1, 8, 3) X(MODE_SELFPLAY, true, 1, 8, 3) X(MODE_SEARCH, false, 1, 8, 3)              \
+    X(MODE_SELFPLAY, false, 2, 8, 3) X(MODE_SELFPLAY, true, 2, 8, 3) X(MODE_SEARCH, false, 2, 8, 3)

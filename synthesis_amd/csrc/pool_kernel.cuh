@@ -39,7 +39,9 @@ namespace syn {
 struct PoolGeom {
     static constexpr int M_MAX = 128;                                   // trees per wave: two per book-keeping lane
     static constexpr int FIELDS = 18;                                   // dwords per tree record (17 used)
-    static constexpr size_t WAVE_BYTES = (size_t)FIELDS * M_MAX * 4;    // 9,216 B
+    static constexpr size_t PARK_OFF = (size_t)FIELDS * M_MAX * 4;      // behind the records: the lanes' own descents during phases B / C,
+    static constexpr int PARK_DW = 11;                                  // [dword][lane] (8 dwords; 11 with Fpu::Func)
+    static constexpr size_t WAVE_BYTES = PARK_OFF + (size_t)PARK_DW * 64 * 4 + 256;   // 12,288 B
 };
 enum : uint32_t { PT_DEAD = 0, PT_READY = 1, PT_BOUND = 2, PT_LEAF = 3 };
 enum { PF_RMY0 = 0, PF_RMY1, PF_ROP0, PF_ROP1, PF_ALLOC, PF_ITER, PF_JOB, PF_TURN, PF_DRAWS, PF_REC, PF_META, PF_QT, PF_PN,
@@ -52,9 +54,11 @@ struct PoolLds {
     static constexpr size_t IDX_OFF = IMG;                                   // 64 B compaction index per wave (rank -> tree)
     static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;              // the four feature shift tables (16 B each)
     static constexpr size_t STATE_OFF = FT_OFF + 64;                         // 128 state bytes per wave
-    static constexpr size_t PARK_OFF = STATE_OFF + (size_t)NW * 128;         // the lanes' descent cursors during phases B / C
-    static constexpr int PARK_DW = FAST == 2 ? 11 : 8;
-    static constexpr size_t BYTES = PARK_OFF + (size_t)PARK_DW * 4 * 64 * NW;
+    // what the start of an explore needs of a tree — root position (4 dwords) and pass counter | "root not expanded yet" << 31 —
+    // lives in LDS ([dword][tree] per wave): binding a READY tree costs no memory round trip in front of its first level
+    static constexpr size_t BEGIN_OFF = STATE_OFF + (size_t)NW * 128;
+    static constexpr int BEGIN_DW = 5;
+    static constexpr size_t BYTES = BEGIN_OFF + (size_t)BEGIN_DW * 4 * PoolGeom::M_MAX * NW;
     static_assert(BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 
@@ -102,7 +106,9 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
     uint32_t* const trec = reinterpret_cast<uint32_t*>(P.vw_buf + wave_g * PoolGeom::WAVE_BYTES);   // [field][M_MAX]
     unsigned char* const st8 = smem_raw + L::STATE_OFF + wave * 128;
     unsigned char* const idxw = smem_raw + L::IDX_OFF + wave * 64;
-    uint32_t* const pk = reinterpret_cast<uint32_t*>(smem_raw + L::PARK_OFF) + tid;   // dword k of this lane at pk[k * NT]
+    uint32_t* const pk = reinterpret_cast<uint32_t*>(P.vw_buf + wave_g * PoolGeom::WAVE_BYTES + PoolGeom::PARK_OFF) + lane;   // dword k at pk[k * 64]
+    uint32_t* const bg = reinterpret_cast<uint32_t*>(smem_raw + L::BEGIN_OFF) + wave * (L::BEGIN_DW * PoolGeom::M_MAX);   // dword k of tree t at bg[k * 128 + t]
+#define SYN_BG(t, k) bg[(k) * PoolGeom::M_MAX + (t)]
     const uint32_t bcap = P.cap / 4u;
     const size_t slab_bytes = (size_t)P.cap * 32u;
     unsigned char* const slab0 = reinterpret_cast<unsigned char*>(P.stat) + wave_g * (size_t)M * slab_bytes;
@@ -126,6 +132,9 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
                 SYN_REC(t, PF_ROP0) = (uint32_t)T.root_op; SYN_REC(t, PF_ROP1) = (uint32_t)(T.root_op >> 32);
                 SYN_REC(t, PF_ALLOC) = 0u; SYN_REC(t, PF_ITER) = 0u; SYN_REC(t, PF_JOB) = (uint32_t)T.job;
                 SYN_REC(t, PF_TURN) = 0u; SYN_REC(t, PF_DRAWS) = 0u;
+                SYN_BG(t, 0) = (uint32_t)T.root_my; SYN_BG(t, 1) = (uint32_t)(T.root_my >> 32);
+                SYN_BG(t, 2) = (uint32_t)T.root_op; SYN_BG(t, 3) = (uint32_t)(T.root_op >> 32);
+                SYN_BG(t, 4) = 0x80000000u;
                 s[h] = T.job >= 0 ? PT_READY : PT_DEAD;
             }
             st8[t] = (unsigned char)s[h];
@@ -135,6 +144,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
     __syncthreads();  // the only workgroup barrier: weights staged. From here on every wave free-runs.
 
     const int n_explores = P.roll.num_explores;
+    const int fire = P.debug_prio;        // a round fires once this many trees are LEAF (whole tiles: 64 by default)
     const int scan_min = P.lane_thresh;   // Fpu::Func: a scan iteration is taken once this many bound lanes wait for draws
     unsigned long long cache_hits = 0, cache_misses = 0;
     // the descent this lane is walking (tree < 0: none)
@@ -170,7 +180,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
             n_leaf += __popcll(__ballot(arrived));
             // (2) a round fires on 64 leaves, or when nothing can move any more
             const unsigned long long freem = __ballot(tree < 0);
-            if (n_leaf >= 64 || (freem == ~0ull && n_ready == 0)) break;
+            if (n_leaf >= fire || (freem == ~0ull && n_ready == 0)) break;
             // (3) free lanes bind READY trees: the r-th free lane takes the r-th READY tree and starts its explore at the root
             if (freem != 0ull && n_ready > 0) {
                 pool_lds_sync();
@@ -188,9 +198,16 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
                     tree = (int)idxw[fr];
                     Td.slab = SYN_SLAB(tree);
                     pl = SYN_PATH(tree);
-                    const uint32_t alloc = SYN_REC(tree, PF_ALLOC), it = SYN_REC(tree, PF_ITER);
-                    C.my = (uint64_t)SYN_REC(tree, PF_RMY0) | ((uint64_t)SYN_REC(tree, PF_RMY1) << 32);
-                    C.op = (uint64_t)SYN_REC(tree, PF_ROP0) | ((uint64_t)SYN_REC(tree, PF_ROP1) << 32);
+                    if (FAST == 2) {   // (global loads, in flight while the root's line is fetched: used by the level's draws only)
+                        const uint32_t job = SYN_REC(tree, PF_JOB), turn = SYN_REC(tree, PF_TURN) & 0xFFu;
+                        Td.fpu_draws = SYN_REC(tree, PF_DRAWS);
+                        noise_seed = noise_tree_seed(P.base_seed + (MODE == MODE_SELFPLAY ? P.first_game : 0ull) + (uint64_t)job,
+                                                     MODE == MODE_SELFPLAY ? turn : 0u);
+                        fwait = false;
+                    }
+                    const uint32_t it = SYN_BG(tree, 4);
+                    C.my = (uint64_t)SYN_BG(tree, 0) | ((uint64_t)SYN_BG(tree, 1) << 32);
+                    C.op = (uint64_t)SYN_BG(tree, 2) | ((uint64_t)SYN_BG(tree, 3) << 32);
                     C.rec = REC_ROOT;
                     C.level = 0;
                     C.nsolved = false;
@@ -198,19 +215,12 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
                     C.qt = 0;
                     // MCTS::with_capacity pushes the root unexpanded (mcts.rs:125): a fresh tree arrives at level 0 (its first
                     // pass is the root's own visit); afterwards the root's block is block 1 and its N the pass counter
-                    const bool fresh = (alloc & 0xFFFFu) == 0u;
+                    const bool fresh = (it >> 31) != 0u;
                     C.blk = fresh ? 0u : 1u;
                     C.pN = fresh ? 0.0f : (float)(it & 0x3FFFu);
                     lm = legal_mask_of(C.my | C.op);
                     pl[0] = make_uint4(REC_ROOT, f32_bits(C.pN), pm_make(C.blk, (uint32_t)__popc(lm), false, 0) | (C.blk != 0u ? PM_HAS_W : 0u), 0u);
                     if (COUNT) ctr[CTR_EXPLORES]++;
-                    if (FAST == 2) {
-                        const uint32_t job = SYN_REC(tree, PF_JOB), turn = SYN_REC(tree, PF_TURN) & 0xFFu;
-                        Td.fpu_draws = SYN_REC(tree, PF_DRAWS);
-                        noise_seed = noise_tree_seed(P.base_seed + (MODE == MODE_SELFPLAY ? P.first_game : 0ull) + (uint64_t)job,
-                                                     MODE == MODE_SELFPLAY ? turn : 0u);
-                        fwait = false;
-                    }
                 }
                 n_ready = nr - take;
             }
@@ -256,14 +266,14 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
         const bool active = bt >= 0;
         // this lane's own descent waits in LDS
         pk[0] = C.rec;
-        pk[NT] = C.blk | (C.kind << 14) | ((C.nsolved ? 1u : 0u) << 16) | ((uint32_t)C.level << 17) | ((uint32_t)(tree & 127) << 24) | (tree >= 0 ? 0x80000000u : 0u);
-        pk[2 * NT] = C.qt;
-        pk[3 * NT] = f32_bits(C.pN);
-        pk[4 * NT] = (uint32_t)C.my; pk[5 * NT] = (uint32_t)(C.my >> 32);
-        pk[6 * NT] = (uint32_t)C.op; pk[7 * NT] = (uint32_t)(C.op >> 32);
+        pk[64] = C.blk | (C.kind << 14) | ((C.nsolved ? 1u : 0u) << 16) | ((uint32_t)C.level << 17) | ((uint32_t)(tree & 127) << 24) | (tree >= 0 ? 0x80000000u : 0u);
+        pk[2 * 64] = C.qt;
+        pk[3 * 64] = f32_bits(C.pN);
+        pk[4 * 64] = (uint32_t)C.my; pk[5 * 64] = (uint32_t)(C.my >> 32);
+        pk[6 * 64] = (uint32_t)C.op; pk[7 * 64] = (uint32_t)(C.op >> 32);
         if (FAST == 2) {
-            pk[8 * NT] = Td.fpu_draws | (fwait ? 0x80000000u : 0u);
-            pk[9 * NT] = (uint32_t)noise_seed; pk[10 * NT] = (uint32_t)(noise_seed >> 32);
+            pk[8 * 64] = Td.fpu_draws | (fwait ? 0x80000000u : 0u);
+            pk[9 * 64] = (uint32_t)noise_seed; pk[10 * 64] = (uint32_t)(noise_seed >> 32);
         }
         // the leaf's tree and cursor
         LaneTree T;
@@ -387,7 +397,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
                 SYN_REC(bt, PF_ROP0) = (uint32_t)T.root_op; SYN_REC(bt, PF_ROP1) = (uint32_t)(T.root_op >> 32);
                 SYN_REC(bt, PF_TURN) = (uint32_t)T.turn | (T.rng_index << 8);
                 SYN_REC(bt, PF_JOB) = (uint32_t)T.job;
+                SYN_BG(bt, 0) = (uint32_t)T.root_my; SYN_BG(bt, 1) = (uint32_t)(T.root_my >> 32);
+                SYN_BG(bt, 2) = (uint32_t)T.root_op; SYN_BG(bt, 3) = (uint32_t)(T.root_op >> 32);
             }
+            SYN_BG(bt, 4) = (uint32_t)T.iter | (T.next_block == 0u ? 0x80000000u : 0u);
             SYN_REC(bt, PF_ALLOC) = T.next_block | (T.num_nodes << 16);
             SYN_REC(bt, PF_ITER) = (uint32_t)T.iter | ((T.root_solved ? 1u : 0u) << 14) | (T.root_sol << 15);
             if (FAST == 2) SYN_REC(bt, PF_DRAWS) = T.fpu_draws;
@@ -398,32 +411,33 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_pool(EngineParams 
         n_ready += __popcll(__ballot(alive));
         // back to this lane's own descent
         {
-            const uint32_t meta = pk[NT];
+            const uint32_t meta = pk[64];
             C.rec = pk[0];
             C.blk = meta & 0x3FFFu;
             C.kind = (meta >> 14) & 3u;
             C.nsolved = ((meta >> 16) & 1u) != 0u;
             C.level = (int)((meta >> 17) & 0x7Fu);
             tree = (meta >> 31) != 0u ? (int)((meta >> 24) & 127u) : -1;
-            C.qt = pk[2 * NT];
-            C.pN = bits_f32(pk[3 * NT]);
-            C.my = (uint64_t)pk[4 * NT] | ((uint64_t)pk[5 * NT] << 32);
-            C.op = (uint64_t)pk[6 * NT] | ((uint64_t)pk[7 * NT] << 32);
+            C.qt = pk[2 * 64];
+            C.pN = bits_f32(pk[3 * 64]);
+            C.my = (uint64_t)pk[4 * 64] | ((uint64_t)pk[5 * 64] << 32);
+            C.op = (uint64_t)pk[6 * 64] | ((uint64_t)pk[7 * 64] << 32);
             lm = legal_mask_of(C.my | C.op);
             const int tz = tree >= 0 ? tree : 0;
             Td.slab = SYN_SLAB(tz);
             pl = SYN_PATH(tz);
             if (FAST == 2) {
-                const uint32_t d = pk[8 * NT];
+                const uint32_t d = pk[8 * 64];
                 Td.fpu_draws = d & 0x7FFFFFFFu;
                 fwait = (d >> 31) != 0u;
-                noise_seed = (uint64_t)pk[9 * NT] | ((uint64_t)pk[10 * NT] << 32);
+                noise_seed = (uint64_t)pk[9 * 64] | ((uint64_t)pk[10 * 64] << 32);
             }
         }
     }
 #undef SYN_SLAB
 #undef SYN_PATH
 #undef SYN_REC
+#undef SYN_BG
 
     if (P.cache != nullptr && lane == 0 && (cache_hits | cache_misses) != 0ull) {
         atomicAdd(P.cache_stats + 0, cache_hits);

@@ -38,7 +38,7 @@ def test_pool_kernel_matches_oracle(blob, oracle, pool, conc):
     eng.load_weights(blob)
     my, op = random_positions(oracle, 300, seed=31, max_moves=60)
     got = eng.mcts_search(sa.parity_mcts_config(), my, op, 120)
-    assert eng.last_launch_shape()[0] == SHAPE_POOL and eng.last_launch_shape()[2] == 768
+    assert eng.last_launch_shape()[0] == SHAPE_POOL and eng.last_launch_shape()[2] == 64 * int(os.environ.get("SYN_POOL_NW", "12"))
     ref = oracle.c4_mcts_search(parity_mcts_config(), blob, my, op, 120, nn_mode=oracle.ACC_FMA)
     assert_search_equal(got, ref, "pool search")
     for explores in (0, 1, 2):

@@ -36,6 +36,10 @@ for c in combos:
     conc, nw = c[0], c[1]
     n = c[2] if len(c) > 2 else 2 * conc
     clog = c[3] if len(c) > 3 else 0
+    if len(c) > 4: os.environ["SYN_POOL_FIRE"] = str(c[4])   # pool kernel: leaves that fire a round
+    else: os.environ.pop("SYN_POOL_FIRE", None)
+    if len(c) > 5: os.environ["SYN_POOL_NW"] = str(c[5])     # pool kernel: waves per workgroup (8 or 12)
+    else: os.environ.pop("SYN_POOL_NW", None)
     os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None); os.environ.pop("SYN_LANES2", None); os.environ.pop("SYN_POOL", None)
     if 365 <= nw <= 428: os.environ["SYN_POOL"] = str(nw - 300)   # the pool kernel with nw - 300 trees per wave (pool_kernel.cuh)
     elif nw == 300: os.environ["SYN_POOL"] = "0"                   # ... switched off (the lane kernel the engine would pick without it)
