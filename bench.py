@@ -202,16 +202,6 @@ def spawn_ranks(n, argv):
 
 def main():
     t_run0 = time.perf_counter()
-    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to stdout when a communicator is created
-    # (every N > 1 run; the learner's world-size-1 leg at N = 1). File descriptor 1 points at stderr for the whole run and the line
-    # goes to the real stdout at the end.
-    sys.stdout.flush()
-    real_stdout = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
-
-    def emit(obj):
-        real_stdout.write(json.dumps(obj) + "\n")
-        real_stdout.flush()
 
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -246,7 +236,17 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))   # (the ranks inherit this process's stdout as it is)
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to stdout when a communicator is created
+    # (every N > 1 run; the learner's world-size-1 leg at N = 1). From here on file descriptor 1 points at stderr and the line goes
+    # to the real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        real_stdout.write(json.dumps(obj) + "\n")
+        real_stdout.flush()
 
     import torch  # device sync + (N > 1) the RCCL barrier / max-reduce; the engine itself does not use torch
                   # (import it BEFORE the engine library so the process holds one HIP runtime: torch's)

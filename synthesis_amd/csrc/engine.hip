@@ -34,7 +34,9 @@
 #include "train_conv_mfma.cuh"
 #include "lane_instances.h"
 #include "free_kernel.cuh"
-#include "pool_kernel.cuh"
+#ifdef SYN_DEBUG_SHAPES
+#include "pool_kernel.cuh"   // round 6's measured dead end (trees unbound from the lanes): a debug shape like the two above
+#endif
 
 #include <hipcub/hipcub.hpp>
 #include <chrono>
@@ -83,11 +85,13 @@ SYN_LANES_REF_LIST(SYN_X)
 SYN_LANES_F16_LIST(SYN_X)
 SYN_LANES_F16_GEN_LIST(SYN_X)
 #undef SYN_X
-// ... and the pool kernels (pool_kernel.cuh) in engine_pool.hip / engine_pool_f16.hip
+// ... and (DEBUG_SHAPES=1 builds only) the pool kernels (pool_kernel.cuh) in engine_pool.hip / engine_pool_f16.hip
+#ifdef SYN_DEBUG_SHAPES
 #define SYN_X(MODE, COUNT, FAST, NW, POLICY) extern template __global__ void selfplay_kernel_pool<MODE, COUNT, FAST, NW, POLICY>(EngineParams);
 SYN_POOL_F32_LIST(SYN_X)
 SYN_POOL_F16_LIST(SYN_X)
 #undef SYN_X
+#endif
 // ... and the free-running four-trees-per-wave kernels (free_kernel.cuh) in engine_free.hip
 #define SYN_FREE(MODE, COUNT)                                                                      \
     extern template __global__ void selfplay_kernel_free<MODE, COUNT, true, false>(EngineParams);  \
@@ -129,7 +133,7 @@ struct syn_engine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int slots = 0;
     int last_shape = 0, last_grid = 0, last_threads = 0;
-    int pool_trees = 0;  // > 64: the pool kernel (pool_kernel.cuh) with that many trees per wave plays the folded Connect4Net families at headline size
+    int pool_trees = 0;  // (DEBUG_SHAPES builds) > 64: the pool kernel with that many trees per wave; never set: the kernel is forced by SYN_POOL only
     int last_pool_trees = 0;
     int pool_slots = 0;  // tree slabs actually allocated (slots rounded up to the largest workgroup + slack)
     int max_explores = 0;
@@ -435,7 +439,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
     // SYN_DEBUG=1 SYN_FREE=0 switches it off (the lane kernel at 4 waves then plays these games).
     if (h->net_kind == 0 && h->net_arith == SYN_NET_ARITH_F16X2 && P.wimg == reinterpret_cast<const float*>(h->d_wimg16) &&
         want_slots <= 16 * h->num_cus && P.mcts.fpu != 2 && P.mcts.noise != 2 && debug_env("SYN_LANES") == nullptr &&
-        !(debug_env("SYN_FREE") && std::atoi(debug_env("SYN_FREE")) == 0) && !(debug_env("SYN_POOL") && std::atoi(debug_env("SYN_POOL")) > 64)) {
+        !(debug_env("SYN_FREE") && std::atoi(debug_env("SYN_FREE")) == 0)
+#ifdef SYN_DEBUG_SHAPES
+        && !(debug_env("SYN_POOL") && std::atoi(debug_env("SYN_POOL")) > 64)
+#endif
+        ) {
         const int mgrid = (want_slots + 15) / 16;
 #define SYN_LAUNCH_FR(FAST, PROFV)                                                                                 \
     {                                                                                                              \
@@ -508,9 +516,12 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
         }
     }
 #endif
+#ifdef SYN_DEBUG_SHAPES
     // The pool kernel (pool_kernel.cuh): a wave's 64 lanes work on a pool of M trees (64 < M <= 128) — a lane whose descent arrives
     // binds the next READY tree in the same iteration, a round fires on 64 leaves — for the two compile-time-folded configuration
-    // families of Connect4Net (f32 and f16x2). 12 waves x M trees per CU. SYN_DEBUG=1 SYN_POOL=<M> forces it (0 = never).
+    // families of Connect4Net (f32 and f16x2), 12 or 8 waves x M trees per CU. Measured slower than the lane kernel on every leg in
+    // three same-box A/B runs (profiles/r06_pool_unbinding_ab.txt, NOTES round 6), so it is never chosen automatically and ships only
+    // in DEBUG_SHAPES=1 builds: SYN_DEBUG=1 SYN_POOL=<M> selects it (parity tests, re-measurement).
     {
         int pm = h->pool_trees;
         if (const char* ev = debug_env("SYN_POOL")) pm = std::atoi(ev);
@@ -579,6 +590,7 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             return hipGetLastError();
         }
     }
+#endif
     {
         int nw = 0;
         // 4 waves per workgroup up to 256 trees per CU, 8 up to 512, 12 up to 768, 16 (hand-pipelined network tile that fits

@@ -4,7 +4,8 @@ lanes: a wave works on a pool of up to 128 trees, a lane whose descent arrives b
 fires on 64 leaves. A schedule must not change a result, so the bar is the lane kernel's: searches, whole self-play games with slot
 refill, event counters, every value target, the policy cache, the reference's own Fpu::Func configuration, the trained checkpoint and
 the f16x2 arithmetic — all bit-identical to the CPU oracle. The kernel is forced on small engines here (partial pools, trees without a
-job, pools of 65 .. 128 trees); tests/test_gpu_bench_shape.py holds it to the oracle at the size bench.py times."""
+job, pools of 65 .. 128 trees). Measured slower than the lane kernel on every leg (profiles/r06_pool_unbinding_ab.txt): a debug
+launch shape of `make DEBUG_SHAPES=1` builds; these tests skip on the default library."""
 import os
 
 import numpy as np
@@ -23,7 +24,7 @@ def blob(golden_dir):
 
 
 @pytest.fixture(params=[128, 80, 65])
-def pool(monkeypatch, request):
+def pool(monkeypatch, request, debug_shapes):
     monkeypatch.setenv("SYN_DEBUG", "1")  # developer knobs are honoured only with SYN_DEBUG=1
     monkeypatch.setenv("SYN_POOL", str(request.param))
     return request.param
