@@ -77,8 +77,8 @@ def algorithmic_bytes(c):
             + 8 * c["expansions"] + 40 * c["backprop_levels"] + 4 * c["solver_children"])
 
 
-SELFPLAY_KERNEL_SOURCES = ("device_common.cuh", "mcts.cuh", "mlp.cuh", "engine_kernels.cuh", "lane_kernel.cuh", "pc_kernel.cuh",
-                           "noise.cuh", "zig_tables.cuh", "convnet.cuh", "f16x2_tile.cuh", "free_kernel.cuh")
+SELFPLAY_KERNEL_SOURCES = ("device_common.cuh", "mcts.cuh", "mlp.cuh", "engine_kernels.cuh", "lane_kernel.cuh",
+                           "noise.cuh", "zig_tables.cuh", "fpu_normal_table.cuh", "convnet.cuh", "f16x2_tile.cuh", "free_kernel.cuh")
 
 
 def kernel_source_hash():

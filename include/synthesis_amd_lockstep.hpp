@@ -44,6 +44,7 @@
 
 #include "synthesis_amd.hpp"
 #include "synthesis_amd_zig_tables.hpp"
+#include "synthesis_amd_fpu_normal_table.hpp"
 
 namespace synthesis {
 
@@ -126,28 +127,29 @@ inline uint64_t noise_tree_seed(uint64_t stream, uint32_t turn) {
     return mix64((stream ^ 0x5851F42D4C957F2Dull) + (uint64_t)(turn + 1u) * NOISE_GOLDEN);
 }
 inline uint64_t noise_splitmix64(uint64_t seed, uint32_t index) { return mix64(seed + (uint64_t)(index + 1u) * NOISE_GOLDEN); }
-// standard normal from 23 random bits k: u = (2k+1)/2^24, z = sqrt(2) erfinv(2u-1), Giles' single-precision erfinv with every
-// step an IEEE f32 operation
-inline float det_std_normal(uint32_t k) {
-    const float x = std::fmaf((float)(2u * k + 1u), 1.1920928955078125e-07f, -1.0f);
-    const float w = -det_logf((1.0f - x) * (1.0f + x));
-    static const float central[9] = {2.81022636e-08f, 3.43273939e-07f, -3.5233877e-06f, -4.39150654e-06f, 0.00021858087f,
-                                     -0.00125372503f, -0.00417768164f, 0.246640727f, 1.50140941f};
-    static const float tail[9] = {-0.000200214257f, 0.000100950558f, 0.00134934322f, -0.00367342844f, 0.00573950773f,
-                                  -0.0076224613f, 0.00943887047f, 1.00167406f, 2.83297682f};
-    const bool in_tail = !(w < 5.0f);
-    const float t = in_tail ? std::sqrt(w) - 3.0f : w - 2.5f;
-    const float* coef = in_tail ? tail : central;
-    float p = coef[0];
-    for (int i = 1; i < 9; i++) p = std::fmaf(p, t, coef[i]);
-    return (p * x) * 1.41421356f;
+// standard normal from 23 random bits k: u = (2k+1)/2^24, z = Phi^-1(u) by piecewise-linear inversion on the 2,944 cells of
+// synthesis_amd_fpu_normal_table.hpp (the table the device reads: csrc/noise.cuh fpu_std_normal): the distance of u to the nearer end
+// of (0, 1) as the odd integer m = 2 min(k, 2^23 - 1 - k) + 1; (float)m's exponent and top seven mantissa bits name the cell, its low
+// sixteen mantissa bits the position inside it; |z| = fma(frac, T[cell + 1] - T[cell], T[cell])
+inline float fpu_std_normal(uint32_t k) {
+    const bool neg = k < (1u << 22);
+    const uint32_t j = neg ? k : 0x7FFFFFu - k;
+    const float f = (float)(2u * j + 1u);   // exact
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    const uint32_t cell = (b >> 16) - (127u << 7);
+    const float frac = (float)(b & 0xFFFFu) * 0x1p-16f;
+    const float t0 = FPU_NORMAL_TABLE[cell];
+    const float z = std::fmaf(frac, FPU_NORMAL_TABLE[cell + 1] - t0, t0);
+    return neg ? -z : z;
 }
-// draw number (scan, slot) of a tree: SplitMix64 output 5 scan + slot/2 of the stream seeded tree_seed ^ NOISE_FPU_TAG; an even
-// slot takes bits 41..63 of it, an odd slot bits 9..31
+// draw number (scan, slot) of a tree: word 0 = SplitMix64 output `scan` of the stream seeded tree_seed ^ NOISE_FPU_TAG, word p + 1 =
+// xorshift64(word p); word slot / 2 serves the slot: an even slot takes bits 41..63 of it, an odd slot bits 9..31
 inline float noise_fpu_normal(uint64_t tree_seed, uint32_t scan, uint32_t slot, float mean, float std_dev) {
-    const uint64_t bits = noise_splitmix64(tree_seed ^ NOISE_FPU_TAG, 5u * scan + (slot >> 1));
-    const uint32_t k = (slot & 1u) ? ((uint32_t)bits >> 9) : (uint32_t)(bits >> 41);
-    return mean + std_dev * det_std_normal(k);
+    uint64_t w = noise_splitmix64(tree_seed ^ NOISE_FPU_TAG, scan);
+    for (uint32_t p = 0; p < (slot >> 1); p++) { w ^= w << 13; w ^= w >> 7; w ^= w << 17; }   // xorshift64
+    const uint32_t k = (slot & 1u) ? ((uint32_t)w >> 9) : (uint32_t)(w >> 41);
+    return mean + std_dev * fpu_std_normal(k);
 }
 
 // rand 0.8.3 `StdRng` as far as run_game draws from it (alpha_zero.rs:189,281,286-287): ChaCha with 12 rounds keyed by rand_core

@@ -87,7 +87,7 @@ void orc_relu(float* x, int n) { relu_inplace(x, n); }
 void orc_tanh(float* x, int n) { tanh_inplace(x, n); }
 // Fpu::Func draws of n_scans consecutive scans of one tree, nine child slots each (oracle/noise.hpp): out[scan][slot]
 void orc_std_normal_from_bits(const uint32_t* k, int n, float* out) {
-    for (int i = 0; i < n; i++) out[i] = det_std_normal(k[i]);
+    for (int i = 0; i < n; i++) out[i] = fpu_std_normal(k[i]);   // the Fpu::Func draw's standard normal (table inversion, round 6)
 }
 void orc_noise_fpu_normals(uint64_t tree_seed, int n_scans, float mean, float std_dev, float* out) {
     for (int s = 0; s < n_scans; s++)

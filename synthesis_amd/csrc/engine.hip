@@ -659,6 +659,11 @@ static hipError_t launch_engine(syn_engine* h, const EngineParams& P, int jobs, 
             PL.lane_thresh &= ~15;  // whole tiles
             PL.debug_stub = 0;
             if (PROF) { if (const char* ev = debug_env("SYN_ABLATE")) PL.debug_stub = std::atoi(ev); }
+            // Fpu::Func: 0 = every level takes its draws on the spot (a scan is ~220 issue slots since round 6); 1..64 = scans are
+            // deferred until that many lanes wait for one or nobody can move without one (rounds 4-5, when a scan was ~600: 64)
+            PL.nv = 0;
+            if (const char* ev = debug_env("SYN_SCAN_MIN")) PL.nv = std::atoi(ev);
+            if (PL.nv < 0 || PL.nv > 64) PL.nv = 0;
 #define SYN_LAUNCH_L(NW, FAST)                                                                                     \
     {                                                                                                              \
         auto k = selfplay_kernel_lanes<MODE, COUNT, FAST, NW, PROF>;                                                     \

@@ -251,7 +251,8 @@ SYN_DEV void lane_begin_explore(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
 // next call with scan_now true (wave-uniform) takes the draws and the level.
 template <bool COUNT, int FAST, bool DEFER = false>
 SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, uint32_t& lm, uint4* pl, uint32_t* ctr,
-                                uint64_t noise_seed, FpuHold* H = nullptr, bool scan_now = true, LaneProf* lp = nullptr) {
+                                uint64_t noise_seed, FpuHold* H = nullptr, bool scan_now = true, LaneProf* lp = nullptr,
+                                const float* fpu_tbl = FPU_NORMAL_TABLE) {
     const CfgView<FAST> cfg{cfg_};
     unsigned char* const slab = T.slab;
     const uint32_t nc = (uint32_t)__popc(lm);
@@ -299,7 +300,7 @@ SYN_DEV void lane_descend_level(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor&
                 return;
             }
         } else if (__ballot(need != 0u) != 0ull) {
-            noise_fpu_scan(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, qf);
+            noise_fpu_scan(noise_seed, T.fpu_draws, need, cfg.fpu_value(), cfg_.fpu_std, qf, fpu_tbl);
             T.fpu_draws += need != 0u ? 1u : 0u;
         }
     }
@@ -470,7 +471,8 @@ SYN_DEV void lane_arrive(const DevMctsCfg& cfg_, LaneTree& T, LaneCursor& C, Lan
 template <bool COUNT, int FAST, bool ROOT_IN_T = false>
 SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& Wk, LaneLeaf& X, bool active, uint4* pl,
                                 uint32_t bcap, int thresh, uint32_t* ctr, int* error, const uint32_t* pk, int pk_stride,
-                                uint64_t noise_seed = 0, LaneProf* lp = nullptr) {
+                                uint64_t noise_seed = 0, LaneProf* lp = nullptr, int scan_min = 64,
+                                const float* fpu_tbl = FPU_NORMAL_TABLE) {
     const bool pending = active && Wk.pending;
     X.at_leaf = false;
     X.was_pending = pending;
@@ -496,8 +498,9 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
     bool hit_solved = false, at_leaf = pending;
     // legal columns of the current position: computed once per round and updated as the descent drops stones
     uint32_t lm = legal_mask_of(C.my | C.op);
-    if (CfgView<FAST>{cfg_}.fpu_normal()) {
-        // Fpu::Func: levels that need no draws first, then one scan for every lane that waits for draws (FpuHold)
+    if (CfgView<FAST>{cfg_}.fpu_normal() && scan_min > 0) {
+        // Fpu::Func with deferred scans (scan_min = 0: no deferral — the plain loop below, whose levels take their draws on the spot):
+        // levels that need no draws first, then one scan for every lane that waits for draws (FpuHold)
         FpuHold H;
         H.wait = false;
         for (;;) {
@@ -506,11 +509,14 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
                 else if (C.blk == 0u) { desc = false; at_leaf = true; }
             }
             if (__popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
-            const bool scan_now = __ballot(desc && !H.wait) == 0ull;
+            // a scan iteration — one noise_fpu_scan for every lane that needs draws, then the level for EVERY descending lane — is
+            // taken when no lane can take a level without draws, or once `scan_min` lanes wait for one (64 = the first rule alone)
+            const unsigned long long waiting = __ballot(desc && H.wait);
+            const bool scan_now = __ballot(desc && !H.wait) == 0ull || __popcll(waiting) >= scan_min;
             if (scan_now && __ballot(desc) == 0ull) break;
-            if (desc && H.wait == scan_now) {
+            if (desc && (scan_now || !H.wait)) {
                 H.wait = false;
-                lane_descend_level<COUNT, FAST, true>(cfg_, T, C, lm, pl, ctr, noise_seed, &H, scan_now, lp);
+                lane_descend_level<COUNT, FAST, true>(cfg_, T, C, lm, pl, ctr, noise_seed, &H, scan_now, lp, fpu_tbl);
             }
         }
     } else
@@ -520,7 +526,7 @@ SYN_DEV void lane_select_expand(const DevMctsCfg& cfg_, LaneTree& T, LaneWalk& W
             else if (C.blk == 0u) { desc = false; at_leaf = true; }
         }
         if (__ballot(desc) == 0ull || __popcll(__ballot(at_leaf && !hit_solved)) >= thresh) break;
-        if (desc) lane_descend_level<COUNT, FAST>(cfg_, T, C, lm, pl, ctr, noise_seed, nullptr, true, lp);
+        if (desc) lane_descend_level<COUNT, FAST>(cfg_, T, C, lm, pl, ctr, noise_seed, nullptr, true, lp, fpu_tbl);
     }
 
     const unsigned long long lp_ta = lp ? lp_now() : 0ull;
@@ -1390,7 +1396,10 @@ struct LaneLds {
     static constexpr size_t IDX_OFF = (size_t)MlpGeom::IMG_FLOATS * 4 > (size_t)F16Geom::IMG_WORDS * 4 ? (size_t)MlpGeom::IMG_FLOATS * 4 : (size_t)F16Geom::IMG_WORDS * 4;
     static constexpr size_t FT_OFF = IDX_OFF + (size_t)NW * 64;        // + 64 B compaction index per wave
     static constexpr size_t PARK_OFF = FT_OFF + 64;                    // + the four feature shift tables (16 B each)
-    static constexpr size_t BYTES = PARK_OFF + (size_t)NW * 64 * 20;   // + 5 parked dwords per lane (root boards, turn|rng)
+    static constexpr size_t FPU_OFF = PARK_OFF + (size_t)NW * 64 * 20;  // + 5 parked dwords per lane (root boards, turn|rng)
+    // + the Fpu::Func draw's table of normal quantiles (noise.cuh: 2,945 floats; staged by the configuration families that draw)
+    static constexpr size_t BYTES = FPU_OFF + (((size_t)FPU_NORMAL_CELLS + 1) * 4 + 15) / 16 * 16;
+    static_assert(BYTES <= 160 * 1024, "one workgroup per CU: 160 KB of LDS");
 };
 
 SYN_DEV uint64_t shfl_u64(uint64_t v, int src) {
@@ -1429,6 +1438,10 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         const FeatureTable f = make_feature_table(tid);
         *reinterpret_cast<uint4*>(smem_raw + LaneLds<NW>::FT_OFF + tid * 16) = make_uint4(f.t[0], f.t[1], f.t[2], f.t[3]);
     }
+    // Fpu::Func: the draw's table of normal quantiles next to the weights (the parity family never draws)
+    float* const fpu_tbl = reinterpret_cast<float*>(smem_raw + LaneLds<NW>::FPU_OFF);
+    if (FAST != 1)
+        for (int i = tid; i <= (int)FPU_NORMAL_CELLS; i += NT) fpu_tbl[i] = FPU_NORMAL_TABLE[i];
 
     uint32_t ctr[COUNT ? CTR_COUNT : 1];
 #pragma unroll
@@ -1490,7 +1503,7 @@ __global__ __launch_bounds__(64 * NW, 1) void selfplay_kernel_lanes(EngineParams
         if (__ballot(active) == 0ull) break;
         pT = SYN_STAMP();
         LaneLeaf X;
-        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT, lane_noise_seed(), lp);
+        lane_select_expand<COUNT, FAST>(P.mcts, T, Wk, X, active, pl, bcap, thresh, ctr, P.error, pk, NT, lane_noise_seed(), lp, P.nv, fpu_tbl);
         SYN_LAP(pA)
         // PROF: timeline of the three waves of SIMD 0 of workgroup 0 (rounds 2000..2015): [A end = B start, B end, C end]
         const bool tl = PROF && P.prof && blockIdx.x == 0 && (wave & 3) == 0 && pRounds >= 2000 && pRounds < 2016;

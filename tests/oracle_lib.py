@@ -159,7 +159,7 @@ class Oracle:
         return y
 
     def std_normal_from_bits(self, k):
-        """oracle/noise.hpp det_std_normal: the standard normal the Fpu::Func draw makes of 23 random bits"""
+        """oracle/noise.hpp fpu_std_normal: the standard normal the Fpu::Func draw makes of 23 random bits"""
         k = np.ascontiguousarray(k, np.uint32)
         out = np.zeros(k.size, np.float32)
         self.lib.orc_std_normal_from_bits(_p(k), int(k.size), _p(out))

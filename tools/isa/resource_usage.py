@@ -20,6 +20,15 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fh
          "-Rpass-analysis=kernel-resource-usage"]
 
 
+# the device translation units of the DEFAULT library (synthesis_amd/csrc/Makefile without DEBUG_SHAPES); `--debug-shapes` adds the
+# forced-only kernels (two trees per lane, trees unbound from the lanes)
+TUS = ["engine", "engine_conv", "engine_lanes_fast", "engine_lanes_gen", "engine_lanes_ref", "engine_lanes_f16", "engine_lanes_f16_gen",
+       "engine_free"]
+if "--debug-shapes" in sys.argv:
+    TUS += ["engine_lanes2", "engine_pool", "engine_pool_f16"]
+    FLAGS.append("-DSYN_DEBUG_SHAPES")
+
+
 def compile_tu(name, tmp):
     out = os.path.join(tmp, name + ".s")
     p = subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, os.path.join(CSRC, name + ".hip")], capture_output=True, text=True)
@@ -54,7 +63,7 @@ def loop_scratch(body):
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         with ThreadPoolExecutor(3) as ex:
-            res = list(ex.map(lambda n: compile_tu(n, tmp), ["engine", "engine_conv", "engine_lanes2", "engine_lanes_fast", "engine_lanes_gen"]))
+            res = list(ex.map(lambda n: compile_tu(n, tmp), TUS))
         rows = []
         for path, err in res:
             if not os.path.exists(path):
@@ -85,7 +94,9 @@ def main():
         print("# kernel-resource-usage of every shipped self-play kernel instantiation (gfx950; hipcc -Rpass-analysis=kernel-resource-usage,")
         print("# the Makefile's flags). scratch ops = static scratch_load/store instructions: whole kernel / inside the MFMA range / inside loops.")
         print("# template arguments: selfplay_kernel_lanes<MODE (0 self-play, 1 search), COUNT, FAST, waves, PROF, POLICY (0 Connect4Net, 1 rollout, 2 conv)>,")
-        print("#                     selfplay_kernel_lanes2<MODE, COUNT, FAST, waves, POLICY, TILE>")
+        print("#                     (POLICY 3 = Connect4Net in the f16x2 arithmetic; FAST 0 runtime-switched, 1 parity family, 2 the reference's self-play configuration)")
+        print("#                     selfplay_kernel<MODE, COUNT, WPS, FAST, PROF>, selfplay_kernel_quads<MODE, COUNT, FAST, NQ, PROF>, selfplay_kernel_free<MODE, COUNT, FAST, PROF>,")
+        print("#                     selfplay_kernel_lanes2<MODE, COUNT, FAST, waves, POLICY, TILE>, selfplay_kernel_pool<MODE, COUNT, FAST, waves, POLICY>")
         print("%-96s %5s %5s %5s %4s %8s %7s %7s  %s" % ("kernel", "VGPR", "AGPR", "SGPR", "occ", "scratchB", "vspill", "sspill", "scratch ops all/mfma/loops"))
         for fn, d in sorted(rows, key=lambda r: names[r[0]]):
             n = names[fn].replace("syn::", "").replace("(syn::EngineParams)", "").replace("void ", "")

@@ -40,6 +40,8 @@ for c in combos:
     else: os.environ.pop("SYN_POOL_FIRE", None)
     if len(c) > 5: os.environ["SYN_POOL_NW"] = str(c[5])     # pool kernel: waves per workgroup (8 or 12)
     else: os.environ.pop("SYN_POOL_NW", None)
+    if len(c) > 6: os.environ["SYN_SCAN_MIN"] = str(c[6])    # lane kernel, Fpu::Func: waiting lanes that trigger a scan iteration
+    else: os.environ.pop("SYN_SCAN_MIN", None)
     os.environ.pop("SYN_LANES", None); os.environ.pop("SYN_PC", None); os.environ.pop("SYN_LANES2", None); os.environ.pop("SYN_POOL", None)
     if 365 <= nw <= 428: os.environ["SYN_POOL"] = str(nw - 300)   # the pool kernel with nw - 300 trees per wave (pool_kernel.cuh)
     elif nw == 300: os.environ["SYN_POOL"] = "0"                   # ... switched off (the lane kernel the engine would pick without it)
