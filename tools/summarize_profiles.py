@@ -66,7 +66,8 @@ leg_cache = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (t
 leg_trained = leg_cache
 leg_f16 = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 12, (false|0), 3>", n) is not None
 leg_conv = lambda n: "selfplay_kernel_lanes" in n and re.search(r"<0, false, (true|1), 16, (false|0), 2>", n) is not None
-timed_general = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (false|0|2),", n) is not None
+# (POLICY 0 only: the reference configuration's f16x2 variant — family 2, POLICY 3 — plays the same number of games right behind it)
+timed_general = lambda n: "selfplay_kernel" in n and re.search(r"<0, false, (false|0|2), \d+, (false|0), 0>", n) is not None
 line = None
 for l in open(f"{out}/{tag}_bench_lines_under_profiler.jsonl"):
     line = json.loads(l)
