@@ -1000,6 +1000,17 @@ public:
         std::vector<LockstepGameRecord<G, N>>& out;
         std::atomic<size_t> next{0};
     };
+    // The reference's own discipline (alpha_zero.rs:140,189,201-205; gather_experience_host_trees below): this worker plays the games
+    // [start, start + count) of the run ONE AFTER ANOTHER on one StdRng::seed_from_u64(worker_seed) that runs through all of them.
+    SelfplayWorker(Shared& shared, size_t start, size_t count, uint64_t worker_seed)
+        : shared_(shared), cfg_(shared.cfg), sequential_(true), seq_next_(start), seq_end_(start + count), seq_count_(count),
+          worker_seed_(worker_seed) {
+        if (count == 0) return;
+        plays_.emplace_back(cfg_.mcts_cfg, cfg_.num_explores);
+        plays_.back().rng = StdRng(worker_seed);
+        plays_.back().start_keeping_rng(seq_next_, (worker_seed << 32) + 0u);
+        seq_next_++;
+    }
     SelfplayWorker(Shared& shared, size_t slots) : shared_(shared), cfg_(shared.cfg) {
         plays_.reserve(slots);
         for (size_t i = 0; i < slots; i++) {
@@ -1019,6 +1030,12 @@ public:
             play_move(p, shared_.out[p.index]);
             if (!p.over) {
                 p.next_tree();
+                continue;
+            }
+            if (sequential_) {
+                if (seq_next_ >= seq_end_) return nullptr;
+                p.start_keeping_rng(seq_next_, (worker_seed_ << 32) + (uint64_t)(seq_next_ - (seq_end_ - seq_count())));
+                seq_next_++;
                 continue;
             }
             const size_t g = shared_.next.fetch_add(1, std::memory_order_relaxed);
@@ -1044,6 +1061,16 @@ private:
             index = g;
             stream = s;
             rng = StdRng(s);
+            num_turns = 0;
+            over = false;
+            infos.clear();
+            next_tree();
+        }
+        // the worker's generator runs on from the previous game (run_n_games passes ONE &mut rng to every run_game)
+        void start_keeping_rng(size_t g, uint64_t noise_stream) {
+            game = G();
+            index = g;
+            stream = noise_stream;
             num_turns = 0;
             over = false;
             infos.clear();
@@ -1114,9 +1141,13 @@ private:
         }
     }
 
+    size_t seq_count() const { return seq_count_; }
     Shared& shared_;
     const RolloutConfig& cfg_;
     std::vector<Play> plays_;
+    bool sequential_ = false;
+    size_t seq_next_ = 0, seq_end_ = 0, seq_count_ = 0;
+    uint64_t worker_seed_ = 0;
 };
 }  // namespace detail
 
@@ -1167,6 +1198,41 @@ std::vector<LockstepGameRecord<G, N>> lockstep_selfplay_sharded(const std::vecto
         detail::SelfplayWorker<G, N> worker(shared, slots * (s + 1) / shards - slots * s / shards);
         auto step = [&worker](uint32_t u, const float* logits, const float* value) { return worker.step(u, logits, value); };
         detail::run_rounds<G, N>(*policies[s], 0u, (uint32_t)worker.slots(), nullptr, step, rounds[s], evals[s]);
+    });
+    if (rounds_out) *rounds_out = std::accumulate(rounds.begin(), rounds.end(), (size_t)0);
+    if (evals_out) *evals_out = std::accumulate(evals.begin(), evals.end(), (size_t)0);
+    return out;
+}
+
+// gather_experience as the reference runs it (alpha_zero.rs:120-209) over host trees: policies.size() = num_workers + 1 workers,
+// worker i plays games_to_schedule / workers_left games ONE AFTER ANOTHER on its own thread, its own policy and ONE
+// StdRng::seed_from_u64(seed * (num_workers + 1) + i) that runs through all of its games (run_n_games: alpha_zero.rs:189,201-205) —
+// so, as in the reference, the games depend on the number of workers, and a worker has one game (one leaf) in flight: this is the
+// driver that can be compared with a run of the reference, not the one to play many games with (lockstep_selfplay[_sharded] gives
+// every game a generator of its own). Records in worker order (buffer.extend per worker, alpha_zero.rs:165-168). The trees' Fpu::Func /
+// Dirichlet draws (thread_rng in the reference) come from the tree stream ((worker seed << 32) + the game's number under its worker, turn).
+template <class G, int N>
+std::vector<LockstepGameRecord<G, N>> gather_experience_host_trees(const std::vector<BatchPolicy<G, N>*>& policies, const RolloutConfig& cfg,
+                                                                   size_t games_per_train, uint64_t seed, size_t* rounds_out = nullptr,
+                                                                   size_t* evals_out = nullptr) {
+    if (policies.empty()) throw Error(SYN_ERR_INVALID_ARGUMENT, "gather_experience_host_trees: no policies");
+    std::vector<LockstepGameRecord<G, N>> out(games_per_train);
+    typename detail::SelfplayWorker<G, N>::Shared shared{cfg, seed, 0, games_per_train, out};
+    const size_t workers = policies.size();
+    std::vector<size_t> start(workers), count(workers), rounds(workers, 0), evals(workers, 0);
+    size_t games_to_schedule = games_per_train, workers_left = workers, at = 0;
+    for (size_t i = 0; i < workers; i++) {   // alpha_zero.rs:132-154
+        count[i] = games_to_schedule / workers_left;
+        start[i] = at;
+        at += count[i];
+        games_to_schedule -= count[i];
+        workers_left--;
+    }
+    detail::run_shards(workers, [&](size_t i) {
+        if (count[i] == 0) return;
+        detail::SelfplayWorker<G, N> worker(shared, start[i], count[i], seed * (uint64_t)workers + (uint64_t)i);
+        auto step = [&worker](uint32_t u, const float* logits, const float* value) { return worker.step(u, logits, value); };
+        detail::run_rounds<G, N>(*policies[i], 0u, (uint32_t)worker.slots(), nullptr, step, rounds[i], evals[i]);
     });
     if (rounds_out) *rounds_out = std::accumulate(rounds.begin(), rounds.end(), (size_t)0);
     if (evals_out) *evals_out = std::accumulate(evals.begin(), evals.end(), (size_t)0);

@@ -539,7 +539,7 @@ template <class Net>
 static double c4_selfplay_impl(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,
                        uint64_t first_game, int n_games, int threads, int use_cache, int* plies, uint64_t* states_bb,
                        float* pis, float* vs, uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind,
-                       uint64_t* counters) {
+                       uint64_t* counters, bool worker_rng = false) {
     RolloutConfig cfg = to_rollout(*cfg_in);
     if (threads < 1) threads = 1;
     std::vector<MCTSCounters> ctrs(threads);
@@ -560,11 +560,19 @@ static double c4_selfplay_impl(const orc_rollout_config* cfg_in, const float* bl
         // counters live on the worker's own stack while it runs: neighbouring elements of `ctrs` share cache lines, and
         // hundreds of threads incrementing them would time false sharing instead of the search
         MCTSCounters local;
+        // worker_rng: the reference's own discipline (alpha_zero.rs:140,189,201-205) — ONE StdRng per worker, seeded
+        // seed * (num_workers + 1) + i_worker, running through all of that worker's games one after another; `base_seed` is the
+        // iteration's `seed`, `threads` = num_workers + 1. (Otherwise every game has a generator of its own: DESIGN.md §7.)
+        const uint64_t worker_seed = base_seed * (uint64_t)threads + (uint64_t)w;
+        ChaChaRng wrng = ChaChaRng::seed_from_u64(worker_seed);
         for (int g = start; g < start + count; g++) {
-            ChaChaRng rng = ChaChaRng::seed_from_u64(base_seed + first_game + (uint64_t)g);
+            ChaChaRng grng = ChaChaRng::seed_from_u64(base_seed + first_game + (uint64_t)g);
+            ChaChaRng& rng = worker_rng ? wrng : grng;
+            // the trees' noise streams (Fpu::Func / Dirichlet; thread_rng in the reference): per game in both disciplines
+            const uint64_t stream = worker_rng ? (worker_seed << 32) + (uint64_t)(g - start) : base_seed + first_game + (uint64_t)g;
             GameRecord rec;
-            if (use_cache) run_game(cfg, cached, rng, rec, &local, base_seed + first_game + (uint64_t)g);
-            else run_game(cfg, net, rng, rec, &local, base_seed + first_game + (uint64_t)g);
+            if (use_cache) run_game(cfg, cached, rng, rec, &local, stream);
+            else run_game(cfg, net, rng, rec, &local, stream);
             if (plies) plies[g] = rec.plies;
             if (final_kind) final_kind[g] = rec.final_kind;
             for (int k = 0; k < rec.plies; k++) {
@@ -608,6 +616,15 @@ double orc_c4_selfplay(const orc_rollout_config* cfg_in, const float* blob, int 
                        uint64_t* counters) {
     return c4_selfplay_impl<Connect4Net>(cfg_in, blob, nn_mode, base_seed, first_game, n_games, threads, use_cache, plies, states_bb,
                                          pis, vs, actions, root_nodes, final_kind, counters);
+}
+// gather_experience as the reference runs it (alpha_zero.rs:120-209): num_workers + 1 workers, worker i plays games_to_schedule /
+// workers_left games ONE AFTER ANOTHER on one StdRng::seed_from_u64(seed * (num_workers + 1) + i_worker) — the games depend on the
+// number of workers, as they do in the reference. Outputs in worker order (buffer.extend per worker, alpha_zero.rs:165-168).
+double orc_c4_gather_experience(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t seed, int n_games,
+                                int workers_plus_1, int use_cache, int* plies, uint64_t* states_bb, float* pis, float* vs,
+                                uint8_t* actions, uint32_t* root_nodes, uint8_t* final_kind, uint64_t* counters) {
+    return c4_selfplay_impl<Connect4Net>(cfg_in, blob, nn_mode, seed, 0, n_games, workers_plus_1, use_cache, plies, states_bb, pis, vs,
+                                         actions, root_nodes, final_kind, counters, /*worker_rng=*/true);
 }
 // the same games with Connect4ConvNet (oracle/nn.hpp) as the policy
 double orc_c4conv_selfplay(const orc_rollout_config* cfg_in, const float* blob, int nn_mode, uint64_t base_seed,

@@ -276,7 +276,8 @@ int main(int argc, char** argv) {
         for (int i = 0; i < std::atoi(argv[3]); i++) std::printf("%u\n", rng.next_u32());
         return 0;
     }
-    if (argc == 10 && std::string(argv[1]) == "selfplay") {
+    if (argc == 10 && (std::string(argv[1]) == "selfplay" || std::string(argv[1]) == "gather")) {
+        const bool gather = std::string(argv[1]) == "gather";   // gather_experience with the reference's per-worker StdRng (threads = -(num_workers + 1))
         // run_n_games over host trees with the oracle's network: every game must equal oracle/selfplay.hpp's sequential run_game
         std::ifstream bf(argv[2], std::ios::binary);
         std::vector<float> blob((size_t)30492);
@@ -299,7 +300,8 @@ int main(int argc, char** argv) {
         Policies policies(threads < 0 ? (size_t)-threads : 1, blob.data());
         size_t rounds = 0, evals = 0;
         const uint64_t seed = std::strtoull(argv[7], nullptr, 10), first_game = std::strtoull(argv[8], nullptr, 10);
-        const auto recs = threads < 0 ? lockstep_selfplay_sharded<Connect4, 9>(policies.list, rc, games, seed, first_game, concurrent, &rounds, &evals)
+        const auto recs = gather ? gather_experience_host_trees<Connect4, 9>(policies.list, rc, games, seed, &rounds, &evals)
+                          : threads < 0 ? lockstep_selfplay_sharded<Connect4, 9>(policies.list, rc, games, seed, first_game, concurrent, &rounds, &evals)
                                       : lockstep_selfplay<Connect4, 9>(*policies.list[0], rc, games, seed, first_game, threads, &rounds, &evals,
                                                                        concurrent);
         // out.bin: per game [plies i32][final_kind i32] then 63 x {my u64, op u64, pi f32[9], v f32[3], action u32, root_nodes u32}

@@ -76,6 +76,7 @@ class Oracle:
     def __init__(self, lib):
         self.lib = lib
         lib.orc_c4_selfplay.restype = C.c_double
+        lib.orc_c4_gather_experience.restype = C.c_double
         lib.orc_c4conv_selfplay.restype = C.c_double
         lib.orc_c4net_num_params.restype = C.c_size_t
         lib.orc_c4conv_num_params.restype = C.c_size_t
@@ -417,6 +418,19 @@ class Oracle:
         return {k: a[:m] for k, a in o.items()}
 
     # ---- self-play
+    def c4_gather_experience(self, cfg, blob, seed, n_games, num_workers, use_cache=True, nn_mode=1):
+        """gather_experience / run_n_games as the reference runs them (alpha_zero.rs:120-209): num_workers + 1 workers, one StdRng per
+        worker (seed * (num_workers + 1) + i_worker) through all of its games. Records in worker order."""
+        blob = np.ascontiguousarray(blob, np.float32)
+        r = dict(plies=np.zeros(n_games, np.int32), final_kind=np.zeros(n_games, np.uint8), counters=np.zeros(12, np.uint64),
+                 states_bb=np.zeros((n_games, 63, 2), np.uint64), pis=np.zeros((n_games, 63, 9), np.float32),
+                 vs=np.zeros((n_games, 63, 3), np.float32), actions=np.zeros((n_games, 63), np.uint8),
+                 root_nodes=np.zeros((n_games, 63), np.uint32))
+        self.lib.orc_c4_gather_experience(C.byref(cfg), _p(blob), nn_mode, C.c_uint64(seed), n_games, int(num_workers) + 1, int(use_cache),
+                                          _p(r["plies"]), _p(r["states_bb"]), _p(r["pis"]), _p(r["vs"]), _p(r["actions"]),
+                                          _p(r["root_nodes"]), _p(r["final_kind"]), _p(r["counters"]))
+        return r
+
     def c4_selfplay(self, cfg, blob, base_seed, n_games, first_game=0, threads=1, use_cache=False, nn_mode=1,
                     outputs=True, net="mlp"):
         blob = np.ascontiguousarray(blob, np.float32)

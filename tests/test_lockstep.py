@@ -147,6 +147,34 @@ def assert_games_equal(got, ref, what):
             np.testing.assert_array_equal(got[k][g, :n].view(np.uint32), ref[k][g, :n].view(np.uint32), err_msg=f"{what}: game {g} {k}")
 
 
+def test_gather_experience_with_the_references_per_worker_rng(harness, oracle, golden_dir):
+    """The reference's own RNG discipline (alpha_zero.rs:120-209): num_workers + 1 workers, worker i plays games_to_schedule /
+    workers_left games one after another on ONE StdRng::seed_from_u64(seed * (num_workers + 1) + i_worker) that runs through all of them —
+    the host-tree driver (gather_experience_host_trees: one thread, one policy, one game in flight per worker) against the oracle's
+    sequential restatement, game for game in worker order; and the games DO depend on the number of workers, as in the reference."""
+    from tests.oracle_lib import parity_mcts_config, parity_rollout_config
+
+    exe, blobf, d = harness
+    blob = np.load(os.path.join(golden_dir, "c4net_blob_f32.npy"))
+    runs = {}
+    for variant, games, explores, workers_plus_1, seed in ((0, 23, 40, 7, 3), (0, 23, 40, 3, 3), (4, 10, 48, 4, 0), (1, 5, 30, 6, 11)):
+        out = str(d / f"gather{variant}_{games}_{workers_plus_1}.bin")
+        p = subprocess.run([exe, "gather", blobf, str(games), str(explores), str(variant), str(-workers_plus_1), str(seed), "0", out],
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout + p.stderr
+        raw = np.fromfile(out, GAME_DTYPE)
+        got = dict(plies=raw["plies"], final_kind=raw["final_kind"].astype(np.uint8), states_bb=raw["pos"]["bb"], pis=raw["pos"]["pi"],
+                   vs=raw["pos"]["v"], actions=raw["pos"]["action"].astype(np.uint8), root_nodes=raw["pos"]["root_nodes"])
+        kw = dict(SELFPLAY_VARIANTS[variant])
+        mk = kw.pop("mcts", None)
+        cfg = parity_rollout_config(explores, mcts=parity_mcts_config(**mk) if mk else None, **kw)
+        ref = oracle.c4_gather_experience(cfg, blob, seed, games, workers_plus_1 - 1, use_cache=True)
+        assert_games_equal(got, ref, f"gather_experience variant {variant}, {workers_plus_1} workers")
+        runs[(variant, workers_plus_1)] = got
+    a, b = runs[(0, 7)], runs[(0, 3)]
+    assert not (np.array_equal(a["plies"], b["plies"]) and np.array_equal(a["actions"], b["actions"]))   # 7 workers != 3 workers
+
+
 def test_lockstep_stdrng_is_the_oracles_stream(harness, oracle):
     """The host StdRng of the lock-step self-play driver (ChaCha12 keyed by seed_from_u64) against the oracle's, word for word
     across several blocks, and against rand's own value-stability constant through it."""
