@@ -13,7 +13,7 @@ Metric   : self-play games/s (and leaf-evals/s, explores/s as extra fields), 9x7
            deterministic parity MCTS config (study-connect4/src/main.rs:58-66). Workload = BASELINE configs[2] (GPU-resident
            SoA MCTS node pool) at 196,608 concurrent games per GPU (768 per CU: the 12-wave lane-per-tree kernel);
            configs[1]'s 4096 concurrent games is measured in the same run and reported under "at_4096_concurrent_games".
-Step     : one pass of the hot path over one batch = GAMES_PER_STEP (2,097,152 = 8 per tree slot) self-play games per GPU played to completion by
+Step     : one pass of the hot path over one batch = GAMES_PER_STEP (2,097,152: 10.7 per tree slot) self-play games per GPU played to completion by
            ONE launch of the fused kernel (finished games hand their tree slot to the next game index, so the slots stay busy).
 Scaling  : weak — every rank plays its own GAMES_PER_STEP games per step (games share nothing; no collective on the
            data path). Timed region = barrier + device sync on both sides, max over ranks.
@@ -210,7 +210,7 @@ def main():
     ap.add_argument("--concurrent", type=int, default=196608,
                     help="concurrent games (tree slots) per GPU: 768 per CU = 12 waves of 64 trees, what the headline launch plays on "
                          "(rounds 1-5 created 262,144 slots and played on 196,608 of them); BASELINE configs[1] names 4096, reported as extra")
-    ap.add_argument("--games-per-step", type=int, default=2097152, help="self-play games per GPU per step (8 per tree slot)")
+    ap.add_argument("--games-per-step", type=int, default=2097152, help="self-play games per GPU per step (10.7 per tree slot at the default engine size)")
     ap.add_argument("--no-4096", action="store_true", help="skip the extra 4096-concurrent-games measurement")
     ap.add_argument("--explores", type=int, default=800)
     ap.add_argument("--no-cpu-baseline", action="store_true")
